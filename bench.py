@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- LR-patches/sec, fwd+bwd, WDSR-B r12 t9, 16x16 patches (+6 px border), batch 128 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic patches already resident in HBM:
+model forward (weight-norm, head, 12 WDSR-B blocks, reducers, pixel shuffle), shift-compensated L1 loss
+forward, and the full backward to all 132 parameter gradients (BASELINE.json metric) --
+plus, for N > 1, the one gradient all-reduce that data parallelism adds (RCCL over xGMI).
+The optimizer update and the cPSNR metric are not part of "fwd+bwd"; `--full-step` times them too and
+reports the result under "full_step" without changing `value`.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: the engine brackets every kernel launch of
+the timed steps with HIP events on the launch stream and reports per-class time and algorithmic MACs;
+the dominant class is priced against the fp32 MFMA/VALU peak of MI355X (157.3 TFLOP/s).
+`cpu_baseline` times the CPU oracle (torch-CPU restatement of the TF path; the TF reference itself
+cannot run here) on the host cores at the reference's CPU-runnable config (batch 8).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLASSES = ["weight_norm", "small", "conv3x3x3_fwd", "conv3x3x3_bwd_data", "conv3x3x3_wgrad",
+           "conv1x1x1_fwd", "conv1x1x1_bwd_data", "conv1x1x1_wgrad"]
+PEAK_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+ALGO_GFLOP_PER_PATCH = 12.436      # SURVEY.md §8d / BASELINE.md §2: fwd + bwd, p16t9c85r12
+
+
+def cpu_baseline(seconds=20.0):
+    """The oracle's torch-CPU restatement, fp32, all host cores, BASELINE.json config 1 (batch 8)."""
+    import torch
+    from oracle import wdsr_torch as ot
+    from probav_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = ot.to_torch_params(synth.synth_params(seed=1234), dtype=torch.float32)
+    x, hr, mask = (torch.as_tensor(a) for a in synth.synth_batch(8, seed=1234))
+    ot.train_step_grads(x, hr, mask, params, synth.NIR_MEAN, synth.NIR_STD)          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ot.train_step_grads(x, hr, mask, params, synth.NIR_MEAN, synth.NIR_STD)
+        n += 1
+        if time.perf_counter() - t0 >= seconds or n >= 40:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(8 * n / dt, 3), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "oracle/wdsr_torch.py fp32, batch 8 (cfg p16t9c85r12 on CPU), fwd + L1 loss + bwd, %d steps in %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="patches per GPU (BASELINE.json: 128)")
+    ap.add_argument("--frames", type=int, default=9, help="numImgLR: 9 (headline), 13 or 7")
+    ap.add_argument("--impl", type=int, default=1, help="1 = MFMA kernels where available, 0 = generic direct kernels")
+    ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    from probav_amd import _lib, synth
+    from probav_amd.loss import Losses
+    from probav_amd.modelsTF import WDSRConv3D
+    from probav_amd.trainClass import allreduce_mean_, make_optimizer
+
+    T, B = args.frames, args.batch
+    model = WDSRConv3D("bench", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, True)
+    model.load_variables(synth.synth_params(seed=1234, numImgLR=T))            # same random-init weights on every rank
+    model = model.to(dev)
+    model.set_impl(args.impl)
+    losses = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(B, seed=1234 + rank, numImgLR=T))
+    opt = make_optimizer("nadam", model, 5e-4)
+    L, h = _lib.lib(), model._handle()
+
+    def step(full=False):
+        pred = model(x, training=True)
+        loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
+        model.flat.grad = None
+        loss.backward()
+        if world > 1:
+            allreduce_mean_(model.flat.grad)
+        if full:
+            opt.step()
+            losses.shiftCompensatedcPSNR(hr, mask, pred.detach())
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    use_events = not args.no_kernel_events
+    if use_events:
+        _lib.check(L.probav_engine_profile(h, 1, 512 * args.steps), "probav_engine_profile")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = None
+    if use_events:
+        n = len(CLASSES)
+        ms, macs, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
+        _lib.check(L.probav_engine_profile_read(h, n, ms, macs, cnt), "probav_engine_profile_read")
+        _lib.check(L.probav_engine_profile(h, 0, 0))
+        prof = {c: {"ms": ms[i], "macs": macs[i], "launches": int(cnt[i])} for i, c in enumerate(CLASSES)}
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    full = None
+    if args.full_step:
+        for _ in range(2):
+            step(True)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        sync()
+        full = (time.perf_counter() - t1) / args.steps * 1e3
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "LR-patches/sec fwd+bwd (WDSR-B r12 t%d, 16x16, bs%d)" % (T, B),
+            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg p16t%dc85r12: %d patches/GPU of [22,22,%d,1] -> [48,48,1], 12 WDSR-B blocks, 32 filters; "
+                                   "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
+                                   (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": "mfma" if args.impl else "direct",
+                       "loss": float(loss), "kernel_events": use_events},
+            "algorithmic_tflops_whole_step": round(value * ALGO_GFLOP_PER_PATCH / 1e3, 3) if T == 9 else None,
+            "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",
+                                  "note": "derived from the reference's TensorBoard logs (BASELINE.md), not a published figure"},
+        }
+        if full is not None:
+            out["full_step"] = {"ms_per_step": round(full, 4), "patches_per_s": round(world * B / full * 1e3, 2),
+                                "includes": "fwd + L1 loss + bwd + Nadam update + cPSNR metric"}
+        if prof:
+            per = {c: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,
+                       "tflops": round(2 * v["macs"] / (v["ms"] * 1e-3) / 1e12, 3) if v["ms"] > 0 and v["macs"] > 0 else None}
+                   for c, v in prof.items()}
+            dom = max((c for c in prof if prof[c]["macs"] > 0), key=lambda c: prof[c]["ms"])
+            ach = 2 * prof[dom]["macs"] / (prof[dom]["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["launches"]), 4),
+                               "algorithmic_gflop_per_launch": round(2 * prof[dom]["macs"] / max(1, prof[dom]["launches"]) / 1e9, 3),
+                               "note": "rank 0, HIP events on the launch stream around every launch of the class during the timed steps"}
+            out["kernel_classes"] = per
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

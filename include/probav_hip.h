@@ -1,0 +1,117 @@
+/* probav_hip.h -- C ABI of libprobav_hip.so: the gfx950 (MI355X) implementation of the WDSR-B Conv3D
+ * forward/backward hot path of mmbajo/PROBA-V and its shift-compensated loss.
+ *
+ * The reference has no native/FFI layer: the path sits behind Python callables that dispatch to
+ * TensorFlow ops.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference repository).  A binding needs nothing but this header: plain
+ * pointers to DEVICE memory (fp32 unless stated), sizes, and a hipStream_t passed as void*.
+ *
+ * Conventions
+ *   - activations [N][H][W][T][C], C innermost (the reference's layout; models/modelsTF.py:19);
+ *     kernels [kh][kw][kt][Cin][Cout] (Keras).  All buffers contiguous, 16-byte aligned.
+ *   - every call only ENQUEUES work on `stream` and returns; it never synchronises, allocates or
+ *     frees device memory (so calls can be captured in a hipGraph).  probav_engine_create /
+ *     _destroy are the only functions that allocate (a few KB for the layer table).
+ *   - return value: 0 = ok, PROBAV_EINVAL (-1) bad argument, PROBAV_ENOSPACE (-2) workspace too small,
+ *     PROBAV_EHIP (-3) a HIP call failed; probav_last_error() gives the text (thread-local).
+ *   - thread-safety: an engine handle and its workspace may be used by one thread at a time;
+ *     distinct handles are independent (one process per GPU under data parallelism).
+ */
+#ifndef PROBAV_HIP_H
+#define PROBAV_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROBAV_ABI_VERSION 1
+
+/* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
+ * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale=True)   (models/modelsTF.py:8-17) */
+typedef struct probav_net_cfg {
+    int32_t scale;            /* 3 */
+    int32_t num_filters;      /* 32 */
+    int32_t num_res_blocks;   /* 12 */
+    int32_t exp_rate;         /* 8 */
+    int32_t dec_channels;     /* int(numFilters*decayRate) = 25 (models/modelsTF.py:182) */
+    int32_t num_img_lr;       /* 9 (7, 13 also defined by the reference; models/modelsTF.py:62-69) */
+    int32_t patch_size_lr;    /* 16 */
+    int32_t max_shift;        /* 6 */
+    float mean, std;          /* per-band constants (train.py:47-52) */
+} probav_net_cfg;
+
+typedef struct probav_engine probav_engine;
+
+int probav_abi_version(void);
+const char* probav_last_error(void);
+
+/* ---- engine: the whole network ------------------------------------------------------------------ */
+/* replaces WDSRConv3D(...).build(...)                                   models/modelsTF.py:15-43     */
+int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out);
+void probav_engine_destroy(probav_engine* e);
+/* number of trainable fp32 parameters (535 267 for p16t9c85r12) and the flat layout: layers in Keras
+ * checkpoint order, per layer [g(Cout) | v(taps*Cin*Cout) | bias(Cout)]               */
+int64_t probav_param_count(const probav_engine* e);
+int probav_num_layers(const probav_engine* e);
+/* name, offsets (in floats) and kernel shape of layer i; shape is [kh,kw,kt,Cin,Cout]               */
+int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_off, int64_t* v_off,
+                      int64_t* b_off, int32_t shape[5]);
+/* 0 = generic direct kernels everywhere, 1 = MFMA kernels where available (default)                */
+int probav_engine_set_impl(probav_engine* e, int impl);
+size_t probav_workspace_bytes(const probav_engine* e, int batch, int training);
+/* per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * probav_engine_profile(e, 1, n) creates events for n launches and starts recording (allocation
+ * happens here, never inside forward/backward); after a stream synchronise,
+ * probav_engine_profile_read sums elapsed ms, algorithmic MACs and launch counts per class
+ * (nclass >= 8: wn, small, conv3 fwd, conv3 bwd-data, conv3 wgrad, 1x1x1 fwd, 1x1x1 bwd-data,
+ * 1x1x1 wgrad) and clears the log.                                                                  */
+int probav_engine_profile(probav_engine* e, int enable, int max_launches);
+int probav_engine_profile_read(probav_engine* e, int nclass, double* ms, double* macs, int64_t* launches);
+
+/* replaces  model(x, training=...)      models/trainClass.py:127,139 ; test.py:117 ; testClass.py:26
+ * x [B, P+maxShift, P+maxShift, T, 1] -> y [B, scale*P, scale*P, 1].  With training != 0 the
+ * activations needed by probav_backward stay in `ws`.                                               */
+int probav_forward(probav_engine* e, const float* params, const float* x, float* y, void* ws,
+                   size_t ws_bytes, int batch, int training, void* stream);
+/* replaces  tape.gradient(loss, model.trainable_variables)              models/trainClass.py:131
+ * dy [B, scale*P, scale*P, 1] -> grads[param_count] (overwritten).  Must follow probav_forward
+ * (training=1) on the same ws / batch.                                                              */
+int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws,
+                    size_t ws_bytes, int batch, void* stream);
+
+/* ---- loss / metric ------------------------------------------------------------------------------ */
+/* replaces Losses.shiftCompensatedL1Loss / L2Loss / cPSNR               models/loss.py:37-84
+ * hr, pred [B,S,S,1] f32; mask [B,S,S,1] uint8 (non-zero = clear pixel).  Outputs (device):
+ * l1[B], l2[B] minima over the (2*border+1)^2 shifts, cpsnr[B] maximum, arg_l1[B]/arg_l2[B] the
+ * arg-min shift ids (i*(2*border+1)+j), mean_l1/mean_l2 the batch means (the two loss scalars).     */
+int probav_shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, int batch, int size,
+                              int border, int bit_depth, float* l1, float* l2, float* cpsnr, int32_t* arg_l1,
+                              int32_t* arg_l2, float* mean_l1, float* mean_l2, void* stream);
+/* gradient of mean_l1 (which=1) or mean_l2 (which=2) w.r.t. pred; `upstream` = device scalar or NULL */
+int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg,
+                               int batch, int size, int border, int which, const float* upstream,
+                               float* dpred, void* stream);
+/* replaces tf.clip_by_value(sr, 0, 2**16); tf.round(sr)                 test.py:118-119             */
+int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi, void* stream);
+
+/* ---- single operators (what the engine is made of; exported for parity tests) ------------------- */
+/* geometry: int32[17] = N, Hi,Wi,Ti,Cin, Ho,Wo,To,Cout, kh,kw,kt, ph,pw,pt, reflect_hw, relu        */
+/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA                           */
+int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w,
+                          const float* bias, const float* skip, float* y, int impl, void* stream);
+size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl);
+int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy, const float* gate,
+                        float* dw, float* db, void* scratch, size_t scratch_bytes, int impl, void* stream);
+/* weight normalisation of every layer of the engine: params -> weff, weffT, inv_norm (ws-internal
+ * layouts, exported for tests): sizes probav_weff_count() floats and probav_cout_total() floats      */
+int64_t probav_weff_count(const probav_engine* e);
+int64_t probav_cout_total(const probav_engine* e);
+int probav_wn_forward(probav_engine* e, const float* params, float* weff, float* weffT, float* inv_norm, void* stream);
+int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm,
+                       float* grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,132 @@
+"""torch (CPU) restatement of the reference's WDSR-B Conv3D network and shift-compensated losses.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- PARITY UNPINNED.
+
+Second, independent formulation of oracle/wdsr_numpy.py: convolutions go through
+``torch.nn.functional.conv3d/conv2d`` on permuted tensors and gradients come from autograd
+(the stand-in for ``tf.GradientTape`` at models/trainClass.py:126-131).  It runs in fp64 as the
+gradient oracle and in fp32 on all host cores as the timed CPU baseline of bench.py.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def reducer_plan(numImgLR):
+    """models/modelsTF.py:62-69, :123-175 (see oracle/wdsr_numpy.reducer_plan)."""
+    return {9: [True, False, False], 13: [True, True, True, False, False], 7: [False, False]}[numImgLR]
+
+
+def weight_norm(v, g):
+    """tf.nn.l2_normalize(v, all-but-last) * g  (models/modelsTF.py:191-197)."""
+    ss = (v * v).reshape(-1, v.shape[-1]).sum(dim=0)
+    return v * torch.rsqrt(torch.clamp(ss, min=1e-12)) * g
+
+
+def _conv(x, w, b, same):
+    """x [N,H,W,T,C] / [N,H,W,C] channels-last as in the reference; w Keras layout."""
+    if w.dim() == 5:
+        y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2), b,
+                     padding=tuple((k - 1) // 2 for k in w.shape[:3]) if same else 0)
+        return y.permute(0, 2, 3, 4, 1)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b,
+                 padding=tuple((k - 1) // 2 for k in w.shape[:2]) if same else 0)
+    return y.permute(0, 2, 3, 1)
+
+
+def wn_conv(x, p, padding, relu):
+    y = _conv(x, weight_norm(p["v"], p["g"]), p["bias"], padding == "same")
+    return torch.relu(y) if relu else y
+
+
+def depth_to_space(x, s):
+    """tf.nn.depth_to_space NHWC == pixel_shuffle on NCHW with Co = C/s^2 (channel = (i*s+j)*Co+c;
+    for Co = 1 the two orderings coincide)."""
+    N, H, W, C = x.shape
+    co = C // (s * s)
+    return x.reshape(N, H, W, s, s, co).permute(0, 1, 3, 2, 4, 5).reshape(N, H * s, W * s, co)
+
+
+def wdsr_forward(x, params, mean, std, numResBlocks=12, numImgLR=9, scale=3):
+    """WDSRConv3D.build graph (models/modelsTF.py:15-43)."""
+    meanLR = x.mean(dim=3)                                     # :23
+    xn = (x - mean) / std                                      # :26
+    mn = (meanLR - mean) / std                                 # :27
+    h = wn_conv(xn, params["mainConv1"], "same", True)         # :58
+    for i in range(numResBlocks):                              # :177-189
+        e = wn_conv(h, params["expConv_%d" % i], "same", True)
+        d = wn_conv(e, params["decConv_%d" % i], "same", False)
+        h = wn_conv(d, params["normConv_%d" % i], "same", False) + h
+    for i, refl in enumerate(reducer_plan(numImgLR)):          # :152-164
+        if refl:
+            N, H, W, T, C = h.shape
+            h2 = F.pad(h.permute(0, 3, 4, 1, 2).reshape(N, T * C, H, W), (1, 1, 1, 1), mode="reflect")
+            h = h2.reshape(N, T, C, H + 2, W + 2).permute(0, 3, 4, 1, 2)
+        h = wn_conv(h, params["convReducer_%d" % (i + 1)], "valid", True)
+    h = wn_conv(h, params["upscaleConv1"], "valid", False)     # :162-163
+    main = depth_to_space(h[:, :, :, 0, :], scale)             # :71-73
+    r = wn_conv(mn, params["residConv1"], "valid", True)       # :45-53
+    r = wn_conv(r, params["residConv2"], "valid", False)
+    r = wn_conv(r, params["residConv3"], "valid", False)
+    return (main + depth_to_space(r, scale)) * std + mean      # :38, :41
+
+
+def _shift_terms(hr, mask, pred, cropBorder=3):
+    """models/loss.py:140-180 scaffolding -> l1[49,B], mse[49,B]."""
+    dt = pred.dtype
+    hr = hr.to(dt)[..., 0]
+    m = mask.to(dt)[..., 0]
+    p = pred[..., 0]
+    S = hr.shape[1]
+    c = cropBorder
+    L = S - 2 * c
+    P = p[:, c:c + L, c:c + L]
+    l1, l2 = [], []
+    for i in range(2 * c + 1):
+        for j in range(2 * c + 1):
+            H = hr[:, i:i + L, j:j + L]
+            M = m[:, i:i + L, j:j + L]
+            n = M.sum(dim=(1, 2))
+            b = (1.0 / n) * (H - P * M).sum(dim=(1, 2))
+            C = (P + b[:, None, None]) * M
+            l1.append((1.0 / n) * (H - C).abs().sum(dim=(1, 2)))
+            l2.append((1.0 / n) * (H - C).square().sum(dim=(1, 2)))
+    return torch.stack(l1), torch.stack(l2)
+
+
+def shift_l1_loss(hr, mask, pred, cropBorder=3):
+    """models/loss.py:73-84.  torch.amin splits the gradient equally among ties like tf.reduce_min."""
+    return _shift_terms(hr, mask, pred, cropBorder)[0].amin(dim=0).mean()
+
+
+def shift_l2_loss(hr, mask, pred, cropBorder=3):
+    """models/loss.py:55-71."""
+    return _shift_terms(hr, mask, pred, cropBorder)[1].amin(dim=0).mean()
+
+
+def shift_cpsnr(hr, mask, pred, cropBorder=3, bitDepth=16):
+    """models/loss.py:37-53, 234-238."""
+    l2 = _shift_terms(hr, mask, pred, cropBorder)[1]
+    nb = float(2 ** bitDepth - 1)
+    ten = torch.log(torch.tensor(10.0, dtype=l2.dtype))
+    return (10.0 * (torch.log(nb * nb / l2) / ten)).amax(dim=0)
+
+
+def to_torch_params(params_np, dtype=torch.float64, requires_grad=True):
+    out = {}
+    for name, p in params_np.items():
+        out[name] = {k: torch.tensor(v, dtype=dtype, requires_grad=requires_grad) for k, v in p.items()}
+    return out
+
+
+def train_step_grads(x, hr, mask, params, mean, std, **kw):
+    """One `trainStep` up to the gradients (models/trainClass.py:124-131): forward, L1 loss,
+    d loss / d every trainable.  Returns (pred, loss, grads{name:{v,g,bias}})."""
+    pred = wdsr_forward(x, params, mean, std, **kw)
+    loss = shift_l1_loss(hr, mask, pred)
+    leaves = [t for p in params.values() for t in (p["g"], p["v"], p["bias"])]
+    gl = torch.autograd.grad(loss, leaves)
+    grads, k = {}, 0
+    for name in params:
+        grads[name] = {"g": gl[k], "v": gl[k + 1], "bias": gl[k + 2]}
+        k += 3
+    return pred.detach(), loss.detach(), grads

@@ -1,0 +1,44 @@
+"""Architecture tables of the reference's WDSR-B Conv3D network (host side, no arithmetic).
+
+Layer inventory and order follow the reference's graph (models/modelsTF.py:15-203) and its own
+checkpoints (modelInfo/ckpt_p16t9c85r12/NIR/ckpt-124.index: `model/layer_with_weights-K/{g,v,layer/bias}`,
+K in Keras topological order).  The native library (csrc/engine.hip) builds the same table in C++;
+tests assert the two agree (parameter count 535 267 for p16t9c85r12).
+
+Flat parameter buffer: layers in checkpoint order, per layer  [ g (Cout) | v (taps*Cin*Cout) | bias (Cout) ],
+`v` in Keras kernel layout [kh, kw, kt, Cin, Cout] (2-D layers [kh, kw, Cin, Cout]).
+"""
+from collections import namedtuple
+
+Layer = namedtuple("Layer", "name vshape cout g_off v_off b_off")
+
+
+def reducer_plan(numImgLR):
+    """Reflect-pad flags per valid `convReducer_i` (models/modelsTF.py:62-69, :123-175)."""
+    plans = {9: (True, False, False), 13: (True, True, True, False, False), 7: (False, False)}
+    if numImgLR not in plans:
+        raise ValueError("numImgLR=%r: the reference defines WDSRConv3D reducers for 7, 9, 13 (and an "
+                         "experimental 5x5x5 variant for 19 that is out of scope)" % (numImgLR,))
+    return plans[numImgLR]
+
+
+def layer_table(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImgLR=9, scale=3):
+    """Ordered list of Layer records and the total parameter count."""
+    f, s2 = numFilters, scale * scale
+    dec = int(numFilters * decayRate)                      # models/modelsTF.py:182
+    shapes = [("mainConv1", (3, 3, 3, 1, f))]
+    for i in range(numResBlocks):
+        shapes += [("expConv_%d" % i, (1, 1, 1, f, f * expRate)),
+                   ("decConv_%d" % i, (1, 1, 1, f * expRate, dec)),
+                   ("normConv_%d" % i, (3, 3, 3, dec, f))]
+    shapes += [("convReducer_%d" % (i + 1), (3, 3, 3, f, f)) for i in range(len(reducer_plan(numImgLR)))]
+    shapes += [("residConv1", (3, 3, 1, s2)), ("upscaleConv1", (3, 3, 3, f, s2)),
+               ("residConv2", (3, 3, s2, s2)), ("residConv3", (3, 3, s2, s2))]
+    layers, off = [], 0
+    for name, vs in shapes:
+        cout, nv = vs[-1], 1
+        for d in vs:
+            nv *= d
+        layers.append(Layer(name, vs, cout, off, off + cout, off + cout + nv))
+        off += 2 * cout + nv
+    return layers, off

@@ -1,0 +1,526 @@
+// Engine: sequences the HIP kernels into the WDSR-B Conv3D network of models/modelsTF.py:15-203
+// (forward) and its reverse-mode gradient (what tf.GradientTape computes at models/trainClass.py:126-131),
+// and exports the C ABI of include/probav_hip.h.  Host-side C++ only decides shapes, offsets and launch
+// order; it never touches tensor data and never synchronises.
+#include "probav_common.h"
+#include "../../include/probav_hip.h"
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace probav;
+
+namespace probav {
+// kernels_mfma.hip
+bool mfma_conv_supported(const ConvGeom& g);
+int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* w, const float* bias,
+                      const float* skip, float* y, hipStream_t s);
+}
+
+struct LayerRec {
+    char name[32];
+    WnLayer wn;
+    int kh, kw, kt;
+};
+
+struct probav_engine {
+    probav_net_cfg cfg;
+    std::vector<LayerRec> layers;
+    int64_t nparams = 0, weff_count = 0, cout_total = 0;
+    WnLayer* d_layers = nullptr;
+    int impl = 1;
+    int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
+    std::vector<int> iExp, iDec, iNorm, iRed, redReflect;
+    int Hin = 0;
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_cls;
+    std::vector<double> prof_macs;
+    size_t prof_used = 0;
+};
+
+enum { CLS_WN = 0, CLS_SMALL, CLS_CONV3_FWD, CLS_CONV3_BWD_DATA, CLS_CONV3_WGRAD, CLS_PW_FWD, CLS_PW_BWD_DATA, CLS_PW_WGRAD, CLS_COUNT };
+
+struct ProfScope {
+    probav_engine* e; hipStream_t s; bool live;
+    ProfScope(const probav_engine* ce, int cls, double macs, hipStream_t st) : e(const_cast<probav_engine*>(ce)), s(st), live(false)
+    {
+        if (!e->prof_on || e->prof_used + 2 > e->prof_ev.size()) return;
+        live = true;
+        e->prof_cls.push_back(cls);
+        e->prof_macs.push_back(macs);
+        (void)hipEventRecord(e->prof_ev[e->prof_used], s);
+    }
+    ~ProfScope()
+    {
+        if (!live) return;
+        (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s);
+        e->prof_used += 2;
+    }
+};
+static double geom_macs(const ConvGeom& g)
+{
+    return (double)g.N * g.Ho * g.Wo * g.To * g.kh * g.kw * g.kt * g.Cin * g.Cout;
+}
+
+static int add_layer(probav_engine* e, const std::string& name, int kh, int kw, int kt, int cin, int cout)
+{
+    LayerRec r;
+    memset(&r, 0, sizeof(r));
+    snprintf(r.name, sizeof(r.name), "%s", name.c_str());
+    r.kh = kh; r.kw = kw; r.kt = kt;
+    r.wn.taps = kh * kw * kt; r.wn.Cin = cin; r.wn.Cout = cout; r.wn.K = r.wn.taps * cin;
+    r.wn.g_off = (int)e->nparams;
+    r.wn.v_off = r.wn.g_off + cout;
+    r.wn.b_off = r.wn.v_off + r.wn.K * cout;
+    r.wn.w_off = (int)e->weff_count;
+    r.wn.n_off = (int)e->cout_total;
+    e->nparams += 2 * cout + (int64_t)r.wn.K * cout;
+    e->weff_count += (int64_t)r.wn.K * cout;
+    e->cout_total += cout;
+    e->layers.push_back(r);
+    return (int)e->layers.size() - 1;
+}
+
+static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }      // 64 floats = 256 B
+
+struct Plan {
+    size_t weff, weffT, invn, dweff, xn, mn;
+    std::vector<size_t> act, dec, red;
+    std::vector<int> redH, redT;              // output extent of each reducer
+    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, total;
+};
+
+static ConvGeom make_geom(int N, int Hi, int Ti, int Cin, int Ho, int To, int Cout, int kh, int kw, int kt,
+                          int ph, int pt, int reflect, int relu)
+{
+    ConvGeom g;
+    g.N = N; g.Hi = Hi; g.Wi = Hi; g.Ti = Ti; g.Cin = Cin; g.Ho = Ho; g.Wo = Ho; g.To = To; g.Cout = Cout;
+    g.kh = kh; g.kw = kw; g.kt = kt; g.ph = ph; g.pw = ph; g.pt = pt; g.reflect_hw = reflect; g.relu = relu;
+    return g;
+}
+
+// backward-data geometry of a forward layer: a correlation of dy with the flipped, channel-swapped
+// kernel and padding k-1-p; for reflect layers the result is the gradient of the PADDED input.
+static ConvGeom bwd_data_geom(const ConvGeom& f)
+{
+    ConvGeom b = f;
+    const int php = f.reflect_hw ? 0 : f.ph, pwp = f.reflect_hw ? 0 : f.pw;
+    b.Hi = f.Ho; b.Wi = f.Wo; b.Ti = f.To; b.Cin = f.Cout;
+    b.Ho = f.reflect_hw ? f.Hi + 2 * f.ph : f.Hi;
+    b.Wo = f.reflect_hw ? f.Wi + 2 * f.pw : f.Wi;
+    b.To = f.Ti; b.Cout = f.Cin;
+    b.ph = f.kh - 1 - php; b.pw = f.kw - 1 - pwp; b.pt = f.kt - 1 - f.pt;
+    b.reflect_hw = 0; b.relu = 0;
+    return b;
+}
+
+static void reducer_extents(const probav_engine* e, std::vector<int>& hh, std::vector<int>& tt)
+{
+    int h = e->Hin, t = e->cfg.num_img_lr;
+    for (size_t k = 0; k < e->iRed.size(); ++k) {
+        if (!e->redReflect[k]) h -= 2;
+        t -= 2;
+        hh.push_back(h); tt.push_back(t);
+    }
+}
+
+static Plan make_plan(const probav_engine* e, int B, int training)
+{
+    Plan p;
+    const probav_net_cfg& c = e->cfg;
+    const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
+    const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
+    const size_t V = (size_t)B * Hin * Hin * T;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
+    p.weff = take(e->weff_count); p.weffT = take(e->weff_count); p.invn = take(e->cout_total);
+    p.dweff = take(training ? e->weff_count : 0);
+    p.xn = take(V); p.mn = take((size_t)B * Hin * Hin);
+    if (training) {
+        for (int i = 0; i <= R; ++i) p.act.push_back(take(V * F));
+        for (int i = 0; i < R; ++i) p.dec.push_back(take(V * D));
+    } else {
+        const size_t a0 = take(V * F), a1 = take(V * F), d0 = take(V * D);
+        for (int i = 0; i <= R; ++i) p.act.push_back((i & 1) ? a1 : a0);
+        for (int i = 0; i < R; ++i) p.dec.push_back(d0);
+    }
+    reducer_extents(e, p.redH, p.redT);
+    for (size_t k = 0; k < e->iRed.size(); ++k) p.red.push_back(take((size_t)B * p.redH[k] * p.redH[k] * p.redT[k] * F));
+    p.up = take((size_t)B * P * P * s2);
+    p.r1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
+    p.r2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
+    p.r3 = take((size_t)B * P * P * s2);
+    p.H = take(V * E);
+    p.dH = p.gA = p.gB = p.gDec = p.dtail = p.dr2 = p.dr1 = p.partial = 0;
+    if (training) {
+        const size_t gmax = (size_t)B * (Hin + 2) * (Hin + 2) * T * F;
+        p.gA = take(gmax); p.gB = take(gmax); p.gDec = take(V * D);
+        p.dtail = take((size_t)B * P * P * s2);
+        p.dr2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
+        p.dr1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
+        p.dH = take(V * E);
+        std::vector<ConvGeom> gs;
+        gs.push_back(make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1));
+        gs.push_back(make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1));
+        gs.push_back(make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0));
+        gs.push_back(make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0));
+        gs.push_back(make_geom(B, Hin, T, F, Hin, T - 2, F, 3, 3, 3, 1, 0, 1, 1));
+        gs.push_back(make_geom(B, Hin, 3, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0));
+        gs.push_back(make_geom(B, Hin, 1, s2, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 0));
+        size_t pmax = 0;
+        for (auto& g : gs) { size_t q = wgrad_partial_floats(g); if (q > pmax) pmax = q; }
+        p.partial = take(pmax);
+    }
+    p.total = off;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
+                    const float* bias, const float* skip, float* y, hipStream_t s)
+{
+    const bool pw = g.kh * g.kw * g.kt == 1;
+    const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
+    ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD), geom_macs(g), s);
+    if (e->impl >= 1 && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, w, bias, skip, y, s);
+    return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
+}
+static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
+                      float* dw, float* db, float* partial, hipStream_t s)
+{
+    ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : CLS_CONV3_WGRAD, geom_macs(g), s);
+    return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s);
+}
+
+#define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+extern "C" {
+
+int probav_abi_version(void) { return PROBAV_ABI_VERSION; }
+const char* probav_last_error(void) { return probav::last_error(); }
+
+int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
+{
+    if (!cfg || !out) { set_error("probav_engine_create: null argument", hipSuccess); return PROBAV_EINVAL; }
+    const int T = cfg->num_img_lr;
+    if (cfg->scale != 3 || cfg->max_shift != 2 * cfg->scale) {
+        set_error("probav_engine_create: the reference graph only closes for scale=3, maxShift=6 (models/modelsTF.py:45-53)", hipSuccess);
+        return PROBAV_EINVAL;
+    }
+    if (T != 7 && T != 9 && T != 13) {
+        set_error("probav_engine_create: numImgLR must be 7, 9 or 13 (models/modelsTF.py:62-69)", hipSuccess);
+        return PROBAV_EINVAL;
+    }
+    if (cfg->num_filters < 1 || cfg->num_res_blocks < 0 || cfg->exp_rate < 1 || cfg->dec_channels < 1 ||
+        cfg->patch_size_lr < 1 || !(cfg->std > 0.f)) {
+        set_error("probav_engine_create: bad hyper-parameter", hipSuccess);
+        return PROBAV_EINVAL;
+    }
+    probav_engine* e = new probav_engine();
+    e->cfg = *cfg;
+    e->Hin = cfg->patch_size_lr + cfg->max_shift;
+    const int F = cfg->num_filters, E = F * cfg->exp_rate, D = cfg->dec_channels, s2 = cfg->scale * cfg->scale;
+    e->iMain = add_layer(e, "mainConv1", 3, 3, 3, 1, F);
+    for (int i = 0; i < cfg->num_res_blocks; ++i) {
+        e->iExp.push_back(add_layer(e, "expConv_" + std::to_string(i), 1, 1, 1, F, E));
+        e->iDec.push_back(add_layer(e, "decConv_" + std::to_string(i), 1, 1, 1, E, D));
+        e->iNorm.push_back(add_layer(e, "normConv_" + std::to_string(i), 3, 3, 3, D, F));
+    }
+    if (T == 9) e->redReflect = {1, 0, 0};
+    else if (T == 13) e->redReflect = {1, 1, 1, 0, 0};
+    else e->redReflect = {0, 0};
+    for (size_t k = 0; k < e->redReflect.size(); ++k)
+        e->iRed.push_back(add_layer(e, "convReducer_" + std::to_string(k + 1), 3, 3, 3, F, F));
+    e->iResid1 = add_layer(e, "residConv1", 3, 3, 1, 1, s2);
+    e->iUp = add_layer(e, "upscaleConv1", 3, 3, 3, F, s2);
+    e->iResid2 = add_layer(e, "residConv2", 3, 3, 1, s2, s2);
+    e->iResid3 = add_layer(e, "residConv3", 3, 3, 1, s2, s2);
+    // the graph must close: after the reducers one valid 3x3x3 conv lands on [P, P, 1]
+    std::vector<int> hh, tt;
+    reducer_extents(e, hh, tt);
+    if (hh.back() - 2 != cfg->patch_size_lr || tt.back() - 2 != 1) {
+        delete e;
+        set_error("probav_engine_create: reducer geometry does not collapse to [P,P,1]", hipSuccess);
+        return PROBAV_EINVAL;
+    }
+    std::vector<WnLayer> h;
+    for (auto& r : e->layers) h.push_back(r.wn);
+    hipError_t err = hipMalloc((void**)&e->d_layers, h.size() * sizeof(WnLayer));
+    if (err == hipSuccess) err = hipMemcpy(e->d_layers, h.data(), h.size() * sizeof(WnLayer), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { set_error("probav_engine_create: layer table upload", err); delete e; return PROBAV_EHIP; }
+    if (const char* env = getenv("PROBAV_IMPL")) e->impl = atoi(env);
+    *out = e;
+    return PROBAV_OK;
+}
+
+int probav_engine_profile(probav_engine* e, int enable, int max_launches)
+{
+    if (!e || max_launches < 0) { set_error("probav_engine_profile: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    while ((int)e->prof_ev.size() < 2 * max_launches) {
+        hipEvent_t ev;
+        hipError_t err = hipEventCreate(&ev);
+        if (err != hipSuccess) { set_error("probav_engine_profile: hipEventCreate", err); return PROBAV_EHIP; }
+        e->prof_ev.push_back(ev);
+    }
+    e->prof_on = enable != 0;
+    e->prof_used = 0; e->prof_cls.clear(); e->prof_macs.clear();
+    return PROBAV_OK;
+}
+
+int probav_engine_profile_read(probav_engine* e, int nclass, double* ms, double* macs, int64_t* launches)
+{
+    if (!e || !ms || !macs || !launches || nclass < CLS_COUNT) { set_error("probav_engine_profile_read: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    for (int c = 0; c < nclass; ++c) { ms[c] = 0; macs[c] = 0; launches[c] = 0; }
+    for (size_t i = 0; i < e->prof_cls.size(); ++i) {
+        float t = 0.f;
+        hipError_t err = hipEventElapsedTime(&t, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]);     // caller has synchronised
+        if (err != hipSuccess) { set_error("probav_engine_profile_read: hipEventElapsedTime", err); return PROBAV_EHIP; }
+        const int c = e->prof_cls[i];
+        ms[c] += t; macs[c] += e->prof_macs[i]; launches[c] += 1;
+    }
+    e->prof_used = 0; e->prof_cls.clear(); e->prof_macs.clear();
+    return PROBAV_OK;
+}
+
+void probav_engine_destroy(probav_engine* e)
+{
+    if (!e) return;
+    for (auto ev : e->prof_ev) (void)hipEventDestroy(ev);
+    if (e->d_layers) (void)hipFree(e->d_layers);
+    delete e;
+}
+
+int64_t probav_param_count(const probav_engine* e) { return e ? e->nparams : -1; }
+int probav_num_layers(const probav_engine* e) { return e ? (int)e->layers.size() : -1; }
+int64_t probav_weff_count(const probav_engine* e) { return e ? e->weff_count : -1; }
+int64_t probav_cout_total(const probav_engine* e) { return e ? e->cout_total : -1; }
+
+int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_off, int64_t* v_off, int64_t* b_off, int32_t shape[5])
+{
+    if (!e || i < 0 || i >= (int)e->layers.size()) { set_error("probav_layer_info: bad index", hipSuccess); return PROBAV_EINVAL; }
+    const LayerRec& r = e->layers[i];
+    if (name) memcpy(name, r.name, 32);
+    if (g_off) *g_off = r.wn.g_off;
+    if (v_off) *v_off = r.wn.v_off;
+    if (b_off) *b_off = r.wn.b_off;
+    if (shape) { shape[0] = r.kh; shape[1] = r.kw; shape[2] = r.kt; shape[3] = r.wn.Cin; shape[4] = r.wn.Cout; }
+    return PROBAV_OK;
+}
+
+int probav_engine_set_impl(probav_engine* e, int impl)
+{
+    if (!e || impl < 0 || impl > 1) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    e->impl = impl;
+    return PROBAV_OK;
+}
+
+size_t probav_workspace_bytes(const probav_engine* e, int batch, int training)
+{
+    if (!e || batch < 1) return 0;
+    return make_plan(e, batch, training).total * sizeof(float);
+}
+
+int probav_forward(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes,
+                   int B, int training, void* stream)
+{
+    if (!e || !params || !x || !y || !ws || B < 1) { set_error("probav_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const Plan p = make_plan(e, B, training);
+    if (ws_bytes < p.total * sizeof(float)) { set_error("probav_forward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
+    float* W = (float*)ws;
+    const probav_net_cfg& c = e->cfg;
+    const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
+    const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
+    auto weff = [&](int li) { return W + p.weff + e->layers[li].wn.w_off; };
+    auto bias = [&](int li) { return params + e->layers[li].wn.b_off; };
+
+    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, s)); }
+    CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
+    CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), bias(e->iMain), nullptr, W + p.act[0], s));
+    for (int i = 0; i < R; ++i) {
+        CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, s));
+        CK(conv_fwd(e, make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0), W + p.H, nullptr, weff(e->iDec[i]), bias(e->iDec[i]), nullptr, W + p.dec[i], s));
+        CK(conv_fwd(e, make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0), W + p.dec[i], nullptr, weff(e->iNorm[i]), bias(e->iNorm[i]), W + p.act[i], W + p.act[i + 1], s));
+    }
+    const float* cur = W + p.act[R];
+    int h = Hin, t = T;
+    for (size_t k = 0; k < e->iRed.size(); ++k) {
+        const int refl = e->redReflect[k];
+        CK(conv_fwd(e, make_geom(B, h, t, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1), cur, nullptr,
+                    weff(e->iRed[k]), bias(e->iRed[k]), nullptr, W + p.red[k], s));
+        cur = W + p.red[k]; h = p.redH[k]; t = p.redT[k];
+    }
+    CK(conv_fwd(e, make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0), cur, nullptr, weff(e->iUp), bias(e->iUp), nullptr, W + p.up, s));
+    CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, s));
+    CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, s));
+    CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, s));
+    CK(tail_forward(W + p.up, W + p.r3, y, B, P, c.scale, c.mean, c.std, s));
+    return PROBAV_OK;
+}
+
+int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes,
+                    int B, void* stream)
+{
+    if (!e || !params || !dy || !grads || !ws || B < 1) { set_error("probav_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const Plan p = make_plan(e, B, 1);
+    if (ws_bytes < p.total * sizeof(float)) { set_error("probav_backward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
+    float* W = (float*)ws;
+    const probav_net_cfg& c = e->cfg;
+    const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
+    const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
+    auto weffT = [&](int li) { return W + p.weffT + e->layers[li].wn.w_off; };
+    auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
+    auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
+    float* part = W + p.partial;
+
+    CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
+    // low-frequency residual path (models/modelsTF.py:45-53), last layer first
+    {
+        const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
+        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), part, s));
+        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), nullptr, nullptr, W + p.dr2, s));
+        const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
+        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), part, s));
+        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), nullptr, nullptr, W + p.dr1, s));
+        const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
+        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), part, s));
+    }
+    // upscale + reducers (models/modelsTF.py:152-164)
+    const int nred = (int)e->iRed.size();
+    float* cur = W + p.gA;
+    float* oth = W + p.gB;
+    {
+        const int h = p.redH[nred - 1], t = p.redT[nred - 1];
+        const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
+        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), part, s));
+        CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), nullptr, nullptr, cur, s));
+    }
+    for (int k = nred - 1; k >= 0; --k) {
+        const int refl = e->redReflect[k];
+        const int hi = k ? p.redH[k - 1] : Hin, ti = k ? p.redT[k - 1] : T;
+        const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
+        const ConvGeom gr = make_geom(B, hi, ti, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1);
+        CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, s));
+        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), nullptr, nullptr, oth, s));
+        if (refl) {
+            CK(reflect_fold(oth, cur, B, hi, hi, ti * F, s));
+        } else {
+            float* tmp = cur; cur = oth; oth = tmp;
+        }
+    }
+    // residual blocks (models/modelsTF.py:177-189), last first.  cur = d loss / d act[i+1]
+    const ConvGeom ge = make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1);
+    const ConvGeom gd = make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0);
+    const ConvGeom gn = make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0);
+    for (int i = R - 1; i >= 0; --i) {
+        float* gDec = W + p.gDec;
+        float* Hbuf = W + p.H;
+        float* dH = W + p.dH;
+        const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
+        // normConv_i: d loss/d w, then d loss/d dec_i
+        CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, s));
+        CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), nullptr, nullptr, gDec, s));
+        // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
+        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
+        // decConv_i
+        CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, s));
+        CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), nullptr, nullptr, dH, s));
+        // expConv_i: ReLU gate (H > 0) applied where dH is consumed; skip path adds d loss/d act[i+1]
+        CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), part, s));
+        CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), nullptr, cur, oth, s));
+        float* tmp = cur; cur = oth; oth = tmp;
+    }
+    // mainConv1 (input-facing: no backward-data)
+    CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
+                  dweff(e->iMain), dbias(e->iMain), part, s));
+    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.dweff, W + p.invn, grads, s)); }
+    return PROBAV_OK;
+}
+
+// ---- single operators ---------------------------------------------------------------------------
+static ConvGeom geom_from(const int32_t a[17])
+{
+    ConvGeom g;
+    g.N = a[0]; g.Hi = a[1]; g.Wi = a[2]; g.Ti = a[3]; g.Cin = a[4]; g.Ho = a[5]; g.Wo = a[6]; g.To = a[7]; g.Cout = a[8];
+    g.kh = a[9]; g.kw = a[10]; g.kt = a[11]; g.ph = a[12]; g.pw = a[13]; g.pt = a[14]; g.reflect_hw = a[15]; g.relu = a[16];
+    return g;
+}
+static bool geom_ok(const ConvGeom& g)
+{
+    if (g.N < 1 || g.Cin < 1 || g.Cout < 1 || g.kh < 1 || g.kw < 1 || g.kt < 1) return false;
+    if (g.Ho < 1 || g.Wo < 1 || g.To < 1 || g.Hi < 1 || g.Wi < 1 || g.Ti < 1) return false;
+    if (g.ph < 0 || g.pw < 0 || g.pt < 0) return false;
+    if (g.reflect_hw && (g.ph >= g.Hi || g.pw >= g.Wi || g.kh - 1 - g.ph >= g.Hi || g.kw - 1 - g.pw >= g.Wi)) return false;
+    return true;
+}
+
+int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w, const float* bias,
+                          const float* skip, float* y, int impl, void* stream)
+{
+    if (!geom || !x || !w || !y) { set_error("probav_conv3d_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    const ConvGeom g = geom_from(geom);
+    if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (impl == 1) {
+        if (!mfma_conv_supported(g)) { set_error("probav_conv3d_forward: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
+        return mfma_conv_forward(g, x, gate, w, bias, skip, y, (hipStream_t)stream);
+    }
+    return conv3d_direct_forward(g, x, gate, w, bias, skip, y, (hipStream_t)stream);
+}
+
+size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl)
+{
+    (void)impl;
+    if (!geom) return 0;
+    return wgrad_partial_floats(geom_from(geom)) * sizeof(float);
+}
+
+int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy, const float* gate, float* dw, float* db,
+                        void* scratch, size_t scratch_bytes, int impl, void* stream)
+{
+    (void)impl;
+    if (!geom || !x || !dy || !dw || !scratch) { set_error("probav_conv3d_wgrad: null argument", hipSuccess); return PROBAV_EINVAL; }
+    const ConvGeom g = geom_from(geom);
+    if (!geom_ok(g)) { set_error("probav_conv3d_wgrad: bad geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (scratch_bytes < wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+    return conv3d_direct_wgrad(g, x, dy, gate, dw, db, (float*)scratch, (hipStream_t)stream);
+}
+
+int probav_wn_forward(probav_engine* e, const float* params, float* weff, float* weffT, float* inv_norm, void* stream)
+{
+    if (!e || !params || !weff || !weffT || !inv_norm) { set_error("probav_wn_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    return wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, weff, weffT, inv_norm, (hipStream_t)stream);
+}
+int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm, float* grads, void* stream)
+{
+    if (!e || !params || !dweff || !inv_norm || !grads) { set_error("probav_wn_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    return wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, dweff, inv_norm, grads, (hipStream_t)stream);
+}
+
+int probav_shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, int batch, int size, int border,
+                              int bit_depth, float* l1, float* l2, float* cpsnr, int32_t* arg_l1, int32_t* arg_l2,
+                              float* mean_l1, float* mean_l2, void* stream)
+{
+    if (!hr || !mask || !pred || !l1 || !l2 || !cpsnr || !arg_l1 || !arg_l2 || !mean_l1 || !mean_l2) {
+        set_error("probav_shift_loss_forward: null argument", hipSuccess); return PROBAV_EINVAL;
+    }
+    const float maxv = (float)((1u << bit_depth) - 1u);        // Losses.numBytes = 2**bitDepth - 1 (models/loss.py:19)
+    return shift_loss_forward(hr, mask, pred, batch, size, border, l1, l2, cpsnr, arg_l1, arg_l2, mean_l1, mean_l2, maxv, (hipStream_t)stream);
+}
+int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg, int batch, int size,
+                               int border, int which, const float* upstream, float* dpred, void* stream)
+{
+    if (!hr || !mask || !pred || !arg || !dpred || batch < 1) { set_error("probav_shift_loss_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    return shift_loss_backward(hr, mask, pred, arg, batch, size, border, which, upstream, dpred, (hipStream_t)stream);
+}
+int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi, void* stream)
+{
+    if (!in || !out) { set_error("probav_clip_round: null argument", hipSuccess); return PROBAV_EINVAL; }
+    if (n == 0) return PROBAV_OK;
+    return clip_round(in, out, n, lo, hi, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// Generic direct (VALU) stride-1 convolution over (H, W, T) for gfx950: forward / backward-data
+// (same kernel, flipped+transposed weights) and backward-filter.  Any geometry the reference's
+// graph produces (models/modelsTF.py:45-203): 3x3x3 / 3x3(x1) / 1x1x1 kernels, zero 'same' padding,
+// 'valid', and tf.pad(reflect) on H,W folded into the indexing.
+//
+// This is the shape-agnostic path: it backs the small layers (mainConv1, residConv*, upscaleConv1),
+// unusual configurations, and serves as the on-device cross-check for the MFMA kernels
+// (kernels_mfma.hip) that carry the 12 residual blocks and the reducers.
+//
+// Forward: one thread per output voxel, all COUT_T output channels in registers; the filter taps are
+// wave-uniform, so the compiler fetches them through the scalar cache (s_load) and the FMAs take
+// them as SGPR operands -- filter reuse costs no vector memory traffic at all.
+#include "probav_common.h"
+
+namespace probav {
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+template <int COUT_T, int VEC>
+__global__ __launch_bounds__(256) void conv_direct_fwd_kernel(
+    ConvGeom g, const float* __restrict__ x, const float* __restrict__ gate, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ y)
+{
+    const long nvox = (long)g.N * g.Ho * g.Wo * g.To;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvox) return;
+    const int co0 = blockIdx.y * COUT_T;
+    long r = v;
+    const int t = (int)(r % g.To); r /= g.To;
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int h = (int)(r % g.Ho);
+    const int n = (int)(r / g.Ho);
+
+    float acc[COUT_T];
+#pragma unroll
+    for (int j = 0; j < COUT_T; ++j) acc[j] = 0.f;
+
+    for (int a = 0; a < g.kh; ++a) {
+        int ih = h + a - g.ph;
+        if (g.reflect_hw) ih = reflect_idx(ih, g.Hi);
+        else if (ih < 0 || ih >= g.Hi) continue;
+        for (int b = 0; b < g.kw; ++b) {
+            int iw = wo + b - g.pw;
+            if (g.reflect_hw) iw = reflect_idx(iw, g.Wi);
+            else if (iw < 0 || iw >= g.Wi) continue;
+            for (int c = 0; c < g.kt; ++c) {
+                const int it = t + c - g.pt;
+                if (it < 0 || it >= g.Ti) continue;
+                const long vin = (((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it;
+                const float* xp = x + vin * g.Cin;
+                const float* gp = gate ? gate + vin * g.Cin : nullptr;
+                const float* wp = w + (long)((a * g.kw + b) * g.kt + c) * g.Cin * g.Cout + co0;
+                for (int ci = 0; ci < g.Cin; ci += VEC) {
+                    float xv[VEC];
+                    if constexpr (VEC == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(xp + ci);
+                        xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+                        if (gp) {
+                            const float4 m = *reinterpret_cast<const float4*>(gp + ci);
+                            xv[0] = m.x > 0.f ? xv[0] : 0.f; xv[1] = m.y > 0.f ? xv[1] : 0.f;
+                            xv[2] = m.z > 0.f ? xv[2] : 0.f; xv[3] = m.w > 0.f ? xv[3] : 0.f;
+                        }
+                    } else {
+                        xv[0] = xp[ci];
+                        if (gp) xv[0] = gp[ci] > 0.f ? xv[0] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < VEC; ++u) {
+                        const float* wr = wp + (long)(ci + u) * g.Cout;
+#pragma unroll
+                        for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(xv[u], wr[j], acc[j]);
+                    }
+                }
+            }
+        }
+    }
+    float* yp = y + v * g.Cout + co0;
+    const float* sp = skip ? skip + v * g.Cout + co0 : nullptr;
+#pragma unroll
+    for (int j = 0; j < COUT_T; ++j) {
+        float o = acc[j] + (bias ? bias[co0 + j] : 0.f);
+        if (g.relu) o = fmaxf(o, 0.f);
+        if (sp) o += sp[j];
+        yp[j] = o;
+    }
+}
+
+template <int COUT_T>
+static int launch_fwd(const ConvGeom& g, const float* x, const float* gate, const float* w, const float* bias,
+                      const float* skip, float* y, hipStream_t s)
+{
+    const long nvox = (long)g.N * g.Ho * g.Wo * g.To;
+    dim3 grid((unsigned)((nvox + 255) / 256), (unsigned)(g.Cout / COUT_T));
+    const bool vec4 = (g.Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                      (!gate || (reinterpret_cast<uintptr_t>(gate) & 15) == 0);
+    if (vec4) hipLaunchKernelGGL((conv_direct_fwd_kernel<COUT_T, 4>), grid, dim3(256), 0, s, g, x, gate, w, bias, skip, y);
+    else      hipLaunchKernelGGL((conv_direct_fwd_kernel<COUT_T, 1>), grid, dim3(256), 0, s, g, x, gate, w, bias, skip, y);
+    return check_launch("conv_direct_fwd");
+}
+
+int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, const float* w,
+                          const float* bias, const float* skip, float* y, hipStream_t s)
+{
+    if (g.N <= 0) return PROBAV_OK;
+    if (g.Cout % 32 == 0) return launch_fwd<32>(g, x, gate, w, bias, skip, y, s);
+    if (g.Cout % 25 == 0) return launch_fwd<25>(g, x, gate, w, bias, skip, y, s);
+    if (g.Cout % 9 == 0)  return launch_fwd<9>(g, x, gate, w, bias, skip, y, s);
+    if (g.Cout % 4 == 0)  return launch_fwd<4>(g, x, gate, w, bias, skip, y, s);
+    return launch_fwd<1>(g, x, gate, w, bias, skip, y, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward-filter.  256 threads = 32 output channels x 8 input-channel groups; every thread keeps
+// TAPS x CI_PER partial sums in registers while the block walks its chunk of output voxels (all
+// threads on the same voxel => bounds tests are scalar and the x loads are 32-lane broadcasts).
+// Per-chunk partials go to scratch and are summed in a fixed order by reduce_partials_kernel, so the
+// result is bitwise reproducible (no float atomics).
+// ---------------------------------------------------------------------------------------------------
+template <int KH, int KW, int KT, int CI_PER>
+__global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(
+    ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gate,
+    float* __restrict__ partial, float* __restrict__ partial_b, long vox_per_chunk)
+{
+    constexpr int TAPS = KH * KW * KT;
+    const int tid = threadIdx.x;
+    const int co = blockIdx.y * 32 + (tid & 31);
+    const bool co_ok = co < g.Cout;
+    const int ci0 = (blockIdx.z * 8 + (tid >> 5)) * CI_PER;
+    const long nvox = (long)g.N * g.Ho * g.Wo * g.To;
+    const long v0 = (long)blockIdx.x * vox_per_chunk;
+    const long v1 = v0 + vox_per_chunk < nvox ? v0 + vox_per_chunk : nvox;
+
+    float acc[TAPS][CI_PER];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int k = 0; k < CI_PER; ++k) acc[tp][k] = 0.f;
+    float accb = 0.f;
+    const bool vec4 = (CI_PER % 4 == 0) && (g.Cin % 4 == 0) && (ci0 + CI_PER <= g.Cin);
+
+    for (long v = v0; v < v1; ++v) {
+        long r = v;
+        const int t = (int)(r % g.To); r /= g.To;
+        const int wo = (int)(r % g.Wo); r /= g.Wo;
+        const int h = (int)(r % g.Ho);
+        const int n = (int)(r / g.Ho);
+        float d = 0.f;
+        if (co_ok) {
+            d = dy[v * g.Cout + co];
+            if (gate) d = gate[v * g.Cout + co] > 0.f ? d : 0.f;
+        }
+        accb += d;
+#pragma unroll
+        for (int a = 0; a < KH; ++a) {
+            int ih = h + a - g.ph;
+            if (g.reflect_hw) ih = reflect_idx(ih, g.Hi);
+            else if (ih < 0 || ih >= g.Hi) continue;
+#pragma unroll
+            for (int b = 0; b < KW; ++b) {
+                int iw = wo + b - g.pw;
+                if (g.reflect_hw) iw = reflect_idx(iw, g.Wi);
+                else if (iw < 0 || iw >= g.Wi) continue;
+#pragma unroll
+                for (int c = 0; c < KT; ++c) {
+                    const int it = t + c - g.pt;
+                    if (it < 0 || it >= g.Ti) continue;
+                    const float* xp = x + ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + ci0;
+                    const int tp = (a * KW + b) * KT + c;
+                    bool done = false;
+                    if constexpr (CI_PER % 4 == 0) {
+                        if (vec4) {
+#pragma unroll
+                            for (int k = 0; k < CI_PER; k += 4) {
+                                const float4 q = *reinterpret_cast<const float4*>(xp + k);
+                                acc[tp][k] = fmaf(q.x, d, acc[tp][k]);
+                                acc[tp][k + 1] = fmaf(q.y, d, acc[tp][k + 1]);
+                                acc[tp][k + 2] = fmaf(q.z, d, acc[tp][k + 2]);
+                                acc[tp][k + 3] = fmaf(q.w, d, acc[tp][k + 3]);
+                            }
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+#pragma unroll
+                        for (int k = 0; k < CI_PER; ++k)
+                            if (ci0 + k < g.Cin) acc[tp][k] = fmaf(xp[k], d, acc[tp][k]);
+                    }
+                }
+            }
+        }
+    }
+    if (co_ok) {
+        float* pp = partial + (long)blockIdx.x * TAPS * g.Cin * g.Cout;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int k = 0; k < CI_PER; ++k)
+                if (ci0 + k < g.Cin) pp[((long)tp * g.Cin + ci0 + k) * g.Cout + co] = acc[tp][k];
+        if (blockIdx.z == 0 && (tid >> 5) == 0) partial_b[(long)blockIdx.x * g.Cout + co] = accb;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             long n, int chunks)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[(long)c * n + i];
+    out[i] = s;
+}
+
+static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& chunks, long& vpc)
+{
+    const bool k3d = (g.kh == 3 && g.kw == 3 && g.kt == 3);
+    const bool k2d = (g.kh == 3 && g.kw == 3 && g.kt == 1);
+    if (k3d) ci_per = g.Cin >= 4 ? 4 : 1;
+    else if (k2d) ci_per = g.Cin >= 4 ? 4 : 1;
+    else ci_per = g.Cin >= 256 ? 32 : (g.Cin >= 4 ? 4 : 1);
+    gy = (g.Cout + 31) / 32;
+    gz = (g.Cin + 8 * ci_per - 1) / (8 * ci_per);
+    const long nvox = (long)g.N * g.Ho * g.Wo * g.To;
+    long want = 2048 / ((long)gy * gz);
+    if (want < 1) want = 1;
+    if (want > nvox) want = nvox;
+    vpc = (nvox + want - 1) / want;
+    if (vpc < 1) vpc = 1;
+    chunks = (int)((nvox + vpc - 1) / vpc);
+}
+
+size_t wgrad_partial_floats(const ConvGeom& g)
+{
+    int ci_per, gy, gz, chunks; long vpc;
+    wgrad_plan(g, ci_per, gy, gz, chunks, vpc);
+    const size_t K = (size_t)g.kh * g.kw * g.kt * g.Cin;
+    return (size_t)chunks * (K * g.Cout + g.Cout);
+}
+
+int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate,
+                        float* dw, float* db, float* partial, hipStream_t s)
+{
+    int ci_per, gy, gz, chunks; long vpc;
+    wgrad_plan(g, ci_per, gy, gz, chunks, vpc);
+    const long K = (long)g.kh * g.kw * g.kt * g.Cin;
+    float* partial_b = partial + (size_t)chunks * K * g.Cout;
+    dim3 grid((unsigned)chunks, (unsigned)gy, (unsigned)gz), block(256);
+    const bool k3d = (g.kh == 3 && g.kw == 3 && g.kt == 3);
+    const bool k2d = (g.kh == 3 && g.kw == 3 && g.kt == 1);
+    const bool k1 = (g.kh == 1 && g.kw == 1 && g.kt == 1);
+#define PROBAV_WG(KH, KW, KT, CP) \
+    hipLaunchKernelGGL((conv_direct_wgrad_kernel<KH, KW, KT, CP>), grid, block, 0, s, g, x, dy, gate, partial, partial_b, vpc)
+    if (k3d && ci_per == 4) PROBAV_WG(3, 3, 3, 4);
+    else if (k3d) PROBAV_WG(3, 3, 3, 1);
+    else if (k2d && ci_per == 4) PROBAV_WG(3, 3, 1, 4);
+    else if (k2d) PROBAV_WG(3, 3, 1, 1);
+    else if (k1 && ci_per == 32) PROBAV_WG(1, 1, 1, 32);
+    else if (k1 && ci_per == 4) PROBAV_WG(1, 1, 1, 4);
+    else if (k1) PROBAV_WG(1, 1, 1, 1);
+    else { set_error("conv3d_direct_wgrad: unsupported kernel size", hipSuccess); return PROBAV_EINVAL; }
+#undef PROBAV_WG
+    int rc = check_launch("conv_direct_wgrad");
+    if (rc) return rc;
+    const long nw = K * g.Cout;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), block, 0, s, partial, dw, nw, chunks);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 255) / 256)), block, 0, s, partial_b, db, (long)g.Cout, chunks);
+    return check_launch("reduce_partials");
+}
+
+}  // namespace probav

@@ -1,0 +1,358 @@
+// Small fused kernels around the convolution stack (gfx950):
+//   weight-norm reparameterisation fwd/bwd   (tensorflow_addons WeightNormalization; models/modelsTF.py:191-197)
+//   head  : mean over T + instance normalisation        (models/modelsTF.py:23-27, 199-200)
+//   tail  : depth_to_space x2 + Add + denormalise       (models/modelsTF.py:38-41, 52, 71-73, 202-203)
+//   reflect-pad gradient fold                           (tf.pad 'reflect', models/modelsTF.py:157-158)
+//   clip + round-half-even                              (test.py:117-119, models/testClass.py:27-28)
+//   shift-compensated L1 / L2 / cPSNR fwd + bwd         (models/loss.py:37-84, 140-187, 226-238)
+#include "probav_common.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace probav {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* what, hipError_t e)
+{
+    if (e != hipSuccess) snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(g_err, sizeof(g_err), "%s", what);
+}
+const char* last_error() { return g_err; }
+int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(what, e); return PROBAV_EHIP; }
+    return PROBAV_OK;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight normalisation.  One 64-lane wave per (layer, output channel): the ||v||^2 reduction over
+// taps*Cin is a strided read folded with a wavefront shuffle reduction; the same wave then writes the
+// effective kernel in both layouts the convolutions consume:
+//   weff  [tap][ci][co]                      forward / backward-filter
+//   weffT [taps-1-tap][co][ci]               backward-data (flipped taps, channels swapped)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_layer(const WnLayer* L, int nl, int chan, int& co)
+{
+    int i = 0;
+    while (i + 1 < nl && chan >= L[i + 1].n_off) ++i;
+    co = chan - L[i].n_off;
+    return i;
+}
+
+__global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restrict__ layers, int nl,
+                                                       const float* __restrict__ params, float* __restrict__ weff,
+                                                       float* __restrict__ weffT, float* __restrict__ inv_norm)
+{
+    int co;
+    const WnLayer L = layers[find_layer(layers, nl, blockIdx.x, co)];
+    const float* v = params + L.v_off;
+    const int lane = threadIdx.x;
+    float ss = 0.f;
+    for (int k = lane; k < L.K; k += 64) { const float q = v[(long)k * L.Cout + co]; ss = fmaf(q, q, ss); }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));            // tf.nn.l2_normalize epsilon
+    const float scale = params[L.g_off + co] * inv;
+    if (lane == 0) inv_norm[L.n_off + co] = inv;
+    for (int k = lane; k < L.K; k += 64) {
+        const float q = v[(long)k * L.Cout + co] * scale;
+        weff[L.w_off + (long)k * L.Cout + co] = q;
+        const int tap = k / L.Cin, ci = k - tap * L.Cin;
+        weffT[L.w_off + ((long)(L.taps - 1 - tap) * L.Cout + co) * L.Cin + ci] = q;
+    }
+}
+
+// d loss/d g = sum(dw * v) / ||v|| ;  d loss/d v = g/||v|| * (dw - v * sum(dw * v) / ||v||^2)
+__global__ __launch_bounds__(64) void wn_backward_kernel(const WnLayer* __restrict__ layers, int nl,
+                                                        const float* __restrict__ params, const float* __restrict__ dweff,
+                                                        const float* __restrict__ inv_norm, float* __restrict__ grads)
+{
+    int co;
+    const WnLayer L = layers[find_layer(layers, nl, blockIdx.x, co)];
+    const float* v = params + L.v_off;
+    const float* dw = dweff + L.w_off;
+    const int lane = threadIdx.x;
+    float dot = 0.f;
+    for (int k = lane; k < L.K; k += 64) dot = fmaf(dw[(long)k * L.Cout + co], v[(long)k * L.Cout + co], dot);
+    dot = wave_sum(dot);
+    const float inv = inv_norm[L.n_off + co];
+    const float gg = params[L.g_off + co];
+    const bool clamped = inv >= 1e6f;                               // ||v||^2 < 1e-12: norm is the constant 1e-6
+    const float proj = clamped ? 0.f : dot * inv * inv;
+    if (lane == 0) grads[L.g_off + co] = dot * inv;
+    for (int k = lane; k < L.K; k += 64) {
+        const long i = (long)k * L.Cout + co;
+        grads[L.v_off + i] = gg * inv * (dw[i] - v[i] * proj);
+    }
+}
+
+int wn_forward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,
+               float* weff, float* weffT, float* inv_norm, hipStream_t s)
+{
+    hipLaunchKernelGGL(wn_forward_kernel, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm);
+    return check_launch("wn_forward");
+}
+int wn_backward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,
+                const float* dweff, const float* inv_norm, float* grads, hipStream_t s)
+{
+    hipLaunchKernelGGL(wn_backward_kernel, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, dweff, inv_norm, grads);
+    return check_launch("wn_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// head: x [N,H,W,T,1] -> xn = (x - mean)/std  [N,H,W,T] ,  mn = (mean_T(x) - mean)/std  [N,H,W]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, float* __restrict__ xn,
+                                                  float* __restrict__ mn, int nhw, int T, float mean, float stdv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nhw) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float q = x[(long)i * T + t];
+        s += q;
+        xn[(long)i * T + t] = (q - mean) / stdv;
+    }
+    mn[i] = (s / (float)T - mean) / stdv;
+}
+int head_forward(const float* x, float* xn, float* mn, int nhw, int T, float mean, float stdv, hipStream_t s)
+{
+    hipLaunchKernelGGL(head_kernel, dim3((nhw + 255) / 256), dim3(256), 0, s, x, xn, mn, nhw, T, mean, stdv);
+    return check_launch("head");
+}
+
+// tail: y[n, s*h+i, s*w+j] = (up[n,h,w,i*s+j] + r3[n,h,w,i*s+j]) * std + mean
+__global__ __launch_bounds__(256) void tail_fwd_kernel(const float* __restrict__ up, const float* __restrict__ r3,
+                                                      float* __restrict__ y, int N, int P, int sc, float mean, float stdv)
+{
+    const int S = P * sc;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * S * S) return;
+    const int X = (int)(i % S), Y = (int)((i / S) % S), n = (int)(i / ((long)S * S));
+    const long src = (((long)n * P + Y / sc) * P + X / sc) * (sc * sc) + (Y % sc) * sc + (X % sc);
+    y[i] = (up[src] + r3[src]) * stdv + mean;
+}
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dtail,
+                                                      int N, int P, int sc, float stdv)
+{
+    const int S = P * sc, C = sc * sc;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * P * P * C) return;
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % P); r /= P;
+    const int h = (int)(r % P);
+    const int n = (int)(r / P);
+    dtail[i] = dy[((long)n * S + h * sc + c / sc) * S + w * sc + c % sc] * stdv;
+}
+int tail_forward(const float* up, const float* r3, float* y, int N, int P, int sc, float mean, float stdv, hipStream_t s)
+{
+    const long n = (long)N * P * sc * P * sc;
+    hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, up, r3, y, N, P, sc, mean, stdv);
+    return check_launch("tail_fwd");
+}
+int tail_backward(const float* dy, float* dtail, int N, int P, int sc, float stdv, hipStream_t s)
+{
+    const long n = (long)N * P * P * sc * sc;
+    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, dtail, N, P, sc, stdv);
+    return check_launch("tail_bwd");
+}
+
+// Gradient of tf.pad(x, 1 on H and W, 'reflect'): padded row 0 mirrors row 1, padded row H+1 mirrors row H-2.
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx,
+                                                          int N, int H, int W, int TC)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W * TC) return;
+    const int e = (int)(i % TC);
+    long r = i / TC;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    int hs[2], ws[2], nh = 1, nw = 1;
+    hs[0] = h + 1; ws[0] = w + 1;
+    if (h == 1) hs[nh++] = 0;
+    if (h == H - 2) hs[nh++] = H + 1;          // H >= 4, so h == 1 and h == H-2 never coincide
+    if (w == 1) ws[nw++] = 0;
+    if (w == W - 2) ws[nw++] = W + 1;
+    float s = 0.f;
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b)
+            s += dpad[(((long)n * (H + 2) + hs[a]) * (W + 2) + ws[b]) * TC + e];
+    dx[i] = s;
+}
+int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, hipStream_t s)
+{
+    if (H < 4 || W < 4) { set_error("reflect_fold: H, W must be >= 4", hipSuccess); return PROBAV_EINVAL; }
+    const long n = (long)N * H * W * TC;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpad, dx, N, H, W, TC);
+    return check_launch("reflect_fold");
+}
+
+// tf.clip_by_value(x, lo, hi) then tf.round (half to even == rintf in the default rounding mode)
+__global__ __launch_bounds__(256) void clip_round_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float lo, float hi)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = rintf(fminf(fmaxf(in[i], lo), hi));
+}
+int clip_round(const float* in, float* out, size_t n, float lo, float hi, hipStream_t s)
+{
+    hipLaunchKernelGGL(clip_round_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, lo, hi);
+    return check_launch("clip_round");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Shift-compensated losses.  One 256-thread block per sample; each of its four waves owns a subset
+// of the (2*border+1)^2 candidate registrations and evaluates them with wavefront shuffle reductions
+// only (no block barrier per shift).  Sums run in fp64: the path is ~1.7 MFLOP per sample, the
+// reference needs ~600 tiny TF ops for it, here it is one launch.
+//   n = sum M ; b = sum(H - P*M)/n ; C = (P + b)*M ; l1 = sum|H - C|/n ; l2 = sum (H - C)^2/n
+// (HR is NOT masked -- reference quirk, models/loss.py:146,151)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shift_loss_fwd_kernel(
+    const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred, int S, int border,
+    float* __restrict__ l1_out, float* __restrict__ l2_out, float* __restrict__ cpsnr_out,
+    int* __restrict__ arg_l1, int* __restrict__ arg_l2, float max_val)
+{
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = S - 2 * border, ns = 2 * border + 1, nshift = ns * ns;
+    const float* H = hr + (long)b * S * S;
+    const uint8_t* M = mask + (long)b * S * S;
+    const float* P = pred + (long)b * S * S;
+    double best1 = 1e300, best2 = 1e300;
+    int a1 = 0, a2 = 0;
+    for (int sft = wave; sft < nshift; sft += 4) {
+        const int i = sft / ns, j = sft - i * ns;
+        double cnt = 0.0, dsum = 0.0;
+        for (int k = lane; k < L * L; k += 64) {
+            const int r = k / L, c = k - r * L;
+            const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
+            cnt += (double)m;
+            dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+        }
+        cnt = wave_sum(cnt); dsum = wave_sum(dsum);
+        const double bias = dsum / cnt;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = lane; k < L * L; k += 64) {
+            const int r = k / L, c = k - r * L;
+            const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+            const double e = (double)H[(i + r) * S + j + c] - ((double)P[(border + r) * S + border + c] + bias) * m;
+            s1 += fabs(e);
+            s2 += e * e;
+        }
+        s1 = wave_sum(s1) / cnt; s2 = wave_sum(s2) / cnt;
+        if (s1 < best1) { best1 = s1; a1 = sft; }
+        if (s2 < best2) { best2 = s2; a2 = sft; }
+    }
+    __shared__ double sb1[4], sb2[4];
+    __shared__ int sa1[4], sa2[4];
+    if (lane == 0) { sb1[wave] = best1; sb2[wave] = best2; sa1[wave] = a1; sa2[wave] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {          // first minimum in shift order wins ties (shift ids ascend per wave)
+            if (sb1[w] < best1 || (sb1[w] == best1 && sa1[w] < a1)) { best1 = sb1[w]; a1 = sa1[w]; }
+            if (sb2[w] < best2 || (sb2[w] == best2 && sa2[w] < a2)) { best2 = sb2[w]; a2 = sa2[w]; }
+        }
+        l1_out[b] = (float)best1;
+        l2_out[b] = (float)best2;
+        cpsnr_out[b] = (float)(10.0 * log10((double)max_val * (double)max_val / best2));
+        arg_l1[b] = a1;
+        arg_l2[b] = a2;
+    }
+}
+
+__global__ __launch_bounds__(64) void batch_mean_kernel(const float* __restrict__ a, const float* __restrict__ b2,
+                                                       float* __restrict__ ma, float* __restrict__ mb, int n)
+{
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) { s1 += (double)a[i]; s2 += (double)b2[i]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (threadIdx.x == 0) { *ma = (float)(s1 / n); *mb = (float)(s2 / n); }
+}
+
+int shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border,
+                       float* l1, float* l2, float* cpsnr, int* arg_l1, int* arg_l2, float* mean_l1, float* mean_l2,
+                       float max_val, hipStream_t s)
+{
+    if (B <= 0 || S <= 2 * border) { set_error("shift_loss_forward: bad shape", hipSuccess); return PROBAV_EINVAL; }
+    hipLaunchKernelGGL(shift_loss_fwd_kernel, dim3(B), dim3(256), 0, s, hr, mask, pred, S, border, l1, l2, cpsnr, arg_l1, arg_l2, max_val);
+    hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, s, l1, l2, mean_l1, mean_l2, B);
+    return check_launch("shift_loss_forward");
+}
+
+// Gradient of mean_B min_shift loss w.r.t. pred for the arg-min shift:
+//   L1: dP_k = -(M_k/n) (s_k - sum(s M)/n),  s = sign(H - C)      L2: s = 2 (H - C)
+__global__ __launch_bounds__(256) void shift_loss_bwd_kernel(
+    const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred,
+    const int* __restrict__ arg, int S, int border, int which, const float* __restrict__ upstream, float inv_b,
+    float* __restrict__ dpred)
+{
+    const float scale = (upstream ? upstream[0] : 1.f) * inv_b;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = S - 2 * border, ns = 2 * border + 1;
+    const float* H = hr + (long)b * S * S;
+    const uint8_t* M = mask + (long)b * S * S;
+    const float* P = pred + (long)b * S * S;
+    float* G = dpred + (long)b * S * S;
+    const int sft = arg[b], i = sft / ns, j = sft - i * ns;
+    __shared__ double red[2][4];
+    double cnt = 0.0, dsum = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
+        cnt += (double)m;
+        dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+    }
+    cnt = wave_sum(cnt); dsum = wave_sum(dsum);
+    if (lane == 0) { red[0][wave] = cnt; red[1][wave] = dsum; }
+    __syncthreads();
+    cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    dsum = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double bias = dsum / cnt;
+    __syncthreads();
+    double ssum = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+        const double e = (double)H[(i + r) * S + j + c] - ((double)P[(border + r) * S + border + c] + bias) * m;
+        const double sg = which == 1 ? (e > 0.0 ? 1.0 : (e < 0.0 ? -1.0 : 0.0)) : 2.0 * e;
+        ssum += sg * m;
+    }
+    ssum = wave_sum(ssum);
+    if (lane == 0) red[0][wave] = ssum;
+    __syncthreads();
+    ssum = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    for (int k = tid; k < S * S; k += 256) {
+        const int Y = k / S, X = k - Y * S, r = Y - border, c = X - border;
+        float gk = 0.f;
+        if (r >= 0 && r < L && c >= 0 && c < L) {
+            const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+            const double e = (double)H[(i + r) * S + j + c] - ((double)P[Y * S + X] + bias) * m;
+            const double sg = which == 1 ? (e > 0.0 ? 1.0 : (e < 0.0 ? -1.0 : 0.0)) : 2.0 * e;
+            gk = (float)(-(m / cnt) * (sg - ssum / cnt) * (double)scale);
+        }
+        G[k] = gk;
+    }
+}
+int shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, int B, int S,
+                        int border, int which, const float* upstream, float* dpred, hipStream_t s)
+{
+    if (which != 1 && which != 2) { set_error("shift_loss_backward: which must be 1 (L1) or 2 (L2)", hipSuccess); return PROBAV_EINVAL; }
+    hipLaunchKernelGGL(shift_loss_bwd_kernel, dim3(B), dim3(256), 0, s, hr, mask, pred, arg, S, border, which, upstream, 1.0f / (float)B, dpred);
+    return check_launch("shift_loss_backward");
+}
+
+}  // namespace probav

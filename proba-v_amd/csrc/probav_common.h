@@ -1,0 +1,68 @@
+// Shared declarations of the gfx950 HIP library behind include/probav_hip.h.
+// Layout conventions (all fp32):
+//   activations  [N][H][W][T][C]  C innermost  (the reference's NDHWC with D,H,W == H,W,T)
+//   kernels      [kh][kw][kt][Cin][Cout]       (Keras layout; models/modelsTF.py:191-197)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define PROBAV_OK 0
+#define PROBAV_EINVAL (-1)      // bad argument (shape / null pointer / unsupported config)
+#define PROBAV_ENOSPACE (-2)    // workspace too small
+#define PROBAV_EHIP (-3)        // a HIP call failed; hipGetLastError() text via probav_last_error()
+
+// Geometry of one stride-1 cross-correlation over (H, W, T).
+// input coordinate = output coordinate + tap - pad ; outside [0, dim): zero, or mirrored on H/W when
+// reflect_hw is set (tf.pad 'reflect', models/modelsTF.py:157-158 folded into the indexing).
+struct ConvGeom {
+    int N;
+    int Hi, Wi, Ti, Cin;
+    int Ho, Wo, To, Cout;
+    int kh, kw, kt;
+    int ph, pw, pt;
+    int reflect_hw;
+    int relu;
+};
+
+namespace probav {
+
+void set_error(const char* what, hipError_t e);
+int check_launch(const char* what);
+const char* last_error();
+
+// ---- kernels_direct.hip : generic direct (VALU) convolution, any geometry ------------------------
+// y = act( conv(x * [gate > 0], w) + bias ) + skip        (gate/bias/skip optional)
+int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, const float* w,
+                          const float* bias, const float* skip, float* y, hipStream_t s);
+// dw[tap][ci][co] = sum_v x[v + tap][ci] * dy[v][co] * [gate[v][co] > 0] ; db[co] = sum_v dy*gate
+// `partial` holds wgrad_partial_floats(g) floats of scratch.
+size_t wgrad_partial_floats(const ConvGeom& g);
+int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate,
+                        float* dw, float* db, float* partial, hipStream_t s);
+
+// ---- kernels_small.hip ---------------------------------------------------------------------------
+struct WnLayer {            // one weight-normalised layer inside the flat parameter buffer
+    int g_off, v_off, b_off;    // offsets into params / grads (floats)
+    int w_off;                  // offset into weff / weffT / dweff (floats) == running sum of K*Cout
+    int n_off;                  // offset into inv_norm (floats) == running sum of Cout
+    int K;                      // taps * Cin
+    int Cin, Cout, taps;
+};
+int wn_forward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
+               float* weff, float* weffT, float* inv_norm, hipStream_t s);
+int wn_backward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
+                const float* dweff, const float* inv_norm, float* grads, hipStream_t s);
+int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, float mean, float stdv, hipStream_t s);
+int tail_forward(const float* up, const float* r3, float* y, int N, int P, int scale, float mean, float stdv, hipStream_t s);
+int tail_backward(const float* dy, float* dtail, int N, int P, int scale, float stdv, hipStream_t s);
+int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, hipStream_t s);
+int clip_round(const float* in, float* out, size_t n, float lo, float hi, hipStream_t s);
+int shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border,
+                       float* l1_per_sample, float* l2_per_sample, float* cpsnr_per_sample,
+                       int* arg_l1, int* arg_l2, float* mean_l1, float* mean_l2, float max_val, hipStream_t s);
+int shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, int B, int S,
+                        int border, int which /*1 = L1, 2 = L2*/, const float* upstream /*device scalar or null*/,
+                        float* dpred, hipStream_t s);
+
+}  // namespace probav

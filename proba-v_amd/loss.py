@@ -1,0 +1,109 @@
+"""Host-side mirror of the reference's models/loss.py::Losses (shift-compensated L1 / L2 / cPSNR).
+
+Argument order is the reference's: ``(patchHR, maskHR, predPatchHR)`` (models/loss.py:37,55,73).  One fused
+HIP launch evaluates all (2*cropBorder+1)^2 candidate registrations of every sample and returns the
+per-sample minima of the L1 and L2 terms, the cPSNR maximum and the arg-min shifts; the backward
+launch differentiates the arg-min shift including the brightness-bias term.  The
+reference unrolls the same work into ~600 TensorFlow ops per step (models/loss.py:79-81).
+"""
+import torch
+
+from . import _lib
+
+
+def _prep(patchHR, maskHR, predPatchHR):
+    pred = _lib.require_device(predPatchHR, "predPatchHR")
+    dev = pred.device
+    hr = torch.as_tensor(patchHR).to(device=dev, dtype=torch.float32).contiguous()
+    m = torch.as_tensor(maskHR).to(device=dev)
+    m = (m if m.dtype == torch.bool else m != 0).contiguous().view(torch.uint8)   # True = clear pixel (train.py:43)
+    pred = pred.contiguous().float()
+    if hr.shape != pred.shape or m.shape != pred.shape or pred.dim() != 4 or pred.shape[3] != 1 or pred.shape[1] != pred.shape[2]:
+        raise ValueError("expected patchHR, maskHR, predPatchHR all [B, S, S, 1]; got %s %s %s"
+                         % (tuple(hr.shape), tuple(m.shape), tuple(pred.shape)))
+    return hr, m, pred
+
+
+def _launch_forward(hr, m, pred, border, bit_depth):
+    B, S = pred.shape[0], pred.shape[1]
+    dev = pred.device
+    f = torch.empty((3, B), dtype=torch.float32, device=dev)          # l1 | l2 | cpsnr
+    arg = torch.empty((2, B), dtype=torch.int32, device=dev)
+    means = torch.empty(2, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().probav_shift_loss_forward(
+        _lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), B, S, border, bit_depth, _lib.ptr(f[0]), _lib.ptr(f[1]),
+        _lib.ptr(f[2]), _lib.ptr(arg[0]), _lib.ptr(arg[1]), _lib.ptr(means[0:1]), _lib.ptr(means[1:2]),
+        _lib.current_stream()), "probav_shift_loss_forward")
+    return f, arg, means
+
+
+class _ShiftLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, hr, m, border, bit_depth, which):
+        f, arg, means = _launch_forward(hr, m, pred, border, bit_depth)
+        ctx.save_for_backward(pred, hr, m, arg[which - 1].contiguous())
+        ctx.border, ctx.which = border, which
+        return means[which - 1].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, hr, m, arg = ctx.saved_tensors
+        g = g.contiguous().float().reshape(1)
+        dpred = torch.empty_like(pred)
+        _lib.check(_lib.lib().probav_shift_loss_backward(
+            _lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), _lib.ptr(arg), pred.shape[0], pred.shape[1], ctx.border,
+            ctx.which, _lib.ptr(g), _lib.ptr(dpred), _lib.current_stream()), "probav_shift_loss_backward")
+        return dpred, None, None, None, None, None
+
+
+class Losses:
+    """models/loss.py:8-35: all losses / metrics in one object; constants follow the reference."""
+
+    def __init__(self, targetShape=(96, 96, 1), cropBorder=3, bitDepth=16):
+        self.targetShapeHeight, self.targetShapeWidth, self.targetShapeChannels = targetShape
+        self.cropBorder = cropBorder
+        self.maxPixelShift = 2 * cropBorder
+        self.bitDepth = bitDepth
+        self.numBytes = 2 ** bitDepth - 1
+        self.cropSizeHeight = self.targetShapeHeight - self.maxPixelShift
+        self.cropSizeWidth = self.targetShapeWidth - self.maxPixelShift
+
+    def _check(self, pred):
+        if pred.shape[1] != self.targetShapeHeight or pred.shape[2] != self.targetShapeWidth:
+            raise ValueError("Losses(targetShape=%r) got a %dx%d prediction"
+                             % ((self.targetShapeHeight, self.targetShapeWidth, self.targetShapeChannels),
+                                pred.shape[1], pred.shape[2]))
+
+    def shiftCompensatedL1Loss(self, patchHR, maskHR, predPatchHR):
+        """models/loss.py:73-84 -> scalar: mean over the batch of the minimum masked, bias-corrected L1."""
+        hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
+        self._check(pred)
+        return _ShiftLoss.apply(pred, hr, m, self.cropBorder, self.bitDepth, 1)
+
+    def shiftCompensatedL2Loss(self, patchHR, maskHR, predPatchHR):
+        """models/loss.py:55-71."""
+        hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
+        self._check(pred)
+        return _ShiftLoss.apply(pred, hr, m, self.cropBorder, self.bitDepth, 2)
+
+    def shiftCompensatedcPSNR(self, patchHR, maskHR, predPatchHR):
+        """models/loss.py:37-53 -> [B]: maximum cPSNR over the shifts (no gradient, as in trainStep)."""
+        hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
+        self._check(pred)
+        with torch.no_grad():
+            f, _, _ = _launch_forward(hr, m, pred.detach(), self.cropBorder, self.bitDepth)
+        return f[2]
+
+    def evaluate_all(self, patchHR, maskHR, predPatchHR):
+        """One launch, everything it computes: dict(l1[B], l2[B], cpsnr[B], arg_l1[B], arg_l2[B], mean_l1, mean_l2)."""
+        hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
+        with torch.no_grad():
+            f, arg, means = _launch_forward(hr, m, pred.detach(), self.cropBorder, self.bitDepth)
+        return {"l1": f[0], "l2": f[1], "cpsnr": f[2], "arg_l1": arg[0], "arg_l2": arg[1],
+                "mean_l1": means[0], "mean_l2": means[1]}
+
+    def shiftCompensatedL1EdgeLoss(self, patchHR, maskHR, predPatchHR):
+        raise NotImplementedError("cfg loss=sobel_l1_mix (models/loss.py:86-97) is not on the hot path yet (SURVEY.md §8f-4)")
+
+    def shiftCompensatedRevSSIM(self, patchHR, maskHR, predPatchHR):
+        raise NotImplementedError("cfg loss=l1msssim (models/loss.py:99-110) is not on the hot path yet (SURVEY.md §8f-4)")

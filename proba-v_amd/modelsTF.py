@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's models/modelsTF.py::WDSRConv3D (the class train.py / test.py build).
+
+``WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize, numResBlocks, expRate,
+decayRate, numImgLR, patchSizeLR, isGrayScale)`` keeps the reference's names, argument order and meaning
+(models/modelsTF.py:8-17) and returns a callable model: ``model(x, training=False)`` maps
+float32 ``[N, P+maxShift, P+maxShift, T, 1]`` to ``[N, scale*P, scale*P, 1]`` and exposes
+``trainable_variables`` in the reference checkpoint's order.  All arithmetic happens in
+libprobav_hip.so (csrc/); torch only owns the device memory, the stream and the autograd edge
+(one custom Function whose backward is the engine's reverse pass).
+"""
+import ctypes
+from ctypes import c_char, c_int32, c_int64, c_void_p, byref
+
+import torch
+
+from . import _lib
+from .arch import layer_table
+
+
+class _WDSRFunction(torch.autograd.Function):
+    """y = model(x); backward = d loss / d (flat parameter buffer).  x gets no gradient (the reference
+    never differentiates w.r.t. the input patches)."""
+
+    @staticmethod
+    def forward(ctx, flat, x, model, training):
+        B = x.shape[0]
+        S = model.scale * model.patchSizeLR
+        y = torch.empty((B, S, S, 1), dtype=torch.float32, device=x.device)
+        ws = model._workspace(B, training)
+        L = _lib.lib()
+        _lib.check(L.probav_forward(model._handle(), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws),
+                                    ws.numel() * 4, B, 1 if training else 0, _lib.current_stream()), "probav_forward")
+        model._ws_gen += 1
+        ctx.model, ctx.B, ctx.gen, ctx.training = model, B, model._ws_gen, training
+        ctx.save_for_backward(flat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        model = ctx.model
+        if not ctx.training:
+            raise RuntimeError("backward through model(x, training=False): call the model with training=True "
+                               "to keep the activations the reverse pass needs")
+        if ctx.gen != model._ws_gen:
+            raise RuntimeError("the engine workspace was overwritten by a later forward pass before this "
+                               "backward ran (one forward/backward pair at a time per model)")
+        (flat,) = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        grads = torch.empty_like(flat)
+        ws = model._workspace(ctx.B, True)
+        L = _lib.lib()
+        _lib.check(L.probav_backward(model._handle(), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws),
+                                     ws.numel() * 4, ctx.B, _lib.current_stream()), "probav_backward")
+        return grads, None, None, None
+
+
+class WDSRModel(torch.nn.Module):
+    """What ``WDSRConv3D.build`` returns (the Keras ``Model`` of models/modelsTF.py:43)."""
+
+    def __init__(self, name, band, mean, std, maxShift, scale, numFilters, numResBlocks, expRate, decayRate,
+                 numImgLR, patchSizeLR, seed=None):
+        super().__init__()
+        self.name, self.band = name, band
+        self.mean, self.std, self.maxShift = float(mean), float(std), int(maxShift)
+        self.scale, self.numFilters, self.numResBlocks = int(scale), int(numFilters), int(numResBlocks)
+        self.expRate, self.decayRate = int(expRate), float(decayRate)
+        self.numImgLR, self.patchSizeLR = int(numImgLR), int(patchSizeLR)
+        self.arch = dict(numFilters=self.numFilters, numResBlocks=self.numResBlocks, expRate=self.expRate,
+                         decayRate=self.decayRate, numImgLR=self.numImgLR, scale=self.scale)
+        self.layers, total = layer_table(**self.arch)
+        # state after the reference's first call: v ~ glorot_uniform, g = ||v||, bias = 0
+        # (tensorflow_addons WeightNormalization with data_init=False)
+        gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
+        flat = torch.zeros(total, dtype=torch.float32)
+        for L in self.layers:
+            vs = L.vshape
+            recept = 1
+            for d in vs[:-2]:
+                recept *= d
+            limit = (6.0 / (recept * vs[-2] + recept * vs[-1])) ** 0.5
+            v = (torch.rand(vs, generator=gen) * 2.0 - 1.0) * limit
+            flat[L.v_off:L.b_off] = v.reshape(-1)
+            flat[L.g_off:L.v_off] = v.double().reshape(-1, vs[-1]).pow(2).sum(0).sqrt().float()
+        self.flat = torch.nn.Parameter(flat)
+        self._engine = None
+        self._ws = {}
+        self._ws_gen = 0
+
+    # -- reference-facing surface ------------------------------------------------------------------
+    @property
+    def variable_names(self):
+        """Keras-style names, `<layer>/g`, `<layer>/v`, `<layer>/bias`, checkpoint order."""
+        return [n for L in self.layers for n in (L.name + "/g", L.name + "/v", L.name + "/bias")]
+
+    @property
+    def trainable_variables(self):
+        """132 views into the flat buffer, ordered like the reference's model.trainable_variables."""
+        out = []
+        for L in self.layers:
+            out += [self.flat[L.g_off:L.v_off], self.flat[L.v_off:L.b_off].view(L.vshape),
+                    self.flat[L.b_off:L.b_off + L.cout]]
+        return out
+
+    def variable_gradients(self):
+        """Gradients of the last backward pass, shaped and ordered like trainable_variables."""
+        g = self.flat.grad
+        if g is None:
+            return None
+        out = []
+        for L in self.layers:
+            out += [g[L.g_off:L.v_off], g[L.v_off:L.b_off].view(L.vshape), g[L.b_off:L.b_off + L.cout]]
+        return out
+
+    def load_variables(self, params):
+        """params: {layer: {"g","v","bias"}} numpy/torch -> flat buffer (e.g. a converted checkpoint)."""
+        with torch.no_grad():
+            for L in self.layers:
+                p = params[L.name]
+                for key, lo, hi in (("g", L.g_off, L.v_off), ("v", L.v_off, L.b_off), ("bias", L.b_off, L.b_off + L.cout)):
+                    t = torch.as_tensor(p[key], dtype=torch.float32).reshape(-1)
+                    if t.numel() != hi - lo:
+                        raise ValueError("%s/%s: expected %d values, got %d" % (L.name, key, hi - lo, t.numel()))
+                    self.flat[lo:hi] = t.to(self.flat.device)
+
+    def forward(self, x, training=False):
+        x = _lib.require_device(x, "model input")
+        hin = self.patchSizeLR + self.maxShift
+        if x.dim() != 5 or tuple(x.shape[1:]) != (hin, hin, self.numImgLR, 1):
+            raise ValueError("model input must be [N, %d, %d, %d, 1] (models/modelsTF.py:19), got %s"
+                             % (hin, hin, self.numImgLR, tuple(x.shape)))
+        if self.flat.device != x.device:
+            raise RuntimeError("model parameters are on %s but the input is on %s" % (self.flat.device, x.device))
+        x = x.contiguous().float()
+        need_grad = bool(training) and torch.is_grad_enabled() and self.flat.requires_grad
+        return _WDSRFunction.apply(self.flat, x, self, need_grad)
+
+    # -- engine plumbing ---------------------------------------------------------------------------
+    def _handle(self):
+        if self._engine is None:
+            L = _lib.lib()
+            cfg = _lib.NetCfg(self.scale, self.numFilters, self.numResBlocks, self.expRate,
+                              int(self.numFilters * self.decayRate), self.numImgLR, self.patchSizeLR,
+                              self.maxShift, self.mean, self.std)
+            h = c_void_p()
+            _lib.check(L.probav_engine_create(byref(cfg), byref(h)), "probav_engine_create")
+            if L.probav_param_count(h) != self.flat.numel():
+                raise RuntimeError("host/native layer tables disagree: %d vs %d parameters"
+                                   % (self.flat.numel(), L.probav_param_count(h)))
+            self._engine = h
+        return self._engine
+
+    def native_layer_table(self):
+        """[(name, g_off, v_off, b_off, shape)] as the native library lays the flat buffer out."""
+        L, h, out = _lib.lib(), self._handle(), []
+        for i in range(L.probav_num_layers(h)):
+            name = (c_char * 32)()
+            g, v, b = c_int64(), c_int64(), c_int64()
+            shp = (c_int32 * 5)()
+            _lib.check(L.probav_layer_info(h, i, byref(name), byref(g), byref(v), byref(b), byref(shp)))
+            out.append((name.value.decode(), g.value, v.value, b.value, tuple(shp)))
+        return out
+
+    def set_impl(self, impl):
+        """0 = generic direct kernels, 1 = MFMA kernels where available (default)."""
+        _lib.check(_lib.lib().probav_engine_set_impl(self._handle(), int(impl)), "probav_engine_set_impl")
+
+    def _workspace(self, batch, training):
+        key = (int(batch), bool(training), self.flat.device)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.lib().probav_workspace_bytes(self._handle(), int(batch), 1 if training else 0)
+            if nbytes == 0:
+                raise RuntimeError("probav_workspace_bytes returned 0")
+            self._ws.clear()                       # one live workspace (sized for 288 GB HBM, but no need to hoard)
+            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.flat.device)
+            self._ws[key] = ws
+        return ws
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                _lib.lib().probav_engine_destroy(self._engine)
+        except Exception:
+            pass
+
+
+class WDSRConv3D:
+    """models/modelsTF.py:7-13."""
+
+    def __init__(self, name, band, mean, std, maxShift):
+        self.name = name
+        self.band = band
+        self.mean = mean
+        self.std = std
+        self.maxShift = maxShift
+
+    def build(self, scale, numFilters, kernelSize, numResBlocks, expRate, decayRate, numImgLR, patchSizeLR,
+              isGrayScale, seed=None):
+        """models/modelsTF.py:15-43.  kernelSize must be (3, 3, 3) and isGrayScale True: the only
+        configuration the reference's cfg files, checkpoints and train.py/test.py use."""
+        ks = tuple(kernelSize) if not isinstance(kernelSize, int) else (kernelSize,) * 3
+        if ks != (3, 3, 3):
+            raise ValueError("kernelSize %r: the HIP engine implements the reference's 3x3x3 configuration" % (ks,))
+        if not isGrayScale:
+            raise NotImplementedError("isGrayScale=False (3-channel input) is outside the PROBA-V hot path")
+        return WDSRModel(self.name, self.band, self.mean, self.std, self.maxShift, scale, numFilters,
+                         numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, seed=seed)
+
+    def normalize(self, x):
+        return (x - self.mean) / self.std
+
+    def denormalize(self, x):
+        return x * self.std + self.mean

@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's models/trainClass.py::ModelTrainer.
+
+Same constructor, ``fitTrainData`` / ``trainStep`` / ``testStep`` / ``restore`` surface and the same
+step / epoch / evaluation / checkpoint cadence (models/trainClass.py:25-143).  What TensorFlow provided
+is restated on torch plumbing: tf.data shuffle/repeat/batch (utils/utils.py:32-39) as a host iterator,
+tf.GradientTape as ``loss.backward()`` through the engine's custom Function, Keras ``Mean`` as running
+sums kept on the device, tf.train.CheckpointManager(max_to_keep=5) as rotating ``ckpt-N.pt`` files with a
+``checkpoint`` index, tf.summary scalars as JSON lines (tags 'Train PSNR', 'Train loss', 'Test loss',
+'Test PSNR').  Under torch.distributed (one process per GPU, backend "nccl" = RCCL) the flat gradient
+buffer is averaged with ONE all-reduce per step -- the data-parallel semantics of the reference's
+unfinished MirroredStrategy experiment (debug/trainMultiGPU.py:65-68).
+"""
+import json
+import logging
+import os
+
+import numpy as np
+import torch
+
+logging.basicConfig(format="%(asctime)s - %(message)s", level=logging.INFO)
+logger = logging.getLogger("probav_amd")
+
+
+class Mean:
+    """Keras ``Mean`` metric: running mean of everything it is called with; state stays on the device
+    so a training step never synchronises unless ``result()`` is read."""
+
+    def __init__(self, name=""):
+        self.name = name
+        self.reset_states()
+
+    def reset_states(self):
+        self.total, self.count = None, 0
+
+    def __call__(self, value):
+        v = value.detach().double()
+        s = v.sum()
+        self.total = s if self.total is None else self.total + s
+        self.count += v.numel()
+
+    def result(self):
+        return float(self.total) / self.count if self.count else 0.0
+
+
+def shuffle_repeat_batch(n, epochs, batchSize, bufferSize, rng, repeat=True):
+    """Index stream with tf.data semantics: from_tensor_slices -> shuffle(bufferSize, reshuffle each
+    iteration) -> repeat(epochs) -> batch(batchSize) (utils/utils.py:32-34).  The shuffle buffer holds
+    `bufferSize` pending elements and emits a uniformly chosen one; batches may straddle epochs because
+    repeat() precedes batch(); the final partial batch is emitted (drop_remainder=False)."""
+    def elements():
+        for _ in range(epochs if repeat else 1):
+            buf = []
+            for i in range(n):
+                buf.append(i)
+                if len(buf) > bufferSize:
+                    k = int(rng.integers(len(buf)))
+                    buf[k], buf[-1] = buf[-1], buf[k]
+                    yield buf.pop()
+            while buf:
+                k = int(rng.integers(len(buf)))
+                buf[k], buf[-1] = buf[-1], buf[k]
+                yield buf.pop()
+    batch = []
+    for i in elements():
+        batch.append(i)
+        if len(batch) == batchSize:
+            yield np.asarray(batch)
+            batch = []
+    if batch:
+        yield np.asarray(batch)
+
+
+def allreduce_mean_(flat_grad):
+    """Average the flat gradient buffer over the data-parallel ranks: one collective per step
+    (2.14 MB for p16t9c85r12).  No-op when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flat_grad.div_(dist.get_world_size())
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return flat_grad
+
+
+def make_optimizer(name, model, learning_rate):
+    """train.py:77-83: 'adam' -> Keras Adam, 'nadam' -> Keras Nadam, anything else -> SGD, with the Keras
+    defaults restated (epsilon 1e-7; Nadam schedule_decay 0.004 -- SURVEY.md A.5)."""
+    params = list(model.parameters())
+    if name == "adam":
+        return torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7)
+    if name == "nadam":
+        return torch.optim.NAdam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
+    return torch.optim.SGD(params, lr=learning_rate)
+
+
+class ModelTrainer:
+    """models/trainClass.py:17-143."""
+
+    def __init__(self, model, loss, metric, optimizer, ckptDir, logDir, multiGPU=True, evalStep=1000):
+        os.makedirs(ckptDir, exist_ok=True)
+        os.makedirs(logDir, exist_ok=True)
+        self._model, self.optimizer = model, optimizer
+        self.loss, self.metric = loss, metric
+        self.ckptDir, self.logDir = ckptDir, logDir
+        self.step, self.psnr, self.save_counter = 0, 1.0, 0       # tf.train.Checkpoint(step, psnr, ...) (:33-36)
+        self.max_to_keep = 5                                       # CheckpointManager(max_to_keep=5)   (:37-39)
+        self.trainLoss, self.trainPSNR = Mean("trainLoss"), Mean("trainPSNR")
+        self.testLoss, self.testPSNR = Mean("testLoss"), Mean("testPSNR")
+        self.evalStep = evalStep
+        self.multiGPU = multiGPU
+        self.strategy = None
+        self._log = None
+        self.restore()
+
+    @property
+    def model(self):
+        return self._model
+
+    # -- checkpointing -------------------------------------------------------------------------------
+    def _index_path(self):
+        return os.path.join(self.ckptDir, "checkpoint")
+
+    def _read_index(self):
+        if not os.path.exists(self._index_path()):
+            return []
+        with open(self._index_path()) as fh:
+            return [ln.strip() for ln in fh if ln.strip()]
+
+    @property
+    def latest_checkpoint(self):
+        names = self._read_index()
+        return os.path.join(self.ckptDir, names[-1]) if names else None
+
+    def restore(self):
+        path = self.latest_checkpoint
+        if path and os.path.exists(path):
+            state = torch.load(path, map_location="cpu")
+            self._model.load_variables(state["model"])
+            if self.optimizer is not None and state.get("optimizer") is not None:
+                self.optimizer.load_state_dict(state["optimizer"])
+            self.step, self.psnr = int(state["step"]), float(state["psnr"])
+            self.save_counter = int(state.get("save_counter", 0))
+            print(f"[ INFO ] Model restored from checkpoint at step {self.step}.")
+
+    def save(self):
+        if self._rank() != 0:
+            return None
+        self.save_counter += 1
+        name = "ckpt-%d.pt" % self.save_counter
+        names = self._model.variable_names
+        tensors = [t.detach().cpu() for t in self._model.trainable_variables]
+        model_state = {}
+        for n, t in zip(names, tensors):
+            layer, key = n.split("/")
+            model_state.setdefault(layer, {})[key] = t
+        torch.save({"model": model_state, "optimizer": self.optimizer.state_dict() if self.optimizer else None,
+                    "step": self.step, "psnr": self.psnr, "save_counter": self.save_counter},
+                   os.path.join(self.ckptDir, name))
+        kept = self._read_index() + [name]
+        for old in kept[:-self.max_to_keep]:
+            try:
+                os.remove(os.path.join(self.ckptDir, old))
+            except OSError:
+                pass
+        with open(self._index_path(), "w") as fh:
+            fh.write("\n".join(kept[-self.max_to_keep:]) + "\n")
+        return name
+
+    # -- summaries ---------------------------------------------------------------------------------
+    def _scalar(self, tag, value, step):
+        if self._rank() != 0:
+            return
+        if self._log is None:
+            self._log = open(os.path.join(self.logDir, "events.jsonl"), "a")
+        self._log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    @staticmethod
+    def _rank():
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _device(self):
+        return self._model.flat.device
+
+    def _to_dev(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        return t.to(device=self._device(), dtype=dtype, non_blocking=True) if dtype else t.to(self._device(), non_blocking=True)
+
+    # -- training loop (models/trainClass.py:61-122) ---------------------------------------------------
+    def fitTrainData(self, X, y, globalBatchSize, epochs, valData, bufferSize=256, valSteps=64,
+                     saveBestOnly=True, initEpoch=0, seed=0):
+        logger.info("[ INFO ] Loading data set to buffer cache...")
+        yHR, yMask = y[0], y[1]
+        rank, world = self._rank(), self._world()
+        if world > 1 and self.multiGPU:                 # per-replica batch = cfg batch (debug/trainClassMultiGPU0.py:67-73)
+            X, yHR, yMask = X[rank::world], yHR[rank::world], yMask[rank::world]
+        rng = np.random.default_rng(seed + rank)
+        dataSetLength = len(X)
+        totalSteps = int(dataSetLength / globalBatchSize)           # tf.cast(len/batch, int64) truncates (:75)
+        if totalSteps < 1:
+            raise ValueError("data set (%d) smaller than one batch (%d)" % (dataSetLength, globalBatchSize))
+        globalStep = self.step
+        step = globalStep % totalSteps
+        epoch = initEpoch
+        logger.info("[ INFO ] Begin training...")
+        for idx in shuffle_repeat_batch(dataSetLength, epochs, globalBatchSize, bufferSize, rng):
+            if (totalSteps - step) == 0:
+                epoch += 1
+                step = self.step % totalSteps
+                logger.info(f"[ ***************  NEW EPOCH  *************** ] Epoch number {epoch}")
+                for m in (self.trainLoss, self.trainPSNR, self.testLoss, self.testPSNR):
+                    m.reset_states()
+            step += 1
+            globalStep += 1
+            self.trainStep(self._to_dev(X[idx], torch.float32), self._to_dev(yHR[idx], torch.float32), self._to_dev(yMask[idx]))
+            self.step += 1
+            logger.info(f"[ EPOCH {epoch}/{epochs} ] - [ STEP {step}/{int(totalSteps)} ] Loss: {self.trainLoss.result():.6f}, cPSNR: {self.trainPSNR.result():.3f}")
+            self._scalar("Train PSNR", self.trainPSNR.result(), globalStep)
+            self._scalar("Train loss", self.trainLoss.result(), globalStep)
+
+            if step != 0 and (step % self.evalStep) == 0:
+                self.testLoss.reset_states()
+                self.testPSNR.reset_states()
+                for k, vidx in enumerate(shuffle_repeat_batch(len(valData[0]), 1, globalBatchSize, bufferSize, rng, repeat=False)):
+                    if k >= valSteps:                   # .take(valSteps) (utils/utils.py:37-39)
+                        break
+                    self.testStep(self._to_dev(valData[0][vidx], torch.float32), self._to_dev(valData[1][vidx], torch.float32),
+                                  self._to_dev(valData[2][vidx]))
+                self._scalar("Test loss", self.testLoss.result(), globalStep)
+                self._scalar("Test PSNR", self.testPSNR.result(), globalStep)
+                logger.info(f"[ *************** VAL INFO *************** ] Validation Loss: {self.testLoss.result():.6f}, Validation PSNR: {self.testPSNR.result():.3f}")
+                if self._log is not None:
+                    self._log.flush()
+                if saveBestOnly and (self.testPSNR.result() <= self.psnr):
+                    continue
+                logger.info("[ SAVE ] Saving checkpoint...")
+                self.psnr = self.testPSNR.result()
+                self.save()
+        if self._log is not None:
+            self._log.flush()
+
+    # -- one step (models/trainClass.py:124-143) -----------------------------------------------------------
+    def trainStep(self, patchLR, patchHR, maskHR):
+        predPatchHR = self._model(patchLR, training=True)
+        loss = self.loss(patchHR, maskHR, predPatchHR)             # Loss(patchHR, maskHR, predPatchHR)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()                                            # tape.gradient(loss, trainable_variables)
+        if self.multiGPU:
+            for p in self._model.parameters():
+                if p.grad is not None:
+                    allreduce_mean_(p.grad)
+        self.optimizer.step()                                      # optimizer.apply_gradients
+        metric = self.metric(patchHR, maskHR, predPatchHR.detach())
+        self.trainLoss(loss)
+        self.trainPSNR(metric)
+
+    def testStep(self, patchLR, patchHR, maskHR):
+        with torch.no_grad():
+            predPatchHR = self._model(patchLR, training=False)
+            loss = self.loss(patchHR, maskHR, predPatchHR)
+            metric = self.metric(patchHR, maskHR, predPatchHR)
+        self.testLoss(loss)
+        self.testPSNR(metric)

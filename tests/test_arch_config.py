@@ -1,0 +1,64 @@
+"""Host tables and the cfg reader (no GPU)."""
+import os
+
+import pytest
+
+from probav_amd.arch import layer_table, reducer_plan
+from probav_amd.parseConfig import parseConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_variable_inventory_matches_reference_checkpoint():
+    """modelInfo/ckpt_p16t9c85r12/NIR/ckpt-124.index: 44 weight-normalised layers, 535 267 fp32
+    (SURVEY.md F3, A.1), in Keras topological order."""
+    layers, total = layer_table()
+    assert len(layers) == 44 and total == 535267 and total * 4 == 2141068
+    names = [L.name for L in layers]
+    assert names[0] == "mainConv1"
+    assert names[1:4] == ["expConv_0", "decConv_0", "normConv_0"]
+    assert names[37:] == ["convReducer_1", "convReducer_2", "convReducer_3", "residConv1", "upscaleConv1", "residConv2", "residConv3"]
+    per = {L.name: 2 * L.cout + (L.b_off - L.v_off) for L in layers}
+    assert per["mainConv1"] == 928 and per["expConv_3"] == 8704 and per["decConv_3"] == 6450
+    assert per["normConv_3"] == 21664 and per["convReducer_2"] == 27712 and per["residConv1"] == 99
+    assert per["upscaleConv1"] == 7794 and per["residConv2"] == 747
+    assert layers[2].vshape == (1, 1, 1, 256, 25) and layers[40].vshape == (3, 3, 1, 9)
+    # contiguous, non-overlapping flat layout
+    off = 0
+    for L in layers:
+        assert (L.g_off, L.v_off) == (off, off + L.cout)
+        off = L.b_off + L.cout
+    assert off == total
+
+
+def test_reducer_plans():
+    assert reducer_plan(9) == (True, False, False)          # models/modelsTF.py:152-164
+    assert reducer_plan(13) == (True, True, True, False, False)   # :123-150
+    assert reducer_plan(7) == (False, False)                 # :166-175
+    with pytest.raises(ValueError):
+        reducer_plan(12)                                     # a literal 12-frame net is undefined
+    assert layer_table(numImgLR=13)[1] == 535267 + 2 * 27712
+
+
+@pytest.mark.parametrize("name", ["p16t9c85r12", "p16t12c85r12"])
+def test_shipped_cfgs_parse(name):
+    cfg = parseConfig(os.path.join(ROOT, "cfg", name + ".cfg"))
+    assert cfg["num_low_res_imgs"] == 9 and cfg["num_res_blocks"] == 12 and cfg["num_filters"] == 32
+    assert cfg["batch_size"] == 128 and cfg["learning_rate"] == 0.0005 and cfg["optimizer"] == "nadam" and cfg["loss"] == "l1"
+    assert cfg["decay_rate"] == 0.8 and cfg["is_grayscale"] is True and cfg["max_shift"] == 6 and cfg["patch_size"] == 16
+    assert cfg["ckpt"] == [1, 2, 3, 4, 5] and cfg["to_flip"] is False and isinstance(cfg["model_out"], str)
+    assert "type" not in cfg
+
+
+def test_cfg_typing_rules_and_whitelist(tmp_path):
+    p = tmp_path / "x.cfg"
+    p.write_text("# comment\n[Directories]\nanything_goes=here\nmodel_out = out dir \n\n[Train]\nbatch_size= 8\nsplit=0.2\nloss= l2 \n"
+                 "[Net]\ndecay_rate=0.5\nscale=3\n[Preprocessing]\nlow_res_patch_thresholds=0.85,0.9\nhigh_res_threshold=0.85\nto_rotate=1\nckpt=2,3\n")
+    cfg = parseConfig(str(p)[:-4])                       # '.cfg' is appended when missing
+    assert cfg["anything_goes"] == "here" and cfg["model_out"] == "out dir"      # first section is not whitelisted
+    assert cfg["batch_size"] == 8 and cfg["split"] == 0.2 and cfg["loss"] == "l2"
+    assert cfg["low_res_patch_thresholds"] == [0.85, 0.9] and cfg["to_rotate"] is True and cfg["ckpt"] == [2, 3]
+    bad = tmp_path / "bad.cfg"
+    bad.write_text("[Directories]\nraw_data=x\n[Train]\nbatch_sizes=8\n")
+    with pytest.raises(AssertionError, match="Unsupported fields"):
+        parseConfig(str(bad))

@@ -1,0 +1,335 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at the benchmark's full size (batch 128) --
+through size-independent properties (batch independence, bitwise determinism, gradient linearity).
+
+Tolerances (north_star): network output within 1e-3 relative fp32 (we hold 2e-5), loss within 1e-5."""
+import ctypes
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wdsr_numpy as on
+from oracle import wdsr_torch as ot
+from probav_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+IMPLS = [0, 1]
+
+
+def _lib():
+    from probav_amd import _lib as L
+    return L
+
+
+def _geom(N, Hi, Wi, Ti, Cin, Ho, Wo, To, Cout, k, pad, reflect=0, relu=0):
+    return (ctypes.c_int32 * 17)(N, Hi, Wi, Ti, Cin, Ho, Wo, To, Cout, k[0], k[1], k[2], pad[0], pad[1], pad[2], reflect, relu)
+
+
+def _t(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
+
+
+def _oracle_conv(x, gate, w, bias, skip, pad, reflect, relu, out_hw_t):
+    x = np.asarray(x, np.float64)
+    if gate is not None:
+        x = x * (np.asarray(gate) > 0)
+    ph, pw, pt = pad
+    if reflect:
+        x = np.pad(x, [(0, 0), (ph, ph), (pw, pw), (0, 0), (0, 0)], mode="reflect")
+        x = np.pad(x, [(0, 0), (0, 0), (0, 0), (pt, pt), (0, 0)])
+    else:
+        x = np.pad(x, [(0, 0), (ph, ph), (pw, pw), (pt, pt), (0, 0)])
+    y = on.conv_valid(x, w)[:, :out_hw_t[0], :out_hw_t[1], :out_hw_t[2]]
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64)
+    if relu:
+        y = np.maximum(y, 0)
+    if skip is not None:
+        y = y + np.asarray(skip, np.float64)
+    return y
+
+
+# name, N, (Hi,Wi,Ti), Cin, Cout, k, pad, reflect, relu, use_gate, use_skip
+CONV_CASES = [
+    ("mainConv1 same 1->32 relu", 2, (22, 22, 9), 1, 32, (3, 3, 3), (1, 1, 1), 0, 1, 0, 0),
+    ("expConv 1x1x1 32->256 relu", 1, (6, 5, 9), 32, 256, (1, 1, 1), (0, 0, 0), 0, 1, 0, 0),
+    ("decConv 1x1x1 256->25", 1, (6, 5, 9), 256, 25, (1, 1, 1), (0, 0, 0), 0, 0, 0, 0),
+    ("normConv same 25->32 + skip", 2, (22, 22, 9), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("normConv small ragged", 3, (7, 5, 3), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("convReducer_1 reflect+valid", 2, (22, 22, 9), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    ("convReducer_2 valid relu", 2, (22, 22, 7), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
+    ("upscaleConv1 valid 32->9", 2, (18, 18, 3), 32, 9, (3, 3, 3), (0, 0, 0), 0, 0, 0, 0),
+    ("residConv1 2-D 1->9 relu", 2, (22, 22, 1), 1, 9, (3, 3, 1), (0, 0, 0), 0, 1, 0, 0),
+    ("residConv2 2-D 9->9", 2, (20, 20, 1), 9, 9, (3, 3, 1), (0, 0, 0), 0, 0, 0, 0),
+    ("bwd-data of normConv: same 32->25", 2, (22, 22, 9), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 0, 0),
+    ("bwd-data of reducer: full 32->32 gated", 2, (20, 20, 5), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
+    ("bwd-data of expConv: 256->32 gated + skip", 1, (6, 5, 9), 256, 32, (1, 1, 1), (0, 0, 0), 0, 0, 1, 1),
+]
+
+
+def _out_dims(hwt, k, pad, reflect):
+    return tuple(hwt[i] + 2 * pad[i] - k[i] + 1 for i in range(3))
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_forward_matches_oracle(dev, case, impl):
+    name, N, hwt, Cin, Cout, k, pad, reflect, relu, use_gate, use_skip = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    ho = _out_dims(hwt, k, pad, reflect)
+    x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
+    w =(rng.normal(size=k + (Cin, Cout)) / np.sqrt(np.prod(k) * Cin)).astype(np.float32)
+    bias = rng.normal(size=Cout).astype(np.float32)
+    gate = rng.normal(size=x.shape).astype(np.float32) if use_gate else None
+    skip = rng.normal(size=(N,) + ho + (Cout,)).astype(np.float32) if use_skip else None
+    g = _geom(N, hwt[0], hwt[1], hwt[2], Cin, ho[0], ho[1], ho[2], Cout, k, pad, reflect, relu)
+    L = _lib()
+    y = torch.full((N,) + ho + (Cout,), float("nan"), device=dev)
+    args = [_t(a, dev) if a is not None else None for a in (x, gate, w, bias, skip)]
+    rc = L.lib().probav_conv3d_forward(ctypes.byref(g), *[L.ptr(a) for a in args], L.ptr(y), impl, L.current_stream())
+    if impl == 1 and rc == L.PROBAV_EINVAL:
+        pytest.skip("geometry not covered by the MFMA kernel (engine falls back to the direct kernel)")
+    L.check(rc, "probav_conv3d_forward")
+    ref = _oracle_conv(x, gate, w, bias, skip, pad, reflect, relu, ho)
+    err = np.abs(y.cpu().double().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, "%s: rel err %.3e" % (name, err)
+
+
+WGRAD_CASES = [c for c in CONV_CASES if not c[0].startswith("bwd-data")]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv3d_wgrad_matches_autograd(dev, case):
+    name, N, hwt, Cin, Cout, k, pad, reflect, relu, _, _ = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
+    ho = _out_dims(hwt, k, pad, reflect)
+    x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
+    dy = rng.normal(size=(N,) + ho + (Cout,)).astype(np.float32)
+    gate = rng.normal(size=dy.shape).astype(np.float32) if relu else None      # the layer's own output (ReLU mask)
+    # oracle: d/dw of sum(conv(x, w) * dy_gated) via torch autograd in fp64
+    xt = torch.tensor(x, dtype=torch.float64)
+    if reflect:
+        xp = torch.tensor(np.pad(x.astype(np.float64), [(0, 0), (pad[0],) * 2, (pad[1],) * 2, (0, 0), (0, 0)], mode="reflect"))
+        xp = torch.nn.functional.pad(xp, (0, 0, pad[2], pad[2]))
+    else:
+        xp = torch.nn.functional.pad(xt, (0, 0, pad[2], pad[2], pad[1], pad[1], pad[0], pad[0]))
+    wt = torch.zeros(k + (Cin, Cout), dtype=torch.float64, requires_grad=True)
+    yt = torch.nn.functional.conv3d(xp.permute(0, 4, 1, 2, 3), wt.permute(4, 3, 0, 1, 2)).permute(0, 2, 3, 4, 1)
+    dyg = torch.tensor(dy, dtype=torch.float64) * (torch.tensor(gate) > 0 if gate is not None else 1.0)
+    (yt * dyg).sum().backward()
+    L = _lib()
+    g = _geom(N, hwt[0], hwt[1], hwt[2], Cin, ho[0], ho[1], ho[2], Cout, k, pad, reflect, relu)
+    nbytes = L.lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(g), 0)
+    scratch = torch.empty(nbytes // 4 + 1, device=dev)
+    dw = torch.full(k + (Cin, Cout), float("nan"), device=dev)
+    db = torch.full((Cout,), float("nan"), device=dev)
+    xd, dyd, gd = _t(x, dev), _t(dy, dev), (_t(gate, dev) if gate is not None else None)
+    L.check(L.lib().probav_conv3d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dyd), L.ptr(gd), L.ptr(dw), L.ptr(db),
+                                        L.ptr(scratch), nbytes, 0, L.current_stream()))
+    ref_w, ref_b = wt.grad.numpy(), dyg.sum(dim=(0, 1, 2, 3)).numpy()
+    assert np.abs(dw.cpu().double().numpy() - ref_w).max() / np.abs(ref_w).max() < 1e-5
+    assert np.abs(db.cpu().double().numpy() - ref_b).max() / np.abs(ref_b).max() < 1e-5
+    # bitwise reproducible (fixed-order partial sums, no float atomics)
+    dw2 = torch.empty_like(dw)
+    L.check(L.lib().probav_conv3d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dyd), L.ptr(gd), L.ptr(dw2), L.ptr(db),
+                                        L.ptr(scratch), nbytes, 0, L.current_stream()))
+    assert torch.equal(dw, dw2)
+
+
+def _model(dev, T=9, params=None, seed=0):
+    from probav_amd.modelsTF import WDSRConv3D
+    m = WDSRConv3D("t", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, True, seed=seed)
+    if params is not None:
+        m.load_variables(params)
+    return m.to(dev)
+
+
+def test_weight_norm_forward_backward(dev):
+    params = synth.synth_params(seed=11, perturb=True)
+    m = _model(dev, params=params)
+    L = _lib()
+    h = m._handle()
+    assert [(n, tuple(s)) for n, _, _, _, s in m.native_layer_table()][:2] == [("mainConv1", (3, 3, 3, 1, 32)), ("expConv_0", (1, 1, 1, 32, 256))]
+    for (n, g, v, b, _), Lh in zip(m.native_layer_table(), m.layers):
+        assert (n, g, v, b) == (Lh.name, Lh.g_off, Lh.v_off, Lh.b_off)
+    nw, nc = L.lib().probav_weff_count(h), L.lib().probav_cout_total(h)
+    weff, weffT, invn = torch.empty(nw, device=dev), torch.empty(nw, device=dev), torch.empty(nc, device=dev)
+    L.check(L.lib().probav_wn_forward(h, L.ptr(m.flat), L.ptr(weff), L.ptr(weffT), L.ptr(invn), L.current_stream()))
+    rng = np.random.default_rng(0)
+    dweff = torch.as_tensor(rng.normal(size=nw).astype(np.float32)).to(dev)
+    grads = torch.zeros_like(m.flat)
+    L.check(L.lib().probav_wn_backward(h, L.ptr(m.flat), L.ptr(dweff), L.ptr(invn), L.ptr(grads), L.current_stream()))
+    weff, weffT, grads, dweff = weff.cpu().double().numpy(), weffT.cpu().double().numpy(), grads.cpu().double().numpy(), dweff.cpu().double().numpy()
+    off = 0
+    for Lh in m.layers:
+        p = params[Lh.name]
+        w = on.weight_norm(p["v"], p["g"])
+        n = w.size
+        got = weff[off:off + n].reshape(w.shape)
+        assert np.abs(got - w).max() < 2e-6 * np.abs(w).max(), Lh.name
+        taps = n // (w.shape[-1] * w.shape[-2])
+        wT = w.reshape(taps, w.shape[-2], w.shape[-1])[::-1].transpose(0, 2, 1)      # flipped taps, [tap][co][ci]
+        assert np.abs(weffT[off:off + n].reshape(wT.shape) - wT).max() < 2e-6 * np.abs(w).max(), Lh.name
+        vt = torch.tensor(p["v"], dtype=torch.float64, requires_grad=True)
+        gt = torch.tensor(p["g"], dtype=torch.float64, requires_grad=True)
+        (ot.weight_norm(vt, gt) * torch.tensor(dweff[off:off + n].reshape(w.shape))).sum().backward()
+        assert np.abs(grads[Lh.g_off:Lh.v_off] - gt.grad.numpy()).max() < 1e-5 * np.abs(gt.grad.numpy()).max(), Lh.name
+        assert np.abs(grads[Lh.v_off:Lh.b_off] - vt.grad.numpy().reshape(-1)).max() < 1e-5 * np.abs(vt.grad.numpy()).max(), Lh.name
+        off += n
+
+
+@pytest.mark.parametrize("B,S,border", [(1, 48, 3), (5, 48, 3), (2, 96, 3), (3, 30, 2)])
+def test_shift_losses_match_oracle(dev, B, S, border):
+    from probav_amd.loss import Losses
+    rng = np.random.default_rng(B * 1000 + S)
+    hr = np.clip(rng.normal(synth.NIR_MEAN, synth.NIR_STD, (B, S, S, 1)), 0, 16383).astype(np.float32)
+    pred = (hr + rng.normal(0, 150, hr.shape)).astype(np.float32)
+    pred = np.roll(pred, (1, -2), axis=(1, 2))                       # true registration is not the centre shift
+    mask = rng.random((B, S, S, 1)) < 0.9
+    mask[0, : S // 3] = False                                        # a heavily clouded sample
+    lo = Losses(targetShape=(S, S, 1), cropBorder=border)
+    hd, md = torch.as_tensor(hr).to(dev), torch.as_tensor(mask).to(dev)
+    pd = torch.as_tensor(pred).to(dev).requires_grad_(True)
+    l1 = lo.shiftCompensatedL1Loss(hd, md, pd)
+    l1.backward()
+    l2 = lo.shiftCompensatedL2Loss(hd, md, pd.detach())
+    ps = lo.shiftCompensatedcPSNR(hd, md, pd.detach())
+    r1, r2 = on.shift_l1_loss(hr, mask, pred, border), on.shift_l2_loss(hr, mask, pred, border)
+    assert abs(float(l1) - r1) < 1e-6 * r1                           # bar: 1e-5 relative
+    assert abs(float(l2) - r2) < 1e-6 * r2
+    np.testing.assert_allclose(ps.cpu().numpy(), on.shift_cpsnr(hr, mask, pred, border), rtol=1e-6)
+    gref = on.shift_l1_grad(hr, mask, pred, border)
+    assert np.abs(pd.grad.cpu().double().numpy() - gref).max() < 1e-6 * np.abs(gref).max()
+    # L2 gradient against autograd, float mask accepted, upstream scale honoured
+    pd2 = torch.as_tensor(pred).to(dev).requires_grad_(True)
+    (3.0 * lo.shiftCompensatedL2Loss(hd, md.float(), pd2)).backward()
+    pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    (3.0 * ot.shift_l2_loss(torch.tensor(hr), torch.tensor(mask), pt, border)).backward()
+    assert np.abs(pd2.grad.cpu().double().numpy() - pt.grad.numpy()).max() < 1e-5 * np.abs(pt.grad.numpy()).max()
+    with pytest.raises(ValueError):
+        lo.shiftCompensatedL1Loss(hd[:, :-1], md, pd)
+
+
+def test_clip_round_half_to_even(dev):
+    L = _lib()
+    x = torch.tensor([-3.2, 0.5, 1.5, 2.5, 65535.5, 65536.4, 70000.0, 123.49], device=dev)
+    y = torch.empty_like(x)
+    L.check(L.lib().probav_clip_round(L.ptr(x), L.ptr(y), x.numel(), 0.0, 65536.0, L.current_stream()))
+    assert y.tolist() == [0.0, 0.0, 2.0, 2.0, 65536.0, 65536.0, 65536.0, 123.0]      # tf.round: half to even
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("T", [9, 13, 7])
+def test_end_to_end_against_golden(dev, T, impl):
+    """forward, loss, metric and all 132 (138 / 129) gradients against the committed fp64 fixtures."""
+    from probav_amd.loss import Losses
+    z = np.load(os.path.join(GOLD, "wdsr_t%d_b2.npz" % T))
+    seeds = {9: (101, 102), 13: (131, 132), 7: (71, 72)}[T]
+    params = synth.synth_params(seed=seeds[0], perturb=True, numImgLR=T)
+    m = _model(dev, T, params)
+    m.set_impl(impl)
+    lo = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(z[k]).to(dev) for k in ("x", "hr", "mask"))
+    pred = m(x, training=True)
+    loss = lo.shiftCompensatedL1Loss(hr, mask, pred)
+    loss.backward()
+    e = np.abs(pred.detach().cpu().double().numpy() - z["pred"]).max() / np.abs(z["pred"]).max()
+    assert e < 2e-5, "output rel err %.3e (bar 1e-3)" % e
+    assert abs(float(loss) - float(z["loss_l1"])) < 1e-5 * float(z["loss_l1"])
+    np.testing.assert_allclose(lo.shiftCompensatedcPSNR(hr, mask, pred.detach()).cpu().numpy(), z["cpsnr"], rtol=1e-5)
+    assert abs(float(lo.shiftCompensatedL2Loss(hr, mask, pred.detach())) - float(z["loss_l2"])) < 1e-4 * float(z["loss_l2"])
+    grads = [g.cpu().double().numpy() for g in m.variable_gradients()]
+    names = m.variable_names
+    assert len(grads) == z["grad_norms"].shape[0]
+    for k, (n, g) in enumerate(zip(names, grads)):
+        ref_norm, ref_max = z["grad_norms"][k]
+        assert abs(np.sqrt((g ** 2).sum()) - ref_norm) < 1e-3 * ref_norm + 1e-12, n
+        key = "grad/" + n
+        if key in z.files:
+            assert np.abs(g - z[key]).max() < 1e-3 * ref_max, n
+    # inference mode (ping-pong workspace) gives the same prediction bit for bit
+    with torch.no_grad():
+        assert torch.equal(m(x, training=False), pred.detach())
+
+
+def test_full_size_batch128_properties(dev):
+    """BASELINE.json config 2 (batch 128): properties that need no oracle run at that size."""
+    from probav_amd.loss import Losses
+    params = synth.synth_params(seed=21, perturb=True)
+    m = _model(dev, params=params)
+    lo = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(128, seed=22))
+
+    def step(xs, hs, ms):
+        m.flat.grad = None
+        p = m(xs, training=True)
+        l = lo.shiftCompensatedL1Loss(hs, ms, p)
+        l.backward()
+        return p.detach().clone(), float(l), m.flat.grad.detach().clone()
+
+    p_full, l_full, g_full = step(x, hr, mask)
+    assert torch.isfinite(p_full).all() and torch.isfinite(g_full).all()
+    p_again, l_again, g_again = step(x, hr, mask)
+    assert torch.equal(p_full, p_again) and l_full == l_again and torch.equal(g_full, g_again)      # deterministic
+    # batch independence: samples are processed independently (no cross-sample term in the forward)
+    with torch.no_grad():
+        p_small = m(x[5:8].contiguous(), training=False)
+    assert torch.equal(p_small, p_full[5:8])
+    # linearity of the gradient in the batch: grad(mean over 128) = mean of the two half-batch gradients
+    _, l_a, g_a = step(x[:64].contiguous(), hr[:64].contiguous(), mask[:64].contiguous())
+    _, l_b, g_b = step(x[64:].contiguous(), hr[64:].contiguous(), mask[64:].contiguous())
+    assert abs(0.5 * (l_a + l_b) - l_full) < 1e-5 * l_full
+    gm = 0.5 * (g_a + g_b)
+    assert float((gm - g_full).abs().max()) < 2e-4 * float(g_full.abs().max())
+    # a zeroed pixel-shuffle head leaves exactly the denormalised zero: y = (0 + 0) * std + mean
+    with torch.no_grad():
+        keep = m.flat.detach().clone()
+        for L in m.layers:
+            if L.name in ("upscaleConv1", "residConv3"):
+                m.flat[L.g_off:L.v_off] = 0
+                m.flat[L.b_off:L.b_off + L.cout] = 0
+        y0 = m(x[:4].contiguous(), training=False)
+        assert float((y0 - synth.NIR_MEAN).abs().max()) < 1e-3
+        m.flat.copy_(keep)
+
+
+def test_trainer_and_inference_on_device(dev, tmp_path):
+    from probav_amd.loss import Losses
+    from probav_amd.trainClass import ModelTrainer, make_optimizer
+    from probav_amd import testClass
+    m = _model(dev, seed=3)
+    lo = Losses(targetShape=(48, 48, 1))
+    tr = ModelTrainer(m, lo.shiftCompensatedL1Loss, lo.shiftCompensatedcPSNR, make_optimizer("nadam", m, 5e-4),
+                      str(tmp_path / "ck"), str(tmp_path / "lg"), multiGPU=False)
+    x, _, mask = synth.synth_batch(8, seed=4)
+    rng = np.random.default_rng(4)
+    hr = np.repeat(np.repeat(x.mean(axis=3)[:, 3:19, 3:19], 3, axis=1), 3, axis=2) + rng.normal(0, 20, (8, 48, 48, 1)).astype(np.float32)
+    xs, hs, ms = torch.as_tensor(x).to(dev), torch.as_tensor(hr.astype(np.float32)).to(dev), torch.as_tensor(mask).to(dev)
+    losses = []
+    for _ in range(12):
+        tr.trainLoss.reset_states()
+        tr.trainStep(xs, hs, ms)
+        losses.append(tr.trainLoss.result())
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    tr.testStep(xs, hs, ms)
+    assert tr.testPSNR.result() > 0
+    # inference path of test.py: 64 patches -> micro-batches of 16 -> clip/round -> 8x8 stitch
+    patches = synth.synth_batch(64, seed=9)[0]
+    sr = testClass.resolveByBatch(m, patches, batch_size=16)
+    assert sr.shape == (64, 48, 48, 1) and np.all(sr == np.round(sr)) and sr.min() >= 0 and sr.max() <= 65536
+    one = testClass.resolve(m, patches[20:21])
+    np.testing.assert_array_equal(one[0], sr[20])
+    img = testClass.reconstruct_from_patches(sr)
+    assert img.shape == (384, 384, 1)
+    np.testing.assert_array_equal(img[48:96, 96:144], sr[8 + 2])          # row-major block order (test.py:149-160)
+    imgs = testClass.evaluate(m, patches[None], batch_size=16)
+    np.testing.assert_array_equal(imgs[0], img)
+    # a second forward before backward is refused instead of silently using clobbered activations
+    p1 = m(xs, training=True)
+    _ = m(xs, training=True)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        p1.sum().backward()

@@ -1,0 +1,102 @@
+"""The CPU oracle against itself and against the committed golden fixtures (no GPU).
+
+Parity is unpinned by the reference (no TF here, no reference tests); what is checked is that the two
+independent restatements agree, that the analytic gradients match finite differences, and that the
+golden vectors in tests/golden/ are reproduced."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wdsr_numpy as on
+from oracle import wdsr_torch as ot
+from probav_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_two_restatements_agree_fp64():
+    p = synth.synth_params(seed=3, perturb=True)
+    x, hr, m = synth.synth_batch(1, seed=4)
+    y = on.wdsr_forward(x, p, synth.NIR_MEAN, synth.NIR_STD)
+    yt = ot.wdsr_forward(torch.tensor(x, dtype=torch.float64), ot.to_torch_params(p, requires_grad=False),
+                         synth.NIR_MEAN, synth.NIR_STD)
+    assert y.shape == (1, 48, 48, 1)
+    assert np.abs(y - yt.numpy()).max() <= 1e-9 * np.abs(y).max()
+    assert abs(on.shift_l1_loss(hr, m, y) - float(ot.shift_l1_loss(torch.tensor(hr), torch.tensor(m), yt))) < 1e-9
+    assert abs(on.shift_l2_loss(hr, m, y) - float(ot.shift_l2_loss(torch.tensor(hr), torch.tensor(m), yt))) < 1e-6
+    np.testing.assert_allclose(on.shift_cpsnr(hr, m, y), ot.shift_cpsnr(torch.tensor(hr), torch.tensor(m), yt).numpy(), rtol=1e-12)
+
+
+def test_loss_gradient_matches_autograd_and_finite_differences():
+    rng = np.random.default_rng(0)
+    _, hr, m = synth.synth_batch(3, seed=5)
+    pred = (hr + rng.normal(0, 200, hr.shape)).astype(np.float64)
+    g = on.shift_l1_grad(hr, m, pred)
+    pt = torch.tensor(pred, requires_grad=True)
+    ot.shift_l1_loss(torch.tensor(hr), torch.tensor(m), pt).backward()
+    np.testing.assert_allclose(g, pt.grad.numpy(), atol=1e-15)
+    # directional finite difference (the loss is piecewise linear in pred; a small step stays in one piece)
+    d = rng.normal(0, 1, pred.shape)
+    eps = 1e-4
+    fd = (on.shift_l1_loss(hr, m, pred + eps * d) - on.shift_l1_loss(hr, m, pred - eps * d)) / (2 * eps)
+    assert abs(fd - (g * d).sum()) < 1e-6 * max(1.0, abs(fd))
+    assert np.all(g[:, :3] == 0) and np.all(g[:, :, :3] == 0)          # the 3-pixel border never gets gradient
+
+
+def test_loss_reference_quirk_hr_not_masked():
+    """models/loss.py:146,151: HR is left un-masked, so masked-out pixels contribute |HR|."""
+    hr = np.full((1, 48, 48, 1), 100.0)
+    pred = np.full((1, 48, 48, 1), 100.0)
+    mask = np.ones((1, 48, 48, 1), bool)
+    assert on.shift_l1_loss(hr, mask, pred) == 0.0
+    mask[0, 10, 10, 0] = False          # one cloudy pixel inside every crop window
+    l = on.shift_l1_loss(hr, mask, pred)
+    n = 42 * 42 - 1
+    b = 100.0 / n                        # bias absorbs the un-masked HR pixel
+    assert abs(l - (n * b + 100.0) / n) < 1e-9
+
+
+def test_weight_norm_and_its_clamp():
+    v = np.random.default_rng(1).normal(size=(3, 3, 3, 4, 5))
+    g = np.arange(1, 6, dtype=np.float64)
+    w = on.weight_norm(v, g)
+    np.testing.assert_allclose(np.sqrt((w ** 2).reshape(-1, 5).sum(0)), g, rtol=1e-12)
+    tiny = np.zeros((1, 1, 1, 2, 1))
+    tiny[..., 0, 0] = 1e-9
+    np.testing.assert_allclose(on.weight_norm(tiny, np.ones(1))[0, 0, 0, 0, 0], 1e-9 / 1e-6)   # eps=1e-12 inside rsqrt
+
+
+def test_depth_to_space_and_reflect_pad_conventions():
+    x = np.arange(2 * 2 * 9, dtype=np.float64).reshape(1, 2, 2, 9)
+    y = on.depth_to_space(x, 3)
+    for h in range(2):
+        for w in range(2):
+            for i in range(3):
+                for j in range(3):
+                    assert y[0, 3 * h + i, 3 * w + j, 0] == x[0, h, w, 3 * i + j]
+    np.testing.assert_array_equal(y, ot.depth_to_space(torch.tensor(x), 3).numpy())
+    a = np.arange(16, dtype=np.float64).reshape(1, 4, 4, 1, 1)
+    p = on.reflect_pad_hw(a)
+    assert p[0, 0, 0, 0, 0] == a[0, 1, 1, 0, 0] and p[0, 5, 2, 0, 0] == a[0, 2, 1, 0, 0]    # mirror without the edge
+
+
+@pytest.mark.parametrize("T", [9, 13, 7])
+def test_golden_fixture_reproduced(T):
+    z = np.load(os.path.join(GOLD, "wdsr_t%d_b2.npz" % T))
+    seeds = {9: (101, 102), 13: (131, 132), 7: (71, 72)}[T]
+    params = synth.synth_params(seed=seeds[0], perturb=True, numImgLR=T)
+    x, hr, mask = synth.synth_batch(2, seed=seeds[1], numImgLR=T)
+    flat = synth.flatten_params(params, numImgLR=T).astype(np.float64)
+    np.testing.assert_allclose([flat.sum(), (flat ** 2).sum()], z["param_checksum"], rtol=1e-12,
+                               err_msg="numpy's generator stream changed: regenerate tests/golden with make_golden.py")
+    np.testing.assert_array_equal(x, z["x"])
+    np.testing.assert_array_equal(mask, z["mask"])
+    pt = ot.to_torch_params(params)
+    pred, loss, grads = ot.train_step_grads(torch.tensor(x, dtype=torch.float64), torch.tensor(hr), torch.tensor(mask),
+                                            pt, synth.NIR_MEAN, synth.NIR_STD, numImgLR=T)
+    np.testing.assert_allclose(pred.numpy(), z["pred"], rtol=1e-10)
+    assert abs(float(loss) - float(z["loss_l1"])) < 1e-9 * float(z["loss_l1"])
+    np.testing.assert_allclose(grads["mainConv1"]["v"].numpy(), z["grad/mainConv1/v"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(on.shift_cpsnr(hr, mask, z["pred"]), z["cpsnr"], rtol=1e-12)

@@ -1,0 +1,80 @@
+"""Host logic of ModelTrainer / the input pipeline on CPU with the HIP forward swapped for a tiny torch
+stand-in (test-only: it exercises step counting, evaluation cadence, checkpoint rotation and restore,
+not the arithmetic of the hot path)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from probav_amd.modelsTF import WDSRModel
+from probav_amd.trainClass import Mean, ModelTrainer, make_optimizer, shuffle_repeat_batch
+
+
+class StubModel(WDSRModel):
+    def forward(self, x, training=False):
+        k = self.flat[:48 * 48].view(1, 48, 48, 1)
+        return x.mean(dim=(1, 2, 3, 4)).view(-1, 1, 1, 1) * 0 + k * 1e-3 + 5.0
+
+
+def _stub():
+    return StubModel("stub", "NIR", 0.0, 1.0, 6, 3, 32, 12, 8, 0.8, 9, 16, seed=0)
+
+
+def _l1(hr, mask, pred):
+    return ((hr - pred).abs() * mask).mean()
+
+
+def _metric(hr, mask, pred):
+    return -((hr - pred) ** 2).mean(dim=(1, 2, 3))
+
+
+def test_shuffle_repeat_batch_semantics():
+    rng = np.random.default_rng(0)
+    batches = list(shuffle_repeat_batch(10, 3, 4, 5, rng))
+    flat = np.concatenate(batches)
+    assert len(flat) == 30 and [len(b) for b in batches] == [4] * 7 + [2]
+    for e in range(3):                                   # every epoch is a permutation (repeat AFTER shuffle)
+        assert sorted(flat[10 * e:10 * (e + 1)]) == list(range(10))
+    assert any(not np.array_equal(flat[:10], flat[10 * e:10 * (e + 1)]) for e in (1, 2))   # reshuffled each iteration
+    first = np.concatenate(list(shuffle_repeat_batch(100, 1, 100, 5, np.random.default_rng(1))))
+    assert max(first[:3]) < 5 + 3                        # a 5-element buffer can only emit early indices first
+
+
+def test_mean_metric():
+    m = Mean()
+    m(torch.tensor([1.0, 3.0]))
+    m(torch.tensor(5.0))
+    assert m.result() == 3.0
+    m.reset_states()
+    assert m.result() == 0.0
+
+
+def test_fit_counts_steps_evaluates_and_rotates_checkpoints(tmp_path):
+    model = _stub()
+    opt = make_optimizer("nadam", model, 5e-4)
+    assert isinstance(opt, torch.optim.NAdam) and opt.defaults["eps"] == 1e-7 and opt.defaults["momentum_decay"] == 0.004
+    tr = ModelTrainer(model, _l1, _metric, opt, str(tmp_path / "ckpt"), str(tmp_path / "logs"), evalStep=2)
+    n = 16
+    X = np.zeros((n, 22, 22, 9, 1), np.float32)
+    y = np.ones((n, 48, 48, 1), np.float32)
+    msk = np.ones((n, 48, 48, 1), bool)
+    before = model.flat.detach().clone()
+    tr.fitTrainData(X, [y, msk], 4, 4, [X[:8], y[:8], msk[:8]], valSteps=1, saveBestOnly=False)
+    assert tr.step == 16                                  # 16 samples / batch 4 * 4 epochs
+    assert not torch.equal(before, model.flat.detach())
+    names = open(tmp_path / "ckpt" / "checkpoint").read().split()
+    assert names == ["ckpt-%d.pt" % k for k in range(4, 9)]          # 8 saves, max_to_keep = 5
+    assert sorted(os.listdir(tmp_path / "ckpt")) == sorted(names + ["checkpoint"])
+    tags = [json.loads(l)["tag"] for l in open(tmp_path / "logs" / "events.jsonl")]
+    assert tags.count("Train loss") == 16 and tags.count("Test PSNR") == 8
+    # restore picks up step, psnr and the weights
+    model2 = _stub()
+    tr2 = ModelTrainer(model2, _l1, _metric, make_optimizer("adam", model2, 1e-3), str(tmp_path / "ckpt"), str(tmp_path / "logs2"))
+    assert tr2.step == 16 and torch.equal(model2.flat.detach(), model.flat.detach())
+    # saveBestOnly keeps the checkpoint only when the validation metric improves (models/trainClass.py:117-122)
+    tr3 = ModelTrainer(_stub(), _l1, _metric, None, str(tmp_path / "c3"), str(tmp_path / "l3"), evalStep=1)
+    tr3.optimizer = make_optimizer("sgd", tr3.model, 0.0)
+    tr3.psnr = 1e9
+    tr3.fitTrainData(X, [y, msk], 8, 1, [X[:8], y[:8], msk[:8]], valSteps=1, saveBestOnly=True)
+    assert not os.path.exists(tmp_path / "c3" / "checkpoint")
