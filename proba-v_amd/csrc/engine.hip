@@ -11,12 +11,7 @@
 
 using namespace probav;
 
-namespace probav {
-// kernels_mfma.hip
-bool mfma_conv_supported(const ConvGeom& g);
-int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* w, const float* bias,
-                      const float* skip, float* y, hipStream_t s);
-}
+#include "kernels_mfma.h"
 
 struct LayerRec {
     char name[32];
@@ -33,6 +28,13 @@ struct probav_engine {
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed, redReflect;
     int Hin = 0;
+    // MFMA operand fragments: one packing job per (layer, use); offsets into the workspace's wpack region
+    std::vector<PackJob> jobs;
+    PackJob* d_jobs = nullptr;
+    int64_t wpack_count = 0;
+    std::vector<long> pkFwd, pkBwd;          // per layer: conv fragments for forward / backward-data (-1 = none)
+    std::vector<long> pkW1, pkW2;            // per block: fused expand/decay forward fragments
+    bool pw_mfma = false;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -90,7 +92,7 @@ struct Plan {
     size_t weff, weffT, invn, dweff, xn, mn;
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
-    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, total;
+    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
 };
 
 static ConvGeom make_geom(int N, int Hi, int Ti, int Cin, int Ho, int To, int Cout, int kh, int kw, int kt,
@@ -138,6 +140,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
     p.weff = take(e->weff_count); p.weffT = take(e->weff_count); p.invn = take(e->cout_total);
     p.dweff = take(training ? e->weff_count : 0);
+    p.wpack = take(e->wpack_count);
     p.xn = take(V); p.mn = take((size_t)B * Hin * Hin);
     if (training) {
         for (int i = 0; i <= R; ++i) p.act.push_back(take(V * F));
@@ -162,16 +165,30 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         p.dr2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
         p.dr1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
         p.dH = take(V * E);
+        // every layer's backward-filter geometry, exactly as probav_backward launches it
         std::vector<ConvGeom> gs;
         gs.push_back(make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1));
         gs.push_back(make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1));
         gs.push_back(make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0));
         gs.push_back(make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0));
-        gs.push_back(make_geom(B, Hin, T, F, Hin, T - 2, F, 3, 3, 3, 1, 0, 1, 1));
-        gs.push_back(make_geom(B, Hin, 3, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0));
-        gs.push_back(make_geom(B, Hin, 1, s2, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 0));
+        {
+            int h = Hin, t = T;
+            for (size_t k = 0; k < e->iRed.size(); ++k) {
+                const int refl = e->redReflect[k];
+                gs.push_back(make_geom(B, h, t, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1));
+                h = p.redH[k]; t = p.redT[k];
+            }
+            gs.push_back(make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0));
+        }
+        gs.push_back(make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1));
+        gs.push_back(make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0));
+        gs.push_back(make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0));
         size_t pmax = 0;
-        for (auto& g : gs) { size_t q = wgrad_partial_floats(g); if (q > pmax) pmax = q; }
+        for (auto& g : gs) {
+            size_t q = wgrad_partial_floats(g);
+            if (mfma_wgrad_supported(g)) { const size_t q2 = mfma_wgrad_partial_floats(g); if (q2 > q) q = q2; }
+            if (q > pmax) pmax = q;
+        }
         p.partial = take(pmax);
     }
     p.total = off;
@@ -180,18 +197,19 @@ static Plan make_plan(const probav_engine* e, int B, int training)
 
 // ---------------------------------------------------------------------------------------------------
 static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
-                    const float* bias, const float* skip, float* y, hipStream_t s)
+                    const float* wfrag, const float* bias, const float* skip, float* y, hipStream_t s)
 {
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD), geom_macs(g), s);
-    if (e->impl >= 1 && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, w, bias, skip, y, s);
+    if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, s);
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
 }
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
                       float* dw, float* db, float* partial, hipStream_t s)
 {
     ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : CLS_CONV3_WGRAD, geom_macs(g), s);
+    if (e->impl >= 1 && mfma_wgrad_supported(g)) return mfma_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s);
 }
 
@@ -246,6 +264,40 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
         set_error("probav_engine_create: reducer geometry does not collapse to [P,P,1]", hipSuccess);
         return PROBAV_EINVAL;
     }
+    // MFMA fragment-packing jobs
+    e->pkFwd.assign(e->layers.size(), -1); e->pkBwd.assign(e->layers.size(), -1);
+    for (size_t li = 0; li < e->layers.size(); ++li) {
+        const LayerRec& r = e->layers[li];
+        if (r.kh != 3 || r.kw != 3 || r.kt != 3) continue;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int cin = dir ? r.wn.Cout : r.wn.Cin, cout = dir ? r.wn.Cin : r.wn.Cout;
+            if ((int)li == e->iMain && dir) continue;               // input-facing: no backward-data
+            if (mfma_conv_wfrag_floats(cin, cout) == 0) continue;
+            PackJob J; memset(&J, 0, sizeof(J));
+            mfma_conv_pack_job(J, cin, cout);
+            J.src_is_T = dir; J.src_off = r.wn.w_off; J.dst_off = e->wpack_count;
+            (dir ? e->pkBwd : e->pkFwd)[li] = J.dst_off;
+            e->wpack_count += J.count;
+            e->jobs.push_back(J);
+        }
+    }
+    e->pw_mfma = mfma_pw_supported(F, E, D);
+    if (e->pw_mfma) {
+        for (int i = 0; i < cfg->num_res_blocks; ++i) {
+            PackJob J; memset(&J, 0, sizeof(J));
+            J.type = PACK_PW_A_KCIN; J.src_is_T = 0; J.src_off = e->layers[e->iExp[i]].wn.w_off; J.dst_off = e->wpack_count;
+            J.count = 8 * 4 * 64 * 4; J.Cin = F; J.Cout = E;
+            e->pkW1.push_back(J.dst_off); e->wpack_count += J.count; e->jobs.push_back(J);
+            J.type = PACK_PW_A_KHCH; J.src_off = e->layers[e->iDec[i]].wn.w_off; J.dst_off = e->wpack_count;
+            J.Cin = E; J.Cout = D;
+            e->pkW2.push_back(J.dst_off); e->wpack_count += J.count; e->jobs.push_back(J);
+        }
+    }
+    if (!e->jobs.empty()) {
+        hipError_t perr = hipMalloc((void**)&e->d_jobs, e->jobs.size() * sizeof(PackJob));
+        if (perr == hipSuccess) perr = hipMemcpy(e->d_jobs, e->jobs.data(), e->jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+        if (perr != hipSuccess) { set_error("probav_engine_create: pack table upload", perr); delete e; return PROBAV_EHIP; }
+    }
     std::vector<WnLayer> h;
     for (auto& r : e->layers) h.push_back(r.wn);
     hipError_t err = hipMalloc((void**)&e->d_layers, h.size() * sizeof(WnLayer));
@@ -290,6 +342,7 @@ void probav_engine_destroy(probav_engine* e)
     if (!e) return;
     for (auto ev : e->prof_ev) (void)hipEventDestroy(ev);
     if (e->d_layers) (void)hipFree(e->d_layers);
+    if (e->d_jobs) (void)hipFree(e->d_jobs);
     delete e;
 }
 
@@ -336,27 +389,37 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
     auto weff = [&](int li) { return W + p.weff + e->layers[li].wn.w_off; };
     auto bias = [&](int li) { return params + e->layers[li].wn.b_off; };
+    auto frag = [&](int li) -> const float* { return e->pkFwd[li] >= 0 ? W + p.wpack + e->pkFwd[li] : nullptr; };
 
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, s)); }
+    if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, s)); }
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
-    CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), bias(e->iMain), nullptr, W + p.act[0], s));
+    CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], s));
     for (int i = 0; i < R; ++i) {
-        CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, s));
-        CK(conv_fwd(e, make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0), W + p.H, nullptr, weff(e->iDec[i]), bias(e->iDec[i]), nullptr, W + p.dec[i], s));
-        CK(conv_fwd(e, make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0), W + p.dec[i], nullptr, weff(e->iNorm[i]), bias(e->iNorm[i]), W + p.act[i], W + p.act[i + 1], s));
+        if (e->impl >= 1 && e->pw_mfma) {
+            // fused expConv + ReLU + decConv: the 256-channel tensor never leaves the accumulators
+            const long nvox = (long)B * Hin * Hin * T;
+            ProfScope ps(e, CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
+            CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                               W + p.dec[i], nvox, D, s));
+        } else {
+            CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), frag(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, s));
+            CK(conv_fwd(e, make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0), W + p.H, nullptr, weff(e->iDec[i]), frag(e->iDec[i]), bias(e->iDec[i]), nullptr, W + p.dec[i], s));
+        }
+        CK(conv_fwd(e, make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0), W + p.dec[i], nullptr, weff(e->iNorm[i]), frag(e->iNorm[i]), bias(e->iNorm[i]), W + p.act[i], W + p.act[i + 1], s));
     }
     const float* cur = W + p.act[R];
     int h = Hin, t = T;
     for (size_t k = 0; k < e->iRed.size(); ++k) {
         const int refl = e->redReflect[k];
         CK(conv_fwd(e, make_geom(B, h, t, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1), cur, nullptr,
-                    weff(e->iRed[k]), bias(e->iRed[k]), nullptr, W + p.red[k], s));
+                    weff(e->iRed[k]), frag(e->iRed[k]), bias(e->iRed[k]), nullptr, W + p.red[k], s));
         cur = W + p.red[k]; h = p.redH[k]; t = p.redT[k];
     }
-    CK(conv_fwd(e, make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0), cur, nullptr, weff(e->iUp), bias(e->iUp), nullptr, W + p.up, s));
-    CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, s));
-    CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, s));
-    CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, s));
+    CK(conv_fwd(e, make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0), cur, nullptr, weff(e->iUp), frag(e->iUp), bias(e->iUp), nullptr, W + p.up, s));
+    CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, s));
+    CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, s));
+    CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, s));
     CK(tail_forward(W + p.up, W + p.r3, y, B, P, c.scale, c.mean, c.std, s));
     return PROBAV_OK;
 }
@@ -373,6 +436,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
     auto weffT = [&](int li) { return W + p.weffT + e->layers[li].wn.w_off; };
+    auto fragT = [&](int li) -> const float* { return e->pkBwd[li] >= 0 ? W + p.wpack + e->pkBwd[li] : nullptr; };
     auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     float* part = W + p.partial;
@@ -382,10 +446,10 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     {
         const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
         CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), part, s));
-        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), nullptr, nullptr, W + p.dr2, s));
+        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, s));
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
         CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), part, s));
-        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), nullptr, nullptr, W + p.dr1, s));
+        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, s));
         const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
         CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), part, s));
     }
@@ -397,7 +461,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
         CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), nullptr, nullptr, cur, s));
+        CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, s));
     }
     for (int k = nred - 1; k >= 0; --k) {
         const int refl = e->redReflect[k];
@@ -405,7 +469,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
         const ConvGeom gr = make_geom(B, hi, ti, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1);
         CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), nullptr, nullptr, oth, s));
+        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, s));
         if (refl) {
             CK(reflect_fold(oth, cur, B, hi, hi, ti * F, s));
         } else {
@@ -423,15 +487,15 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
         // normConv_i: d loss/d w, then d loss/d dec_i
         CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), nullptr, nullptr, gDec, s));
+        CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, s));
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
-        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
+        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, nullptr, params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
         // decConv_i
         CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), nullptr, nullptr, dH, s));
+        CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, s));
         // expConv_i: ReLU gate (H > 0) applied where dH is consumed; skip path adds d loss/d act[i+1]
         CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), part, s));
-        CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), nullptr, cur, oth, s));
+        CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), fragT(le), nullptr, cur, oth, s));
         float* tmp = cur; cur = oth; oth = tmp;
     }
     // mainConv1 (input-facing: no backward-data)
@@ -458,6 +522,28 @@ static bool geom_ok(const ConvGeom& g)
     return true;
 }
 
+// scratch owned by the library for the single-operator entry points (parity tests): packing raw Keras-layout
+// weights into MFMA fragments needs a device buffer, allocated on first use -- the engine path never does this.
+static float* g_op_frag = nullptr;
+static PackJob* g_op_job = nullptr;
+static int op_pack(const ConvGeom& g, const float* w, hipStream_t s)
+{
+    const size_t n = mfma_conv_wfrag_floats(g.Cin, g.Cout);
+    if (n == 0) { set_error("probav_conv3d_forward: channel configuration not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
+    if (!g_op_frag) {
+        hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
+        if (err == hipSuccess) err = hipMalloc((void**)&g_op_job, sizeof(PackJob));
+        if (err != hipSuccess) { set_error("probav_conv3d_forward: scratch allocation", err); return PROBAV_EHIP; }
+    }
+    if (n * sizeof(float) > ((size_t)4 << 20)) { set_error("probav_conv3d_forward: fragment scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+    PackJob J; memset(&J, 0, sizeof(J));
+    mfma_conv_pack_job(J, g.Cin, g.Cout);
+    hipError_t err = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = hipMemcpy(g_op_job, &J, sizeof(J), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { set_error("probav_conv3d_forward: job upload", err); return PROBAV_EHIP; }
+    return mfma_pack(g_op_job, 1, w, w, g_op_frag, s);
+}
+
 int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w, const float* bias,
                           const float* skip, float* y, int impl, void* stream)
 {
@@ -466,25 +552,32 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
     if (impl == 1) {
         if (!mfma_conv_supported(g)) { set_error("probav_conv3d_forward: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
-        return mfma_conv_forward(g, x, gate, w, bias, skip, y, (hipStream_t)stream);
+        int rc = op_pack(g, w, (hipStream_t)stream);
+        if (rc) return rc;
+        return mfma_conv_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
     }
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, (hipStream_t)stream);
 }
 
 size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl)
 {
-    (void)impl;
     if (!geom) return 0;
-    return wgrad_partial_floats(geom_from(geom)) * sizeof(float);
+    const ConvGeom g = geom_from(geom);
+    if (impl == 1) return mfma_wgrad_supported(g) ? mfma_wgrad_partial_floats(g) * sizeof(float) : 0;
+    return wgrad_partial_floats(g) * sizeof(float);
 }
 
 int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy, const float* gate, float* dw, float* db,
                         void* scratch, size_t scratch_bytes, int impl, void* stream)
 {
-    (void)impl;
     if (!geom || !x || !dy || !dw || !scratch) { set_error("probav_conv3d_wgrad: null argument", hipSuccess); return PROBAV_EINVAL; }
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_wgrad: bad geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (impl == 1) {
+        if (!mfma_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
+        if (scratch_bytes < mfma_wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+        return mfma_conv_wgrad(g, x, dy, gate, dw, db, (float*)scratch, (hipStream_t)stream);
+    }
     if (scratch_bytes < wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, (float*)scratch, (hipStream_t)stream);
 }

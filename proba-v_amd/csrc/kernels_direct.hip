@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[(long)c * n + i];
-    out[i] = s;
+    double s = 0.0;                       // fp64 across chunks: the filter gradient is a sum with heavy cancellation
+    for (int c = 0; c < chunks; ++c) s += (double)partial[(long)c * n + i];
+    out[i] = (float)s;
 }
 
 static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& chunks, long& vpc)

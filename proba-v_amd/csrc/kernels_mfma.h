@@ -1,0 +1,33 @@
+// Host-visible interface of kernels_mfma.hip (fp32-MFMA kernels + weight fragment packing).
+#pragma once
+#include "probav_common.h"
+
+namespace probav {
+
+enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4 };
+
+// One packing job: effective weights (weff / weffT, layout [tap][Cin][Cout]) -> MFMA operand fragments.
+struct PackJob {
+    int type, src_is_T;
+    long src_off, dst_off, count;     // offsets in floats; count = floats written (multiple of 256)
+    int Cin, Cout, CC, KS, taps;
+};
+
+int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, hipStream_t s);
+
+bool mfma_conv_supported(const ConvGeom& g);
+size_t mfma_conv_wfrag_floats(int Cin, int Cout);          // 0 = this channel configuration is not packed
+void mfma_conv_pack_job(PackJob& J, int Cin, int Cout);    // fills type/Cin/Cout/CC/KS/taps/count
+int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
+                      const float* skip, float* y, hipStream_t s);
+
+bool mfma_wgrad_supported(const ConvGeom& g);
+size_t mfma_wgrad_partial_floats(const ConvGeom& g);
+int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db,
+                    float* partial, hipStream_t s);
+
+bool mfma_pw_supported(int F, int E, int D);
+int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
+                    long nvox, int D, hipStream_t s);
+
+}  // namespace probav

@@ -1,11 +1,546 @@
-// MFMA kernels (placeholder until the fp32-MFMA implicit-GEMM kernels land): nothing supported yet,
-// so the engine routes every layer through the generic direct kernels.
+// fp32 MFMA kernels for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
+//
+//  conv3_mfma_kernel        3x3x3 convolution as an im2col-free implicit GEMM: M = 32 output voxels,
+//                           N = 32 output channels, K = (tap, cin).  The input halo tile of a few output rows
+//                           is staged ONCE in LDS ([row][w][t][c], odd channel stride => conflict-free
+//                           ds_read_b32); the A operand of every one of the 27 taps is the same LDS image
+//                           read at a shifted address, the B operand (filter) streams from L2 in a
+//                           pre-packed fragment order.  Forward and backward-data (flipped, channel-swapped
+//                           filter) are the same kernel.
+//  conv3_wgrad_mfma_kernel  backward-filter: M = 32 rows of the flattened (tap, cin) filter matrix, N = cout,
+//                           K = output voxels.  Persistent workgroups keep the filter-gradient tiles in
+//                           accumulators across all their row tiles; per-workgroup slabs are summed in a fixed
+//                           order afterwards (bitwise reproducible, no float atomics).
+//  pw_fwd_mfma_kernel       fused expConv(1x1x1, 32->256)+ReLU -> decConv(1x1x1, 256->25): the 256-channel
+//                           tensor lives only in accumulators (the first product's accumulator tile is the next
+//                           MFMA's B operand, no LDS round trip), 1 KB/voxel/block of HBM traffic removed.
+//
+// Lane maps (MI355X guide §3): A: lane l holds A[i = l&31][k = l>>5]; B: B[k = l>>5][j = l&31];
+// D: register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 #include "probav_common.h"
+#include "kernels_mfma.h"
+
 namespace probav {
-bool mfma_conv_supported(const ConvGeom&) { return false; }
-int mfma_conv_forward(const ConvGeom&, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+__device__ __forceinline__ int fdiv(int v, int d, unsigned m) { return d == 1 ? v : (int)__umulhi((unsigned)v, m); }
+__device__ __forceinline__ int reflect_clamped(int i, int n)
 {
-    set_error("mfma_conv_forward: not built", hipSuccess);
-    return PROBAV_EINVAL;
+    i = i < -(n - 1) ? -(n - 1) : (i > 2 * n - 2 ? 2 * n - 2 : i);
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
 }
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+static unsigned magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+// XCD-aware block remap (guide §5.5 T1, bijective form): blocks b and b+8 share an XCD, so give each XCD a
+// contiguous run of (patch, row) tiles -- neighbouring rows re-read each other's halo rows from that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight fragment packing (one launch per forward for all layers)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ weff,
+                                                  const float* __restrict__ weffT, float* __restrict__ wpack)
+{
+    const PackJob J = jobs[blockIdx.y];
+    const float* src = (J.src_is_T ? weffT : weff) + J.src_off;
+    float* dst = wpack + J.dst_off;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < J.count; i += (long)gridDim.x * 256) {
+        const int u = (int)(i & 3), lane = (int)((i >> 2) & 63), half = lane >> 5, col = lane & 31;
+        long q = i >> 8;                                   // float4 index (per lane)
+        float v = 0.f;
+        if (J.type == PACK_CONV) {
+            // [chunk][tap][q4][lane][4]; step s = 4*q4+u; k-pair channel = 2s+half of chunk
+            const int KS4 = (J.KS + 3) >> 2;
+            const int q4 = (int)(q % KS4); q /= KS4;
+            const int tap = (int)(q % J.taps), chunk = (int)(q / J.taps);
+            const int s = 4 * q4 + u, cl = 2 * s + half, ci = chunk * J.CC + cl;
+            if (s < J.KS && cl < J.CC && ci < J.Cin && col < J.Cout) v = src[((long)tap * J.Cin + ci) * J.Cout + col];
+        } else if (J.type == PACK_PW_A_KCIN) {
+            // A[i = hch col of chunk c][k: cin = 16*half + s]   from W1 [cin 32][hch 256];  [c][q4][lane][4]
+            const int q4 = (int)(q & 3), c = (int)(q >> 2), s = 4 * q4 + u;
+            v = src[(long)(16 * half + s) * J.Cout + 32 * c + col];
+        } else if (J.type == PACK_PW_A_KHCH) {
+            // A[i = out col][k: hch = 32c + rowmap(s, half)]      from W2 [hch 256][out 25];  [c][q4][lane][4]
+            const int q4 = (int)(q & 3), c = (int)(q >> 2), s = 4 * q4 + u;
+            if (col < J.Cout) v = src[(long)(32 * c + (s & 3) + 8 * (s >> 2) + 4 * half) * J.Cout + col];
+        } else if (J.type == PACK_PW_A_KOUT) {
+            // A[i = hch col of chunk c][k: out = 13*half + s], s < 13 (16 slots)  from W2 [hch][out]
+            const int q4 = (int)(q & 3), c = (int)(q >> 2), s = 4 * q4 + u, o = 13 * half + s;
+            if (s < 13 && o < J.Cout) v = src[(long)(32 * c + col) * J.Cout + o];
+        } else if (J.type == PACK_PW_A_CIN_KHCH) {
+            // A[i = cin col][k: hch = 32c + rowmap(s, half)]     from W1 [cin 32][hch 256]
+            const int q4 = (int)(q & 3), c = (int)(q >> 2), s = 4 * q4 + u;
+            v = src[(long)col * J.Cout + 32 * c + (s & 3) + 8 * (s >> 2) + 4 * half];
+        }
+        dst[i] = v;
+    }
+}
+
+int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, hipStream_t s)
+{
+    if (njobs <= 0) return PROBAV_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(32, njobs), dim3(256), 0, s, d_jobs, weff, weffT, wpack);
+    return check_launch("mfma_pack");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shared: stage the input halo tile of `rows` rows into LDS, [r][wp][tp][c] with channel stride CP
+// ---------------------------------------------------------------------------------------------------
+struct TileArgs {
+    ConvGeom g;
+    int R, rows, Wp, Tp;          // output rows per tile, staged rows (R + kh - 1), staged width / depth
+    int ntile_rows;               // ceil(Ho / R)
+    unsigned mTp, mWp, mTo, mWoTo;
+};
+
+template <int CC, int CP>
+__device__ __forceinline__ void fill_tile(const TileArgs& a, float* lds, const float* __restrict__ x,
+                                          const float* __restrict__ gate, int n, int h0, int c0, int tid)
+{
+    const ConvGeom& g = a.g;
+    const int nvox = a.rows * a.Wp * a.Tp;
+    constexpr int V = (CC % 4 == 0) ? 4 : 1;
+    constexpr int CG = CC / V;
+    for (int idx = tid; idx < nvox * CG; idx += 256) {
+        const int vox = idx / CG, cg = idx - vox * CG;
+        const int q = fdiv(vox, a.Tp, a.mTp), tp = vox - q * a.Tp;
+        const int r = fdiv(q, a.Wp, a.mWp), wp = q - r * a.Wp;
+        int ih = h0 + r - g.ph, iw = wp - g.pw;
+        const int it = tp - g.pt;
+        bool ok = it >= 0 && it < g.Ti;
+        if (g.reflect_hw) { ih = reflect_clamped(ih, g.Hi); iw = reflect_clamped(iw, g.Wi); }
+        else ok = ok && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+        float* d = lds + vox * CP + cg * V;
+        if constexpr (V == 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const long src = ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + c0 + cg * 4;
+                v = *reinterpret_cast<const float4*>(x + src);
+                if (gate) {
+                    const float4 m = *reinterpret_cast<const float4*>(gate + src);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+            }
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            float v = 0.f;
+            if (ok) {
+                const long src = ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + c0 + cg;
+                v = x[src];
+                if (gate) v = gate[src] > 0.f ? v : 0.f;
+            }
+            d[0] = v;
+        }
+    }
+    if (tid == 0) lds[nvox * CP] = 0.f;      // slack word: the odd-K alias read of the last voxel lands here
+}
+
+// LDS float offset of output voxel `vi` of the tile (row-major over (rr, w, t)) at tap (0,0,0)
+__device__ __forceinline__ int tile_voxel_off(const TileArgs& a, int vi, int CP)
+{
+    const int rr = fdiv(vi, a.g.Wo * a.g.To, a.mWoTo), rem = vi - rr * a.g.Wo * a.g.To;
+    const int w = fdiv(rem, a.g.To, a.mTo), t = rem - w * a.g.To;
+    return ((rr * a.Wp + w) * a.Tp + t) * CP;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv3 forward / backward-data
+// ---------------------------------------------------------------------------------------------------
+template <int CC, int KS, int MT>
+__device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0, const float* ldsA1,
+                                          const float4* __restrict__ wf, f32x16& acc0, f32x16& acc1)
+{
+    constexpr int CP = (CC & 1) ? CC : CC + 1;
+    constexpr int KS4 = (KS + 3) / 4;
+    float4 bcur[KS4];
+#pragma unroll
+    for (int q = 0; q < KS4; ++q) bcur[q] = wf[q * 64];
+    for (int tap = 0; tap < 27; ++tap) {
+        float4 bnxt[KS4];
+        const int tn = tap + 1 < 27 ? tap + 1 : tap;
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) bnxt[q] = wf[(tn * KS4 + q) * 64];
+        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
+        const int toff = ((dh * a.Wp + dw) * a.Tp + dt) * CP;
+        const float* p0 = ldsA0 + toff;
+        const float* p1 = ldsA1 + toff;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float b = f4c(bcur[s >> 2], s & 3);
+            acc0 = MFMA32(p0[2 * s], b, acc0);
+            if (MT == 2) acc1 = MFMA32(p1[2 * s], b, acc1);
+        }
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) bcur[q] = bnxt[q];
+    }
+}
+
+template <int CC, int KS>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
+                                                           const float4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                           const float* __restrict__ skip, float* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CP = (CC & 1) ? CC : CC + 1;
+    constexpr int KS4 = (KS + 3) / 4;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = wg / a.ntile_rows, h0 = (wg - n * a.ntile_rows) * a.R;
+    const int Rr = g.Ho - h0 < a.R ? g.Ho - h0 : a.R;
+    const int nv = Rr * g.Wo * g.To, ntiles = (nv + 31) >> 5;
+    const int nchunk = g.Cin / CC;
+    const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
+
+    for (int pass = 0; pass * 8 < ntiles; ++pass) {
+        const int t0 = pass * 8 + 2 * wave, t1 = t0 + 1;
+        const bool v0 = t0 < ntiles, v1 = t1 < ntiles;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        int vi0 = t0 * 32 + col, vi1 = t1 * 32 + col;
+        vi0 = vi0 < nv ? vi0 : nv - 1; vi1 = vi1 < nv ? vi1 : nv - 1;
+        const float* ldsA0 = lds + tile_voxel_off(a, vi0, CP) + half;
+        const float* ldsA1 = lds + tile_voxel_off(a, vi1, CP) + half;
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            if (pass == 0 || nchunk > 1) {
+                if (pass > 0 || chunk > 0) __syncthreads();
+                fill_tile<CC, CP>(a, lds, x, gate, n, h0, chunk * CC, tid);
+                __syncthreads();
+            }
+            const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
+            if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
+            else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1);
+        }
+        // epilogue: D row = output voxel, column = output channel
+        const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+#pragma unroll
+        for (int tsel = 0; tsel < 2; ++tsel) {
+            const int tt = tsel ? t1 : t0;
+            if (tt >= ntiles) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int vi = tt * 32 + rowmap(r, half);
+                if (vi < nv && col < g.Cout) {
+                    const long o = (out_base + vi) * g.Cout + col;
+                    float v = (tsel ? acc1[r] : acc0[r]) + bv;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (skip) v += skip[o];
+                    y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+struct ConvPlan { bool ok; int CC, KS, R; size_t lds_bytes; TileArgs a; };
+
+static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
+{
+    ConvPlan p;
+    p.ok = false;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3) return p;
+    if (g.Cout > 32 && !all_channels) return p;
+    int CC;
+    if (all_channels) CC = g.Cin;                           // wgrad stages every input channel
+    else if (g.Cin == 25) CC = 25;
+    else if (g.Cin % 16 == 0) CC = 16;
+    else return p;
+    if (all_channels && g.Cin != 25 && g.Cin != 32) return p;
+    // consistency of the geometry: a stride-1 correlation with these pads
+    if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return p;
+    const int CP = (CC & 1) ? CC : CC + 1;
+    const int Wp = g.Wo + 2, Tp = g.To + 2;
+    int R = 0;
+    size_t lds = 0;
+    const size_t lim2 = 81920, lim1 = 163840;
+    for (int r = 1; r <= g.Ho; ++r) {
+        const size_t need = ((size_t)(r + 2) * Wp * Tp * CP + 4) * sizeof(float);
+        const int nv = r * g.Wo * g.To;
+        if (r > 1 && (nv > 256 || need > lim2)) break;
+        if (r == 1 && need > lim1) return p;
+        R = r; lds = need;
+    }
+    if (R == 0) return p;
+    if (R * g.Wo * g.To > 512) return p;                    // at most two passes of 8 tiles
+    p.ok = true; p.CC = CC; p.KS = (CC + 1) / 2; p.R = R; p.lds_bytes = (lds + 15) & ~(size_t)15;
+    p.a.g = g; p.a.R = R; p.a.rows = R + 2; p.a.Wp = Wp; p.a.Tp = Tp; p.a.ntile_rows = (g.Ho + R - 1) / R;
+    p.a.mTp = magic(Tp); p.a.mWp = magic(Wp); p.a.mTo = magic(g.To); p.a.mWoTo = magic(g.Wo * g.To);
+    return p;
+}
+
+bool mfma_conv_supported(const ConvGeom& g) { return conv_plan(g, false).ok; }
+
+size_t mfma_conv_wfrag_floats(int Cin, int Cout)
+{
+    if (Cout > 32) return 0;
+    int CC;
+    if (Cin == 25) CC = 25; else if (Cin % 16 == 0) CC = 16; else return 0;
+    const int KS = (CC + 1) / 2, KS4 = (KS + 3) / 4;
+    return (size_t)(Cin / CC) * 27 * KS4 * 256;
+}
+
+void mfma_conv_pack_job(PackJob& J, int Cin, int Cout)
+{
+    J.type = PACK_CONV; J.Cin = Cin; J.Cout = Cout; J.taps = 27;
+    J.CC = Cin == 25 ? 25 : 16; J.KS = (J.CC + 1) / 2;
+    J.count = (long)mfma_conv_wfrag_floats(Cin, Cout);
+}
+
+template <typename K>
+static void allow_big_lds(K kernel)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+}
+
+int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
+                      const float* skip, float* y, hipStream_t s)
+{
+    const ConvPlan p = conv_plan(g, false);
+    if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
+    static bool once = false;
+    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13>); allow_big_lds(conv3_mfma_kernel<16, 8>); once = true; }
+    if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    return check_launch("conv3_mfma");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv3 backward-filter
+// ---------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, int total_tiles, const float* __restrict__ x,
+                                                                 const float* __restrict__ dy, const float* __restrict__ gate,
+                                                                 float* __restrict__ partial, float* __restrict__ partial_b)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CP = (CIN & 1) ? CIN : CIN + 1;
+    constexpr int KR = 27 * CIN;                    // rows of the flattened filter matrix
+    constexpr int NMT = (KR + 31) / 32;             // M tiles (22 for Cin 25, 27 for Cin 32)
+    constexpr int MTW = (NMT + 3) / 4;              // M tiles per wave
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+
+    // per-lane LDS offset of filter-matrix row (tap, ci) for each M tile this wave owns
+    int offA[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int row = (wave + 4 * j) * 32 + col;
+        const int tap = row / CIN, ci = row - tap * CIN;
+        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
+        offA[j] = (row < KR) ? ((dh * a.Wp + dw) * a.Tp + dt) * CP + ci : 0;
+    }
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / a.ntile_rows, h0 = (tile - n * a.ntile_rows) * a.R;
+        const int Rr = g.Ho - h0 < a.R ? g.Ho - h0 : a.R;
+        const int nv = Rr * g.Wo * g.To, nsteps = (nv + 1) >> 1;
+        const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
+        __syncthreads();
+        fill_tile<CIN, CP>(a, lds, x, nullptr, n, h0, 0, tid);
+        __syncthreads();
+        // B operand: dy[voxel 2s+half][col], prefetched PF steps ahead
+        constexpr int PF = 4;
+        float bq[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int vi = 2 * u + half;
+            float d = 0.f;
+            if (vi < nv && col < g.Cout) {
+                const long o = (out_base + vi) * g.Cout + col;
+                d = dy[o];
+                if (gate) d = gate[o] > 0.f ? d : 0.f;
+            }
+            bq[u] = d;
+        }
+        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+            float bn[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int vi = 2 * (s0 + PF + u) + half;
+                float d = 0.f;
+                if (vi < nv && col < g.Cout) {
+                    const long o = (out_base + vi) * g.Cout + col;
+                    d = dy[o];
+                    if (gate) d = gate[o] > 0.f ? d : 0.f;
+                }
+                bn[u] = d;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (s0 + u < nsteps) {
+                    int vi = 2 * (s0 + u) + half;
+                    vi = vi < nv ? vi : nv - 1;
+                    const float* pv = lds + tile_voxel_off(a, vi, CP);
+                    const float b = bq[u];
+                    bsum += b;
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j)
+                        if (wave + 4 * j < NMT) acc[j] = MFMA32(pv[offA[j]], b, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) bq[u] = bn[u];
+        }
+    }
+    // slab of this workgroup: [KR][Cout]
+    float* pp = partial + (long)blockIdx.x * KR * g.Cout;
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        if (wave + 4 * j >= NMT) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wave + 4 * j) * 32 + rowmap(r, half);
+            if (row < KR && col < g.Cout) pp[(long)row * g.Cout + col] = acc[j][r];
+        }
+    }
+    if (wave == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (half == 0 && col < g.Cout) partial_b[(long)blockIdx.x * g.Cout + col] = bsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int slabs)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
+    out[i] = (float)s;
+}
+
+static int wgrad_grid(const ConvPlan& p, const ConvGeom& g)
+{
+    const int total = g.N * p.a.ntile_rows;
+    const int per_cu = p.lds_bytes <= 81920 ? 2 : 1;
+    int grid = 256 * per_cu;
+    return grid < total ? grid : total;
+}
+
+bool mfma_wgrad_supported(const ConvGeom& g)
+{
+    if (g.Cout > 32) return false;
+    return conv_plan(g, true).ok;
+}
+
+size_t mfma_wgrad_partial_floats(const ConvGeom& g)
+{
+    const ConvPlan p = conv_plan(g, true);
+    if (!p.ok) return 0;
+    return (size_t)wgrad_grid(p, g) * ((size_t)27 * g.Cin * g.Cout + g.Cout);
+}
+
+int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db,
+                    float* partial, hipStream_t s)
+{
+    const ConvPlan p = conv_plan(g, true);
+    if (!p.ok || g.Cout > 32) { set_error("mfma_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    const int grid = wgrad_grid(p, g), total = g.N * p.a.ntile_rows;
+    const long nw = (long)27 * g.Cin * g.Cout;
+    float* partial_b = partial + (size_t)grid * nw;
+    static bool once = false;
+    if (!once) { allow_big_lds(conv3_wgrad_mfma_kernel<25>); allow_big_lds(conv3_wgrad_mfma_kernel<32>); once = true; }
+    if (g.Cin == 25) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<25>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
+    else             hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<32>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
+    int rc = check_launch("conv3_wgrad_mfma");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, partial, dw, nw, grid);
+    if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)g.Cout, grid);
+    return check_launch("reduce_slabs");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused expConv + ReLU + decConv forward (1x1x1, F=32 -> E=256 -> D<=32)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void pw_fwd_mfma_kernel(const float* __restrict__ x, const float4* __restrict__ w1frag,
+                                                            const float4* __restrict__ w2frag, const float* __restrict__ b1,
+                                                            const float* __restrict__ b2, float* __restrict__ dec,
+                                                            long nvox, int D)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* sW1 = reinterpret_cast<float4*>(lds);              // [8 chunks][4][64] float4  (32 KB)
+    float4* sW2 = sW1 + 8 * 4 * 64;                              // same (32 KB)
+    float* sB1 = reinterpret_cast<float*>(sW2 + 8 * 4 * 64);    // 256
+    float* sB2 = sB1 + 256;                                      // 32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    for (int i = tid; i < 8 * 4 * 64; i += 256) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
+    sB1[tid] = b1[tid];
+    if (tid < 32) sB2[tid] = tid < D ? b2[tid] : 0.f;
+    __syncthreads();
+
+    const long ntiles = (nvox + 31) >> 5;
+    const long wstride = (long)gridDim.x * 4;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+        long v = tile * 32 + col;
+        const bool vok = v < nvox;
+        if (!vok) v = nvox - 1;
+        // B operand of the first product: X^T, k = (s, half) <-> cin = 16*half + s
+        float xs[16];
+        const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 16 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t = xp[q]; xs[4 * q] = t.x; xs[4 * q + 1] = t.y; xs[4 * q + 2] = t.z; xs[4 * q + 3] = t.w; }
+        f32x16 T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[r] = sB2[rowmap(r, half)];
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            f32x16 H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H[r] = sB1[32 * c + rowmap(r, half)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 aw = sW1[(c * 4 + q) * 64 + lane];
+                H = MFMA32(aw.x, xs[4 * q], H); H = MFMA32(aw.y, xs[4 * q + 1], H);
+                H = MFMA32(aw.z, xs[4 * q + 2], H); H = MFMA32(aw.w, xs[4 * q + 3], H);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H[r] = fmaxf(H[r], 0.f);
+            // second product contracts over the hidden channels = the ROW index of H: accumulator registers
+            // feed the B operand directly (k-step s <-> register s, k = lane half)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 aw = sW2[(c * 4 + q) * 64 + lane];
+                T = MFMA32(aw.x, H[4 * q], T); T = MFMA32(aw.y, H[4 * q + 1], T);
+                T = MFMA32(aw.z, H[4 * q + 2], T); T = MFMA32(aw.w, H[4 * q + 3], T);
+            }
+        }
+        if (vok) {
+            float* o = dec + v * D;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = rowmap(r, half);
+                if (ch < D) o[ch] = T[r];
+            }
+        }
+    }
+}
+
+bool mfma_pw_supported(int F, int E, int D) { return F == 32 && E == 256 && D >= 1 && D <= 26; }
+
+int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
+                    long nvox, int D, hipStream_t s)
+{
+    static bool once = false;
+    if (!once) { allow_big_lds(pw_fwd_mfma_kernel); once = true; }
+    const size_t lds = (size_t)(2 * 8 * 4 * 64 * 4 + 256 + 32) * sizeof(float);
+    hipLaunchKernelGGL(pw_fwd_mfma_kernel, dim3(512), dim3(256), lds, s, x, (const float4*)w1frag, (const float4*)w2frag, b1, b2, dec, nvox, D);
+    return check_launch("pw_fwd_mfma");
+}
+
 }  // namespace probav
