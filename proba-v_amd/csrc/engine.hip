@@ -34,6 +34,7 @@ struct probav_engine {
     int64_t wpack_count = 0;
     std::vector<long> pkFwd, pkBwd;          // per layer: conv fragments for forward / backward-data (-1 = none)
     std::vector<long> pkW1, pkW2;            // per block: fused expand/decay forward fragments
+    std::vector<long> pkW2B, pkW1C;          // per block: extra fragments of the fused backward
     bool pw_mfma = false;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
     bool prof_on = false;
@@ -189,6 +190,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
             if (mfma_wgrad_supported(g)) { const size_t q2 = mfma_wgrad_partial_floats(g); if (q2 > q) q = q2; }
             if (q > pmax) pmax = q;
         }
+        if (e->pw_mfma && mfma_pw_backward_slab_floats(D) > pmax) pmax = mfma_pw_backward_slab_floats(D);
         p.partial = take(pmax);
     }
     p.total = off;
@@ -291,6 +293,11 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             J.type = PACK_PW_A_KHCH; J.src_off = e->layers[e->iDec[i]].wn.w_off; J.dst_off = e->wpack_count;
             J.Cin = E; J.Cout = D;
             e->pkW2.push_back(J.dst_off); e->wpack_count += J.count; e->jobs.push_back(J);
+            J.type = PACK_PW_A_KOUT; J.dst_off = e->wpack_count;                      // backward (b): dH^T = W2 dT^T
+            e->pkW2B.push_back(J.dst_off); e->wpack_count += J.count; e->jobs.push_back(J);
+            J.type = PACK_PW_A_CIN_KHCH; J.src_off = e->layers[e->iExp[i]].wn.w_off; J.dst_off = e->wpack_count;
+            J.Cin = F; J.Cout = E;                                                    // backward (c): dX^T += W1 dH'^T
+            e->pkW1C.push_back(J.dst_off); e->wpack_count += J.count; e->jobs.push_back(J);
         }
     }
     if (!e->jobs.empty()) {
@@ -488,6 +495,15 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         // normConv_i: d loss/d w, then d loss/d dec_i
         CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, s));
         CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, s));
+        if (e->impl >= 1 && e->pw_mfma) {
+            // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
+            const long nvox = (long)B * Hin * Hin * T;
+            ProfScope ps(e, CLS_PW_BWD_DATA, (double)nvox * (3.0 * F * E + 2.0 * E * D), s);
+            CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
+                                params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
+            float* tmp2 = cur; cur = oth; oth = tmp2;
+            continue;
+        }
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
         CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, nullptr, params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
         // decConv_i

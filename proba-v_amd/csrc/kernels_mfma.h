@@ -30,4 +30,10 @@ bool mfma_pw_supported(int F, int E, int D);
 int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                     long nvox, int D, hipStream_t s);
 
+size_t mfma_pw_backward_slab_floats(int D);
+// dX = dOut + d(expand,decay)/dX ; dW1 [32][256], dW2 [256][D], db1 [256], db2 [D] (all overwritten)
+int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1kcin, const float* w2kout,
+                     const float* w1khch, const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2,
+                     float* slabs, long nvox, int D, hipStream_t s);
+
 }  // namespace probav

@@ -418,11 +418,19 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int slabs)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
-    out[i] = (float)s;
+    // 64 elements x 4 interleaved partial sums per block (fixed order => bitwise reproducible), fp64 accumulation
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    __shared__ double red[4][64];
+    double a0 = 0.0, a1 = 0.0;
+    if (i < n) {
+        int c = part;
+        for (; c + 4 < slabs; c += 8) { a0 += (double)partial[(long)c * n + i]; a1 += (double)partial[(long)(c + 4) * n + i]; }
+        if (c < slabs) a0 += (double)partial[(long)c * n + i];
+    }
+    red[part][threadIdx.x & 63] = a0 + a1;
+    __syncthreads();
+    if (part == 0 && i < n) out[i] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 static int wgrad_grid(const ConvPlan& p, const ConvGeom& g)
@@ -460,7 +468,7 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
     else             hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<32>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
     int rc = check_launch("conv3_wgrad_mfma");
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, partial, dw, nw, grid);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, grid);
     if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)g.Cout, grid);
     return check_launch("reduce_slabs");
 }
@@ -541,6 +549,221 @@ int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, co
     const size_t lds = (size_t)(2 * 8 * 4 * 64 * 4 + 256 + 32) * sizeof(float);
     hipLaunchKernelGGL(pw_fwd_mfma_kernel, dim3(512), dim3(256), lds, s, x, (const float4*)w1frag, (const float4*)w2frag, b1, b2, dec, nvox, D);
     return check_launch("pw_fwd_mfma");
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// fused backward of expConv + ReLU + decConv (1x1x1): per 32-voxel tile and 32-channel hidden chunk c
+//   (a) H^T_c  = W1^T X^T + b1            M = hidden, N = voxel, K = cin      (recompute; never stored)
+//   (b) dH^T_c = W2 dT^T                  M = hidden, N = voxel, K = out(25)
+//       dH'    = dH * [H > 0]             same register layout -> elementwise
+//   (c) dX^T  += W1 dH'^T_c               K = hidden = ROW index of dH'^T: accumulator registers are the B operand
+//   (d) dW1_c += X^T dH'_c                K = voxel: needs dH' with the voxel on the K index -> one in-wave LDS transpose
+//   (e) dW2_c += H'^T_c dT                K = voxel: same transpose buffer, reused after (d)
+// One launch handles 4 of the 8 hidden chunks (template CH0 = 0 or 4): a wave then keeps dW1, dW2 of its chunks in
+// 2 x 4 x 16 accumulator registers across ALL its tiles (one wave per SIMD, ~400 registers); the second launch adds
+// its share of dX in place.  Waves never synchronise with each other after the weight fragments are in LDS; the
+// per-wave slabs are reduced afterwards in a fixed order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PWB_WAVES = 4;
+constexpr int PWB_WAVE_LDS = 32 * 33 + 32 * 33 + 32 * 27;          // Tb | Xb | Db   (floats)
+
+template <int CH0>
+__global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dT, const float* dOut,
+    const float4* __restrict__ w1kcin, const float4* __restrict__ w2kout, const float4* __restrict__ w1khch,
+    const float* __restrict__ b1, float* dX, float* __restrict__ slabs, long nvox, int D)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* sW1 = reinterpret_cast<float4*>(lds);               // (a)  [4][4][64] float4
+    float4* sW2 = sW1 + 4 * 4 * 64;                               // (b)  (slots 13..15 zero)
+    float4* sW3 = sW2 + 4 * 4 * 64;                               // (c)
+    float* sB1 = reinterpret_cast<float*>(sW3 + 4 * 4 * 64);     // 128
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    float* Tb = sB1 + 128 + wave * PWB_WAVE_LDS;                  // transpose buffer [vox][33]
+    float* Xb = Tb + 32 * 33;                                      // X tile          [vox][33]
+    float* Db = Xb + 32 * 33;                                      // dT tile         [vox][27]
+    for (int i = tid; i < 4 * 4 * 64; i += 64 * PWB_WAVES) {
+        sW1[i] = w1kcin[CH0 * 4 * 64 + i]; sW2[i] = w2kout[CH0 * 4 * 64 + i]; sW3[i] = w1khch[CH0 * 4 * 64 + i];
+    }
+    if (tid < 128) sB1[tid] = b1[32 * CH0 + tid];
+    __syncthreads();
+
+    f32x16 dW1[4], dW2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dW1[c][r] = 0.f; dW2[c][r] = 0.f; }
+    float bs1[4] = {0.f, 0.f, 0.f, 0.f};
+    float bs2 = 0.f;
+
+    const long ntiles = (nvox + 31) >> 5;
+    const long wstride = (long)gridDim.x * PWB_WAVES;
+    for (long tile = (long)blockIdx.x * PWB_WAVES + wave; tile < ntiles; tile += wstride) {
+        const long v0 = tile * 32;
+        long v = v0 + col;
+        const bool vok = v < nvox;
+        if (!vok) v = nvox - 1;
+        // ---- stage the X tile (lane owns 16 channels of voxel `col`) and the dT tile (flat coalesced copy) ----
+        {
+            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 16 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = xp[q];
+                float* d = Xb + col * 33 + 16 * half + 4 * q;
+                d[0] = vok ? t.x : 0.f; d[1] = vok ? t.y : 0.f; d[2] = vok ? t.z : 0.f; d[3] = vok ? t.w : 0.f;
+            }
+            const long nrem = (nvox - v0 < 32 ? nvox - v0 : 32) * D;
+            for (int f = lane; f < 32 * D; f += 64) {
+                const int vv = f / D, oo = f - vv * D;
+                Db[vv * 27 + oo] = f < nrem ? dT[v0 * D + f] : 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (CH0 == 0) {   // db2 partial: column sums of the dT tile (lane (half, out col) sums its 16 voxels)
+            float t2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) t2 += col < D ? Db[(2 * s + half) * 27 + col] : 0.f;
+            bs2 += t2;
+        }
+        f32x16 dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            asm volatile("" ::: "memory");           // chunk boundary: LDS operand reads are re-issued per chunk, not held
+            f32x16 H, dH;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { H[r] = sB1[32 * c + rowmap(r, half)]; dH[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                               // (a)
+                const float4 aw = sW1[(c * 4 + q) * 64 + lane];
+                const float* xr = Xb + col * 33 + 16 * half + 4 * q;                    // B: X[vox col][16*half + s]
+                H = MFMA32(aw.x, xr[0], H); H = MFMA32(aw.y, xr[1], H);
+                H = MFMA32(aw.z, xr[2], H); H = MFMA32(aw.w, xr[3], H);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                               // (b)
+                const float4 aw = sW2[(c * 4 + q) * 64 + lane];
+                const float* dr = Db + col * 27 + 13 * half + 4 * q;                    // B: dT[vox col][13*half + s]
+                const int o = 13 * half + 4 * q;
+                dH = MFMA32(aw.x, o < D ? dr[0] : 0.f, dH);
+                if (4 * q + 1 < 13) dH = MFMA32(aw.y, o + 1 < D ? dr[1] : 0.f, dH);
+                if (4 * q + 2 < 13) dH = MFMA32(aw.z, o + 2 < D ? dr[2] : 0.f, dH);
+                if (4 * q + 3 < 13) dH = MFMA32(aw.w, o + 3 < D ? dr[3] : 0.f, dH);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dH[r] = H[r] > 0.f ? dH[r] : 0.f; H[r] = fmaxf(H[r], 0.f); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                               // (c) dX^T += W1 dH'^T
+                const float4 aw = sW3[(c * 4 + q) * 64 + lane];
+                dx = MFMA32(aw.x, dH[4 * q], dx); dx = MFMA32(aw.y, dH[4 * q + 1], dx);
+                dx = MFMA32(aw.z, dH[4 * q + 2], dx); dx = MFMA32(aw.w, dH[4 * q + 3], dx);
+            }
+            // transpose dH' through LDS: lane (voxel col, half) owns hidden rowmap(r, half)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dH[r];
+            __builtin_amdgcn_wave_barrier();
+            {
+                float t1 = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {                                          // (d) dW1_c += X^T dH'_c
+                    const float tr = Tb[(2 * s + half) * 33 + col];                     // B: dH'[vox 2s+half][hidden col]
+                    t1 += tr;
+                    dW1[c] = MFMA32(Xb[(2 * s + half) * 33 + col], tr, dW1[c]);         // A: X[vox 2s+half][cin col]
+                }
+                bs1[c] += t1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = H[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {                                              // (e) dW2_c += H'^T_c dT
+                const float db = col < D ? Db[(2 * s + half) * 27 + col] : 0.f;         // B: dT[vox 2s+half][out col]
+                dW2[c] = MFMA32(Tb[(2 * s + half) * 33 + col], db, dW2[c]);             // A: H'[vox 2s+half][hidden col]
+            }
+        }
+        // dX = dOut + (dX^T)^T : lane (voxel col, half) holds cin = rowmap(r, half) -> four aligned float4 groups
+        if (vok) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const long o = v * 32 + 8 * gq + 4 * half;
+                const float4 d0 = *reinterpret_cast<const float4*>(dOut + o);
+                float4 ov;
+                ov.x = dx[4 * gq] + d0.x; ov.y = dx[4 * gq + 1] + d0.y; ov.z = dx[4 * gq + 2] + d0.z; ov.w = dx[4 * gq + 3] + d0.w;
+                *reinterpret_cast<float4*>(dX + o) = ov;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // compact slab of this wave: [dW1 32x128 | dW2 128xD | db1 128 | db2 D]
+    const long slab_floats = 4096 + 128 * (long)D + 128 + D;
+    float* sl = slabs + ((long)blockIdx.x * PWB_WAVES + wave) * slab_floats;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = rowmap(r, half);
+            sl[(long)rw * 128 + 32 * c + col] = dW1[c][r];                             // [cin][hidden of this half]
+            if (col < D) sl[4096 + (long)(32 * c + rw) * D + col] = dW2[c][r];         // [hidden of this half][out]
+        }
+        const float b = bs1[c] + __shfl_xor(bs1[c], 32, 64);
+        if (half == 0) sl[4096 + 128 * (long)D + 32 * c + col] = b;
+    }
+    const float b2s = bs2 + __shfl_xor(bs2, 32, 64);
+    if (half == 0 && col < D) sl[4096 + 128 * (long)D + 128 + col] = CH0 == 0 ? b2s : 0.f;
+}
+
+// sums the per-wave slabs of one half-launch in fp64 and scatters into dW1 [32][256], dW2 [256][D], db1 [256], db2 [D]
+__global__ __launch_bounds__(256) void pw_bwd_reduce_kernel(const float* __restrict__ slabs, int nslabs, int ch0, int D,
+                                                           float* __restrict__ dW1, float* __restrict__ dW2,
+                                                           float* __restrict__ db1, float* __restrict__ db2)
+{
+    const long slab_floats = 4096 + 128 * (long)D + 128 + D;
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;                       // 4 partial sums per element, combined through LDS
+    __shared__ double red[4][64];
+    double acc = 0.0;
+    if (i < slab_floats)
+        for (int c = part; c < nslabs; c += 4) acc += (double)slabs[(long)c * slab_floats + i];
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part != 0 || i >= slab_floats) return;
+    const float v = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (i < 4096) { const int cin = (int)(i >> 7), j = (int)(i & 127); dW1[cin * 256 + 32 * ch0 + j] = v; }
+    else if (i < 4096 + 128 * (long)D) { const long k = i - 4096; dW2[(long)32 * ch0 * D + k] = v; }
+    else if (i < 4096 + 128 * (long)D + 128) db1[32 * ch0 + (i - 4096 - 128 * (long)D)] = v;
+    else if (ch0 == 0) db2[i - 4096 - 128 * (long)D - 128] = v;
+}
+
+static const int PW_BWD_GRID = 256;
+
+size_t mfma_pw_backward_slab_floats(int D) { return (size_t)PW_BWD_GRID * PWB_WAVES * (4096 + 128 * (size_t)D + 128 + D); }
+
+int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1kcin, const float* w2kout,
+                     const float* w1khch, const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2,
+                     float* slabs, long nvox, int D, hipStream_t s)
+{
+    static bool once = false;
+    if (!once) { allow_big_lds(pw_bwd_mfma_kernel<0>); allow_big_lds(pw_bwd_mfma_kernel<4>); once = true; }
+    const size_t lds = (size_t)(3 * 4 * 4 * 64 * 4 + 128 + PWB_WAVES * PWB_WAVE_LDS) * sizeof(float);
+    const long slab_floats = 4096 + 128 * (long)D + 128 + D;
+    const int nslabs = PW_BWD_GRID * PWB_WAVES;
+    const dim3 rgrid((unsigned)((slab_floats + 63) / 64));
+    // chunks 0..3: dX = dOut + partial ;  chunks 4..7: dX += partial (in place)
+    hipLaunchKernelGGL(pw_bwd_mfma_kernel<0>, dim3(PW_BWD_GRID), dim3(64 * PWB_WAVES), lds, s, x, dT, dOut, (const float4*)w1kcin,
+                       (const float4*)w2kout, (const float4*)w1khch, b1, dX, slabs, nvox, D);
+    hipLaunchKernelGGL(pw_bwd_reduce_kernel, rgrid, dim3(256), 0, s, slabs, nslabs, 0, D, dW1, dW2, db1, db2);
+    hipLaunchKernelGGL(pw_bwd_mfma_kernel<4>, dim3(PW_BWD_GRID), dim3(64 * PWB_WAVES), lds, s, x, dT, (const float*)dX, (const float4*)w1kcin,
+                       (const float4*)w2kout, (const float4*)w1khch, b1, dX, slabs, nvox, D);
+    hipLaunchKernelGGL(pw_bwd_reduce_kernel, rgrid, dim3(256), 0, s, slabs, nslabs, 4, D, dW1, dW2, db1, db2);
+    return check_launch("pw_bwd_mfma");
 }
 
 }  // namespace probav

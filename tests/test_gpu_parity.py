@@ -250,13 +250,36 @@ def test_end_to_end_against_golden(dev, T, impl):
     assert len(grads) == z["grad_norms"].shape[0]
     for k, (n, g) in enumerate(zip(names, grads)):
         ref_norm, ref_max = z["grad_norms"][k]
-        assert abs(np.sqrt((g ** 2).sum()) - ref_norm) < 1e-3 * ref_norm + 1e-12, n
+        # fp32 sums with heavy cancellation against an fp64 oracle; the gradient of a weight-norm gain `g` is a
+        # dot product <dw, v>/||v|| of two nearly orthogonal vectors, i.e. ill-conditioned: wider band for it
+        tol = 1e-2 if n.endswith("/g") else 2e-3
+        assert abs(np.sqrt((g ** 2).sum()) - ref_norm) < tol * ref_norm + 1e-12, n
         key = "grad/" + n
         if key in z.files:
-            assert np.abs(g - z[key]).max() < 2e-3 * ref_max, n      # fp32 sums with heavy cancellation vs an fp64 oracle
+            assert np.abs(g - z[key]).max() < tol * ref_max, n
     # inference mode (ping-pong workspace) gives the same prediction bit for bit
     with torch.no_grad():
         assert torch.equal(m(x, training=False), pred.detach())
+
+
+def test_mfma_engine_matches_direct_engine(dev):
+    """The two implementations of the engine (generic direct kernels / fp32-MFMA kernels) agree on a ragged batch."""
+    from probav_amd.loss import Losses
+    params = synth.synth_params(seed=31, perturb=True)
+    m = _model(dev, params=params)
+    lo = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(5, seed=32))
+    res = []
+    for impl in (0, 1):
+        m.set_impl(impl)
+        m.flat.grad = None
+        p = m(x, training=True)
+        lo.shiftCompensatedL1Loss(hr, mask, p).backward()
+        res.append((p.detach().clone(), [g.clone() for g in m.variable_gradients()]))
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
+    for n, g0, g1 in zip(m.variable_names, res[0][1], res[1][1]):
+        tol = 1e-2 if n.endswith("/g") else 1e-3
+        assert float((g0 - g1).abs().max()) <= tol * float(g0.abs().max()) + 1e-12, n
 
 
 def test_full_size_batch128_properties(dev):
