@@ -103,6 +103,16 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
 size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl);
 int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy, const float* gate,
                         float* dw, float* db, void* scratch, size_t scratch_bytes, int impl, void* stream);
+/* fused expConv_i (1x1x1, 32->256) + ReLU + decConv_i (1x1x1, 256->D<=26)      models/modelsTF.py:179-183
+ * x [nvox,32], w1 [32,256], b1 [256], w2 [256,D], b2 [D] -> dec [nvox,D]; the 256-channel tensor never reaches HBM */
+int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
+                      int64_t nvox, int D, void* stream);
+/* its reverse pass: d_dec [nvox,D], d_skip [nvox,32] (gradient arriving over the residual connection)
+ * -> dx = d_skip + dL/dx [nvox,32], dw1 [32,256], db1 [256], dw2 [256,D], db2 [D]                              */
+size_t probav_pw_backward_scratch_bytes(int D);
+int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1,
+                       const float* w2, float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch,
+                       size_t scratch_bytes, int64_t nvox, int D, void* stream);
 /* weight normalisation of every layer of the engine: params -> weff, weffT, inv_norm (ws-internal
  * layouts, exported for tests): sizes probav_weff_count() floats and probav_cout_total() floats      */
 int64_t probav_weff_count(const probav_engine* e);

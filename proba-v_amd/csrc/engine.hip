@@ -598,6 +598,59 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, (float*)scratch, (hipStream_t)stream);
 }
 
+// fused pointwise pair, single-operator form (packs the Keras-layout weights into MFMA fragments in library scratch)
+static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2, const float** f2b, const float** f1c)
+{
+    if (!g_op_frag) {
+        hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
+        if (err == hipSuccess) err = hipMalloc((void**)&g_op_job, sizeof(PackJob));
+        if (err != hipSuccess) { set_error("probav_pw: scratch allocation", err); return PROBAV_EHIP; }
+    }
+    static PackJob* d_jobs4 = nullptr;
+    if (!d_jobs4) { hipError_t err = hipMalloc((void**)&d_jobs4, 4 * sizeof(PackJob)); if (err != hipSuccess) { set_error("probav_pw: job allocation", err); return PROBAV_EHIP; } }
+    PackJob J[4]; memset(J, 0, sizeof(J));
+    const int types[4] = {PACK_PW_A_KCIN, PACK_PW_A_KHCH, PACK_PW_A_KOUT, PACK_PW_A_CIN_KHCH};
+    for (int k = 0; k < 4; ++k) {
+        J[k].type = types[k]; J[k].count = 8192; J[k].dst_off = 262144 + 8192 * k;       // behind the conv fragment area
+        const bool from_w1 = (k == 0 || k == 3);
+        J[k].src_is_T = from_w1 ? 0 : 1;                                                  // weff := w1, weffT := w2
+        J[k].Cin = from_w1 ? 32 : 256; J[k].Cout = from_w1 ? 256 : D;
+    }
+    hipError_t err = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = hipMemcpy(d_jobs4, J, sizeof(J), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { set_error("probav_pw: job upload", err); return PROBAV_EHIP; }
+    *f1 = g_op_frag + J[0].dst_off; *f2 = g_op_frag + J[1].dst_off; *f2b = g_op_frag + J[2].dst_off; *f1c = g_op_frag + J[3].dst_off;
+    return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, s);
+}
+
+int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
+                      int64_t nvox, int D, void* stream)
+{
+    if (!x || !w1 || !b1 || !w2 || !b2 || !dec || nvox < 1) { set_error("probav_pw_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_forward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
+    const float *f1, *f2, *f2b, *f1c;
+    int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
+    if (rc) return rc;
+    return mfma_pw_forward(x, f1, f2, b1, b2, dec, (long)nvox, D, (hipStream_t)stream);
+}
+
+size_t probav_pw_backward_scratch_bytes(int D) { return mfma_pw_backward_slab_floats(D) * sizeof(float); }
+
+int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1, const float* w2,
+                       float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
+                       int64_t nvox, int D, void* stream)
+{
+    if (!x || !d_dec || !d_skip || !w1 || !b1 || !w2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch || nvox < 1) {
+        set_error("probav_pw_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL;
+    }
+    if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_backward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
+    if (scratch_bytes < probav_pw_backward_scratch_bytes(D)) { set_error("probav_pw_backward: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+    const float *f1, *f2, *f2b, *f1c;
+    int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
+    if (rc) return rc;
+    return mfma_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, D, (hipStream_t)stream);
+}
+
 int probav_wn_forward(probav_engine* e, const float* params, float* weff, float* weffT, float* inv_norm, void* stream)
 {
     if (!e || !params || !weff || !weffT || !inv_norm) { set_error("probav_wn_forward: null argument", hipSuccess); return PROBAV_EINVAL; }

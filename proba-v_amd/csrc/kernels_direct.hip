@@ -206,11 +206,24 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                              long n, int chunks)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;                       // fp64 across chunks: the filter gradient is a sum with heavy cancellation
-    for (int c = 0; c < chunks; ++c) s += (double)partial[(long)c * n + i];
-    out[i] = (float)s;
+    // 32 elements x 8 interleaved partial sums per block, fixed order (bitwise reproducible); fp64 across chunks:
+    // the filter gradient is a sum with heavy cancellation
+    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + e;
+    __shared__ double red[8][32];
+    double a0 = 0.0, a1 = 0.0;
+    if (i < n) {
+        int c = part;
+        for (; c + 8 < chunks; c += 16) { a0 += (double)partial[(long)c * n + i]; a1 += (double)partial[(long)(c + 8) * n + i]; }
+        if (c < chunks) a0 += (double)partial[(long)c * n + i];
+    }
+    red[part][e] = a0 + a1;
+    __syncthreads();
+    if (part != 0 || i >= n) return;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][e];
+    out[i] = (float)t;
 }
 
 static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& chunks, long& vpc)
@@ -264,8 +277,8 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     int rc = check_launch("conv_direct_wgrad");
     if (rc) return rc;
     const long nw = K * g.Cout;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), block, 0, s, partial, dw, nw, chunks);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 255) / 256)), block, 0, s, partial_b, db, (long)g.Cout, chunks);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), block, 0, s, partial, dw, nw, chunks);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), block, 0, s, partial_b, db, (long)g.Cout, chunks);
     return check_launch("reduce_partials");
 }
 

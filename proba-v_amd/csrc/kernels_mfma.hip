@@ -110,35 +110,50 @@ __device__ __forceinline__ void fill_tile(const TileArgs& a, float* lds, const f
     const int nvox = a.rows * a.Wp * a.Tp;
     constexpr int V = (CC % 4 == 0) ? 4 : 1;
     constexpr int CG = CC / V;
-    for (int idx = tid; idx < nvox * CG; idx += 256) {
-        const int vox = idx / CG, cg = idx - vox * CG;
-        const int q = fdiv(vox, a.Tp, a.mTp), tp = vox - q * a.Tp;
-        const int r = fdiv(q, a.Wp, a.mWp), wp = q - r * a.Wp;
-        int ih = h0 + r - g.ph, iw = wp - g.pw;
-        const int it = tp - g.pt;
-        bool ok = it >= 0 && it < g.Ti;
-        if (g.reflect_hw) { ih = reflect_clamped(ih, g.Hi); iw = reflect_clamped(iw, g.Wi); }
-        else ok = ok && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
-        float* d = lds + vox * CP + cg * V;
-        if constexpr (V == 4) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const long src = ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + c0 + cg * 4;
-                v = *reinterpret_cast<const float4*>(x + src);
-                if (gate) {
-                    const float4 m = *reinterpret_cast<const float4*>(gate + src);
-                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    constexpr int U = (V == 4) ? 4 : 8;             // independent loads in flight per thread before the LDS stores
+    const int total = nvox * CG;
+    for (int base = tid; base < total; base += 256 * U) {
+        float4 val[U];
+        int dof[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256;
+            dof[u] = -1;
+            val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total) {
+                const int vox = idx / CG, cg = idx - vox * CG;
+                const int q = fdiv(vox, a.Tp, a.mTp), tp = vox - q * a.Tp;
+                const int r = fdiv(q, a.Wp, a.mWp), wp = q - r * a.Wp;
+                int ih = h0 + r - g.ph, iw = wp - g.pw;
+                const int it = tp - g.pt;
+                bool ok = it >= 0 && it < g.Ti;
+                if (g.reflect_hw) { ih = reflect_clamped(ih, g.Hi); iw = reflect_clamped(iw, g.Wi); }
+                else ok = ok && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+                dof[u] = vox * CP + cg * V;
+                if (ok) {
+                    const long src = ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + c0 + cg * V;
+                    if constexpr (V == 4) {
+                        float4 v = *reinterpret_cast<const float4*>(x + src);
+                        if (gate) {
+                            const float4 m = *reinterpret_cast<const float4*>(gate + src);
+                            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                        }
+                        val[u] = v;
+                    } else {
+                        float v = x[src];
+                        if (gate) v = gate[src] > 0.f ? v : 0.f;
+                        val[u].x = v;
+                    }
                 }
             }
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        } else {
-            float v = 0.f;
-            if (ok) {
-                const long src = ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + c0 + cg;
-                v = x[src];
-                if (gate) v = gate[src] > 0.f ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (dof[u] >= 0) {
+                float* d = lds + dof[u];
+                d[0] = val[u].x;
+                if constexpr (V == 4) { d[1] = val[u].y; d[2] = val[u].z; d[3] = val[u].w; }
             }
-            d[0] = v;
         }
     }
     if (tid == 0) lds[nvox * CP] = 0.f;      // slack word: the odd-K alias read of the last voxel lands here
@@ -253,9 +268,10 @@ static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
     int CC;
     if (all_channels) CC = g.Cin;                           // wgrad stages every input channel
     else if (g.Cin == 25) CC = 25;
+    else if (g.Cin == 1) CC = 1;
     else if (g.Cin % 16 == 0) CC = 16;
     else return p;
-    if (all_channels && g.Cin != 25 && g.Cin != 32) return p;
+    if (all_channels && g.Cin != 25 && g.Cin != 32 && g.Cin != 1) return p;
     // consistency of the geometry: a stride-1 correlation with these pads
     if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return p;
     const int CP = (CC & 1) ? CC : CC + 1;
@@ -284,7 +300,7 @@ size_t mfma_conv_wfrag_floats(int Cin, int Cout)
 {
     if (Cout > 32) return 0;
     int CC;
-    if (Cin == 25) CC = 25; else if (Cin % 16 == 0) CC = 16; else return 0;
+    if (Cin == 25) CC = 25; else if (Cin == 1) CC = 1; else if (Cin % 16 == 0) CC = 16; else return 0;
     const int KS = (CC + 1) / 2, KS4 = (KS + 3) / 4;
     return (size_t)(Cin / CC) * 27 * KS4 * 256;
 }
@@ -292,7 +308,7 @@ size_t mfma_conv_wfrag_floats(int Cin, int Cout)
 void mfma_conv_pack_job(PackJob& J, int Cin, int Cout)
 {
     J.type = PACK_CONV; J.Cin = Cin; J.Cout = Cout; J.taps = 27;
-    J.CC = Cin == 25 ? 25 : 16; J.KS = (J.CC + 1) / 2;
+    J.CC = Cin == 25 ? 25 : (Cin == 1 ? 1 : 16); J.KS = (J.CC + 1) / 2;
     J.count = (long)mfma_conv_wfrag_floats(Cin, Cout);
 }
 
@@ -309,8 +325,9 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
     if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13>); allow_big_lds(conv3_mfma_kernel<16, 8>); once = true; }
-    if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13>); allow_big_lds(conv3_mfma_kernel<16, 8>); allow_big_lds(conv3_mfma_kernel<1, 1>); once = true; }
+    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     return check_launch("conv3_mfma");
 }
@@ -463,8 +480,9 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_wgrad_mfma_kernel<25>); allow_big_lds(conv3_wgrad_mfma_kernel<32>); once = true; }
-    if (g.Cin == 25) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<25>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
+    if (!once) { allow_big_lds(conv3_wgrad_mfma_kernel<25>); allow_big_lds(conv3_wgrad_mfma_kernel<32>); allow_big_lds(conv3_wgrad_mfma_kernel<1>); once = true; }
+    if (g.Cin == 1) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<1>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
+    else if (g.Cin == 25) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<25>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
     else             hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<32>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
     int rc = check_launch("conv3_wgrad_mfma");
     if (rc) return rc;
@@ -726,16 +744,22 @@ __global__ __launch_bounds__(256) void pw_bwd_reduce_kernel(const float* __restr
                                                            float* __restrict__ db1, float* __restrict__ db2)
 {
     const long slab_floats = 4096 + 128 * (long)D + 128 + D;
-    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;                       // 4 partial sums per element, combined through LDS
-    __shared__ double red[4][64];
-    double acc = 0.0;
-    if (i < slab_floats)
-        for (int c = part; c < nslabs; c += 4) acc += (double)slabs[(long)c * slab_floats + i];
-    red[part][threadIdx.x & 63] = acc;
+    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;     // 32 elements x 8 interleaved partial sums
+    const long i = (long)blockIdx.x * 32 + e;
+    __shared__ double red[8][32];
+    double a0 = 0.0, a1 = 0.0;
+    if (i < slab_floats) {
+        int c = part;
+        for (; c + 8 < nslabs; c += 16) { a0 += (double)slabs[(long)c * slab_floats + i]; a1 += (double)slabs[(long)(c + 8) * slab_floats + i]; }
+        if (c < nslabs) a0 += (double)slabs[(long)c * slab_floats + i];
+    }
+    red[part][e] = a0 + a1;
     __syncthreads();
     if (part != 0 || i >= slab_floats) return;
-    const float v = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][e];
+    const float v = (float)t;
     if (i < 4096) { const int cin = (int)(i >> 7), j = (int)(i & 127); dW1[cin * 256 + 32 * ch0 + j] = v; }
     else if (i < 4096 + 128 * (long)D) { const long k = i - 4096; dW2[(long)32 * ch0 * D + k] = v; }
     else if (i < 4096 + 128 * (long)D + 128) db1[32 * ch0 + (i - 4096 - 128 * (long)D)] = v;
@@ -755,7 +779,7 @@ int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const f
     const size_t lds = (size_t)(3 * 4 * 4 * 64 * 4 + 128 + PWB_WAVES * PWB_WAVE_LDS) * sizeof(float);
     const long slab_floats = 4096 + 128 * (long)D + 128 + D;
     const int nslabs = PW_BWD_GRID * PWB_WAVES;
-    const dim3 rgrid((unsigned)((slab_floats + 63) / 64));
+    const dim3 rgrid((unsigned)((slab_floats + 31) / 32));
     // chunks 0..3: dX = dOut + partial ;  chunks 4..7: dX += partial (in place)
     hipLaunchKernelGGL(pw_bwd_mfma_kernel<0>, dim3(PW_BWD_GRID), dim3(64 * PWB_WAVES), lds, s, x, dT, dOut, (const float4*)w1kcin,
                        (const float4*)w2kout, (const float4*)w1khch, b1, dX, slabs, nvox, D);
