@@ -176,14 +176,17 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
 {
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     constexpr int KS4 = (KS + 3) / 4;
-    float4 bcur[KS4];
+    float4 bcur[KS4], bnxt[KS4];
 #pragma unroll
     for (int q = 0; q < KS4; ++q) bcur[q] = wf[q * 64];
+#pragma unroll 1
     for (int tap = 0; tap < 27; ++tap) {
-        float4 bnxt[KS4];
+        // filter fragments of the NEXT tap are requested first and consumed a whole tap (>= 8 MFMAs) later; the
+        // scheduling barriers keep hipcc from sinking the loads down to their use (which exposes the L2 latency)
         const int tn = tap + 1 < 27 ? tap + 1 : tap;
 #pragma unroll
         for (int q = 0; q < KS4; ++q) bnxt[q] = wf[(tn * KS4 + q) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
         const int toff = ((dh * a.Wp + dw) * a.Tp + dt) * CP;
         const float* p0 = ldsA0 + toff;
@@ -194,6 +197,7 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
             acc0 = MFMA32(p0[2 * s], b, acc0);
             if (MT == 2) acc1 = MFMA32(p1[2 * s], b, acc1);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < KS4; ++q) bcur[q] = bnxt[q];
     }
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
                 }
                 bn[u] = d;
             }
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch a whole group (4 x 6-7 MFMAs) ahead of its use
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 if (s0 + u < nsteps) {
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
                         if (wave + 4 * j < NMT) acc[j] = MFMA32(pv[offA[j]], b, acc[j]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < PF; ++u) bq[u] = bn[u];
         }
@@ -584,7 +590,7 @@ int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, co
 // per-wave slabs are reduced afterwards in a fixed order.
 // ---------------------------------------------------------------------------------------------------
 constexpr int PWB_WAVES = 4;
-constexpr int PWB_WAVE_LDS = 32 * 33 + 32 * 33 + 32 * 27;          // Tb | Xb | Db   (floats)
+constexpr int PWB_WAVE_LDS = 3 * 32 * 33 + 32 * 27;                // Tb1 | Tb2 | Xb | Db   (floats)
 
 template <int CH0>
 __global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
@@ -598,8 +604,9 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
     float4* sW3 = sW2 + 4 * 4 * 64;                               // (c)
     float* sB1 = reinterpret_cast<float*>(sW3 + 4 * 4 * 64);     // 128
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    float* Tb = sB1 + 128 + wave * PWB_WAVE_LDS;                  // transpose buffer [vox][33]
-    float* Xb = Tb + 32 * 33;                                      // X tile          [vox][33]
+    float* Tb = sB1 + 128 + wave * PWB_WAVE_LDS;                  // transpose buffer for dH' [vox][33]
+    float* Tb2 = Tb + 32 * 33;                                     // transpose buffer for H'  [vox][33]
+    float* Xb = Tb2 + 32 * 33;                                     // X tile                   [vox][33]
     float* Db = Xb + 32 * 33;                                      // dT tile         [vox][27]
     for (int i = tid; i < 4 * 4 * 64; i += 64 * PWB_WAVES) {
         sW1[i] = w1kcin[CH0 * 4 * 64 + i]; sW2[i] = w2kout[CH0 * 4 * 64 + i]; sW3[i] = w1khch[CH0 * 4 * 64 + i];
@@ -673,19 +680,18 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dH[r] = H[r] > 0.f ? dH[r] : 0.f; H[r] = fmaxf(H[r], 0.f); }
-            __builtin_amdgcn_sched_barrier(0);
+            // both transposes go to LDS now (lane (voxel col, half) owns hidden rowmap(r, half)); they land while (c)
+            // keeps the matrix pipe busy.  LDS operations of one wave execute in order, so only the COMPILER must be
+            // kept from reordering the reads above the writes: a memory clobber, which register-only MFMAs may cross.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Tb[col * 33 + rowmap(r, half)] = dH[r]; Tb2[col * 33 + rowmap(r, half)] = H[r]; }
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                                               // (c) dX^T += W1 dH'^T
                 const float4 aw = sW3[(c * 4 + q) * 64 + lane];
                 dx = MFMA32(aw.x, dH[4 * q], dx); dx = MFMA32(aw.y, dH[4 * q + 1], dx);
                 dx = MFMA32(aw.z, dH[4 * q + 2], dx); dx = MFMA32(aw.w, dH[4 * q + 3], dx);
             }
-            // transpose dH' through LDS: lane (voxel col, half) owns hidden rowmap(r, half)
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dH[r];
-            __builtin_amdgcn_wave_barrier();
             {
                 float t1 = 0.f;
 #pragma unroll
@@ -696,15 +702,10 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
                 }
                 bs1[c] += t1;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = H[r];
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int s = 0; s < 16; ++s) {                                              // (e) dW2_c += H'^T_c dT
                 const float db = col < D ? Db[(2 * s + half) * 27 + col] : 0.f;         // B: dT[vox 2s+half][out col]
-                dW2[c] = MFMA32(Tb[(2 * s + half) * 33 + col], db, dW2[c]);             // A: H'[vox 2s+half][hidden col]
+                dW2[c] = MFMA32(Tb2[(2 * s + half) * 33 + col], db, dW2[c]);            // A: H'[vox 2s+half][hidden col]
             }
         }
         // dX = dOut + (dX^T)^T : lane (voxel col, half) holds cin = rowmap(r, half) -> four aligned float4 groups
