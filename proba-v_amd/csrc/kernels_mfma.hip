@@ -23,10 +23,20 @@
 namespace probav {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// In-kernel phase stamps for tools/diag_conv.hip (a separate diagnostic build defines PROBAV_STAMP; the product
+// library never does, so no stamp executes in it).  Stamps go to a buffer nothing else reads.
+#ifdef PROBAV_STAMP
+__device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-__device__ __forceinline__ int fdiv(int v, int d, unsigned m) { return d == 1 ? v : (int)__umulhi((unsigned)v, m); }
+// floor(v / d) for 0 <= v, v*d < 2^32, branch-free: m = ceil(2^32 / d), or m = 0 when d == 1 (then the quotient is v itself)
+__device__ __forceinline__ int fdiv(int v, int d, unsigned m) { return (int)__umulhi((unsigned)v, m) + (d == 1 ? v : 0); }
 __device__ __forceinline__ int reflect_clamped(int i, int n)
 {
     i = i < -(n - 1) ? -(n - 1) : (i > 2 * n - 2 ? 2 * n - 2 : i);
@@ -99,64 +109,165 @@ struct TileArgs {
     ConvGeom g;
     int R, rows, Wp, Tp;          // output rows per tile, staged rows (R + kh - 1), staged width / depth
     int ntile_rows;               // ceil(Ho / R)
-    unsigned mTp, mWp, mTo, mWoTo;
+    unsigned mTp, mWp, mTo, mWoTo, mColE;   // magic multipliers for fdiv (mColE: Tp * loads-per-voxel)
+    unsigned mTi, mSrcCol;                  // Ti ; Ti * CC (floats per source column)
 };
+
+template <int CC, int CP, bool REFLECT, bool GATE>
+__device__ __forceinline__ void fill_tile_impl(const TileArgs& a, float* lds, const float* __restrict__ x,
+                                               const float* __restrict__ gate, int n, int h0, int c0, int tid)
+{
+    // Scalar (wave-uniform) loop over the staged rows: row validity / reflection and the 64-bit row base pointer are
+    // SGPR work; a lane only derives (column, plane, channel group) of its element from ONE divide and uses 32-bit
+    // offsets.  No conditional loads and no conditional stores: a runtime `if` around a load (even a uniform one such
+    // as `if (gate)`) makes hipcc branch and drain vmcnt(0) per element -- measured, that serialised fill took 58 % of
+    // the workgroup's lifetime.  Out-of-range elements load from offset 0 of a valid row and select 0 afterwards; dead
+    // lanes of a row's last batch store their 0 into the slack word behind the tile.
+    const ConvGeom& g = a.g;
+    constexpr int V = (CC % 4 == 0) ? 4 : 1;
+    constexpr int CG = CC / V;                      // loads per voxel
+    constexpr int U = (V == 4) ? 4 : 7;             // loads in flight per thread before the LDS stores
+    const int colE = a.Tp * CG;                     // elements per (row, column)
+    const int rowE = a.Wp * colE;                   // elements per staged row
+    const int slack = a.rows * a.Wp * a.Tp * CP;
+    for (int r = 0; r < a.rows; ++r) {
+        int ih = h0 + r - g.ph;
+        bool rok = true;
+        if constexpr (REFLECT) ih = reflect_clamped(ih, g.Hi);
+        else { rok = ih >= 0 && ih < g.Hi; ih = rok ? ih : 0; }
+        const long rbase = (((long)n * g.Hi + ih) * g.Wi) * (long)g.Ti * g.Cin + c0;
+        const float* xrow = x + rbase;
+        const float* grow = GATE ? gate + rbase : nullptr;
+        const int lrow = r * a.Wp * a.Tp * CP;
+        for (int j0 = tid; j0 < rowE; j0 += 256 * U) {
+            float4 val[U];
+            int dof[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ju = j0 + u * 256;
+                const bool live = ju < rowE;
+                const int j = live ? ju : 0;
+                const int wp = fdiv(j, colE, a.mColE), e = j - wp * colE;
+                const int tp = e / CG, cg = e - tp * CG;             // CG is a compile-time constant
+                int iw = wp - g.pw;
+                const int it = tp - g.pt;
+                bool ok = live && rok && it >= 0 && it < g.Ti;
+                if constexpr (REFLECT) iw = reflect_clamped(iw, g.Wi);
+                else ok = ok && iw >= 0 && iw < g.Wi;
+                dof[u] = live ? lrow + (wp * a.Tp + tp) * CP + cg * V : slack;
+                const int so = ok ? (iw * g.Ti + it) * g.Cin + cg * V : 0;
+                if constexpr (V == 4) {
+                    float4 v = *reinterpret_cast<const float4*>(xrow + so);
+                    if constexpr (GATE) {
+                        const float4 m = *reinterpret_cast<const float4*>(grow + so);
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                    val[u].x = ok ? v.x : 0.f; val[u].y = ok ? v.y : 0.f; val[u].z = ok ? v.z : 0.f; val[u].w = ok ? v.w : 0.f;
+                } else {
+                    float v = xrow[so];
+                    if constexpr (GATE) v = grow[so] > 0.f ? v : 0.f;
+                    val[u] = make_float4(ok ? v : 0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float* d = lds + dof[u];
+                d[0] = val[u].x;
+                if constexpr (V == 4) {
+                    const bool dead = dof[u] == slack;       // a dead lane's extra stores must stay on the slack word
+                    d[dead ? 0 : 1] = val[u].y; d[dead ? 0 : 2] = val[u].z; d[dead ? 0 : 3] = val[u].w;
+                }
+            }
+        }
+    }
+    if (tid == 0) lds[slack] = 0.f;          // slack word: the odd-K alias read of the last voxel lands here
+}
+
+// Zero-padded (non-reflect) layers: a source row [w][t][c] is contiguous in HBM and its image inside the padded LDS tile
+// is the same sequence with a constant gap per column, so only VALID source elements are visited and the destination is
+// `source index + gap * column + const` -- a handful of integer instructions per element, no validity tests.  The halo
+// (pads, out-of-range rows) is produced by zeroing the whole tile first with 16-byte stores.
+template <int CC, int CP, bool GATE>
+__device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, const float* __restrict__ x,
+                                                 const float* __restrict__ gate, int n, int h0, int c0, int tid)
+{
+    const ConvGeom& g = a.g;
+    constexpr int V = (CC % 4 == 0) ? 4 : 1;
+    constexpr int CG = CC / V;
+    constexpr int U = (V == 4) ? 4 : 8;
+    const int tile_floats = a.rows * a.Wp * a.Tp * CP + 1;                  // + slack word
+    {
+        float4* z = reinterpret_cast<float4*>(lds);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < (tile_floats + 3) / 4; i += 256) z[i] = zero;   // the launch reserves (tile + 4) floats
+    }
+    __syncthreads();
+    const int srcE = g.Wi * g.Ti * CG;                                        // valid elements per source row
+    for (int r = 0; r < a.rows; ++r) {
+        const int ih = h0 + r - g.ph;
+        if (ih < 0 || ih >= g.Hi) continue;                                   // wave-uniform
+        const long rbase = (((long)n * g.Hi + ih) * g.Wi) * (long)g.Ti * g.Cin + c0;
+        const float* xrow = x + rbase;
+        const float* grow = GATE ? gate + rbase : nullptr;
+        const int lrow = (r * a.Wp + g.pw) * a.Tp * CP + g.pt * CP;           // LDS offset of source voxel (w=0, t=0)
+        for (int j0 = tid; j0 < srcE; j0 += 256 * U) {
+            float4 val[U];
+            int dof[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ju = j0 + u * 256;
+                const bool live = ju < srcE;
+                const int j = live ? ju : 0;
+                int so, d;
+                if constexpr (V == 1 && CC == CP) {
+                    const int w = fdiv(j, g.Ti * CC, a.mSrcCol);              // source column
+                    so = j + w * (g.Cin - CC) * g.Ti;                          // (Cin == CC here: so == j)
+                    d = lrow + j + w * (a.Tp - g.Ti) * CP;
+                } else {
+                    const int vs = j / CG, cg = j - vs * CG;                   // source voxel (w*Ti + t), channel group
+                    const int w = fdiv(vs, g.Ti, a.mTi);
+                    so = vs * g.Cin + cg * V;
+                    d = lrow + (vs + w * (a.Tp - g.Ti)) * CP + cg * V;
+                }
+                dof[u] = live ? d : tile_floats - 1;
+                if constexpr (V == 4) {
+                    float4 v = *reinterpret_cast<const float4*>(xrow + so);
+                    if constexpr (GATE) {
+                        const float4 m = *reinterpret_cast<const float4*>(grow + so);
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                    val[u].x = live ? v.x : 0.f; val[u].y = live ? v.y : 0.f; val[u].z = live ? v.z : 0.f; val[u].w = live ? v.w : 0.f;
+                } else {
+                    float v = xrow[so];
+                    if constexpr (GATE) v = grow[so] > 0.f ? v : 0.f;
+                    val[u] = make_float4(live ? v : 0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float* d = lds + dof[u];
+                d[0] = val[u].x;
+                if constexpr (V == 4) {
+                    const bool dead = dof[u] == tile_floats - 1;
+                    d[dead ? 0 : 1] = val[u].y; d[dead ? 0 : 2] = val[u].z; d[dead ? 0 : 3] = val[u].w;
+                }
+            }
+        }
+    }
+}
 
 template <int CC, int CP>
 __device__ __forceinline__ void fill_tile(const TileArgs& a, float* lds, const float* __restrict__ x,
                                           const float* __restrict__ gate, int n, int h0, int c0, int tid)
 {
-    const ConvGeom& g = a.g;
-    const int nvox = a.rows * a.Wp * a.Tp;
-    constexpr int V = (CC % 4 == 0) ? 4 : 1;
-    constexpr int CG = CC / V;
-    constexpr int U = (V == 4) ? 4 : 8;             // independent loads in flight per thread before the LDS stores
-    const int total = nvox * CG;
-    for (int base = tid; base < total; base += 256 * U) {
-        float4 val[U];
-        int dof[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * 256;
-            dof[u] = -1;
-            val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < total) {
-                const int vox = idx / CG, cg = idx - vox * CG;
-                const int q = fdiv(vox, a.Tp, a.mTp), tp = vox - q * a.Tp;
-                const int r = fdiv(q, a.Wp, a.mWp), wp = q - r * a.Wp;
-                int ih = h0 + r - g.ph, iw = wp - g.pw;
-                const int it = tp - g.pt;
-                bool ok = it >= 0 && it < g.Ti;
-                if (g.reflect_hw) { ih = reflect_clamped(ih, g.Hi); iw = reflect_clamped(iw, g.Wi); }
-                else ok = ok && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
-                dof[u] = vox * CP + cg * V;
-                if (ok) {
-                    const long src = ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + c0 + cg * V;
-                    if constexpr (V == 4) {
-                        float4 v = *reinterpret_cast<const float4*>(x + src);
-                        if (gate) {
-                            const float4 m = *reinterpret_cast<const float4*>(gate + src);
-                            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                        }
-                        val[u] = v;
-                    } else {
-                        float v = x[src];
-                        if (gate) v = gate[src] > 0.f ? v : 0.f;
-                        val[u].x = v;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (dof[u] >= 0) {
-                float* d = lds + dof[u];
-                d[0] = val[u].x;
-                if constexpr (V == 4) { d[1] = val[u].y; d[2] = val[u].z; d[3] = val[u].w; }
-            }
-        }
+    // straight-line instantiations chosen by ONE uniform branch (never a branch per element)
+    if (a.g.reflect_hw) {
+        if (gate) fill_tile_impl<CC, CP, true, true>(a, lds, x, gate, n, h0, c0, tid);
+        else      fill_tile_impl<CC, CP, true, false>(a, lds, x, gate, n, h0, c0, tid);
+    } else {
+        if (gate) fill_tile_linear<CC, CP, true>(a, lds, x, gate, n, h0, c0, tid);
+        else      fill_tile_linear<CC, CP, false>(a, lds, x, gate, n, h0, c0, tid);
     }
-    if (tid == 0) lds[nvox * CP] = 0.f;      // slack word: the odd-K alias read of the last voxel lands here
 }
 
 // LDS float offset of output voxel `vi` of the tile (row-major over (rr, w, t)) at tap (0,0,0)
@@ -174,32 +285,39 @@ template <int CC, int KS, int MT>
 __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0, const float* ldsA1,
                                           const float4* __restrict__ wf, f32x16& acc0, f32x16& acc1)
 {
+    // Software pipeline, one tap deep: the A operands (LDS, shifted view of the halo tile) and the B fragments
+    // (L2) of tap t+1 are requested BEFORE the MFMAs of tap t, which then run register-only, back to back.
+    // hipcc on its own emits ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs and exposes the LDS latency on every
+    // pair; the scheduling barriers pin the order written here.
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     constexpr int KS4 = (KS + 3) / 4;
     float4 bcur[KS4], bnxt[KS4];
+    float a0c[KS], a1c[KS], a0n[KS], a1n[KS];
 #pragma unroll
     for (int q = 0; q < KS4; ++q) bcur[q] = wf[q * 64];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { a0c[s] = ldsA0[2 * s]; a1c[s] = MT == 2 ? ldsA1[2 * s] : 0.f; }
 #pragma unroll 1
     for (int tap = 0; tap < 27; ++tap) {
-        // filter fragments of the NEXT tap are requested first and consumed a whole tap (>= 8 MFMAs) later; the
-        // scheduling barriers keep hipcc from sinking the loads down to their use (which exposes the L2 latency)
         const int tn = tap + 1 < 27 ? tap + 1 : tap;
+        const int dh = tn / 9, dw = (tn / 3) % 3, dt = tn % 3;
+        const int toff = ((dh * a.Wp + dw) * a.Tp + dt) * CP;
 #pragma unroll
         for (int q = 0; q < KS4; ++q) bnxt[q] = wf[(tn * KS4 + q) * 64];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { a0n[s] = ldsA0[toff + 2 * s]; a1n[s] = MT == 2 ? ldsA1[toff + 2 * s] : 0.f; }
         __builtin_amdgcn_sched_barrier(0);
-        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
-        const int toff = ((dh * a.Wp + dw) * a.Tp + dt) * CP;
-        const float* p0 = ldsA0 + toff;
-        const float* p1 = ldsA1 + toff;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float b = f4c(bcur[s >> 2], s & 3);
-            acc0 = MFMA32(p0[2 * s], b, acc0);
-            if (MT == 2) acc1 = MFMA32(p1[2 * s], b, acc1);
+            acc0 = MFMA32(a0c[s], b, acc0);
+            if (MT == 2) acc1 = MFMA32(a1c[s], b, acc1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < KS4; ++q) bcur[q] = bnxt[q];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { a0c[s] = a0n[s]; a1c[s] = a1n[s]; }
     }
 }
 
@@ -220,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
     const int nchunk = g.Cin / CC;
     const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
 
+    STAMP(0);
     for (int pass = 0; pass * 8 < ntiles; ++pass) {
         const int t0 = pass * 8 + 2 * wave, t1 = t0 + 1;
         const bool v0 = t0 < ntiles, v1 = t1 < ntiles;
@@ -234,31 +353,56 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
             if (pass == 0 || nchunk > 1) {
                 if (pass > 0 || chunk > 0) __syncthreads();
                 fill_tile<CC, CP>(a, lds, x, gate, n, h0, chunk * CC, tid);
+                STAMP(1 + 2 * chunk);
                 __syncthreads();
             }
             const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
             if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
             else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1);
+            STAMP(2 + 2 * chunk);
         }
-        // epilogue: D row = output voxel, column = output channel
+        // epilogue: D row = output voxel, column = output channel.  All loads (bias, skip) and the arithmetic happen in
+        // straight-line code first; full tiles (the common case) then store without any predicate.  (Predicated stores
+        // written naively become one exec-masked block each with its own s_waitcnt vmcnt(0): measured 19k cycles.)
         const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+        float* ybase = y + out_base * g.Cout;                     // wave-uniform; per-lane offsets stay 32-bit
+        const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
 #pragma unroll
         for (int tsel = 0; tsel < 2; ++tsel) {
             const int tt = tsel ? t1 : t0;
             if (tt >= ntiles) continue;
+            const bool full = (tt * 32 + 32 <= nv) && g.Cout == 32;          // wave-uniform
+            int oo[16];
+            float ov[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int vi = tt * 32 + rowmap(r, half);
-                if (vi < nv && col < g.Cout) {
-                    const long o = (out_base + vi) * g.Cout + col;
-                    float v = (tsel ? acc1[r] : acc0[r]) + bv;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    if (skip) v += skip[o];
-                    y[o] = v;
-                }
+                const bool live = vi < nv && col < g.Cout;
+                oo[r] = live ? vi * g.Cout + col : -1;
+            }
+            if (sbase) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ov[r] = sbase[oo[r] < 0 ? 0 : oo[r]];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ov[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (tsel ? acc1[r] : acc0[r]) + bv;
+                if (g.relu) v = fmaxf(v, 0.f);
+                ov[r] += v;
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ybase[oo[r]] = ov[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (oo[r] >= 0) ybase[oo[r]] = ov[r];
             }
         }
     }
+    STAMP(7);
 }
 
 struct ConvPlan { bool ok; int CC, KS, R; size_t lds_bytes; TileArgs a; };
@@ -284,7 +428,7 @@ static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
     size_t lds = 0;
     const size_t lim2 = 81920, lim1 = 163840;
     for (int r = 1; r <= g.Ho; ++r) {
-        const size_t need = ((size_t)(r + 2) * Wp * Tp * CP + 4) * sizeof(float);
+        const size_t need = ((size_t)(r + 2) * Wp * Tp * CP + 8) * sizeof(float);
         const int nv = r * g.Wo * g.To;
         if (r > 1 && (nv > 256 || need > lim2)) break;
         if (r == 1 && need > lim1) return p;
@@ -295,6 +439,8 @@ static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
     p.ok = true; p.CC = CC; p.KS = (CC + 1) / 2; p.R = R; p.lds_bytes = (lds + 15) & ~(size_t)15;
     p.a.g = g; p.a.R = R; p.a.rows = R + 2; p.a.Wp = Wp; p.a.Tp = Tp; p.a.ntile_rows = (g.Ho + R - 1) / R;
     p.a.mTp = magic(Tp); p.a.mWp = magic(Wp); p.a.mTo = magic(g.To); p.a.mWoTo = magic(g.Wo * g.To);
+    p.a.mColE = magic(Tp * ((CC % 4 == 0) ? CC / 4 : CC));
+    p.a.mTi = magic(g.Ti); p.a.mSrcCol = magic(g.Ti * CC);
     return p;
 }
 
@@ -339,7 +485,7 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
 // ---------------------------------------------------------------------------------------------------
 // conv3 backward-filter
 // ---------------------------------------------------------------------------------------------------
-template <int CIN>
+template <int CIN, bool GATE>
 __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, int total_tiles, const float* __restrict__ x,
                                                                  const float* __restrict__ dy, const float* __restrict__ gate,
                                                                  float* __restrict__ partial, float* __restrict__ partial_b)
@@ -376,48 +522,47 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
         __syncthreads();
         fill_tile<CIN, CP>(a, lds, x, nullptr, n, h0, 0, tid);
         __syncthreads();
-        // B operand: dy[voxel 2s+half][col], prefetched PF steps ahead
-        constexpr int PF = 4;
-        float bq[PF];
+        // B operand dy[voxel 2s+half][col] is requested a whole group of PF steps ahead (HBM/L2 latency), the A operands
+        // (LDS) one step ahead; the MFMAs of a step then run register-only.  Scheduling barriers pin this order.
+        constexpr int PF = 8;
+        float bq[PF], bn[PF];
+        auto load_dy = [&](int step) -> float {
+            const int vi = 2 * step + half;
+            const bool live = vi < nv && col < g.Cout;
+            const long o = live ? (out_base + vi) * g.Cout + col : 0;      // unconditional load, clamped address
+            float d = dy[o];
+            if constexpr (GATE) d = gate[o] > 0.f ? d : 0.f;
+            return live ? d : 0.f;
+        };
+        float acur[MTW], anxt[MTW];
+        auto load_a = [&](int step, float* dst) {
+            int vi = 2 * step + half;
+            vi = vi < nv ? vi : nv - 1;
+            const float* pv = lds + tile_voxel_off(a, vi, CP);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int vi = 2 * u + half;
-            float d = 0.f;
-            if (vi < nv && col < g.Cout) {
-                const long o = (out_base + vi) * g.Cout + col;
-                d = dy[o];
-                if (gate) d = gate[o] > 0.f ? d : 0.f;
-            }
-            bq[u] = d;
-        }
+            for (int j = 0; j < MTW; ++j) dst[j] = pv[offA[j]];
+        };
+#pragma unroll
+        for (int u = 0; u < PF; ++u) bq[u] = load_dy(u);
+        load_a(0, acur);
         for (int s0 = 0; s0 < nsteps; s0 += PF) {
-            float bn[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) bn[u] = load_dy(s0 + PF + u);
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int vi = 2 * (s0 + PF + u) + half;
-                float d = 0.f;
-                if (vi < nv && col < g.Cout) {
-                    const long o = (out_base + vi) * g.Cout + col;
-                    d = dy[o];
-                    if (gate) d = gate[o] > 0.f ? d : 0.f;
-                }
-                bn[u] = d;
-            }
-            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch a whole group (4 x 6-7 MFMAs) ahead of its use
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
+                load_a(s0 + u + 1, anxt);
+                __builtin_amdgcn_sched_barrier(0);
                 if (s0 + u < nsteps) {
-                    int vi = 2 * (s0 + u) + half;
-                    vi = vi < nv ? vi : nv - 1;
-                    const float* pv = lds + tile_voxel_off(a, vi, CP);
                     const float b = bq[u];
                     bsum += b;
 #pragma unroll
                     for (int j = 0; j < MTW; ++j)
-                        if (wave + 4 * j < NMT) acc[j] = MFMA32(pv[offA[j]], b, acc[j]);
+                        if (wave + 4 * j < NMT) acc[j] = MFMA32(acur[j], b, acc[j]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) acur[j] = anxt[j];
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < PF; ++u) bq[u] = bn[u];
         }
@@ -486,10 +631,17 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_wgrad_mfma_kernel<25>); allow_big_lds(conv3_wgrad_mfma_kernel<32>); allow_big_lds(conv3_wgrad_mfma_kernel<1>); once = true; }
-    if (g.Cin == 1) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<1>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
-    else if (g.Cin == 25) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<25>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
-    else             hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<32>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b);
+#define PROBAV_WGRAD(CI, GT) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<CI, GT>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b)
+    if (!once) {
+        allow_big_lds(conv3_wgrad_mfma_kernel<25, false>); allow_big_lds(conv3_wgrad_mfma_kernel<25, true>);
+        allow_big_lds(conv3_wgrad_mfma_kernel<32, false>); allow_big_lds(conv3_wgrad_mfma_kernel<32, true>);
+        allow_big_lds(conv3_wgrad_mfma_kernel<1, false>); allow_big_lds(conv3_wgrad_mfma_kernel<1, true>);
+        once = true;
+    }
+    if (g.Cin == 1) { if (gate) PROBAV_WGRAD(1, true); else PROBAV_WGRAD(1, false); }
+    else if (g.Cin == 25) { if (gate) PROBAV_WGRAD(25, true); else PROBAV_WGRAD(25, false); }
+    else { if (gate) PROBAV_WGRAD(32, true); else PROBAV_WGRAD(32, false); }
+#undef PROBAV_WGRAD
     int rc = check_launch("conv3_wgrad_mfma");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, grid);
@@ -641,7 +793,8 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
             const long nrem = (nvox - v0 < 32 ? nvox - v0 : 32) * D;
             for (int f = lane; f < 32 * D; f += 64) {
                 const int vv = f / D, oo = f - vv * D;
-                Db[vv * 27 + oo] = f < nrem ? dT[v0 * D + f] : 0.f;
+                const float dv = dT[v0 * D + (f < nrem ? f : 0)];          // unconditional load, clamped
+                Db[vv * 27 + oo] = f < nrem ? dv : 0.f;
             }
         }
         __builtin_amdgcn_wave_barrier();
