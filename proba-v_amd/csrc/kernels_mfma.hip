@@ -110,7 +110,7 @@ struct TileArgs {
     int R, rows, Wp, Tp;          // output rows per tile, staged rows (R + kh - 1), staged width / depth
     int ntile_rows;               // ceil(Ho / R)
     unsigned mTp, mWp, mTo, mWoTo, mColE;   // magic multipliers for fdiv (mColE: Tp * loads-per-voxel)
-    unsigned mTi, mSrcCol;                  // Ti ; Ti * CC (floats per source column)
+    unsigned mTi, mSrcCol, mSrcRow;         // Ti ; Ti * CC (floats per source column) ; Wi * Ti * loads-per-voxel
 };
 
 template <int CC, int CP, bool REFLECT, bool GATE>
@@ -194,7 +194,7 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
     const ConvGeom& g = a.g;
     constexpr int V = (CC % 4 == 0) ? 4 : 1;
     constexpr int CG = CC / V;
-    constexpr int U = (V == 4) ? 4 : 8;
+    constexpr int U = (V == 4) ? 4 : 10;            // loads in flight per thread (float4 resp. float)
     const int tile_floats = a.rows * a.Wp * a.Tp * CP + 1;                  // + slack word
     {
         float4* z = reinterpret_cast<float4*>(lds);
@@ -202,10 +202,14 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
         for (int i = tid; i < (tile_floats + 3) / 4; i += 256) z[i] = zero;   // the launch reserves (tile + 4) floats
     }
     __syncthreads();
+    // wave-uniform loop over the staged rows (row validity and the 64-bit row base are scalar work); per element only
+    // 32-bit offsets.  (Flattening the rows into the element index was tried: the per-element 64-bit row base made the
+    // scalar path 2x slower.)
     const int srcE = g.Wi * g.Ti * CG;                                        // valid elements per source row
+    const int dead_slot = tile_floats - 1;
     for (int r = 0; r < a.rows; ++r) {
         const int ih = h0 + r - g.ph;
-        if (ih < 0 || ih >= g.Hi) continue;                                   // wave-uniform
+        if (ih < 0 || ih >= g.Hi) continue;                                   // wave-uniform: row stays zero
         const long rbase = (((long)n * g.Hi + ih) * g.Wi) * (long)g.Ti * g.Cin + c0;
         const float* xrow = x + rbase;
         const float* grow = GATE ? gate + rbase : nullptr;
@@ -229,7 +233,7 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
                     so = vs * g.Cin + cg * V;
                     d = lrow + (vs + w * (a.Tp - g.Ti)) * CP + cg * V;
                 }
-                dof[u] = live ? d : tile_floats - 1;
+                dof[u] = live ? d : dead_slot;
                 if constexpr (V == 4) {
                     float4 v = *reinterpret_cast<const float4*>(xrow + so);
                     if constexpr (GATE) {
@@ -248,7 +252,7 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
                 float* d = lds + dof[u];
                 d[0] = val[u].x;
                 if constexpr (V == 4) {
-                    const bool dead = dof[u] == tile_floats - 1;
+                    const bool dead = dof[u] == dead_slot;
                     d[dead ? 0 : 1] = val[u].y; d[dead ? 0 : 2] = val[u].z; d[dead ? 0 : 3] = val[u].w;
                 }
             }
@@ -440,7 +444,7 @@ static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
     p.a.g = g; p.a.R = R; p.a.rows = R + 2; p.a.Wp = Wp; p.a.Tp = Tp; p.a.ntile_rows = (g.Ho + R - 1) / R;
     p.a.mTp = magic(Tp); p.a.mWp = magic(Wp); p.a.mTo = magic(g.To); p.a.mWoTo = magic(g.Wo * g.To);
     p.a.mColE = magic(Tp * ((CC % 4 == 0) ? CC / 4 : CC));
-    p.a.mTi = magic(g.Ti); p.a.mSrcCol = magic(g.Ti * CC);
+    p.a.mTi = magic(g.Ti); p.a.mSrcCol = magic(g.Ti * CC); p.a.mSrcRow = magic(g.Wi * g.Ti * ((CC % 4 == 0) ? CC / 4 : CC));
     return p;
 }
 
@@ -797,69 +801,93 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
                 Db[vv * 27 + oo] = f < nrem ? dv : 0.f;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        // tile-invariant operands stay in registers for all four chunks
+        float xs[16], dts[13], xa[16], dtb[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            xs[s] = Xb[col * 33 + 16 * half + s];                                       // B of (a): X[vox col][16*half + s]
+            xa[s] = Xb[(2 * s + half) * 33 + col];                                      // A of (d): X[vox 2s+half][cin col]
+            dtb[s] = col < D ? Db[(2 * s + half) * 27 + col] : 0.f;                     // B of (e): dT[vox 2s+half][out col]
+        }
+#pragma unroll
+        for (int s = 0; s < 13; ++s) dts[s] = (13 * half + s) < D ? Db[col * 27 + 13 * half + s] : 0.f;   // B of (b)
         if (CH0 == 0) {   // db2 partial: column sums of the dT tile (lane (half, out col) sums its 16 voxels)
             float t2 = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) t2 += col < D ? Db[(2 * s + half) * 27 + col] : 0.f;
+            for (int s = 0; s < 16; ++s) t2 += dtb[s];
             bs2 += t2;
         }
         f32x16 dx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dx[r] = 0.f;
 
+        // Per chunk: P1 = (a)+(b) [29 MFMAs], gate, both transposes to LDS, then P2 = (c)+(d)+(e) [48 MFMAs].  The weight
+        // fragments + bias of chunk c+1 and the transposed reads of chunk c are requested BEFORE P2 starts; (c) needs only
+        // registers, so those LDS latencies are covered by its 16 MFMAs.  sched_barrier pins this order (hipcc otherwise
+        // emits ds_read -> s_waitcnt lgkmcnt(0) -> MFMA and exposes every LDS latency at one wave per SIMD).
+        float4 w1c[4], w2c[4], w3c[4];
+        float hbc[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w1c[q] = sW1[q * 64 + lane]; w2c[q] = sW2[q * 64 + lane]; w3c[q] = sW3[q * 64 + lane]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hbc[r] = sB1[rowmap(r, half)];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            asm volatile("" ::: "memory");           // chunk boundary: LDS operand reads are re-issued per chunk, not held
+            asm volatile("" ::: "memory");           // chunk boundary (orders this chunk's LDS writes after the previous reads)
             f32x16 H, dH;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { H[r] = sB1[32 * c + rowmap(r, half)]; dH[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { H[r] = hbc[r]; dH[r] = 0.f; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // (a)
-                const float4 aw = sW1[(c * 4 + q) * 64 + lane];
-                const float* xr = Xb + col * 33 + 16 * half + 4 * q;                    // B: X[vox col][16*half + s]
-                H = MFMA32(aw.x, xr[0], H); H = MFMA32(aw.y, xr[1], H);
-                H = MFMA32(aw.z, xr[2], H); H = MFMA32(aw.w, xr[3], H);
+            for (int q = 0; q < 4; ++q) {                                               // (a) H^T = W1^T X^T + b1
+                H = MFMA32(w1c[q].x, xs[4 * q], H); H = MFMA32(w1c[q].y, xs[4 * q + 1], H);
+                H = MFMA32(w1c[q].z, xs[4 * q + 2], H); H = MFMA32(w1c[q].w, xs[4 * q + 3], H);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // (b)
-                const float4 aw = sW2[(c * 4 + q) * 64 + lane];
-                const float* dr = Db + col * 27 + 13 * half + 4 * q;                    // B: dT[vox col][13*half + s]
-                const int o = 13 * half + 4 * q;
-                dH = MFMA32(aw.x, o < D ? dr[0] : 0.f, dH);
-                if (4 * q + 1 < 13) dH = MFMA32(aw.y, o + 1 < D ? dr[1] : 0.f, dH);
-                if (4 * q + 2 < 13) dH = MFMA32(aw.z, o + 2 < D ? dr[2] : 0.f, dH);
-                if (4 * q + 3 < 13) dH = MFMA32(aw.w, o + 3 < D ? dr[3] : 0.f, dH);
+            for (int q = 0; q < 4; ++q) {                                               // (b) dH^T = W2 dT^T
+                dH = MFMA32(w2c[q].x, dts[4 * q], dH);
+                if (4 * q + 1 < 13) dH = MFMA32(w2c[q].y, dts[(4 * q + 1) % 13], dH);
+                if (4 * q + 2 < 13) dH = MFMA32(w2c[q].z, dts[(4 * q + 2) % 13], dH);
+                if (4 * q + 3 < 13) dH = MFMA32(w2c[q].w, dts[(4 * q + 3) % 13], dH);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dH[r] = H[r] > 0.f ? dH[r] : 0.f; H[r] = fmaxf(H[r], 0.f); }
-            // both transposes go to LDS now (lane (voxel col, half) owns hidden rowmap(r, half)); they land while (c)
-            // keeps the matrix pipe busy.  LDS operations of one wave execute in order, so only the COMPILER must be
-            // kept from reordering the reads above the writes: a memory clobber, which register-only MFMAs may cross.
+            // transposes: lane (voxel col, half) owns hidden rowmap(r, half).  LDS operations of one wave execute in order,
+            // so only the COMPILER must be kept from hoisting the reads above the writes (memory clobber).
 #pragma unroll
             for (int r = 0; r < 16; ++r) { Tb[col * 33 + rowmap(r, half)] = dH[r]; Tb2[col * 33 + rowmap(r, half)] = H[r]; }
             asm volatile("" ::: "memory");
+            float tr[16], tr2[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // (c) dX^T += W1 dH'^T
-                const float4 aw = sW3[(c * 4 + q) * 64 + lane];
-                dx = MFMA32(aw.x, dH[4 * q], dx); dx = MFMA32(aw.y, dH[4 * q + 1], dx);
-                dx = MFMA32(aw.z, dH[4 * q + 2], dx); dx = MFMA32(aw.w, dH[4 * q + 3], dx);
+            for (int s = 0; s < 16; ++s) { tr[s] = Tb[(2 * s + half) * 33 + col]; tr2[s] = Tb2[(2 * s + half) * 33 + col]; }
+            float4 w1n[4], w2n[4], w3n[4];
+            float hbn[16];
+            {
+                const int cn = c + 1 < 4 ? c + 1 : c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { w1n[q] = sW1[(cn * 4 + q) * 64 + lane]; w2n[q] = sW2[(cn * 4 + q) * 64 + lane]; w3n[q] = sW3[(cn * 4 + q) * 64 + lane]; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hbn[r] = sB1[32 * cn + rowmap(r, half)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                               // (c) dX^T += W1 dH'^T   (registers only)
+                dx = MFMA32(w3c[q].x, dH[4 * q], dx); dx = MFMA32(w3c[q].y, dH[4 * q + 1], dx);
+                dx = MFMA32(w3c[q].z, dH[4 * q + 2], dx); dx = MFMA32(w3c[q].w, dH[4 * q + 3], dx);
             }
             {
                 float t1 = 0.f;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {                                          // (d) dW1_c += X^T dH'_c
-                    const float tr = Tb[(2 * s + half) * 33 + col];                     // B: dH'[vox 2s+half][hidden col]
-                    t1 += tr;
-                    dW1[c] = MFMA32(Xb[(2 * s + half) * 33 + col], tr, dW1[c]);         // A: X[vox 2s+half][cin col]
-                }
+                for (int s = 0; s < 16; ++s) { t1 += tr[s]; dW1[c] = MFMA32(xa[s], tr[s], dW1[c]); }     // (d) dW1_c += X^T dH'_c
                 bs1[c] += t1;
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {                                              // (e) dW2_c += H'^T_c dT
-                const float db = col < D ? Db[(2 * s + half) * 27 + col] : 0.f;         // B: dT[vox 2s+half][out col]
-                dW2[c] = MFMA32(Tb2[(2 * s + half) * 33 + col], db, dW2[c]);            // A: H'[vox 2s+half][hidden col]
-            }
+            for (int s = 0; s < 16; ++s) dW2[c] = MFMA32(tr2[s], dtb[s], dW2[c]);                        // (e) dW2_c += H'^T_c dT
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { w1c[q] = w1n[q]; w2c[q] = w2n[q]; w3c[q] = w3n[q]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hbc[r] = hbn[r];
         }
         // dX = dOut + (dX^T)^T : lane (voxel col, half) holds cin = rowmap(r, half) -> four aligned float4 groups
         if (vok) {
