@@ -155,6 +155,7 @@ __device__ __forceinline__ void fill_tile_impl(const TileArgs& a, float* lds, co
                 if constexpr (REFLECT) iw = reflect_clamped(iw, g.Wi);
                 else ok = ok && iw >= 0 && iw < g.Wi;
                 dof[u] = live ? lrow + (wp * a.Tp + tp) * CP + cg * V : slack;
+                ok = ok && (c0 + cg * V < g.Cin);                      // ragged last chunk
                 const int so = ok ? (iw * g.Ti + it) * g.Cin + cg * V : 0;
                 if constexpr (V == 4) {
                     float4 v = *reinterpret_cast<const float4*>(xrow + so);
@@ -223,14 +224,16 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
                 const bool live = ju < srcE;
                 const int j = live ? ju : 0;
                 int so, d;
-                if constexpr (V == 1 && CC == CP) {
+                bool chan_ok = true;
+                if constexpr (V == 1 && CC == CP && (CC == 25 || CC == 1)) {     // the chunk IS the channel axis: linear per column
                     const int w = fdiv(j, g.Ti * CC, a.mSrcCol);              // source column
-                    so = j + w * (g.Cin - CC) * g.Ti;                          // (Cin == CC here: so == j)
+                    so = j;
                     d = lrow + j + w * (a.Tp - g.Ti) * CP;
                 } else {
                     const int vs = j / CG, cg = j - vs * CG;                   // source voxel (w*Ti + t), channel group
                     const int w = fdiv(vs, g.Ti, a.mTi);
-                    so = vs * g.Cin + cg * V;
+                    chan_ok = c0 + cg * V < g.Cin;                              // ragged last chunk (25 = 13 + 12)
+                    so = chan_ok ? vs * g.Cin + cg * V : 0;
                     d = lrow + (vs + w * (a.Tp - g.Ti)) * CP + cg * V;
                 }
                 dof[u] = live ? d : dead_slot;
@@ -244,7 +247,7 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
                 } else {
                     float v = xrow[so];
                     if constexpr (GATE) v = grow[so] > 0.f ? v : 0.f;
-                    val[u] = make_float4(live ? v : 0.f, 0.f, 0.f, 0.f);
+                    val[u] = make_float4(live && chan_ok ? v : 0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
@@ -287,7 +290,7 @@ __device__ __forceinline__ int tile_voxel_off(const TileArgs& a, int vi, int CP)
 // ---------------------------------------------------------------------------------------------------
 template <int CC, int KS, int MT>
 __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0, const float* ldsA1,
-                                          const float4* __restrict__ wf, f32x16& acc0, f32x16& acc1)
+                                          const float4* __restrict__ wf, f32x16& acc0, f32x16& acc1, int ks)
 {
     // Software pipeline, one tap deep: the A operands (LDS, shifted view of the halo tile) and the B fragments
     // (L2) of tap t+1 are requested BEFORE the MFMAs of tap t, which then run register-only, back to back.
@@ -313,9 +316,11 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float b = f4c(bcur[s >> 2], s & 3);
-            acc0 = MFMA32(a0c[s], b, acc0);
-            if (MT == 2) acc1 = MFMA32(a1c[s], b, acc1);
+            if (s < ks) {                              // wave-uniform: the last channel chunk may have fewer k-steps
+                const float b = f4c(bcur[s >> 2], s & 3);
+                acc0 = MFMA32(a0c[s], b, acc0);
+                if (MT == 2) acc1 = MFMA32(a1c[s], b, acc1);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -325,8 +330,8 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
     }
 }
 
-template <int CC, int KS>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
+template <int CC, int KS, int WPE>
+__global__ __launch_bounds__(256, WPE) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                            const float4* __restrict__ wfrag, const float* __restrict__ bias,
                                                            const float* __restrict__ skip, float* __restrict__ y)
 {
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
     const int n = wg / a.ntile_rows, h0 = (wg - n * a.ntile_rows) * a.R;
     const int Rr = g.Ho - h0 < a.R ? g.Ho - h0 : a.R;
     const int nv = Rr * g.Wo * g.To, ntiles = (nv + 31) >> 5;
-    const int nchunk = g.Cin / CC;
+    const int nchunk = (g.Cin + CC - 1) / CC;
     const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
 
     STAMP(0);
@@ -361,8 +366,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
                 __syncthreads();
             }
             const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
-            if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
-            else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1);
+            const int cv = g.Cin - chunk * CC < CC ? g.Cin - chunk * CC : CC;      // valid channels of this chunk
+            const int ks = (cv + 1) >> 1;
+            if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1, ks);
+            else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1, ks);
             STAMP(2 + 2 * chunk);
         }
         // epilogue: D row = output voxel, column = output channel.  All loads (bias, skip) and the arithmetic happen in
@@ -419,7 +426,7 @@ static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
     if (g.Cout > 32 && !all_channels) return p;
     int CC;
     if (all_channels) CC = g.Cin;                           // wgrad stages every input channel
-    else if (g.Cin == 25) CC = 25;
+    else if (g.Cin == 25) CC = 13;                          // 13 + 12 channels: 41 KB tile, three workgroups per CU
     else if (g.Cin == 1) CC = 1;
     else if (g.Cin % 16 == 0) CC = 16;
     else return p;
@@ -454,15 +461,15 @@ size_t mfma_conv_wfrag_floats(int Cin, int Cout)
 {
     if (Cout > 32) return 0;
     int CC;
-    if (Cin == 25) CC = 25; else if (Cin == 1) CC = 1; else if (Cin % 16 == 0) CC = 16; else return 0;
+    if (Cin == 25) CC = 13; else if (Cin == 1) CC = 1; else if (Cin % 16 == 0) CC = 16; else return 0;
     const int KS = (CC + 1) / 2, KS4 = (KS + 3) / 4;
-    return (size_t)(Cin / CC) * 27 * KS4 * 256;
+    return (size_t)((Cin + CC - 1) / CC) * 27 * KS4 * 256;
 }
 
 void mfma_conv_pack_job(PackJob& J, int Cin, int Cout)
 {
     J.type = PACK_CONV; J.Cin = Cin; J.Cout = Cout; J.taps = 27;
-    J.CC = Cin == 25 ? 25 : (Cin == 1 ? 1 : 16); J.KS = (J.CC + 1) / 2;
+    J.CC = Cin == 25 ? 13 : (Cin == 1 ? 1 : 16); J.KS = (J.CC + 1) / 2;
     J.count = (long)mfma_conv_wfrag_floats(Cin, Cout);
 }
 
@@ -479,10 +486,10 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
     if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13>); allow_big_lds(conv3_mfma_kernel<16, 8>); allow_big_lds(conv3_mfma_kernel<1, 1>); once = true; }
-    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    if (!once) { allow_big_lds(conv3_mfma_kernel<13, 7, 3>); allow_big_lds(conv3_mfma_kernel<16, 8, 2>); allow_big_lds(conv3_mfma_kernel<1, 1, 2>); once = true; }
+    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1, 2>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else if (p.CC == 13) hipLaunchKernelGGL((conv3_mfma_kernel<13, 7, 3>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, 2>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     return check_launch("conv3_mfma");
 }
 
@@ -739,237 +746,26 @@ int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, co
 //       dH'    = dH * [H > 0]             same register layout -> elementwise
 //   (c) dX^T  += W1 dH'^T_c               K = hidden = ROW index of dH'^T: accumulator registers are the B operand
 //   (d) dW1_c += X^T dH'_c                K = voxel: needs dH' with the voxel on the K index -> one in-wave LDS transpose
-//   (e) dW2_c += H'^T_c dT                K = voxel: same transpose buffer, reused after (d)
-// One launch handles 4 of the 8 hidden chunks (template CH0 = 0 or 4): a wave then keeps dW1, dW2 of its chunks in
-// 2 x 4 x 16 accumulator registers across ALL its tiles (one wave per SIMD, ~400 registers); the second launch adds
-// its share of dX in place.  Waves never synchronise with each other after the weight fragments are in LDS; the
-// per-wave slabs are reduced afterwards in a fixed order.
-// ---------------------------------------------------------------------------------------------------
-constexpr int PWB_WAVES = 4;
-constexpr int PWB_WAVE_LDS = 3 * 32 * 33 + 32 * 27;                // Tb1 | Tb2 | Xb | Db   (floats)
-
-template <int CH0>
-__global__ __launch_bounds__(256, 1) void pw_bwd_mfma_kernel(
-    const float* __restrict__ x, const float* __restrict__ dT, const float* dOut,
-    const float4* __restrict__ w1kcin, const float4* __restrict__ w2kout, const float4* __restrict__ w1khch,
-    const float* __restrict__ b1, float* dX, float* __restrict__ slabs, long nvox, int D)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float4* sW1 = reinterpret_cast<float4*>(lds);               // (a)  [4][4][64] float4
-    float4* sW2 = sW1 + 4 * 4 * 64;                               // (b)  (slots 13..15 zero)
-    float4* sW3 = sW2 + 4 * 4 * 64;                               // (c)
-    float* sB1 = reinterpret_cast<float*>(sW3 + 4 * 4 * 64);     // 128
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    float* Tb = sB1 + 128 + wave * PWB_WAVE_LDS;                  // transpose buffer for dH' [vox][33]
-    float* Tb2 = Tb + 32 * 33;                                     // transpose buffer for H'  [vox][33]
-    float* Xb = Tb2 + 32 * 33;                                     // X tile                   [vox][33]
-    float* Db = Xb + 32 * 33;                                      // dT tile         [vox][27]
-    for (int i = tid; i < 4 * 4 * 64; i += 64 * PWB_WAVES) {
-        sW1[i] = w1kcin[CH0 * 4 * 64 + i]; sW2[i] = w2kout[CH0 * 4 * 64 + i]; sW3[i] = w1khch[CH0 * 4 * 64 + i];
-    }
-    if (tid < 128) sB1[tid] = b1[32 * CH0 + tid];
-    __syncthreads();
-
-    f32x16 dW1[4], dW2[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dW1[c][r] = 0.f; dW2[c][r] = 0.f; }
-    float bs1[4] = {0.f, 0.f, 0.f, 0.f};
-    float bs2 = 0.f;
-
-    const long ntiles = (nvox + 31) >> 5;
-    const long wstride = (long)gridDim.x * PWB_WAVES;
-    for (long tile = (long)blockIdx.x * PWB_WAVES + wave; tile < ntiles; tile += wstride) {
-        const long v0 = tile * 32;
-        long v = v0 + col;
-        const bool vok = v < nvox;
-        if (!vok) v = nvox - 1;
-        // ---- stage the X tile (lane owns 16 channels of voxel `col`) and the dT tile (flat coalesced copy) ----
-        {
-            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 16 * half);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 t = xp[q];
-                float* d = Xb + col * 33 + 16 * half + 4 * q;
-                d[0] = vok ? t.x : 0.f; d[1] = vok ? t.y : 0.f; d[2] = vok ? t.z : 0.f; d[3] = vok ? t.w : 0.f;
-            }
-            const long nrem = (nvox - v0 < 32 ? nvox - v0 : 32) * D;
-            for (int f = lane; f < 32 * D; f += 64) {
-                const int vv = f / D, oo = f - vv * D;
-                const float dv = dT[v0 * D + (f < nrem ? f : 0)];          // unconditional load, clamped
-                Db[vv * 27 + oo] = f < nrem ? dv : 0.f;
-            }
-        }
-        asm volatile("" ::: "memory");
-        // tile-invariant operands stay in registers for all four chunks
-        float xs[16], dts[13], xa[16], dtb[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            xs[s] = Xb[col * 33 + 16 * half + s];                                       // B of (a): X[vox col][16*half + s]
-            xa[s] = Xb[(2 * s + half) * 33 + col];                                      // A of (d): X[vox 2s+half][cin col]
-            dtb[s] = col < D ? Db[(2 * s + half) * 27 + col] : 0.f;                     // B of (e): dT[vox 2s+half][out col]
-        }
-#pragma unroll
-        for (int s = 0; s < 13; ++s) dts[s] = (13 * half + s) < D ? Db[col * 27 + 13 * half + s] : 0.f;   // B of (b)
-        if (CH0 == 0) {   // db2 partial: column sums of the dT tile (lane (half, out col) sums its 16 voxels)
-            float t2 = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) t2 += dtb[s];
-            bs2 += t2;
-        }
-        f32x16 dx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
-
-        // Per chunk: P1 = (a)+(b) [29 MFMAs], gate, both transposes to LDS, then P2 = (c)+(d)+(e) [48 MFMAs].  The weight
-        // fragments + bias of chunk c+1 and the transposed reads of chunk c are requested BEFORE P2 starts; (c) needs only
-        // registers, so those LDS latencies are covered by its 16 MFMAs.  sched_barrier pins this order (hipcc otherwise
-        // emits ds_read -> s_waitcnt lgkmcnt(0) -> MFMA and exposes every LDS latency at one wave per SIMD).
-        float4 w1c[4], w2c[4], w3c[4];
-        float hbc[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { w1c[q] = sW1[q * 64 + lane]; w2c[q] = sW2[q * 64 + lane]; w3c[q] = sW3[q * 64 + lane]; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hbc[r] = sB1[rowmap(r, half)];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            asm volatile("" ::: "memory");           // chunk boundary (orders this chunk's LDS writes after the previous reads)
-            f32x16 H, dH;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { H[r] = hbc[r]; dH[r] = 0.f; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // (a) H^T = W1^T X^T + b1
-                H = MFMA32(w1c[q].x, xs[4 * q], H); H = MFMA32(w1c[q].y, xs[4 * q + 1], H);
-                H = MFMA32(w1c[q].z, xs[4 * q + 2], H); H = MFMA32(w1c[q].w, xs[4 * q + 3], H);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // (b) dH^T = W2 dT^T
-                dH = MFMA32(w2c[q].x, dts[4 * q], dH);
-                if (4 * q + 1 < 13) dH = MFMA32(w2c[q].y, dts[(4 * q + 1) % 13], dH);
-                if (4 * q + 2 < 13) dH = MFMA32(w2c[q].z, dts[(4 * q + 2) % 13], dH);
-                if (4 * q + 3 < 13) dH = MFMA32(w2c[q].w, dts[(4 * q + 3) % 13], dH);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dH[r] = H[r] > 0.f ? dH[r] : 0.f; H[r] = fmaxf(H[r], 0.f); }
-            // transposes: lane (voxel col, half) owns hidden rowmap(r, half).  LDS operations of one wave execute in order,
-            // so only the COMPILER must be kept from hoisting the reads above the writes (memory clobber).
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Tb[col * 33 + rowmap(r, half)] = dH[r]; Tb2[col * 33 + rowmap(r, half)] = H[r]; }
-            asm volatile("" ::: "memory");
-            float tr[16], tr2[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { tr[s] = Tb[(2 * s + half) * 33 + col]; tr2[s] = Tb2[(2 * s + half) * 33 + col]; }
-            float4 w1n[4], w2n[4], w3n[4];
-            float hbn[16];
-            {
-                const int cn = c + 1 < 4 ? c + 1 : c;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { w1n[q] = sW1[(cn * 4 + q) * 64 + lane]; w2n[q] = sW2[(cn * 4 + q) * 64 + lane]; w3n[q] = sW3[(cn * 4 + q) * 64 + lane]; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hbn[r] = sB1[32 * cn + rowmap(r, half)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // (c) dX^T += W1 dH'^T   (registers only)
-                dx = MFMA32(w3c[q].x, dH[4 * q], dx); dx = MFMA32(w3c[q].y, dH[4 * q + 1], dx);
-                dx = MFMA32(w3c[q].z, dH[4 * q + 2], dx); dx = MFMA32(w3c[q].w, dH[4 * q + 3], dx);
-            }
-            {
-                float t1 = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) { t1 += tr[s]; dW1[c] = MFMA32(xa[s], tr[s], dW1[c]); }     // (d) dW1_c += X^T dH'_c
-                bs1[c] += t1;
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) dW2[c] = MFMA32(tr2[s], dtb[s], dW2[c]);                        // (e) dW2_c += H'^T_c dT
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { w1c[q] = w1n[q]; w2c[q] = w2n[q]; w3c[q] = w3n[q]; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hbc[r] = hbn[r];
-        }
-        // dX = dOut + (dX^T)^T : lane (voxel col, half) holds cin = rowmap(r, half) -> four aligned float4 groups
-        if (vok) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const long o = v * 32 + 8 * gq + 4 * half;
-                const float4 d0 = *reinterpret_cast<const float4*>(dOut + o);
-                float4 ov;
-                ov.x = dx[4 * gq] + d0.x; ov.y = dx[4 * gq + 1] + d0.y; ov.z = dx[4 * gq + 2] + d0.z; ov.w = dx[4 * gq + 3] + d0.w;
-                *reinterpret_cast<float4*>(dX + o) = ov;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // compact slab of this wave: [dW1 32x128 | dW2 128xD | db1 128 | db2 D]
-    const long slab_floats = 4096 + 128 * (long)D + 128 + D;
-    float* sl = slabs + ((long)blockIdx.x * PWB_WAVES + wave) * slab_floats;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rw = rowmap(r, half);
-            sl[(long)rw * 128 + 32 * c + col] = dW1[c][r];                             // [cin][hidden of this half]
-            if (col < D) sl[4096 + (long)(32 * c + rw) * D + col] = dW2[c][r];         // [hidden of this half][out]
-        }
-        const float b = bs1[c] + __shfl_xor(bs1[c], 32, 64);
-        if (half == 0) sl[4096 + 128 * (long)D + 32 * c + col] = b;
-    }
-    const float b2s = bs2 + __shfl_xor(bs2, 32, 64);
-    if (half == 0 && col < D) sl[4096 + 128 * (long)D + 128 + col] = CH0 == 0 ? b2s : 0.f;
-}
-
-// sums the per-wave slabs of one half-launch in fp64 and scatters into dW1 [32][256], dW2 [256][D], db1 [256], db2 [D]
-__global__ __launch_bounds__(256) void pw_bwd_reduce_kernel(const float* __restrict__ slabs, int nslabs, int ch0, int D,
-                                                           float* __restrict__ dW1, float* __restrict__ dW2,
-                                                           float* __restrict__ db1, float* __restrict__ db2)
-{
-    const long slab_floats = 4096 + 128 * (long)D + 128 + D;
-    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;     // 32 elements x 8 interleaved partial sums
-    const long i = (long)blockIdx.x * 32 + e;
-    __shared__ double red[8][32];
-    double a0 = 0.0, a1 = 0.0;
-    if (i < slab_floats) {
-        int c = part;
-        for (; c + 8 < nslabs; c += 16) { a0 += (double)slabs[(long)c * slab_floats + i]; a1 += (double)slabs[(long)(c + 8) * slab_floats + i]; }
-        if (c < nslabs) a0 += (double)slabs[(long)c * slab_floats + i];
-    }
-    red[part][e] = a0 + a1;
-    __syncthreads();
-    if (part != 0 || i >= slab_floats) return;
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][e];
-    const float v = (float)t;
-    if (i < 4096) { const int cin = (int)(i >> 7), j = (int)(i & 127); dW1[cin * 256 + 32 * ch0 + j] = v; }
-    else if (i < 4096 + 128 * (long)D) { const long k = i - 4096; dW2[(long)32 * ch0 * D + k] = v; }
-    else if (i < 4096 + 128 * (long)D + 128) db1[32 * ch0 + (i - 4096 - 128 * (long)D)] = v;
-    else if (ch0 == 0) db2[i - 4096 - 128 * (long)D - 128] = v;
-}
-
+//   (e) dW2_c += H'^T_c dT                K = voxel: second in-wave transpose
+// (A first decomposition -- every wave owning all chunks of its own tiles, 2 launches x 4 chunks, 1 wave per SIMD at
+// ~445 VGPRs -- reached 69 TFLOP/s; the wave-per-chunk form below reaches 90.)
 static const int PW_BWD_GRID = 256;
 
-size_t mfma_pw_backward_slab_floats(int D) { return (size_t)PW_BWD_GRID * PWB_WAVES * (4096 + 128 * (size_t)D + 128 + D); }
+size_t mfma_pw_backward_slab_floats(int D) { return (size_t)PW_BWD_GRID * (8192 + 256 * (size_t)D + 256 + D); }
 
 int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1kcin, const float* w2kout,
                      const float* w1khch, const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2,
                      float* slabs, long nvox, int D, hipStream_t s)
 {
     static bool once = false;
-    if (!once) { allow_big_lds(pw_bwd_mfma_kernel<0>); allow_big_lds(pw_bwd_mfma_kernel<4>); once = true; }
-    const size_t lds = (size_t)(3 * 4 * 4 * 64 * 4 + 128 + PWB_WAVES * PWB_WAVE_LDS) * sizeof(float);
-    const long slab_floats = 4096 + 128 * (long)D + 128 + D;
-    const int nslabs = PW_BWD_GRID * PWB_WAVES;
-    const dim3 rgrid((unsigned)((slab_floats + 31) / 32));
-    // chunks 0..3: dX = dOut + partial ;  chunks 4..7: dX += partial (in place)
-    hipLaunchKernelGGL(pw_bwd_mfma_kernel<0>, dim3(PW_BWD_GRID), dim3(64 * PWB_WAVES), lds, s, x, dT, dOut, (const float4*)w1kcin,
+    if (!once) { allow_big_lds(pw_bwd2_mfma_kernel); once = true; }
+    const size_t lds = (size_t)(2 * PW2_XT + 2 * PW2_DT + PW2_WAVES * 2 * PW2_TB) * sizeof(float);
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    hipLaunchKernelGGL(pw_bwd2_mfma_kernel, dim3(PW_BWD_GRID), dim3(64 * PW2_WAVES), lds, s, x, dT, dOut, (const float4*)w1kcin,
                        (const float4*)w2kout, (const float4*)w1khch, b1, dX, slabs, nvox, D);
-    hipLaunchKernelGGL(pw_bwd_reduce_kernel, rgrid, dim3(256), 0, s, slabs, nslabs, 0, D, dW1, dW2, db1, db2);
-    hipLaunchKernelGGL(pw_bwd_mfma_kernel<4>, dim3(PW_BWD_GRID), dim3(64 * PWB_WAVES), lds, s, x, dT, (const float*)dX, (const float4*)w1kcin,
-                       (const float4*)w2kout, (const float4*)w1khch, b1, dX, slabs, nvox, D);
-    hipLaunchKernelGGL(pw_bwd_reduce_kernel, rgrid, dim3(256), 0, s, slabs, nslabs, 4, D, dW1, dW2, db1, db2);
-    return check_launch("pw_bwd_mfma");
+    hipLaunchKernelGGL(pw_bwd2_reduce_kernel, dim3((unsigned)((slab_floats + 31) / 32)), dim3(256), 0, s, slabs, PW_BWD_GRID, D,
+                       dW1, dW2, db1, db2);
+    return check_launch("pw_bwd2_mfma");
 }
 
 }  // namespace probav
