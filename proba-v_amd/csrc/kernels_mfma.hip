@@ -155,7 +155,6 @@ __device__ __forceinline__ void fill_tile_impl(const TileArgs& a, float* lds, co
                 if constexpr (REFLECT) iw = reflect_clamped(iw, g.Wi);
                 else ok = ok && iw >= 0 && iw < g.Wi;
                 dof[u] = live ? lrow + (wp * a.Tp + tp) * CP + cg * V : slack;
-                ok = ok && (c0 + cg * V < g.Cin);                      // ragged last chunk
                 const int so = ok ? (iw * g.Ti + it) * g.Cin + cg * V : 0;
                 if constexpr (V == 4) {
                     float4 v = *reinterpret_cast<const float4*>(xrow + so);
@@ -224,16 +223,14 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
                 const bool live = ju < srcE;
                 const int j = live ? ju : 0;
                 int so, d;
-                bool chan_ok = true;
-                if constexpr (V == 1 && CC == CP && (CC == 25 || CC == 1)) {     // the chunk IS the channel axis: linear per column
+                if constexpr (V == 1 && CC == CP) {
                     const int w = fdiv(j, g.Ti * CC, a.mSrcCol);              // source column
-                    so = j;
+                    so = j + w * (g.Cin - CC) * g.Ti;                          // (Cin == CC here: so == j)
                     d = lrow + j + w * (a.Tp - g.Ti) * CP;
                 } else {
                     const int vs = j / CG, cg = j - vs * CG;                   // source voxel (w*Ti + t), channel group
                     const int w = fdiv(vs, g.Ti, a.mTi);
-                    chan_ok = c0 + cg * V < g.Cin;                              // ragged last chunk (25 = 13 + 12)
-                    so = chan_ok ? vs * g.Cin + cg * V : 0;
+                    so = vs * g.Cin + cg * V;
                     d = lrow + (vs + w * (a.Tp - g.Ti)) * CP + cg * V;
                 }
                 dof[u] = live ? d : dead_slot;
@@ -247,7 +244,7 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
                 } else {
                     float v = xrow[so];
                     if constexpr (GATE) v = grow[so] > 0.f ? v : 0.f;
-                    val[u] = make_float4(live && chan_ok ? v : 0.f, 0.f, 0.f, 0.f);
+                    val[u] = make_float4(live ? v : 0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
@@ -290,7 +287,7 @@ __device__ __forceinline__ int tile_voxel_off(const TileArgs& a, int vi, int CP)
 // ---------------------------------------------------------------------------------------------------
 template <int CC, int KS, int MT>
 __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0, const float* ldsA1,
-                                          const float4* __restrict__ wf, f32x16& acc0, f32x16& acc1, int ks)
+                                          const float4* __restrict__ wf, f32x16& acc0, f32x16& acc1)
 {
     // Software pipeline, one tap deep: the A operands (LDS, shifted view of the halo tile) and the B fragments
     // (L2) of tap t+1 are requested BEFORE the MFMAs of tap t, which then run register-only, back to back.
@@ -316,11 +313,9 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if (s < ks) {                              // wave-uniform: the last channel chunk may have fewer k-steps
-                const float b = f4c(bcur[s >> 2], s & 3);
-                acc0 = MFMA32(a0c[s], b, acc0);
-                if (MT == 2) acc1 = MFMA32(a1c[s], b, acc1);
-            }
+            const float b = f4c(bcur[s >> 2], s & 3);
+            acc0 = MFMA32(a0c[s], b, acc0);
+            if (MT == 2) acc1 = MFMA32(a1c[s], b, acc1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -330,8 +325,8 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
     }
 }
 
-template <int CC, int KS, int WPE>
-__global__ __launch_bounds__(256, WPE) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
+template <int CC, int KS>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                            const float4* __restrict__ wfrag, const float* __restrict__ bias,
                                                            const float* __restrict__ skip, float* __restrict__ y)
 {
@@ -344,7 +339,7 @@ __global__ __launch_bounds__(256, WPE) void conv3_mfma_kernel(TileArgs a, const 
     const int n = wg / a.ntile_rows, h0 = (wg - n * a.ntile_rows) * a.R;
     const int Rr = g.Ho - h0 < a.R ? g.Ho - h0 : a.R;
     const int nv = Rr * g.Wo * g.To, ntiles = (nv + 31) >> 5;
-    const int nchunk = (g.Cin + CC - 1) / CC;
+    const int nchunk = g.Cin / CC;
     const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
 
     STAMP(0);
@@ -366,10 +361,8 @@ __global__ __launch_bounds__(256, WPE) void conv3_mfma_kernel(TileArgs a, const 
                 __syncthreads();
             }
             const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
-            const int cv = g.Cin - chunk * CC < CC ? g.Cin - chunk * CC : CC;      // valid channels of this chunk
-            const int ks = (cv + 1) >> 1;
-            if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1, ks);
-            else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1, ks);
+            if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
+            else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1);
             STAMP(2 + 2 * chunk);
         }
         // epilogue: D row = output voxel, column = output channel.  All loads (bias, skip) and the arithmetic happen in
@@ -426,7 +419,7 @@ static ConvPlan conv_plan(const ConvGeom& g, bool all_channels)
     if (g.Cout > 32 && !all_channels) return p;
     int CC;
     if (all_channels) CC = g.Cin;                           // wgrad stages every input channel
-    else if (g.Cin == 25) CC = 13;                          // 13 + 12 channels: 41 KB tile, three workgroups per CU
+    else if (g.Cin == 25) CC = 25;
     else if (g.Cin == 1) CC = 1;
     else if (g.Cin % 16 == 0) CC = 16;
     else return p;
@@ -461,15 +454,15 @@ size_t mfma_conv_wfrag_floats(int Cin, int Cout)
 {
     if (Cout > 32) return 0;
     int CC;
-    if (Cin == 25) CC = 13; else if (Cin == 1) CC = 1; else if (Cin % 16 == 0) CC = 16; else return 0;
+    if (Cin == 25) CC = 25; else if (Cin == 1) CC = 1; else if (Cin % 16 == 0) CC = 16; else return 0;
     const int KS = (CC + 1) / 2, KS4 = (KS + 3) / 4;
-    return (size_t)((Cin + CC - 1) / CC) * 27 * KS4 * 256;
+    return (size_t)(Cin / CC) * 27 * KS4 * 256;
 }
 
 void mfma_conv_pack_job(PackJob& J, int Cin, int Cout)
 {
     J.type = PACK_CONV; J.Cin = Cin; J.Cout = Cout; J.taps = 27;
-    J.CC = Cin == 25 ? 13 : (Cin == 1 ? 1 : 16); J.KS = (J.CC + 1) / 2;
+    J.CC = Cin == 25 ? 25 : (Cin == 1 ? 1 : 16); J.KS = (J.CC + 1) / 2;
     J.count = (long)mfma_conv_wfrag_floats(Cin, Cout);
 }
 
@@ -486,10 +479,10 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
     if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<13, 7, 3>); allow_big_lds(conv3_mfma_kernel<16, 8, 2>); allow_big_lds(conv3_mfma_kernel<1, 1, 2>); once = true; }
-    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1, 2>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else if (p.CC == 13) hipLaunchKernelGGL((conv3_mfma_kernel<13, 7, 3>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, 2>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13>); allow_big_lds(conv3_mfma_kernel<16, 8>); allow_big_lds(conv3_mfma_kernel<1, 1>); once = true; }
+    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     return check_launch("conv3_mfma");
 }
 
@@ -747,8 +740,217 @@ int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, co
 //   (c) dX^T  += W1 dH'^T_c               K = hidden = ROW index of dH'^T: accumulator registers are the B operand
 //   (d) dW1_c += X^T dH'_c                K = voxel: needs dH' with the voxel on the K index -> one in-wave LDS transpose
 //   (e) dW2_c += H'^T_c dT                K = voxel: second in-wave transpose
-// (A first decomposition -- every wave owning all chunks of its own tiles, 2 launches x 4 chunks, 1 wave per SIMD at
-// ~445 VGPRs -- reached 69 TFLOP/s; the wave-per-chunk form below reaches 90.)
+//
+// Decomposition: ONE WAVE PER HIDDEN CHUNK.  A workgroup has 8 waves = the 8 chunks of 32 hidden channels; all of
+// them work on the same 32-voxel tile.  Consequences:
+//   * the chunk's weight fragments (W1 for (a), W2 for (b), W1 for (c)) and its bias live in REGISTERS for the whole
+//     kernel -- no LDS traffic for weights at all;
+//   * a wave carries only its own dW1/dW2 chunk (32 accumulator registers), so 2 waves per SIMD fit (<= 256 VGPRs);
+//   * X / dT tiles are staged once per workgroup (double-buffered: tile t+1 is loaded while tile t is computed);
+//   * dX = dOut + sum over the 8 chunks: every wave leaves its partial in LDS and each wave then reduces 4 voxels;
+//   * one pass over the voxels, one slab per workgroup, summed afterwards in a fixed order (fp64).
+// (A first decomposition -- every wave owning all chunks of its own tiles, two launches x 4 chunks, one wave per SIMD
+// at ~445 VGPRs -- reached 69 TFLOP/s; this one reaches 90.)
+// ---------------------------------------------------------------------------------------------------
+constexpr int PW2_WAVES = 8;
+constexpr int PW2_XT = 32 * 33, PW2_DT = 32 * 27, PW2_TB = 32 * 33;
+
+__global__ __launch_bounds__(512, 2) void pw_bwd2_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
+    const float4* __restrict__ w1kcin, const float4* __restrict__ w2kout, const float4* __restrict__ w1khch,
+    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int D)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xt = lds;                                   // [2][32][33]
+    float* Dt = Xt + 2 * PW2_XT;                       // [2][32][27]
+    float* TbAll = Dt + 2 * PW2_DT;                    // [8 waves][2][32][33]   (dH' | H' ; dH' slot reused for the dX partial)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    float* Tb = TbAll + wave * 2 * PW2_TB;
+    float* Tb2 = Tb + PW2_TB;
+    const int c = wave;                                // this wave's hidden chunk
+
+    // chunk-resident operands
+    float4 w1c[4], w2c[4], w3c[4];
+    float hb[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { w1c[q] = w1kcin[(c * 4 + q) * 64 + lane]; w2c[q] = w2kout[(c * 4 + q) * 64 + lane]; w3c[q] = w1khch[(c * 4 + q) * 64 + lane]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hb[r] = b1[32 * c + rowmap(r, half)];
+    f32x16 dW1, dW2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2[r] = 0.f; }
+    float bs1 = 0.f, bs2 = 0.f;
+
+    const long ntiles = (nvox + 31) >> 5;
+    // staging roles: threads 0..255 move one float4 of the X tile, threads 0..(32*D-1) (two rounds of 512) the dT tile.
+    // Loads are unconditional (clamped address), zero selected afterwards.
+    auto stage_load = [&](long tile, float4& xv, float& d0, float& d1) {
+        const long v0 = tile * 32;
+        const long nrem = nvox - v0 < 32 ? nvox - v0 : 32;
+        if (tid < 256) {
+            const int vv = tid >> 3;
+            const long vsrc = vv < nrem ? v0 + vv : v0;
+            const float4 t = reinterpret_cast<const float4*>(x + vsrc * 32)[tid & 7];
+            xv = vv < nrem ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int f0 = tid, f1 = tid + 512;
+        const float a0 = dT[v0 * D + (f0 < nrem * D ? f0 : 0)];
+        const float a1 = dT[v0 * D + (f1 < nrem * D ? f1 : 0)];
+        d0 = f0 < nrem * D ? a0 : 0.f;
+        d1 = f1 < nrem * D ? a1 : 0.f;
+    };
+    auto stage_store = [&](int buf, const float4& xv, float d0, float d1) {
+        if (tid < 256) {
+            float* d = Xt + buf * PW2_XT + (tid >> 3) * 33 + (tid & 7) * 4;
+            d[0] = xv.x; d[1] = xv.y; d[2] = xv.z; d[3] = xv.w;
+        }
+        const int f0 = tid, f1 = tid + 512;
+        if (f0 < 32 * D) { const int vv = f0 / D; Dt[buf * PW2_DT + vv * 27 + (f0 - vv * D)] = d0; }
+        if (f1 < 32 * D) { const int vv = f1 / D; Dt[buf * PW2_DT + vv * 27 + (f1 - vv * D)] = d1; }
+    };
+
+    long tile = blockIdx.x;
+    int buf = 0;
+    {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d0 = 0.f, d1 = 0.f;
+        if (tile < ntiles) { stage_load(tile, xv, d0, d1); stage_store(0, xv, d0, d1); }
+    }
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        __syncthreads();                               // tile `tile` is staged in buffer `buf`; previous dX reduce is done
+        const long tnext = tile + gridDim.x;
+        float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd0 = 0.f, nd1 = 0.f;
+        if (tnext < ntiles) stage_load(tnext, nxv, nd0, nd1);          // in flight during this tile's MFMAs
+        const long v0 = tile * 32;
+        // dOut for the reduce step (this wave reduces voxels 4*wave .. 4*wave+3; lane -> (voxel, cin))
+        const int rv0 = 4 * wave + (lane >> 5), rv1 = rv0 + 2;
+        const bool rok0 = v0 + rv0 < nvox, rok1 = v0 + rv1 < nvox;
+        const float do0 = dOut[(rok0 ? v0 + rv0 : v0) * 32 + col];
+        const float do1 = dOut[(rok1 ? v0 + rv1 : v0) * 32 + col];
+
+        const float* Xb = Xt + buf * PW2_XT;
+        const float* Db = Dt + buf * PW2_DT;
+        float xs[16], dts[13], xa[16], dtb[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            xs[s] = Xb[col * 33 + 16 * half + s];                                       // B of (a): X[vox col][16*half + s]
+            xa[s] = Xb[(2 * s + half) * 33 + col];                                      // A of (d): X[vox 2s+half][cin col]
+            dtb[s] = col < D ? Db[(2 * s + half) * 27 + col] : 0.f;                     // B of (e): dT[vox 2s+half][out col]
+        }
+#pragma unroll
+        for (int s = 0; s < 13; ++s) dts[s] = (13 * half + s) < D ? Db[col * 27 + 13 * half + s] : 0.f;   // B of (b)
+        if (c == 0) {
+            float t2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) t2 += dtb[s];
+            bs2 += t2;
+        }
+        f32x16 H, dH, dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { H[r] = hb[r]; dH[r] = 0.f; dx[r] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                                   // (a) H^T = W1^T X^T + b1
+            H = MFMA32(w1c[q].x, xs[4 * q], H); H = MFMA32(w1c[q].y, xs[4 * q + 1], H);
+            H = MFMA32(w1c[q].z, xs[4 * q + 2], H); H = MFMA32(w1c[q].w, xs[4 * q + 3], H);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                                   // (b) dH^T = W2 dT^T
+            dH = MFMA32(w2c[q].x, dts[4 * q], dH);
+            if (4 * q + 1 < 13) dH = MFMA32(w2c[q].y, dts[(4 * q + 1) % 13], dH);
+            if (4 * q + 2 < 13) dH = MFMA32(w2c[q].z, dts[(4 * q + 2) % 13], dH);
+            if (4 * q + 3 < 13) dH = MFMA32(w2c[q].w, dts[(4 * q + 3) % 13], dH);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dH[r] = H[r] > 0.f ? dH[r] : 0.f; H[r] = fmaxf(H[r], 0.f); }
+        // transposes: lane (voxel col, half) owns hidden rowmap(r, half).  LDS operations of one wave execute in order,
+        // so only the COMPILER must be kept from hoisting the reads above the writes (memory clobber).
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Tb[col * 33 + rowmap(r, half)] = dH[r]; Tb2[col * 33 + rowmap(r, half)] = H[r]; }
+        asm volatile("" ::: "memory");
+        float tr[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) tr[s] = Tb[(2 * s + half) * 33 + col];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                                   // (c) dX^T partial = W1 dH'^T  (registers only)
+            dx = MFMA32(w3c[q].x, dH[4 * q], dx); dx = MFMA32(w3c[q].y, dH[4 * q + 1], dx);
+            dx = MFMA32(w3c[q].z, dH[4 * q + 2], dx); dx = MFMA32(w3c[q].w, dH[4 * q + 3], dx);
+        }
+        float tr2[16];                                                                  // requested under (c)/(d), consumed by (e)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) tr2[s] = Tb2[(2 * s + half) * 33 + col];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float t1 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { t1 += tr[s]; dW1 = MFMA32(xa[s], tr[s], dW1); }              // (d) dW1_c += X^T dH'_c
+            bs1 += t1;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dW2 = MFMA32(tr2[s], dtb[s], dW2);                                  // (e) dW2_c += H'^T_c dT
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's dX partial -> its dH' slot ([voxel][33]); next tile's data -> the other staging buffer
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dx[r];
+        if (tnext < ntiles) stage_store(buf ^ 1, nxv, nd0, nd1);
+        __syncthreads();                               // all 8 partials (and the next tile) are in LDS
+        {
+            float s0 = do0, s1 = do1;
+#pragma unroll
+            for (int j = 0; j < PW2_WAVES; ++j) {
+                const float* P = TbAll + j * 2 * PW2_TB;
+                s0 += P[rv0 * 33 + col];
+                s1 += P[rv1 * 33 + col];
+            }
+            if (rok0) dX[(v0 + rv0) * 32 + col] = s0;
+            if (rok1) dX[(v0 + rv1) * 32 + col] = s1;
+        }
+    }
+    // one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    float* sl = slabs + (long)blockIdx.x * slab_floats;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rw = rowmap(r, half);
+        sl[(long)rw * 256 + 32 * c + col] = dW1[r];                                    // [cin][hidden]
+        if (col < D) sl[8192 + (long)(32 * c + rw) * D + col] = dW2[r];                // [hidden][out]
+    }
+    const float b = bs1 + __shfl_xor(bs1, 32, 64);
+    if (half == 0) sl[8192 + 256 * (long)D + 32 * c + col] = b;
+    if (c == 0) {
+        const float b2s = bs2 + __shfl_xor(bs2, 32, 64);
+        if (half == 0 && col < D) sl[8192 + 256 * (long)D + 256 + col] = b2s;
+    }
+}
+
+// fixed-order fp64 sum of the workgroup slabs, scattered to the four gradient tensors
+__global__ __launch_bounds__(256) void pw_bwd2_reduce_kernel(const float* __restrict__ slabs, int nslabs, int D,
+                                                            float* __restrict__ dW1, float* __restrict__ dW2,
+                                                            float* __restrict__ db1, float* __restrict__ db2)
+{
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + e;
+    __shared__ double red[8][32];
+    double a0 = 0.0, a1 = 0.0;
+    if (i < slab_floats) {
+        int k = part;
+        for (; k + 8 < nslabs; k += 16) { a0 += (double)slabs[(long)k * slab_floats + i]; a1 += (double)slabs[(long)(k + 8) * slab_floats + i]; }
+        if (k < nslabs) a0 += (double)slabs[(long)k * slab_floats + i];
+    }
+    red[part][e] = a0 + a1;
+    __syncthreads();
+    if (part != 0 || i >= slab_floats) return;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][e];
+    const float v = (float)t;
+    if (i < 8192) dW1[i] = v;
+    else if (i < 8192 + 256 * (long)D) dW2[i - 8192] = v;
+    else if (i < 8192 + 256 * (long)D + 256) db1[i - 8192 - 256 * (long)D] = v;
+    else db2[i - 8192 - 256 * (long)D - 256] = v;
+}
+
 static const int PW_BWD_GRID = 256;
 
 size_t mfma_pw_backward_slab_floats(int D) { return (size_t)PW_BWD_GRID * (8192 + 256 * (size_t)D + 256 + D); }
