@@ -29,8 +29,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef PROBAV_STAMP
 __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_DECL unsigned long long st_t0 = 0, st_fill = 0, st_steps = 0
+#define STAMP_T0 st_t0 = __builtin_amdgcn_s_memtime()
+#define STAMP_ACC(var) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); var += t_ - st_t0; st_t0 = t_; } while (0)
+#define STAMP_OUT do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_stamps[blockIdx.x * 8 + 1] = st_fill; g_stamps[blockIdx.x * 8 + 2] = st_steps; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define STAMP_DECL do { } while (0)
+#define STAMP_T0 do { } while (0)
+#define STAMP_ACC(var) do { } while (0)
+#define STAMP_OUT do { } while (0)
 #endif
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -189,17 +197,26 @@ __device__ __forceinline__ void fill_tile_impl(const TileArgs& a, float* lds, co
 // (pads, out-of-range rows) is produced by zeroing the whole tile first with 16-byte stores.
 template <int CC, int CP, bool GATE>
 __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, const float* __restrict__ x,
-                                                 const float* __restrict__ gate, int n, int h0, int c0, int tid)
+                                                 const float* __restrict__ gate, int n, int h0, int c0, int tid,
+                                                 int rsel = -1, int rot = 0)
 {
+    // rsel < 0: stage every row of the tile; rsel >= 0: refill only tile row `rsel` (ring reuse: the other rows are
+    // still in LDS from the previous output row).  Tile row r lives in LDS row slot (r + rot) % rows.
     const ConvGeom& g = a.g;
     constexpr int V = (CC % 4 == 0) ? 4 : 1;
     constexpr int CG = CC / V;
     constexpr int U = (V == 4) ? 4 : 10;            // loads in flight per thread (float4 resp. float)
-    const int tile_floats = a.rows * a.Wp * a.Tp * CP + 1;                  // + slack word
+    const int rowfloats = a.Wp * a.Tp * CP;
+    const int tile_floats = a.rows * rowfloats + 1;                          // + slack word
     {
-        float4* z = reinterpret_cast<float4*>(lds);
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < (tile_floats + 3) / 4; i += 256) z[i] = zero;   // the launch reserves (tile + 4) floats
+        if (rsel < 0) {
+            float4* z = reinterpret_cast<float4*>(lds);
+            for (int i = tid; i < (tile_floats + 3) / 4; i += 256) z[i] = zero;   // the launch reserves (tile + 8) floats
+        } else {                                                              // one row slot (rowfloats % 4 == 0 is required)
+            float4* z = reinterpret_cast<float4*>(lds + ((rsel + rot) % a.rows) * rowfloats);
+            for (int i = tid; i < rowfloats / 4; i += 256) z[i] = zero;
+        }
     }
     __syncthreads();
     // wave-uniform loop over the staged rows (row validity and the 64-bit row base are scalar work); per element only
@@ -207,13 +224,13 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
     // scalar path 2x slower.)
     const int srcE = g.Wi * g.Ti * CG;                                        // valid elements per source row
     const int dead_slot = tile_floats - 1;
-    for (int r = 0; r < a.rows; ++r) {
+    for (int r = (rsel < 0 ? 0 : rsel); r < (rsel < 0 ? a.rows : rsel + 1); ++r) {
         const int ih = h0 + r - g.ph;
         if (ih < 0 || ih >= g.Hi) continue;                                   // wave-uniform: row stays zero
         const long rbase = (((long)n * g.Hi + ih) * g.Wi) * (long)g.Ti * g.Cin + c0;
         const float* xrow = x + rbase;
         const float* grow = GATE ? gate + rbase : nullptr;
-        const int lrow = (r * a.Wp + g.pw) * a.Tp * CP + g.pt * CP;           // LDS offset of source voxel (w=0, t=0)
+        const int lrow = (((r + rot) % a.rows) * a.Wp + g.pw) * a.Tp * CP + g.pt * CP;   // LDS offset of source voxel (w=0, t=0)
         for (int j0 = tid; j0 < srcE; j0 += 256 * U) {
             float4 val[U];
             int dof[U];
@@ -262,15 +279,16 @@ __device__ __forceinline__ void fill_tile_linear(const TileArgs& a, float* lds, 
 
 template <int CC, int CP>
 __device__ __forceinline__ void fill_tile(const TileArgs& a, float* lds, const float* __restrict__ x,
-                                          const float* __restrict__ gate, int n, int h0, int c0, int tid)
+                                          const float* __restrict__ gate, int n, int h0, int c0, int tid,
+                                          int rsel = -1, int rot = 0)
 {
     // straight-line instantiations chosen by ONE uniform branch (never a branch per element)
     if (a.g.reflect_hw) {
         if (gate) fill_tile_impl<CC, CP, true, true>(a, lds, x, gate, n, h0, c0, tid);
         else      fill_tile_impl<CC, CP, true, false>(a, lds, x, gate, n, h0, c0, tid);
     } else {
-        if (gate) fill_tile_linear<CC, CP, true>(a, lds, x, gate, n, h0, c0, tid);
-        else      fill_tile_linear<CC, CP, false>(a, lds, x, gate, n, h0, c0, tid);
+        if (gate) fill_tile_linear<CC, CP, true>(a, lds, x, gate, n, h0, c0, tid, rsel, rot);
+        else      fill_tile_linear<CC, CP, false>(a, lds, x, gate, n, h0, c0, tid, rsel, rot);
     }
 }
 
@@ -502,14 +520,15 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
 
-    // per-lane LDS offset of filter-matrix row (tap, ci) for each M tile this wave owns
-    int offA[MTW];
+    // per-lane constants of filter-matrix row (tap, ci) for each M tile this wave owns: its dh and its offset inside a row slot
+    int offB[MTW], dhA[MTW];
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
         const int row = (wave + 4 * j) * 32 + col;
         const int tap = row / CIN, ci = row - tap * CIN;
         const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
-        offA[j] = (row < KR) ? ((dh * a.Wp + dw) * a.Tp + dt) * CP + ci : 0;
+        dhA[j] = (row < KR) ? dh : 0;
+        offB[j] = (row < KR) ? (dw * a.Tp + dt) * CP + ci : 0;
     }
     f32x16 acc[MTW];
 #pragma unroll
@@ -518,14 +537,34 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
 
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    // Each workgroup walks a CONTIGUOUS run of (patch, row) tiles.  With one output row per tile the three staged input rows
+    // form a ring in LDS: moving to the next row of the same patch re-stages ONE row instead of three.
+    const int rowfloats = a.Wp * a.Tp * CP;
+    const bool ring = a.R == 1 && a.rows == 3 && !g.reflect_hw && (rowfloats & 3) == 0;
+    const int tbeg = (int)((long)blockIdx.x * total_tiles / gridDim.x), tend = (int)((long)(blockIdx.x + 1) * total_tiles / gridDim.x);
+    int prev_n = -1, prev_h = -1000;
+    STAMP_DECL;
+    STAMP(0);
+    for (int tile = tbeg; tile < tend; ++tile) {
+        STAMP_T0;
         const int n = tile / a.ntile_rows, h0 = (tile - n * a.ntile_rows) * a.R;
         const int Rr = g.Ho - h0 < a.R ? g.Ho - h0 : a.R;
         const int nv = Rr * g.Wo * g.To, nsteps = (nv + 1) >> 1;
         const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
+        const int rot = ring ? ((h0 - g.ph) % 3 + 3) % 3 : 0;
         __syncthreads();
-        fill_tile<CIN, CP>(a, lds, x, nullptr, n, h0, 0, tid);
+        if (ring && n == prev_n && h0 == prev_h + 1) fill_tile<CIN, CP>(a, lds, x, nullptr, n, h0, 0, tid, 2, rot);
+        else fill_tile<CIN, CP>(a, lds, x, nullptr, n, h0, 0, tid, -1, rot);
         __syncthreads();
+        STAMP_ACC(st_fill);
+        prev_n = n; prev_h = h0;
+        int offA[MTW];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            int slot = dhA[j] + rot;
+            slot = slot >= 3 ? slot - 3 : slot;
+            offA[j] = (ring ? slot : dhA[j]) * rowfloats + offB[j];
+        }
         // B operand dy[voxel 2s+half][col] is requested a whole group of PF steps ahead (HBM/L2 latency), the A operands
         // (LDS) one step ahead; the MFMAs of a step then run register-only.  Scheduling barriers pin this order.
         constexpr int PF = 8;
@@ -570,7 +609,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
 #pragma unroll
             for (int u = 0; u < PF; ++u) bq[u] = bn[u];
         }
+        STAMP_ACC(st_steps);
     }
+    STAMP_OUT;
+    STAMP(7);
     // slab of this workgroup: [KR][Cout]
     float* pp = partial + (long)blockIdx.x * KR * g.Cout;
 #pragma unroll

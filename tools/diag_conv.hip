@@ -43,6 +43,25 @@ int main(int argc, char** argv)
         fill += f; taps += t; epi += (double)(s[7] - prev); life += (double)(s[7] - s[0]); ++n;
         tmin = std::min(tmin, s[0]); tmax = std::max(tmax, s[7]);
     }
+    {   // backward-filter of the same layer
+        float *dy, *dw, *db, *part;
+        hipMalloc(&dy, nout * 4); hipMemcpy(dy, y, nout * 4, hipMemcpyDeviceToDevice);
+        hipMalloc(&dw, 27 * cin * cout * 4); hipMalloc(&db, cout * 4);
+        if (mfma_wgrad_supported(g)) {
+            hipMalloc(&part, mfma_wgrad_partial_floats(g) * 4);
+            for (int it = 0; it < 3; ++it) mfma_conv_wgrad(g, x, dy, nullptr, dw, db, part, 0);
+            hipDeviceSynchronize();
+            hipEventRecord(e0, 0);
+            for (int it = 0; it < 5; ++it) mfma_conv_wgrad(g, x, dy, nullptr, dw, db, part, 0);
+            hipEventRecord(e1, 0); hipDeviceSynchronize();
+            float ms2; hipEventElapsedTime(&ms2, e0, e1);
+            std::vector<unsigned long long> s2(8192 * 8);
+            hipMemcpyFromSymbol(s2.data(), HIP_SYMBOL(g_stamps), s2.size() * 8);
+            double f = 0, st = 0, life2 = 0; int m = 0;
+            for (int b = 0; b < 512; ++b) { f += (double)s2[b * 8 + 1]; st += (double)s2[b * 8 + 2]; life2 += (double)(s2[b * 8 + 7] - s2[b * 8]); ++m; }
+            printf("wgrad Cin %d Cout %d: %.1f us/launch incl. slab reduce (stamped); per workgroup (cycles): fill %.0f  steps %.0f  lifetime %.0f\n", cin, cout, ms2 / 5 * 1e3, f / m, st / m, life2 / m);
+        }
+    }
     printf("Cin %d Cout %d: %.1f us/launch (stamped build); per workgroup (shader cycles): fill %.0f  taps %.0f  epilogue %.0f  lifetime %.0f ; kernel span %.0f ticks, %d WGs\n",
            cin, cout, ms / 5 * 1e3, fill / n, taps / n, epi / n, life / n, (double)(tmax - tmin), n);
     return 0;
