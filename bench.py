@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="patches per GPU (BASELINE.json: 128)")
     ap.add_argument("--frames", type=int, default=9, help="numImgLR: 9 (headline), 13 or 7")
-    ap.add_argument("--impl", type=int, default=1, help="1 = MFMA kernels where available, 0 = generic direct kernels")
+    ap.add_argument("--impl", type=int, default=2, help="2 = MFMA + strip convolution (default), 1 = MFMA row-tile kernels, 0 = generic direct kernels")
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -175,7 +175,7 @@ def main():
             "config": {"workload": "cfg p16t%dc85r12: %d patches/GPU of [22,22,%d,1] -> [48,48,1], 12 WDSR-B blocks, 32 filters; "
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
                                    (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": "mfma" if args.impl else "direct",
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip"}[args.impl],
                        "loss": float(loss.detach()), "kernel_events": use_events},
             "algorithmic_tflops_whole_step": round(value * ALGO_GFLOP_PER_PATCH / 1e3, 3) if T == 9 else None,
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",

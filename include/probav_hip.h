@@ -57,7 +57,7 @@ int probav_num_layers(const probav_engine* e);
 /* name, offsets (in floats) and kernel shape of layer i; shape is [kh,kw,kt,Cin,Cout]               */
 int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_off, int64_t* v_off,
                       int64_t* b_off, int32_t shape[5]);
-/* 0 = generic direct kernels everywhere, 1 = MFMA kernels where available (default)                */
+/* 0 = generic direct kernels everywhere, 1 = MFMA row-tile kernels, 2 = MFMA + strip convolution (default) */
 int probav_engine_set_impl(probav_engine* e, int impl);
 size_t probav_workspace_bytes(const probav_engine* e, int batch, int training);
 /* per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
@@ -97,7 +97,7 @@ int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi,
 
 /* ---- single operators (what the engine is made of; exported for parity tests) ------------------- */
 /* geometry: int32[17] = N, Hi,Wi,Ti,Cin, Ho,Wo,To,Cout, kh,kw,kt, ph,pw,pt, reflect_hw, relu        */
-/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA                           */
+/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA row-tile, 2 = MFMA strip  */
 int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w,
                           const float* bias, const float* skip, float* y, int impl, void* stream);
 size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl);

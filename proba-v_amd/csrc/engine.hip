@@ -24,7 +24,7 @@ struct probav_engine {
     std::vector<LayerRec> layers;
     int64_t nparams = 0, weff_count = 0, cout_total = 0;
     WnLayer* d_layers = nullptr;
-    int impl = 1;
+    int impl = 2;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed, redReflect;
     int Hin = 0;
@@ -204,6 +204,7 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD), geom_macs(g), s);
+    if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, s);
     if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, s);
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
 }
@@ -372,7 +373,7 @@ int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_o
 
 int probav_engine_set_impl(probav_engine* e, int impl)
 {
-    if (!e || impl < 0 || impl > 1) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    if (!e || impl < 0 || impl > 2) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
     e->impl = impl;
     return PROBAV_OK;
 }
@@ -566,10 +567,12 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     if (!geom || !x || !w || !y) { set_error("probav_conv3d_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
-    if (impl == 1) {
-        if (!mfma_conv_supported(g)) { set_error("probav_conv3d_forward: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
+    if (impl == 1 || impl == 2) {
+        const bool okk = impl == 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g);
+        if (!okk) { set_error("probav_conv3d_forward: geometry not supported by this MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
         int rc = op_pack(g, w, (hipStream_t)stream);
         if (rc) return rc;
+        if (impl == 2) return mfma_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
         return mfma_conv_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
     }
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, (hipStream_t)stream);

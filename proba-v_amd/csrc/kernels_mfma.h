@@ -21,6 +21,11 @@ void mfma_conv_pack_job(PackJob& J, int Cin, int Cout);    // fills type/Cin/Cou
 int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
                       const float* skip, float* y, hipStream_t s);
 
+// strip form (ring of input rows, flattened tiles, K split over wave pairs); same fragment layout as mfma_conv_forward
+bool mfma_conv_strip_supported(const ConvGeom& g);
+int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
+                            const float* skip, float* y, hipStream_t s);
+
 bool mfma_wgrad_supported(const ConvGeom& g);
 size_t mfma_wgrad_partial_floats(const ConvGeom& g);
 int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db,

@@ -19,6 +19,7 @@
 // D: register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 #include "probav_common.h"
 #include "kernels_mfma.h"
+#include <type_traits>
 
 namespace probav {
 
@@ -502,6 +503,335 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
     else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     return check_launch("conv3_mfma");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv3 forward / backward-data, "strip" form (zero-padded layers whose output row has >= 128 voxels)
+//
+// One workgroup = a strip of consecutive output rows of ONE patch.  What it fixes relative to conv3_mfma_kernel
+// (profiles/r01_pmc_summary.csv: 56 % MFMA-busy there):
+//   * input rows live in a 5-slot LDS ring: every row is staged ONCE (not three times), and asynchronously -- the loads
+//     of the next row are issued before a round's MFMAs and written to LDS after them;
+//   * M tiles are cut from the flattened voxel stream of the strip, so only the strip's last tile is partial (a 22x9 row
+//     is 6.19 tiles: the row-tile kernel pays 7 and leaves one of its four waves half idle);
+//   * 8 waves: waves w and w+4 split the 27 taps of the SAME tile (14 / 13) and meet in LDS.  Two partial sums add
+//     commutatively, so the result does not depend on arrival order (bitwise reproducible); both waves sit on the same
+//     SIMD, which therefore always has two independent MFMA streams;
+//   * one workgroup per CU, no tail: a round = 4 tiles = 128 voxels, one barrier (+ a short one for the exchange).
+// Inputs with more channels than CC run nchunk passes over the strip; pass p > 0 adds to the partial output of pass p-1
+// (re-read from L2), the last pass applies bias / ReLU / skip.
+// ---------------------------------------------------------------------------------------------------
+struct StripArgs {
+    ConvGeom g;
+    int Wp, Tp;                 // staged width / depth (Wo + 2, To + 2)
+    int SR, nstrips;            // output rows per strip, strips per patch
+    unsigned mTo, mNvr, mTi, mSrcCol;
+};
+
+constexpr int STRIP_SLOTS = 5;
+
+template <int CC, int KS>
+__device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds, const int (&base)[3], int tap0, int ntap,
+                                           const float4* __restrict__ wf, f32x16& acc, int ks)
+{
+    // taps tap0 .. tap0+ntap-1 of one tile; the A operands (LDS) and B fragments (L2) of tap i+1 are requested before
+    // the MFMAs of tap i, which then run register-only (scheduling barriers pin that order).  The loop stays rolled:
+    // fully unrolled it needed > 400 VGPRs.
+    constexpr int CP = (CC & 1) ? CC : CC + 1;
+    constexpr int KS4 = (KS + 3) / 4;
+    float4 bcur[KS4], bnxt[KS4];
+    float acur[KS], anxt[KS];
+    auto a_ptr = [&](int tap) -> const float* {
+        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;             // wave-uniform
+        const int b = dh == 0 ? base[0] : (dh == 1 ? base[1] : base[2]);
+        return lds + b + (dw * a.Tp + dt) * CP;
+    };
+    {
+        const float* pa = a_ptr(tap0);
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) bcur[q] = wf[(tap0 * KS4 + q) * 64];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acur[s] = pa[2 * s];
+    }
+#pragma unroll 1
+    for (int i = 0; i < ntap; ++i) {
+        const int tn = (i + 1 < ntap) ? tap0 + i + 1 : tap0 + i;
+        const float* pa = a_ptr(tn);
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) bnxt[q] = wf[(tn * KS4 + q) * 64];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) anxt[s] = pa[2 * s];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (s < ks) acc = MFMA32(acur[s], f4c(bcur[s >> 2], s & 3), acc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) bcur[q] = bnxt[q];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acur[s] = anxt[s];
+    }
+}
+
+template <int CC, int KS, bool GATE>
+__global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
+                                                            const float4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                            const float* __restrict__ skip, float* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CP = (CC & 1) ? CC : CC + 1;
+    constexpr int KS4 = (KS + 3) / 4;
+    constexpr int V = (CC % 4 == 0) ? 4 : 1;        // floats per load when staging
+    constexpr int CG = CC / V;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int tsel = wave & 3, grp = wave >> 2;     // tile of the round, tap group (0: taps 0..13, 1: taps 14..26)
+    const int rowfloats = a.Wp * a.Tp * CP;
+    float* part = lds + STRIP_SLOTS * rowfloats + 8; // [4 tiles][16 regs][64 lanes]
+    const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
+    const int hb = strip * a.SR;
+    const int SRr = g.Ho - hb < a.SR ? g.Ho - hb : a.SR;
+    const int nvr = g.Wo * g.To;                     // voxels per output row (>= 128)
+    const int NV = SRr * nvr, NTL = (NV + 31) >> 5, nrounds = (NTL + 3) >> 2;
+    const int nchunk = (g.Cin + CC - 1) / CC;
+    const long out_base = ((long)n * g.Ho + hb) * nvr;
+    float* ybase = y + out_base * g.Cout;
+    const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
+    const int srcE = g.Wi * g.Ti * CG;               // staged loads per input row
+    constexpr int RV = (V == 4) ? 3 : 10;            // staged loads per thread: ceil(srcE / 512) must be <= RV
+    typedef typename std::conditional<V == 4, float4, float>::type stage_t;
+    const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+
+    // ring row q <-> input row ih = hb - ph + q, slot q % 5.  stage(): row interior only; the pads of every slot are
+    // zeroed once and never written again; rows outside the patch get a zero interior.
+    auto row_src = [&](int q, int c0, const float*& xrow, const float*& grow) -> bool {
+        const int ih = hb - g.ph + q;
+        const bool ok = ih >= 0 && ih < g.Hi;
+        const long rbase = (((long)n * g.Hi + (ok ? ih : 0)) * g.Wi) * (long)g.Ti * g.Cin + c0;
+        xrow = x + rbase;
+        grow = GATE ? gate + rbase : nullptr;
+        return ok;
+    };
+    auto elem = [&](int j, int c0, int& so, int& d, bool& chan_ok) {           // j-th staged load of a row -> offsets
+        chan_ok = true;
+        if constexpr (V == 1 && CC == CP && (CC == 25 || CC == 1)) {
+            const int w = fdiv(j, g.Ti * CC, a.mSrcCol);
+            so = j;
+            d = j + w * (a.Tp - g.Ti) * CP;
+        } else {
+            const int vs = j / CG, cgi = j - vs * CG;
+            const int w = fdiv(vs, g.Ti, a.mTi);
+            chan_ok = c0 + cgi * V < g.Cin;
+            so = chan_ok ? vs * g.Cin + cgi * V : 0;
+            d = (vs + w * (a.Tp - g.Ti)) * CP + cgi * V;
+        }
+    };
+    auto stage_load = [&](int q, int c0, stage_t (&rv)[RV]) {
+        const float *xrow, *grow;
+        const bool rok = row_src(q, c0, xrow, grow);
+#pragma unroll
+        for (int k = 0; k < RV; ++k) {
+            const int ju = tid + k * 512;
+            const bool live = ju < srcE;
+            int so, d; bool cok;
+            elem(live ? ju : 0, c0, so, d, cok);
+            const bool ok = live && rok && cok;
+            if constexpr (V == 4) {
+                float4 v = *reinterpret_cast<const float4*>(xrow + so);
+                if constexpr (GATE) {
+                    const float4 m = *reinterpret_cast<const float4*>(grow + so);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                rv[k].x = ok ? v.x : 0.f; rv[k].y = ok ? v.y : 0.f; rv[k].z = ok ? v.z : 0.f; rv[k].w = ok ? v.w : 0.f;
+            } else {
+                float v = xrow[so];
+                if constexpr (GATE) v = grow[so] > 0.f ? v : 0.f;
+                rv[k] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto stage_store = [&](int q, int c0, const stage_t (&rv)[RV]) {
+        float* slot = lds + (q % STRIP_SLOTS) * rowfloats + (g.pw * a.Tp + g.pt) * CP;
+        const int dead = STRIP_SLOTS * rowfloats;                                // slack word behind the ring
+#pragma unroll
+        for (int k = 0; k < RV; ++k) {
+            const int ju = tid + k * 512;
+            const bool live = ju < srcE;
+            int so, d; bool cok;
+            elem(live ? ju : 0, c0, so, d, cok);
+            float* dst = live ? slot + d : lds + dead;
+            if constexpr (V == 4) { dst[0] = rv[k].x; dst[live ? 1 : 0] = rv[k].y; dst[live ? 2 : 0] = rv[k].z; dst[live ? 3 : 0] = rv[k].w; }
+            else dst[0] = rv[k];
+        }
+    };
+
+    for (int pass = 0; pass < nchunk; ++pass) {
+        const int c0 = pass * CC;
+        const int cv = g.Cin - c0 < CC ? g.Cin - c0 : CC, ks = (cv + 1) >> 1;
+        const float4* wf = wfrag + (long)pass * 27 * KS4 * 64 + lane;
+        __syncthreads();
+        {   // zero the whole ring (pads stay zero for the rest of the pass), then rows q = 0..3
+            float4* z = reinterpret_cast<float4*>(lds);
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = tid; i < (STRIP_SLOTS * rowfloats + 8) / 4; i += 512) z[i] = zero;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            stage_t rv[RV];
+            stage_load(q, c0, rv);
+            stage_store(q, c0, rv);
+        }
+        int hiq = 3;
+        __syncthreads();
+
+        for (int r = 0; r < nrounds; ++r) {
+            // does round r+1 need a row that is not resident yet?  (at most one new row per round: 128 <= voxels per row)
+            const int vlast_next = (r + 2) * 128 - 1 < NV - 1 ? (r + 2) * 128 - 1 : NV - 1;
+            const int need_next = fdiv(vlast_next, nvr, a.mNvr) + 2;
+            const bool do_load = r + 1 < nrounds && need_next > hiq;                 // wave-uniform
+            stage_t rv[RV];
+            if (do_load) stage_load(hiq + 1, c0, rv);                                // in flight during this round's MFMAs
+
+            const int tile = 4 * r + tsel;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            float sk[16];                                      // skip / previous-pass values of this wave's output rows,
+#pragma unroll                                                 // requested now so that their latency hides under the taps
+            for (int i = 0; i < 16; ++i) sk[i] = 0.f;
+            if (grp == 0 && tile < NTL && (sbase || pass > 0)) {
+                const float* src = (pass == nchunk - 1 && sbase && pass == 0) ? sbase : (pass > 0 ? (const float*)ybase : sbase);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int vi = tile * 32 + rowmap(i, half);
+                    const int o = (vi < NV && col < g.Cout) ? vi * g.Cout + col : 0;
+                    sk[i] = src[o];
+                }
+            }
+            if (tile < NTL) {
+                int vi = tile * 32 + col;
+                vi = vi < NV ? vi : NV - 1;
+                const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+                const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+                int base[3];
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) base[dh] = ((hrel + dh) % STRIP_SLOTS) * rowfloats + (w * a.Tp + t) * CP + half;
+                strip_taps<CC, KS>(a, lds, base, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks);
+                if (grp == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
+                }
+            }
+            if (do_load) { stage_store(hiq + 1, c0, rv); ++hiq; }
+            __syncthreads();                                   // partials + the new row are in LDS
+            float pv[16];
+            if (grp == 0 && tile < NTL) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pv[i] = part[(tsel * 16 + i) * 64 + lane];
+            }
+            __syncthreads();                                   // partial buffer may be rewritten by the next round
+            if (grp == 0 && tile < NTL) {
+                const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
+                int oo[16];
+                float ov[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int vi = tile * 32 + rowmap(i, half);
+                    oo[i] = (vi < NV && col < g.Cout) ? vi * g.Cout + col : -1;
+                    ov[i] = acc[i] + pv[i];
+                }
+                // single-pass layers (the only ones routed here): sk = skip connection.  Multi-pass: pass 0 stores the raw
+                // partial, later passes add the previous partial (sk), the last one finishes with bias / ReLU / skip.
+                if (nchunk == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float v = ov[i] + bv;
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        ov[i] = v + sk[i];
+                    }
+                } else {
+                    if (pass > 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) ov[i] += sk[i];
+                    }
+                    if (pass == nchunk - 1) {
+                        float s2[16];
+                        if (sbase) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) s2[i] = sbase[oo[i] < 0 ? 0 : oo[i]];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) s2[i] = 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            float v = ov[i] + bv;
+                            if (g.relu) v = fmaxf(v, 0.f);
+                            ov[i] = v + s2[i];
+                        }
+                    }
+                }
+                if (full) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ybase[oo[i]] = ov[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (oo[i] >= 0) ybase[oo[i]] = ov[i];
+                }
+            }
+        }
+    }
+}
+
+struct StripPlan { bool ok; int CC, KS; size_t lds_bytes; int grid; StripArgs a; };
+
+static StripPlan strip_plan(const ConvGeom& g)
+{
+    StripPlan p;
+    p.ok = false;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.Cout > 32) return p;
+    if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return p;
+    int CC;
+    if (g.Cin == 25) CC = 25; else return p;      // 32-channel inputs need two passes here: measured no faster than the row-tile kernel
+    const int CP = (CC & 1) ? CC : CC + 1;
+    const int nvr = g.Wo * g.To;
+    if (nvr < 128 || g.Ho < 3) return p;
+    const int Wp = g.Wo + 2, Tp = g.To + 2;
+    const int CG = (CC % 4 == 0) ? CC / 4 : CC;
+    if ((g.Wi * g.Ti * CG + 511) / 512 > ((CC % 4 == 0) ? 3 : 10)) return p;  // staging registers per thread
+    const size_t lds = ((size_t)STRIP_SLOTS * Wp * Tp * CP + 8 + 4 * 16 * 64) * sizeof(float);
+    if (lds > 163840) return p;
+    // strips per patch: fill the 256 CUs, but keep strips long enough to amortise the 4-row prologue
+    int nstrips = (256 + g.N - 1) / g.N;
+    if (nstrips < 1) nstrips = 1;
+    if (nstrips > g.Ho / 4) nstrips = g.Ho / 4 > 0 ? g.Ho / 4 : 1;
+    const int SR = (g.Ho + nstrips - 1) / nstrips;
+    nstrips = (g.Ho + SR - 1) / SR;
+    p.ok = true; p.CC = CC; p.KS = (CC + 1) / 2; p.lds_bytes = (lds + 15) & ~(size_t)15; p.grid = g.N * nstrips;
+    p.a.g = g; p.a.Wp = Wp; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips;
+    p.a.mTo = magic(g.To); p.a.mNvr = magic(nvr); p.a.mTi = magic(g.Ti); p.a.mSrcCol = magic(g.Ti * CC);
+    return p;
+}
+
+bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
+
+int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
+                            const float* skip, float* y, hipStream_t s)
+{
+    const StripPlan p = strip_plan(g);
+    if (!p.ok) { set_error("mfma_conv_strip_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    static bool once = false;
+    if (!once) {
+        allow_big_lds(conv3_strip_kernel<25, 13, false>); allow_big_lds(conv3_strip_kernel<25, 13, true>);
+        allow_big_lds(conv3_strip_kernel<16, 8, false>); allow_big_lds(conv3_strip_kernel<16, 8, true>);
+        once = true;
+    }
+#define PROBAV_STRIP(C, K, G) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y)
+    if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true); else PROBAV_STRIP(25, 13, false); }
+    else            { if (gate) PROBAV_STRIP(16, 8, true); else PROBAV_STRIP(16, 8, false); }
+#undef PROBAV_STRIP
+    return check_launch("conv3_strip");
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -161,7 +161,7 @@ class WDSRModel(torch.nn.Module):
         return out
 
     def set_impl(self, impl):
-        """0 = generic direct kernels, 1 = MFMA kernels where available (default)."""
+        """0 = generic direct kernels, 1 = MFMA row-tile kernels, 2 = MFMA + strip convolution (default)."""
         _lib.check(_lib.lib().probav_engine_set_impl(self._handle(), int(impl)), "probav_engine_set_impl")
 
     def _workspace(self, batch, training):
