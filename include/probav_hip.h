@@ -92,6 +92,12 @@ int probav_shift_loss_forward(const float* hr, const uint8_t* mask, const float*
 int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg,
                                int batch, int size, int border, int which, const float* upstream,
                                float* dpred, void* stream);
+/* replaces optimizer.apply_gradients with Keras Nadam                   models/trainClass.py:132, train.py:79-81
+ * in place on the flat parameter buffer; m, v = first / second moment slots (n floats each).  The caller supplies the
+ * step-dependent scalars of SURVEY.md A.5 (computed in double): c_g = (1-mu_t)/(1-Pi_t), c_m = mu_{t+1}/(1-Pi_t*mu_{t+1}),
+ * c_v = 1/(1-beta2^t).                                                                                               */
+int probav_nadam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float c_g, float c_m, float c_v, void* stream);
 /* replaces tf.clip_by_value(sr, 0, 2**16); tf.round(sr)                 test.py:118-119             */
 int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi, void* stream);
 

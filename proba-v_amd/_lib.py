@@ -42,6 +42,8 @@ SIGNATURES = {
     "probav_shift_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_void_p, c_void_p, c_void_p]),
     "probav_clip_round": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
+    "probav_nadam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                  c_float, c_float, c_float, c_void_p]),
     "probav_conv3d_forward": (c_int, [POINTER(c_int32 * 17), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_void_p]),
     "probav_conv3d_wgrad_scratch_bytes": (c_size_t, [POINTER(c_int32 * 17), c_int]),

@@ -681,6 +681,13 @@ int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float
     if (!hr || !mask || !pred || !arg || !dpred || batch < 1) { set_error("probav_shift_loss_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
     return shift_loss_backward(hr, mask, pred, arg, batch, size, border, which, upstream, dpred, (hipStream_t)stream);
 }
+int probav_nadam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float c_g, float c_m, float c_v, void* stream)
+{
+    if (!params || !grads || !m || !v || n < 0) { set_error("probav_nadam_step: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    return nadam_step(params, grads, m, v, (long)n, lr, beta1, beta2, eps, c_g, c_m, c_v, (hipStream_t)stream);
+}
+
 int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi, void* stream)
 {
     if (!in || !out) { set_error("probav_clip_round: null argument", hipSuccess); return PROBAV_EINVAL; }

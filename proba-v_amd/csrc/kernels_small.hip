@@ -355,4 +355,31 @@ int shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred,
     return check_launch("shift_loss_backward");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Keras Nadam (optimizer_v2; train.py:79-81) on the flat parameter buffer, one launch:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+//   theta -= lr * ( (1-mu_t) g / (1-Pi_t) + mu_{t+1} m / (1-Pi_t mu_{t+1}) ) / ( sqrt(v / (1-b2^t)) + eps )
+// The step-dependent scalars (c_g = (1-mu_t)/(1-Pi_t), c_m = mu_{t+1}/(1-Pi_t mu_{t+1}), c_v = 1/(1-b2^t)) are computed by the
+// host in double and passed by value.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float c_g, float c_m, float c_v)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i];
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    theta[i] -= lr * (c_g * g + c_m * mi) / (sqrtf(vi * c_v) + eps);
+}
+int nadam_step(float* theta, const float* grad, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+               float c_g, float c_m, float c_v, hipStream_t s)
+{
+    if (n <= 0) return PROBAV_OK;
+    hipLaunchKernelGGL(nadam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, theta, grad, m, v, n, lr, b1, b2, eps, c_g, c_m, c_v);
+    return check_launch("nadam");
+}
+
 }  // namespace probav

@@ -65,4 +65,7 @@ int shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred,
                         int border, int which /*1 = L1, 2 = L2*/, const float* upstream /*device scalar or null*/,
                         float* dpred, hipStream_t s);
 
+int nadam_step(float* theta, const float* grad, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+               float c_g, float c_m, float c_v, hipStream_t s);
+
 }  // namespace probav

@@ -85,3 +85,44 @@ class Enhancer:
                 img[i * 96:(i + 1) * 96, j * 96:(j + 1) * 96] = patches[k]
                 k += 1
         return img.reshape((384, 384, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device-side image pipeline around the forward kernels.  Tensor re-arrangement only (torch plumbing);
+# the arithmetic stays in the HIP engine and in probav_clip_round.
+# ---------------------------------------------------------------------------------------------------------------------
+def unfold_frames(frames, patchSizeLR=16, maxShift=6):
+    """Registered LR frames [sets, T, H, W] (H = W = 128) -> patches [sets, n*n, P+s, P+s, T, 1] on the frames' device.
+
+    Restates what the reference's offline preprocessing does before test.py sees the data
+    (utils/dataGenerator.py:108-121: reflect-pad every frame by maxShift//2, then unfold (P+maxShift)-sized windows with
+    stride P, row-major) followed by test.py:38's transpose to [sets, patch, H, W, T, C]."""
+    import torch.nn.functional as F
+    f = torch.as_tensor(frames)
+    S, T, H, W = f.shape
+    pad, win = maxShift // 2, patchSizeLR + maxShift
+    fp = F.pad(f.reshape(S * T, 1, H, W).float(), (pad, pad, pad, pad), mode="reflect")
+    u = fp.unfold(2, win, patchSizeLR).unfold(3, win, patchSizeLR)           # [S*T, 1, n, n, win, win]
+    n = u.shape[2]
+    u = u.reshape(S, T, n * n, win, win).permute(0, 2, 3, 4, 1).contiguous()  # [S, n*n, win, win, T]
+    return u.unsqueeze(-1)
+
+
+def stitch_device(sr, sets):
+    """[sets*n*n, ps, ps, 1] -> [sets, n*ps, n*ps]: the row-major block layout of test.py:149-160, on the device."""
+    nn_, ps = sr.shape[0] // sets, sr.shape[1]
+    n = int(round(nn_ ** 0.5))
+    return sr.reshape(sets, n, n, ps, ps).permute(0, 1, 3, 2, 4).reshape(sets, n * ps, n * ps)
+
+
+def resolve_images(model, patches, micro_batch=2048):
+    """All image sets at once: patches [sets, n*n, P+s, P+s, T, 1] -> uint16-range images [sets, 3nP, 3nP] (device tensor).
+    Samples are independent, so any micro-batch gives bit-identical pixels to the reference's batches of 16."""
+    dev = _device_of(model)
+    p = torch.as_tensor(patches)
+    sets = p.shape[0]
+    flat = p.reshape((-1,) + tuple(p.shape[2:]))
+    outs = []
+    for i in range(0, flat.shape[0], micro_batch):
+        outs.append(resolve_device(model, flat[i:i + micro_batch].to(dev)))
+    return stitch_device(torch.cat(outs), sets)

@@ -80,13 +80,53 @@ def allreduce_mean_(flat_grad):
     return flat_grad
 
 
+class HipNadam(torch.optim.Optimizer):
+    """Keras ``Nadam`` (optimizer_v2 defaults: beta_1 0.9, beta_2 0.999, epsilon 1e-7, schedule_decay 0.004)
+    as ONE fused HIP launch per parameter tensor (the model has a single flat one).  The momentum schedule
+    (mu_t, the running product Pi_t = `momentum_cache`) is tracked on the host in double, like Keras tracks it in
+    variables; `state_dict()` carries step, momentum cache and the two slots, so checkpoints resume exactly."""
+
+    def __init__(self, params, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, schedule_decay=0.004):
+        super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon, schedule_decay=schedule_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        for group in self.param_groups:
+            b1, b2 = group["beta_1"], group["beta_2"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_device(p, "parameter")
+                st = self.state[p]
+                if not st:
+                    st["step"], st["momentum_cache"] = 0, 1.0
+                    st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                t = st["step"]
+                mu_t = b1 * (1.0 - 0.5 * 0.96 ** (t * group["schedule_decay"]))
+                mu_t1 = b1 * (1.0 - 0.5 * 0.96 ** ((t + 1) * group["schedule_decay"]))
+                pi_t = st["momentum_cache"] * mu_t
+                st["momentum_cache"] = pi_t
+                c_g = (1.0 - mu_t) / (1.0 - pi_t)
+                c_m = mu_t1 / (1.0 - pi_t * mu_t1)
+                c_v = 1.0 / (1.0 - b2 ** t)
+                g = p.grad.contiguous()
+                _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]), p.numel(),
+                                                        group["lr"], b1, b2, group["epsilon"], c_g, c_m, c_v,
+                                                        _lib.current_stream()), "probav_nadam_step")
+
+
 def make_optimizer(name, model, learning_rate):
     """train.py:77-83: 'adam' -> Keras Adam, 'nadam' -> Keras Nadam, anything else -> SGD, with the Keras
-    defaults restated (epsilon 1e-7; Nadam schedule_decay 0.004 -- SURVEY.md A.5)."""
+    defaults restated (epsilon 1e-7; Nadam schedule_decay 0.004 -- SURVEY.md A.5).  On a HIP device Nadam is the
+    fused kernel (`HipNadam`); on CPU (host-logic tests only) the algebraically identical torch.optim.NAdam."""
     params = list(model.parameters())
     if name == "adam":
         return torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7)
     if name == "nadam":
+        if params and params[0].is_cuda:
+            return HipNadam(params, lr=learning_rate)
         return torch.optim.NAdam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
     return torch.optim.SGD(params, lr=learning_rate)
 

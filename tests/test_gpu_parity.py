@@ -223,6 +223,27 @@ def test_shift_losses_match_oracle(dev, B, S, border):
         lo.shiftCompensatedL1Loss(hd[:, :-1], md, pd)
 
 
+def test_fused_nadam_matches_keras_restatement(dev):
+    """HIP Nadam (probav_nadam_step) against the fp64 restatement of the Keras rule, incl. checkpoint round trip."""
+    from oracle.nadam_numpy import Nadam
+    from probav_amd.trainClass import HipNadam
+    rng = np.random.default_rng(1)
+    theta = rng.normal(size=535267).astype(np.float32)
+    p = torch.nn.Parameter(torch.as_tensor(theta).to(dev))
+    opt, ref = HipNadam([p], lr=5e-4), Nadam(lr=5e-4)
+    th = theta.astype(np.float64)
+    for k in range(5):
+        g = (rng.normal(size=theta.shape) * (10.0 ** rng.integers(-3, 2))).astype(np.float32)
+        p.grad = torch.as_tensor(g).to(dev)
+        opt.step()
+        th = ref.step(th, g)
+        if k == 2:                                      # resume from a state_dict, like ModelTrainer.restore does
+            sd = opt.state_dict()
+            opt = HipNadam([p], lr=1.0)
+            opt.load_state_dict(sd)
+    assert np.abs(p.detach().cpu().double().numpy() - th).max() < 2e-6 * np.abs(th).max()
+
+
 def test_clip_round_half_to_even(dev):
     L = _lib()
     x = torch.tensor([-3.2, 0.5, 1.5, 2.5, 65535.5, 65536.4, 70000.0, 123.49], device=dev)
@@ -379,7 +400,10 @@ def test_trainer_and_inference_on_device(dev, tmp_path):
     from probav_amd import testClass
     m = _model(dev, seed=3)
     lo = Losses(targetShape=(48, 48, 1))
-    tr = ModelTrainer(m, lo.shiftCompensatedL1Loss, lo.shiftCompensatedcPSNR, make_optimizer("nadam", m, 5e-4),
+    from probav_amd.trainClass import HipNadam
+    opt = make_optimizer("nadam", m, 5e-4)
+    assert isinstance(opt, HipNadam)                   # on the device the optimizer update is the fused HIP kernel
+    tr = ModelTrainer(m, lo.shiftCompensatedL1Loss, lo.shiftCompensatedcPSNR, opt,
                       str(tmp_path / "ck"), str(tmp_path / "lg"), multiGPU=False)
     x, _, mask = synth.synth_batch(8, seed=4)
     rng = np.random.default_rng(4)
@@ -404,6 +428,15 @@ def test_trainer_and_inference_on_device(dev, tmp_path):
     np.testing.assert_array_equal(img[48:96, 96:144], sr[8 + 2])          # row-major block order (test.py:149-160)
     imgs = testClass.evaluate(m, patches[None], batch_size=16)
     np.testing.assert_array_equal(imgs[0], img)
+    # device-side pipeline for whole images: unfold of the reflect-padded frame, any micro-batch, on-device stitch
+    frames = np.clip(np.random.default_rng(2).normal(synth.NIR_MEAN, synth.NIR_STD, (2, 9, 128, 128)), 0, 16383).astype(np.float32)
+    pt = testClass.unfold_frames(torch.as_tensor(frames).to(dev))
+    assert tuple(pt.shape) == (2, 64, 22, 22, 9, 1)
+    padded = np.pad(frames, [(0, 0), (0, 0), (3, 3), (3, 3)], mode="reflect")
+    np.testing.assert_array_equal(pt[1, 8 * 3 + 5, :, :, 4, 0].cpu().numpy(), padded[1, 4, 48:70, 80:102])      # patch (3,5): rows 48.., cols 80..
+    big = testClass.resolve_images(m, pt, micro_batch=128)
+    ref_imgs = testClass.evaluate(m, pt.cpu().numpy(), batch_size=16)
+    np.testing.assert_array_equal(big.cpu().numpy(), np.stack(ref_imgs)[..., 0])
     # a second forward before backward is refused instead of silently using clobbered activations
     p1 = m(xs, training=True)
     _ = m(xs, training=True)

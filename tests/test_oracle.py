@@ -100,3 +100,19 @@ def test_golden_fixture_reproduced(T):
     assert abs(float(loss) - float(z["loss_l1"])) < 1e-9 * float(z["loss_l1"])
     np.testing.assert_allclose(grads["mainConv1"]["v"].numpy(), z["grad/mainConv1/v"], rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(on.shift_cpsnr(hr, mask, z["pred"]), z["cpsnr"], rtol=1e-12)
+
+
+def test_nadam_restatement_equals_torch_nadam():
+    """Keras Nadam restated (oracle/nadam_numpy.py) == torch.optim.NAdam(eps=1e-7, momentum_decay=0.004)."""
+    from oracle.nadam_numpy import Nadam
+    rng = np.random.default_rng(0)
+    theta = rng.normal(size=1000)
+    p = torch.nn.Parameter(torch.tensor(theta))
+    opt_t = torch.optim.NAdam([p], lr=5e-4, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
+    opt_n = Nadam(lr=5e-4)
+    for _ in range(6):
+        g = rng.normal(size=1000) * 10
+        p.grad = torch.tensor(g)
+        opt_t.step()
+        theta = opt_n.step(theta, g)
+    np.testing.assert_allclose(p.detach().numpy(), theta, rtol=1e-7, atol=1e-10)     # same rule, different fp64 op order
