@@ -169,7 +169,25 @@ class ModelTrainer:
         names = self._read_index()
         return os.path.join(self.ckptDir, names[-1]) if names else None
 
+    def _tf_latest(self):
+        """Prefix of the latest TensorFlow-format checkpoint if `ckptDir/checkpoint` is a TF CheckpointState text file
+        (`model_checkpoint_path: "ckpt-124"`), i.e. a directory written by the reference itself."""
+        if not os.path.exists(self._index_path()):
+            return None
+        with open(self._index_path()) as fh:
+            first = fh.readline().strip()
+        if not first.startswith("model_checkpoint_path:"):
+            return None
+        return os.path.join(self.ckptDir, first.split(":", 1)[1].strip().strip('"'))
+
     def restore(self):
+        tf_prefix = self._tf_latest()
+        if tf_prefix is not None:                       # weights trained by the reference (tf.train.Checkpoint bundle)
+            from .tfckpt import load_reference_checkpoint
+            step = load_reference_checkpoint(self._model, tf_prefix)
+            self.step = int(step or 0)
+            print(f"[ INFO ] Model restored from TensorFlow checkpoint {tf_prefix} at step {self.step}.")
+            return
         path = self.latest_checkpoint
         if path and os.path.exists(path):
             state = torch.load(path, map_location="cpu")
@@ -194,7 +212,7 @@ class ModelTrainer:
         torch.save({"model": model_state, "optimizer": self.optimizer.state_dict() if self.optimizer else None,
                     "step": self.step, "psnr": self.psnr, "save_counter": self.save_counter},
                    os.path.join(self.ckptDir, name))
-        kept = self._read_index() + [name]
+        kept = ([] if self._tf_latest() else self._read_index()) + [name]     # a TF CheckpointState file is superseded
         for old in kept[:-self.max_to_keep]:
             try:
                 os.remove(os.path.join(self.ckptDir, old))
