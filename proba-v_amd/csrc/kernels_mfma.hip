@@ -528,12 +528,13 @@ struct StripArgs {
     unsigned mTo, mNvr, mTi, mSrcCol;
 };
 
-constexpr int STRIP_SLOTS = 5;
 
 template <int CC, int KS>
 __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds, const int (&base)[3], int tap0, int ntap,
                                            const float4* __restrict__ wf, f32x16& acc, int ks)
 {
+    // (CC == 32: the filter fragments are the two packed 16-channel chunks [chunk][tap][2][lane]; k-steps 0..7 come from
+    //  chunk 0, 8..15 from chunk 1)
     // taps tap0 .. tap0+ntap-1 of one tile; the A operands (LDS) and B fragments (L2) of tap i+1 are requested before
     // the MFMAs of tap i, which then run register-only (scheduling barriers pin that order).  The loop stays rolled:
     // fully unrolled it needed > 400 VGPRs.
@@ -546,10 +547,18 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
         const int b = dh == 0 ? base[0] : (dh == 1 ? base[1] : base[2]);
         return lds + b + (dw * a.Tp + dt) * CP;
     };
+    auto b_load = [&](int tap, float4 (&dst)[KS4]) {
+        if constexpr (CC == 32) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = wf[(((q >> 1) * 27 + tap) * 2 + (q & 1)) * 64];
+        } else {
+#pragma unroll
+            for (int q = 0; q < KS4; ++q) dst[q] = wf[(tap * KS4 + q) * 64];
+        }
+    };
     {
         const float* pa = a_ptr(tap0);
-#pragma unroll
-        for (int q = 0; q < KS4; ++q) bcur[q] = wf[(tap0 * KS4 + q) * 64];
+        b_load(tap0, bcur);
 #pragma unroll
         for (int s = 0; s < KS; ++s) acur[s] = pa[2 * s];
     }
@@ -557,8 +566,7 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
     for (int i = 0; i < ntap; ++i) {
         const int tn = (i + 1 < ntap) ? tap0 + i + 1 : tap0 + i;
         const float* pa = a_ptr(tn);
-#pragma unroll
-        for (int q = 0; q < KS4; ++q) bnxt[q] = wf[(tn * KS4 + q) * 64];
+        b_load(tn, bnxt);
 #pragma unroll
         for (int s = 0; s < KS; ++s) anxt[s] = pa[2 * s];
         __builtin_amdgcn_sched_barrier(0);
@@ -573,7 +581,7 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
     }
 }
 
-template <int CC, int KS, bool GATE>
+template <int CC, int KS, bool GATE, int STRIP_SLOTS>
 __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                             const float4* __restrict__ wfrag, const float* __restrict__ bias,
                                                             const float* __restrict__ skip, float* __restrict__ y)
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
     float* ybase = y + out_base * g.Cout;
     const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
     const int srcE = g.Wi * g.Ti * CG;               // staged loads per input row
-    constexpr int RV = (V == 4) ? 3 : 10;            // staged loads per thread: ceil(srcE / 512) must be <= RV
+    constexpr int RV = (V == 4) ? 4 : 10;            // staged loads per thread: ceil(srcE / 512) must be <= RV
     typedef typename std::conditional<V == 4, float4, float>::type stage_t;
     const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
 
@@ -690,8 +698,9 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
             const int vlast_next = (r + 2) * 128 - 1 < NV - 1 ? (r + 2) * 128 - 1 : NV - 1;
             const int need_next = fdiv(vlast_next, nvr, a.mNvr) + 2;
             const bool do_load = r + 1 < nrounds && need_next > hiq;                 // wave-uniform
+            constexpr bool ASYNC = STRIP_SLOTS >= 5;                                 // a spare slot lets the load overlap the MFMAs
             stage_t rv[RV];
-            if (do_load) stage_load(hiq + 1, c0, rv);                                // in flight during this round's MFMAs
+            if (ASYNC && do_load) stage_load(hiq + 1, c0, rv);                       // in flight during this round's MFMAs
 
             const int tile = 4 * r + tsel;
             f32x16 acc;
@@ -723,12 +732,17 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                     for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
                 }
             }
-            if (do_load) { stage_store(hiq + 1, c0, rv); ++hiq; }
-            __syncthreads();                                   // partials + the new row are in LDS
+            if (ASYNC && do_load) { stage_store(hiq + 1, c0, rv); ++hiq; }
+            __syncthreads();                                   // partials (+ the new row) are in LDS
             float pv[16];
             if (grp == 0 && tile < NTL) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pv[i] = part[(tsel * 16 + i) * 64 + lane];
+            }
+            if (!ASYNC && do_load) {                           // 4-slot ring: every wave is past its taps, the oldest row is dead
+                stage_load(hiq + 1, c0, rv);
+                stage_store(hiq + 1, c0, rv);
+                ++hiq;
             }
             __syncthreads();                                   // partial buffer may be rewritten by the next round
             if (grp == 0 && tile < NTL) {
@@ -792,15 +806,17 @@ static StripPlan strip_plan(const ConvGeom& g)
     p.ok = false;
     if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.Cout > 32) return p;
     if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return p;
-    int CC;
-    if (g.Cin == 25) CC = 25; else return p;      // 32-channel inputs need two passes here: measured no faster than the row-tile kernel
+    int CC, slots;
+    if (g.Cin == 25) { CC = 25; slots = 5; }            // 5-slot ring: the next row is staged asynchronously
+    else if (g.Cin == 32) { CC = 32; slots = 4; }       // CP = 33: only four rows fit, staged between rounds
+    else return p;
     const int CP = (CC & 1) ? CC : CC + 1;
     const int nvr = g.Wo * g.To;
     if (nvr < 128 || g.Ho < 3) return p;
     const int Wp = g.Wo + 2, Tp = g.To + 2;
     const int CG = (CC % 4 == 0) ? CC / 4 : CC;
-    if ((g.Wi * g.Ti * CG + 511) / 512 > ((CC % 4 == 0) ? 3 : 10)) return p;  // staging registers per thread
-    const size_t lds = ((size_t)STRIP_SLOTS * Wp * Tp * CP + 8 + 4 * 16 * 64) * sizeof(float);
+    if ((g.Wi * g.Ti * CG + 511) / 512 > ((CC % 4 == 0) ? 4 : 10)) return p;  // staging registers per thread
+    const size_t lds = ((size_t)slots * Wp * Tp * CP + 8 + 4 * 16 * 64) * sizeof(float);
     if (lds > 163840) return p;
     // strips per patch: fill the 256 CUs, but keep strips long enough to amortise the 4-row prologue
     int nstrips = (256 + g.N - 1) / g.N;
@@ -823,13 +839,13 @@ int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate
     if (!p.ok) { set_error("mfma_conv_strip_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     static bool once = false;
     if (!once) {
-        allow_big_lds(conv3_strip_kernel<25, 13, false>); allow_big_lds(conv3_strip_kernel<25, 13, true>);
-        allow_big_lds(conv3_strip_kernel<16, 8, false>); allow_big_lds(conv3_strip_kernel<16, 8, true>);
+        allow_big_lds(conv3_strip_kernel<25, 13, false, 5>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5>);
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4>);
         once = true;
     }
-#define PROBAV_STRIP(C, K, G) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y)
-    if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true); else PROBAV_STRIP(25, 13, false); }
-    else            { if (gate) PROBAV_STRIP(16, 8, true); else PROBAV_STRIP(16, 8, false); }
+#define PROBAV_STRIP(C, K, G, S) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G, S>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y)
+    if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5); else PROBAV_STRIP(25, 13, false, 5); }
+    else            { if (gate) PROBAV_STRIP(32, 16, true, 4); else PROBAV_STRIP(32, 16, false, 4); }
 #undef PROBAV_STRIP
     return check_launch("conv3_strip");
 }
