@@ -110,9 +110,10 @@ size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl);
 int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy, const float* gate,
                         float* dw, float* db, void* scratch, size_t scratch_bytes, int impl, void* stream);
 /* fused expConv_i (1x1x1, 32->256) + ReLU + decConv_i (1x1x1, 256->D<=26)      models/modelsTF.py:179-183
- * x [nvox,32], w1 [32,256], b1 [256], w2 [256,D], b2 [D] -> dec [nvox,D]; the 256-channel tensor never reaches HBM */
+ * x [nvox,32], w1 [32,256], b1 [256], w2 [256,D], b2 [D] -> dec [nvox,D]; the 256-channel tensor never reaches HBM
+ * impl 2 = fp32 MFMA, 3 = fp32 products as six bf16-piece products on the bf16 MFMA pipe ("x6", same accuracy class) */
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
-                      int64_t nvox, int D, void* stream);
+                      int64_t nvox, int D, int impl, void* stream);
 /* its reverse pass: d_dec [nvox,D], d_skip [nvox,32] (gradient arriving over the residual connection)
  * -> dx = d_skip + dL/dx [nvox,32], dw1 [32,256], db1 [256], dw2 [256,D], db2 [D]                              */
 size_t probav_pw_backward_scratch_bytes(int D);

@@ -49,7 +49,7 @@ SIGNATURES = {
     "probav_conv3d_wgrad_scratch_bytes": (c_size_t, [POINTER(c_int32 * 17), c_int]),
     "probav_conv3d_wgrad": (c_int, [POINTER(c_int32 * 17), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_int, c_void_p]),
-    "probav_pw_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "probav_pw_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "probav_pw_backward_scratch_bytes": (c_size_t, [c_int]),
     "probav_pw_backward": (c_int, [c_void_p] * 12 + [c_size_t, c_int64, c_int, c_void_p]),
     "probav_weff_count": (c_int64, [c_void_p]),

@@ -12,6 +12,7 @@
 using namespace probav;
 
 #include "kernels_mfma.h"
+#include "kernels_x6.h"
 
 struct LayerRec {
     char name[32];
@@ -626,11 +627,36 @@ static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, co
     return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, s);
 }
 
-int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
-                      int64_t nvox, int D, void* stream)
+static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2)
 {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !dec || nvox < 1) { set_error("probav_pw_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    static float* frag = nullptr;
+    static X6PackJob* d_jobs = nullptr;
+    if (!frag) {
+        hipError_t err = hipMalloc((void**)&frag, (size_t)2 * X6_PW_FRAG_WORDS * 4);
+        if (err == hipSuccess) err = hipMalloc((void**)&d_jobs, 2 * sizeof(X6PackJob));
+        if (err != hipSuccess) { set_error("probav_pw (x6): scratch allocation", err); return PROBAV_EHIP; }
+    }
+    X6PackJob J[2]; memset(J, 0, sizeof(J));
+    J[0].type = X6_PW_W1; J[0].src_is_T = 0; J[0].dst_off = 0; J[0].count = X6_PW_FRAG_WORDS; J[0].Cin = 32; J[0].Cout = 256;
+    J[1].type = X6_PW_W2; J[1].src_is_T = 1; J[1].dst_off = X6_PW_FRAG_WORDS; J[1].count = X6_PW_FRAG_WORDS; J[1].Cin = 256; J[1].Cout = D;
+    hipError_t err = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = hipMemcpy(d_jobs, J, sizeof(J), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { set_error("probav_pw (x6): job upload", err); return PROBAV_EHIP; }
+    *f1 = frag; *f2 = frag + X6_PW_FRAG_WORDS;
+    return x6_pack(d_jobs, 2, w1, w2, frag, s);
+}
+
+int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
+                      int64_t nvox, int D, int impl, void* stream)
+{
+    if (!x || !w1 || !b1 || !w2 || !b2 || !dec || nvox < 1 || (impl != 2 && impl != 3)) { set_error("probav_pw_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_forward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
+    if (impl == 3) {
+        const float *g1, *g2;
+        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &g1, &g2);
+        if (rc) return rc;
+        return x6_pw_forward(x, g1, g2, b1, b2, dec, (long)nvox, D, (hipStream_t)stream);
+    }
     const float *f1, *f2, *f2b, *f1c;
     int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
     if (rc) return rc;

@@ -1,0 +1,42 @@
+"""Launch single operators of libprobav_hip.so at the bench workload's size, for `rocprofv3 --kernel-trace --stats`.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/ops -- python3 tools/bench_ops.py pw_fwd
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from probav_amd import _lib as L  # noqa: E402
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "pw_fwd"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    dev = torch.device("cuda:0")
+    nvox, D = 128 * 22 * 22 * 9, 25
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(nvox, 32, generator=g).to(dev)
+    w1 = (torch.randn(32, 256, generator=g) / 32 ** 0.5).to(dev)
+    b1 = (0.3 * torch.randn(256, generator=g)).to(dev)
+    w2 = (torch.randn(256, D, generator=g) / 16).to(dev)
+    b2 = (0.3 * torch.randn(D, generator=g)).to(dev)
+    dec = torch.empty(nvox, D, device=dev)
+    if what == "pw_fwd":
+        outs = {}
+        for impl in (2, 3):
+            for _ in range(reps):
+                L.check(L.lib().probav_pw_forward(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(dec), nvox, D, impl,
+                                                  L.current_stream()))
+            torch.cuda.synchronize()
+            outs[impl] = dec.double().cpu()
+        ref = torch.relu(x.double().cpu() @ w1.double().cpu() + b1.double().cpu()) @ w2.double().cpu() + b2.double().cpu()
+        for impl, o in outs.items():
+            print("impl %d: max err %.3g  rms err %.3g (relative to max |ref|)" % (
+                impl, float((o - ref).abs().max() / ref.abs().max()), float((o - ref).pow(2).mean().sqrt() / ref.abs().max())))
+
+
+if __name__ == "__main__":
+    main()
