@@ -175,7 +175,7 @@ def main():
             "config": {"workload": "cfg p16t%dc85r12: %d patches/GPU of [22,22,%d,1] -> [48,48,1], 12 WDSR-B blocks, 32 filters; "
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
                                    (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip"}[args.impl],
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16"}[args.impl],
                        "loss": float(loss.detach()), "kernel_events": use_events},
             "algorithmic_tflops_whole_step": round(value * ALGO_GFLOP_PER_PATCH / 1e3, 3) if T == 9 else None,
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",

@@ -25,7 +25,8 @@ struct probav_engine {
     std::vector<LayerRec> layers;
     int64_t nparams = 0, weff_count = 0, cout_total = 0;
     WnLayer* d_layers = nullptr;
-    int impl = 2;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies
+    int impl = 2;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
+                              // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed, redReflect;
     int Hin = 0;
@@ -34,6 +35,8 @@ struct probav_engine {
     PackJob* d_jobs = nullptr;
     int64_t wpack_count = 0;
     std::vector<long> pkFwd, pkBwd;          // per layer: conv fragments for forward / backward-data (-1 = none)
+    std::vector<long> pkFwd6, pkBwd6;        // per layer: x6 (pre-split bf16) conv fragments, impl 3
+    std::vector<long> pkW1x6, pkW2x6;        // per block: x6 fragments of the fused expand/decay forward
     std::vector<long> pkW1, pkW2;            // per block: fused expand/decay forward fragments
     std::vector<long> pkW2B, pkW1C;          // per block: extra fragments of the fused backward
     bool pw_mfma = false;
@@ -199,12 +202,16 @@ static Plan make_plan(const probav_engine* e, int B, int training)
 }
 
 // ---------------------------------------------------------------------------------------------------
+struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; };
+
 static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
-                    const float* wfrag, const float* bias, const float* skip, float* y, hipStream_t s)
+                    const Frags& wf, const float* bias, const float* skip, float* y, hipStream_t s)
 {
+    const float* wfrag = wf.f32;
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD), geom_macs(g), s);
+    if (e->impl >= 3 && wf.x6 && mfma_conv_strip_supported(g)) return x6_conv_strip_forward(g, x, gate, wf.x6, bias, skip, y, s);
     if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, s);
     if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, s);
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
@@ -270,6 +277,7 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
     }
     // MFMA fragment-packing jobs
     e->pkFwd.assign(e->layers.size(), -1); e->pkBwd.assign(e->layers.size(), -1);
+    e->pkFwd6.assign(e->layers.size(), -1); e->pkBwd6.assign(e->layers.size(), -1);
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const LayerRec& r = e->layers[li];
         if (r.kh != 3 || r.kw != 3 || r.kt != 3) continue;
@@ -283,6 +291,14 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             (dir ? e->pkBwd : e->pkFwd)[li] = J.dst_off;
             e->wpack_count += J.count;
             e->jobs.push_back(J);
+            if ((cin == 25 || cin == 32) && cout <= 32) {           // strip-kernel shapes: also the x6 fragments
+                PackJob X; memset(&X, 0, sizeof(X));
+                X.type = PACK_X6_CONV; X.src_is_T = dir; X.src_off = r.wn.w_off; X.dst_off = e->wpack_count;
+                X.count = X6_CONV_FRAG_WORDS; X.Cin = cin; X.Cout = cout; X.taps = 27;
+                (dir ? e->pkBwd6 : e->pkFwd6)[li] = X.dst_off;
+                e->wpack_count += X.count;
+                e->jobs.push_back(X);
+            }
         }
     }
     e->pw_mfma = mfma_pw_supported(F, E, D);
@@ -300,6 +316,13 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             J.type = PACK_PW_A_CIN_KHCH; J.src_off = e->layers[e->iExp[i]].wn.w_off; J.dst_off = e->wpack_count;
             J.Cin = F; J.Cout = E;                                                    // backward (c): dX^T += W1 dH'^T
             e->pkW1C.push_back(J.dst_off); e->wpack_count += J.count; e->jobs.push_back(J);
+            PackJob X; memset(&X, 0, sizeof(X));
+            X.type = PACK_X6_PW_W1; X.src_off = e->layers[e->iExp[i]].wn.w_off; X.dst_off = e->wpack_count;
+            X.count = X6_PW_FRAG_WORDS; X.Cin = F; X.Cout = E;
+            e->pkW1x6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.type = PACK_X6_PW_W2; X.src_off = e->layers[e->iDec[i]].wn.w_off; X.dst_off = e->wpack_count;
+            X.Cin = E; X.Cout = D;
+            e->pkW2x6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
         }
     }
     if (!e->jobs.empty()) {
@@ -374,7 +397,7 @@ int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_o
 
 int probav_engine_set_impl(probav_engine* e, int impl)
 {
-    if (!e || impl < 0 || impl > 2) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    if (!e || impl < 0 || impl > 3) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
     e->impl = impl;
     return PROBAV_OK;
 }
@@ -398,7 +421,7 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
     auto weff = [&](int li) { return W + p.weff + e->layers[li].wn.w_off; };
     auto bias = [&](int li) { return params + e->layers[li].wn.b_off; };
-    auto frag = [&](int li) -> const float* { return e->pkFwd[li] >= 0 ? W + p.wpack + e->pkFwd[li] : nullptr; };
+    auto frag = [&](int li) -> Frags { Frags f; if (e->pkFwd[li] >= 0) f.f32 = W + p.wpack + e->pkFwd[li]; if (e->pkFwd6[li] >= 0) f.x6 = W + p.wpack + e->pkFwd6[li]; return f; };
 
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, s)); }
     if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, s)); }
@@ -409,8 +432,12 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
             // fused expConv + ReLU + decConv: the 256-channel tensor never leaves the accumulators
             const long nvox = (long)B * Hin * Hin * T;
             ProfScope ps(e, CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
-            CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
-                               W + p.dec[i], nvox, D, s));
+            if (e->impl >= 3)
+                CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                                 W + p.dec[i], nvox, D, s));
+            else
+                CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                                   W + p.dec[i], nvox, D, s));
         } else {
             CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), frag(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, s));
             CK(conv_fwd(e, make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0), W + p.H, nullptr, weff(e->iDec[i]), frag(e->iDec[i]), bias(e->iDec[i]), nullptr, W + p.dec[i], s));
@@ -445,7 +472,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
     auto weffT = [&](int li) { return W + p.weffT + e->layers[li].wn.w_off; };
-    auto fragT = [&](int li) -> const float* { return e->pkBwd[li] >= 0 ? W + p.wpack + e->pkBwd[li] : nullptr; };
+    auto fragT = [&](int li) -> Frags { Frags f; if (e->pkBwd[li] >= 0) f.f32 = W + p.wpack + e->pkBwd[li]; if (e->pkBwd6[li] >= 0) f.x6 = W + p.wpack + e->pkBwd6[li]; return f; };
     auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     float* part = W + p.partial;
@@ -507,7 +534,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
             continue;
         }
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
-        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, nullptr, params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
+        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
         // decConv_i
         CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, s));
         CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, s));
@@ -544,9 +571,9 @@ static bool geom_ok(const ConvGeom& g)
 // weights into MFMA fragments needs a device buffer, allocated on first use -- the engine path never does this.
 static float* g_op_frag = nullptr;
 static PackJob* g_op_job = nullptr;
-static int op_pack(const ConvGeom& g, const float* w, hipStream_t s)
+static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, bool x6 = false)
 {
-    const size_t n = mfma_conv_wfrag_floats(g.Cin, g.Cout);
+    const size_t n = x6 ? (size_t)X6_CONV_FRAG_WORDS : mfma_conv_wfrag_floats(g.Cin, g.Cout);
     if (n == 0) { set_error("probav_conv3d_forward: channel configuration not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
     if (!g_op_frag) {
         hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
@@ -555,7 +582,8 @@ static int op_pack(const ConvGeom& g, const float* w, hipStream_t s)
     }
     if (n * sizeof(float) > ((size_t)4 << 20)) { set_error("probav_conv3d_forward: fragment scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     PackJob J; memset(&J, 0, sizeof(J));
-    mfma_conv_pack_job(J, g.Cin, g.Cout);
+    if (x6) { J.type = PACK_X6_CONV; J.count = X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27; }
+    else mfma_conv_pack_job(J, g.Cin, g.Cout);
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(g_op_job, &J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_conv3d_forward: job upload", err); return PROBAV_EHIP; }
@@ -568,11 +596,13 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     if (!geom || !x || !w || !y) { set_error("probav_conv3d_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
-    if (impl == 1 || impl == 2) {
-        const bool okk = impl == 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g);
+    if (impl < 0 || impl > 3) { set_error("probav_conv3d_forward: impl must be 0..3", hipSuccess); return PROBAV_EINVAL; }
+    if (impl >= 1) {
+        const bool okk = impl >= 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g);
         if (!okk) { set_error("probav_conv3d_forward: geometry not supported by this MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
-        int rc = op_pack(g, w, (hipStream_t)stream);
+        int rc = op_pack(g, w, (hipStream_t)stream, impl == 3);
         if (rc) return rc;
+        if (impl == 3) return x6_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
         if (impl == 2) return mfma_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
         return mfma_conv_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
     }
@@ -630,20 +660,20 @@ static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, co
 static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2)
 {
     static float* frag = nullptr;
-    static X6PackJob* d_jobs = nullptr;
+    static PackJob* d_jobs = nullptr;
     if (!frag) {
         hipError_t err = hipMalloc((void**)&frag, (size_t)2 * X6_PW_FRAG_WORDS * 4);
-        if (err == hipSuccess) err = hipMalloc((void**)&d_jobs, 2 * sizeof(X6PackJob));
+        if (err == hipSuccess) err = hipMalloc((void**)&d_jobs, 2 * sizeof(PackJob));
         if (err != hipSuccess) { set_error("probav_pw (x6): scratch allocation", err); return PROBAV_EHIP; }
     }
-    X6PackJob J[2]; memset(J, 0, sizeof(J));
-    J[0].type = X6_PW_W1; J[0].src_is_T = 0; J[0].dst_off = 0; J[0].count = X6_PW_FRAG_WORDS; J[0].Cin = 32; J[0].Cout = 256;
-    J[1].type = X6_PW_W2; J[1].src_is_T = 1; J[1].dst_off = X6_PW_FRAG_WORDS; J[1].count = X6_PW_FRAG_WORDS; J[1].Cin = 256; J[1].Cout = D;
+    PackJob J[2]; memset(J, 0, sizeof(J));
+    J[0].type = PACK_X6_PW_W1; J[0].src_is_T = 0; J[0].dst_off = 0; J[0].count = X6_PW_FRAG_WORDS; J[0].Cin = 32; J[0].Cout = 256;
+    J[1].type = PACK_X6_PW_W2; J[1].src_is_T = 1; J[1].dst_off = X6_PW_FRAG_WORDS; J[1].count = X6_PW_FRAG_WORDS; J[1].Cin = 256; J[1].Cout = D;
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(d_jobs, J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_pw (x6): job upload", err); return PROBAV_EHIP; }
     *f1 = frag; *f2 = frag + X6_PW_FRAG_WORDS;
-    return x6_pack(d_jobs, 2, w1, w2, frag, s);
+    return mfma_pack(d_jobs, 2, w1, w2, frag, s);
 }
 
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,

@@ -4,7 +4,11 @@
 
 namespace probav {
 
-enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4 };
+enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4,
+       // pre-split bf16 operand fragments of the x6 kernels (three truncation pieces per value, 16 B per lane and fragment)
+       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12 };
+constexpr long X6_PW_FRAG_WORDS = 8 * 2 * 3 * 64 * 4;      // [8 chunks][2 k-blocks][3 pieces][64 lanes] x 16 B
+constexpr long X6_CONV_FRAG_WORDS = 27 * 2 * 3 * 64 * 4;   // [27 taps][2 k-blocks][3 pieces][64 lanes] x 16 B
 
 // One packing job: effective weights (weff / weffT, layout [tap][Cin][Cout]) -> MFMA operand fragments.
 struct PackJob {
@@ -25,6 +29,9 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
 bool mfma_conv_strip_supported(const ConvGeom& g);
 int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
                             const float* skip, float* y, hipStream_t s);
+// the same kernel with the x6 tap loop; wfrag6 = PACK_X6_CONV fragments
+int x6_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
+                          const float* skip, float* y, hipStream_t s);
 
 bool mfma_wgrad_supported(const ConvGeom& g);
 size_t mfma_wgrad_partial_floats(const ConvGeom& g);

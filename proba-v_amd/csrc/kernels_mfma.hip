@@ -19,11 +19,10 @@
 // D: register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 #include "probav_common.h"
 #include "kernels_mfma.h"
+#include "x6_device.h"
 #include <type_traits>
 
 namespace probav {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // In-kernel phase stamps for tools/diag_conv.hip (a separate diagnostic build defines PROBAV_STAMP; the product
 // library never does, so no stamp executes in it).  Stamps go to a buffer nothing else reads.
@@ -43,7 +42,6 @@ __device__ unsigned long long g_stamps[8192 * 8];
 #endif
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 // floor(v / d) for 0 <= v, v*d < 2^32, branch-free: m = ceil(2^32 / d), or m = 0 when d == 1 (then the quotient is v itself)
 __device__ __forceinline__ int fdiv(int v, int d, unsigned m) { return (int)__umulhi((unsigned)v, m) + (d == 1 ? v : 0); }
 __device__ __forceinline__ int reflect_clamped(int i, int n)
@@ -75,6 +73,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < J.count; i += (long)gridDim.x * 256) {
         const int u = (int)(i & 3), lane = (int)((i >> 2) & 63), half = lane >> 5, col = lane & 31;
         long q = i >> 8;                                   // float4 index (per lane)
+        if (J.type >= PACK_X6_PW_W1) {
+            // x6 fragments: this dword holds k-slots j = 2u, 2u+1 of lane `lane` in fragment q = (outer * 2 + kb) * 3 + piece
+            const int piece = (int)(q % 3), kb = (int)((q / 3) & 1), outer = (int)(q / 6);
+            float v2[2] = {0.f, 0.f};
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * u + e;
+                if (J.type == PACK_X6_PW_W1) {          // A[row = hidden 32c + col][k = cin 16kb + 8h + j]      W1 [cin 32][hidden 256]
+                    v2[e] = src[(long)(16 * kb + 8 * half + j) * J.Cout + 32 * outer + col];
+                } else if (J.type == PACK_X6_PW_W2) {   // A[row = out col][k-slot = hidden 32c + rowmap(8kb + j, h)]  W2 [hidden][out D]
+                    if (col < J.Cout) v2[e] = src[(long)(32 * outer + rowmap(8 * kb + j, half)) * J.Cout + col];
+                } else {                                // PACK_X6_CONV: B[k = cin 16kb + 8h + j][col = cout] of tap `outer`
+                    const int ci = 16 * kb + 8 * half + j;
+                    if (ci < J.Cin && col < J.Cout) v2[e] = src[((long)outer * J.Cin + ci) * J.Cout + col];
+                }
+            }
+            unsigned pc[3];
+            split_pair(v2[0], v2[1], pc[0], pc[1], pc[2]);
+            reinterpret_cast<unsigned*>(dst)[i] = pc[piece];
+            continue;
+        }
         float v = 0.f;
         if (J.type == PACK_CONV) {
             // [chunk][tap][q4][lane][4]; step s = 4*q4+u; k-pair channel = 2s+half of chunk
@@ -581,7 +599,54 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
     }
 }
 
-template <int CC, int KS, bool GATE, int STRIP_SLOTS>
+// x6 form of the tap loop: the activation operand is read as fp32 from the same LDS ring (16 channels per k-block:
+// channels 16kb + 8*half + j of the lane's voxel) and cut into bf16 pieces in registers; the filter operand arrives
+// pre-split from L2 ([tap][kb][piece][lane] x 16 B, X6_CONV packing).  For CC = 25 the second k-block reads seven
+// floats past the voxel's channels (the next voxel's, finite) against zero filter pieces.
+// Three-stage software pipeline per tap: loads of tap i+1 | split of tap i+1's activations | MFMAs of tap i.
+template <int CC>
+__device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, const int (&base)[3], int tap0, int ntap,
+                                              const uint4* __restrict__ wf, f32x16& acc)
+{
+    constexpr int CP = (CC & 1) ? CC : CC + 1;
+    auto a_ptr = [&](int tap) -> const float* {
+        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;             // wave-uniform
+        const int b = dh == 0 ? base[0] : (dh == 1 ? base[1] : base[2]);
+        return lds + b + (dw * a.Tp + dt) * CP;
+    };
+    float raw[2][8];
+    Frag wcur[2][3], wnxt[2][3], acur[2][3];
+    auto loads = [&](int tap, Frag (&w)[2][3]) {
+        const float* pa = a_ptr(tap);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[kb][j] = pa[16 * kb + j];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[kb][p].u = wf[((tap * 2 + kb) * 3 + p) * 64];
+        }
+    };
+    loads(tap0, wcur);
+    split8(raw[0], acur[0]);
+    split8(raw[1], acur[1]);
+#pragma unroll 1
+    for (int i = 0; i < ntap; ++i) {
+        const int tn = (i + 1 < ntap) ? tap0 + i + 1 : tap0 + i;
+        loads(tn, wnxt);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = mac6(acur[0], wcur[0], acc);
+        acc = mac6(acur[1], wcur[1], acc);
+        split8(raw[0], acur[0]);                 // the scheduler is free to slide these under the MFMAs above
+        split8(raw[1], acur[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wcur[kb][p] = wnxt[kb][p];
+    }
+}
+
+template <int CC, int KS, bool GATE, int STRIP_SLOTS, bool X6>
 __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                             const float4* __restrict__ wfrag, const float* __restrict__ bias,
                                                             const float* __restrict__ skip, float* __restrict__ y)
@@ -725,8 +790,9 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
                 int base[3];
 #pragma unroll
-                for (int dh = 0; dh < 3; ++dh) base[dh] = ((hrel + dh) % STRIP_SLOTS) * rowfloats + (w * a.Tp + t) * CP + half;
-                strip_taps<CC, KS>(a, lds, base, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks);
+                for (int dh = 0; dh < 3; ++dh) base[dh] = ((hrel + dh) % STRIP_SLOTS) * rowfloats + (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
+                if constexpr (X6) strip_taps_x6<CC>(a, lds, base, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc);
+                else strip_taps<CC, KS>(a, lds, base, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks);
                 if (grp == 1) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
@@ -832,22 +898,40 @@ static StripPlan strip_plan(const ConvGeom& g)
 
 bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
 
-int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
-                            const float* skip, float* y, hipStream_t s)
+static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
+                        const float* skip, float* y, bool x6, hipStream_t s)
 {
     const StripPlan p = strip_plan(g);
     if (!p.ok) { set_error("mfma_conv_strip_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     static bool once = false;
     if (!once) {
-        allow_big_lds(conv3_strip_kernel<25, 13, false, 5>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5>);
-        allow_big_lds(conv3_strip_kernel<32, 16, false, 4>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4>);
+        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, false>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, false>);
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, false>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, false>);
+        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, true>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, true>);
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, true>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, true>);
         once = true;
     }
-#define PROBAV_STRIP(C, K, G, S) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G, S>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y)
-    if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5); else PROBAV_STRIP(25, 13, false, 5); }
-    else            { if (gate) PROBAV_STRIP(32, 16, true, 4); else PROBAV_STRIP(32, 16, false, 4); }
+#define PROBAV_STRIP(C, K, G, S, X) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G, S, X>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y)
+    if (x6) {
+        if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5, true); else PROBAV_STRIP(25, 13, false, 5, true); }
+        else            { if (gate) PROBAV_STRIP(32, 16, true, 4, true); else PROBAV_STRIP(32, 16, false, 4, true); }
+    } else {
+        if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5, false); else PROBAV_STRIP(25, 13, false, 5, false); }
+        else            { if (gate) PROBAV_STRIP(32, 16, true, 4, false); else PROBAV_STRIP(32, 16, false, 4, false); }
+    }
 #undef PROBAV_STRIP
     return check_launch("conv3_strip");
+}
+
+int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
+                            const float* skip, float* y, hipStream_t s)
+{
+    return strip_launch(g, x, gate, wfrag, bias, skip, y, false, s);
+}
+int x6_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
+                          const float* skip, float* y, hipStream_t s)
+{
+    return strip_launch(g, x, gate, wfrag6, bias, skip, y, true, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -15,91 +15,9 @@
 // feeds the next product's B operand when that product contracts over the tile's ROW index: registers 0..7 are the
 // k-slots of k-block 0, registers 8..15 those of k-block 1, and the A operand is packed with the same permutation.
 #include "kernels_x6.h"
+#include "x6_device.h"
 
 namespace probav {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-union Frag { uint4 u; bf16x8 v; };
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).v, (b).v, (c), 0, 0, 0)
-
-__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// the three truncation pieces of one value, as fp32 bit patterns whose low 16 bits are zero
-__device__ __forceinline__ void pieces(float x, unsigned& p0, unsigned& p1, unsigned& p2)
-{
-    p0 = __float_as_uint(x) & 0xffff0000u;
-    const float r = x - __uint_as_float(p0);
-    p1 = __float_as_uint(r) & 0xffff0000u;
-    p2 = __float_as_uint(r - __uint_as_float(p1));          // <= 8 significant bits left: already a bf16 value
-}
-// pieces of a pair, packed (a -> low half, b -> high half of each dword)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& q0, unsigned& q1, unsigned& q2)
-{
-    unsigned a0, a1, a2, b0, b1, b2;
-    pieces(a, a0, a1, a2);
-    pieces(b, b0, b1, b2);
-    q0 = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
-    q1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-    q2 = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
-}
-// eight consecutive k-slots -> three fragments
-__device__ __forceinline__ void split8(const float (&x)[8], Frag (&f)[3])
-{
-    split_pair(x[0], x[1], f[0].u.x, f[1].u.x, f[2].u.x);
-    split_pair(x[2], x[3], f[0].u.y, f[1].u.y, f[2].u.y);
-    split_pair(x[4], x[5], f[0].u.z, f[1].u.z, f[2].u.z);
-    split_pair(x[6], x[7], f[0].u.w, f[1].u.w, f[2].u.w);
-}
-// acc += A * B over one k-block of 16, smallest terms first
-__device__ __forceinline__ f32x16 mac6(const Frag (&a)[3], const Frag (&b)[3], f32x16 acc)
-{
-    acc = MFMA16(a[2], b[0], acc);
-    acc = MFMA16(a[1], b[1], acc);
-    acc = MFMA16(a[0], b[2], acc);
-    acc = MFMA16(a[1], b[0], acc);
-    acc = MFMA16(a[0], b[1], acc);
-    acc = MFMA16(a[0], b[0], acc);
-    return acc;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// fragment packing: effective fp32 weights -> pre-split bf16 A operands.  One thread per dword (two k-slots).
-//   dword i: u = i & 3 (k-slots 2u, 2u+1), lane = (i >> 2) & 63, fragment f = i >> 8 = ((c * 2 + kb) * 3 + piece)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_x6_kernel(const X6PackJob* __restrict__ jobs, const float* __restrict__ weff,
-                                                     const float* __restrict__ weffT, unsigned* __restrict__ wpack)
-{
-    const X6PackJob J = jobs[blockIdx.y];
-    const float* src = (J.src_is_T ? weffT : weff) + J.src_off;
-    unsigned* dst = wpack + J.dst_off;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < J.count; i += (long)gridDim.x * 256) {
-        const int u = (int)(i & 3), lane = (int)((i >> 2) & 63), h = lane >> 5, col = lane & 31;
-        const int f = (int)(i >> 8), piece = f % 3, kb = (f / 3) & 1, c = f / 6;
-        float v[2] = {0.f, 0.f};
-        for (int e = 0; e < 2; ++e) {
-            const int j = 2 * u + e;
-            if (J.type == X6_PW_W1) {
-                // A[row = hidden 32c + col][k = cin 16kb + 8h + j]           from W1 [cin 32][hidden 256]
-                v[e] = src[(long)(16 * kb + 8 * h + j) * J.Cout + 32 * c + col];
-            } else if (J.type == X6_PW_W2) {
-                // A[row = out col][k-slot = hidden 32c + rowmap(8kb + j, h)]  from W2 [hidden 256][out D]
-                if (col < J.Cout) v[e] = src[(long)(32 * c + rowmap(8 * kb + j, h)) * J.Cout + col];
-            }
-        }
-        unsigned q[3];
-        split_pair(v[0], v[1], q[0], q[1], q[2]);
-        dst[i] = q[piece];
-    }
-}
-
-int x6_pack(const X6PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, hipStream_t s)
-{
-    if (njobs <= 0) return PROBAV_OK;
-    hipLaunchKernelGGL(pack_x6_kernel, dim3(32, njobs), dim3(256), 0, s, d_jobs, weff, weffT, reinterpret_cast<unsigned*>(wpack));
-    return check_launch("x6_pack");
-}
 
 // ---------------------------------------------------------------------------------------------------
 // fused expConv + ReLU + decConv forward (1x1x1, 32 -> 256 -> D <= 32); one 32-voxel tile per wave and round.

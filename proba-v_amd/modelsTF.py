@@ -161,7 +161,8 @@ class WDSRModel(torch.nn.Module):
         return out
 
     def set_impl(self, impl):
-        """0 = generic direct kernels, 1 = MFMA row-tile kernels, 2 = MFMA + strip convolution (default)."""
+        """0 = generic direct kernels, 1 = MFMA row-tile kernels, 2 = MFMA + strip convolution (default),
+        3 = 2 with the x6 kernels (fp32 products as six bf16-piece products on the bf16 MFMA pipe)."""
         _lib.check(_lib.lib().probav_engine_set_impl(self._handle(), int(impl)), "probav_engine_set_impl")
 
     def _workspace(self, batch, training):
