@@ -119,7 +119,7 @@ int probav_pw_forward(const float* x, const float* w1, const float* b1, const fl
 size_t probav_pw_backward_scratch_bytes(int D);
 int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1,
                        const float* w2, float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch,
-                       size_t scratch_bytes, int64_t nvox, int D, void* stream);
+                       size_t scratch_bytes, int64_t nvox, int D, int impl, void* stream);
 /* weight normalisation of every layer of the engine: params -> weff, weffT, inv_norm (ws-internal
  * layouts, exported for tests): sizes probav_weff_count() floats and probav_cout_total() floats      */
 int64_t probav_weff_count(const probav_engine* e);

@@ -51,7 +51,7 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_int, c_void_p]),
     "probav_pw_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "probav_pw_backward_scratch_bytes": (c_size_t, [c_int]),
-    "probav_pw_backward": (c_int, [c_void_p] * 12 + [c_size_t, c_int64, c_int, c_void_p]),
+    "probav_pw_backward": (c_int, [c_void_p] * 12 + [c_size_t, c_int64, c_int, c_int, c_void_p]),
     "probav_weff_count": (c_int64, [c_void_p]),
     "probav_cout_total": (c_int64, [c_void_p]),
     "probav_wn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -37,6 +37,7 @@ struct probav_engine {
     std::vector<long> pkFwd, pkBwd;          // per layer: conv fragments for forward / backward-data (-1 = none)
     std::vector<long> pkFwd6, pkBwd6;        // per layer: x6 (pre-split bf16) conv fragments, impl 3
     std::vector<long> pkW1x6, pkW2x6;        // per block: x6 fragments of the fused expand/decay forward
+    std::vector<long> pkW2Kx6, pkW1Cx6;      // per block: extra x6 fragments of the fused backward
     std::vector<long> pkW1, pkW2;            // per block: fused expand/decay forward fragments
     std::vector<long> pkW2B, pkW1C;          // per block: extra fragments of the fused backward
     bool pw_mfma = false;
@@ -323,6 +324,11 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             X.type = PACK_X6_PW_W2; X.src_off = e->layers[e->iDec[i]].wn.w_off; X.dst_off = e->wpack_count;
             X.Cin = E; X.Cout = D;
             e->pkW2x6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.type = PACK_X6_PW_W2K; X.dst_off = e->wpack_count;
+            e->pkW2Kx6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.type = PACK_X6_PW_W1C; X.src_off = e->layers[e->iExp[i]].wn.w_off; X.dst_off = e->wpack_count;
+            X.Cin = F; X.Cout = E;
+            e->pkW1Cx6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
         }
     }
     if (!e->jobs.empty()) {
@@ -528,8 +534,12 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
             // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
             const long nvox = (long)B * Hin * Hin * T;
             ProfScope ps(e, CLS_PW_BWD_DATA, (double)nvox * (3.0 * F * E + 2.0 * E * D), s);
-            CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
-                                params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
+            if (e->impl >= 3)
+                CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2Kx6[i], W + p.wpack + e->pkW1Cx6[i],
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
+            else
+                CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
+                                    params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
             float* tmp2 = cur; cur = oth; oth = tmp2;
             continue;
         }
@@ -657,23 +667,28 @@ static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, co
     return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, s);
 }
 
-static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2)
+static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2,
+                         const float** f2k = nullptr, const float** f1c = nullptr)
 {
     static float* frag = nullptr;
     static PackJob* d_jobs = nullptr;
     if (!frag) {
-        hipError_t err = hipMalloc((void**)&frag, (size_t)2 * X6_PW_FRAG_WORDS * 4);
-        if (err == hipSuccess) err = hipMalloc((void**)&d_jobs, 2 * sizeof(PackJob));
+        hipError_t err = hipMalloc((void**)&frag, (size_t)4 * X6_PW_FRAG_WORDS * 4);
+        if (err == hipSuccess) err = hipMalloc((void**)&d_jobs, 4 * sizeof(PackJob));
         if (err != hipSuccess) { set_error("probav_pw (x6): scratch allocation", err); return PROBAV_EHIP; }
     }
-    PackJob J[2]; memset(J, 0, sizeof(J));
+    PackJob J[4]; memset(J, 0, sizeof(J));
+    J[2].type = PACK_X6_PW_W2K; J[2].src_is_T = 1; J[2].dst_off = 2 * X6_PW_FRAG_WORDS; J[2].count = X6_PW_FRAG_WORDS; J[2].Cin = 256; J[2].Cout = D;
+    J[3].type = PACK_X6_PW_W1C; J[3].src_is_T = 0; J[3].dst_off = 3 * X6_PW_FRAG_WORDS; J[3].count = X6_PW_FRAG_WORDS; J[3].Cin = 32; J[3].Cout = 256;
     J[0].type = PACK_X6_PW_W1; J[0].src_is_T = 0; J[0].dst_off = 0; J[0].count = X6_PW_FRAG_WORDS; J[0].Cin = 32; J[0].Cout = 256;
     J[1].type = PACK_X6_PW_W2; J[1].src_is_T = 1; J[1].dst_off = X6_PW_FRAG_WORDS; J[1].count = X6_PW_FRAG_WORDS; J[1].Cin = 256; J[1].Cout = D;
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(d_jobs, J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_pw (x6): job upload", err); return PROBAV_EHIP; }
     *f1 = frag; *f2 = frag + X6_PW_FRAG_WORDS;
-    return mfma_pack(d_jobs, 2, w1, w2, frag, s);
+    if (f2k) *f2k = frag + 2 * X6_PW_FRAG_WORDS;
+    if (f1c) *f1c = frag + 3 * X6_PW_FRAG_WORDS;
+    return mfma_pack(d_jobs, 4, w1, w2, frag, s);
 }
 
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
@@ -697,14 +712,19 @@ size_t probav_pw_backward_scratch_bytes(int D) { return mfma_pw_backward_slab_fl
 
 int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1, const float* w2,
                        float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
-                       int64_t nvox, int D, void* stream)
+                       int64_t nvox, int D, int impl, void* stream)
 {
-    if (!x || !d_dec || !d_skip || !w1 || !b1 || !w2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch || nvox < 1) {
+    if (!x || !d_dec || !d_skip || !w1 || !b1 || !w2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch || nvox < 1 || (impl != 2 && impl != 3)) {
         set_error("probav_pw_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL;
     }
     if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_backward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
     if (scratch_bytes < probav_pw_backward_scratch_bytes(D)) { set_error("probav_pw_backward: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     const float *f1, *f2, *f2b, *f1c;
+    if (impl == 3) {
+        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
+        if (rc) return rc;
+        return x6_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, D, (hipStream_t)stream);
+    }
     int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
     if (rc) return rc;
     return mfma_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, D, (hipStream_t)stream);

@@ -6,7 +6,7 @@ namespace probav {
 
 enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4,
        // pre-split bf16 operand fragments of the x6 kernels (three truncation pieces per value, 16 B per lane and fragment)
-       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12 };
+       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14 };
 constexpr long X6_PW_FRAG_WORDS = 8 * 2 * 3 * 64 * 4;      // [8 chunks][2 k-blocks][3 pieces][64 lanes] x 16 B
 constexpr long X6_CONV_FRAG_WORDS = 27 * 2 * 3 * 64 * 4;   // [27 taps][2 k-blocks][3 pieces][64 lanes] x 16 B
 
@@ -47,5 +47,9 @@ size_t mfma_pw_backward_slab_floats(int D);
 int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1kcin, const float* w2kout,
                      const float* w1khch, const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2,
                      float* slabs, long nvox, int D, hipStream_t s);
+
+// fixed-order fp64 sum of the per-workgroup slabs of the fused pointwise backward (both the fp32 and the x6 kernel write them)
+int mfma_pw_backward_reduce(const float* slabs, int D, float* dW1, float* dW2, float* db1, float* db2, hipStream_t s);
+int mfma_pw_backward_grid();
 
 }  // namespace probav

@@ -78,14 +78,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
             const int piece = (int)(q % 3), kb = (int)((q / 3) & 1), outer = (int)(q / 6);
             float v2[2] = {0.f, 0.f};
             for (int e = 0; e < 2; ++e) {
-                const int j = 2 * u + e;
-                if (J.type == PACK_X6_PW_W1) {          // A[row = hidden 32c + col][k = cin 16kb + 8h + j]      W1 [cin 32][hidden 256]
-                    v2[e] = src[(long)(16 * kb + 8 * half + j) * J.Cout + 32 * outer + col];
-                } else if (J.type == PACK_X6_PW_W2) {   // A[row = out col][k-slot = hidden 32c + rowmap(8kb + j, h)]  W2 [hidden][out D]
-                    if (col < J.Cout) v2[e] = src[(long)(32 * outer + rowmap(8 * kb + j, half)) * J.Cout + col];
-                } else {                                // PACK_X6_CONV: B[k = cin 16kb + 8h + j][col = cout] of tap `outer`
-                    const int ci = 16 * kb + 8 * half + j;
-                    if (ci < J.Cin && col < J.Cout) v2[e] = src[((long)outer * J.Cin + ci) * J.Cout + col];
+                const int j = 2 * u + e, kn = 16 * kb + 8 * half + j, kp = rowmap(8 * kb + j, half);   // natural / accumulator-order k
+                if (J.type == PACK_X6_PW_W1) {          // [row|col = hidden 32c + col][k = cin kn]              W1 [cin 32][hidden 256]
+                    v2[e] = src[(long)kn * J.Cout + 32 * outer + col];
+                } else if (J.type == PACK_X6_PW_W2) {   // [row = out col][k-slot = hidden 32c + kp]             W2 [hidden 256][out D]
+                    if (col < J.Cout) v2[e] = src[(long)(32 * outer + kp) * J.Cout + col];
+                } else if (J.type == PACK_X6_PW_W2K) {  // [row|col = hidden 32c + col][k = out kn]              W2 [hidden 256][out D]
+                    if (kn < J.Cout) v2[e] = src[(long)(32 * outer + col) * J.Cout + kn];
+                } else if (J.type == PACK_X6_PW_W1C) {  // [row = cin col][k-slot = hidden 32c + kp]             W1 [cin 32][hidden 256]
+                    v2[e] = src[(long)col * J.Cout + 32 * outer + kp];
+                } else {                                // PACK_X6_CONV: [k = cin kn][col = cout] of tap `outer`
+                    if (kn < J.Cin && col < J.Cout) v2[e] = src[((long)outer * J.Cin + kn) * J.Cout + col];
                 }
             }
             unsigned pc[3];
@@ -1424,6 +1427,15 @@ __global__ __launch_bounds__(256) void pw_bwd2_reduce_kernel(const float* __rest
 }
 
 static const int PW_BWD_GRID = 256;
+
+int mfma_pw_backward_reduce(const float* slabs, int D, float* dW1, float* dW2, float* db1, float* db2, hipStream_t s)
+{
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    hipLaunchKernelGGL(pw_bwd2_reduce_kernel, dim3((unsigned)((slab_floats + 31) / 32)), dim3(256), 0, s, slabs, PW_BWD_GRID, D,
+                       dW1, dW2, db1, db2);
+    return check_launch("pw_bwd2_reduce");
+}
+int mfma_pw_backward_grid() { return PW_BWD_GRID; }
 
 size_t mfma_pw_backward_slab_floats(int D) { return (size_t)PW_BWD_GRID * (8192 + 256 * (size_t)D + 256 + D); }
 

@@ -8,4 +8,10 @@ namespace probav {
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                   long nvox, int D, hipStream_t s);
 
+// reverse pass of the fused pair; w1f = PACK_X6_PW_W1, w2kf = PACK_X6_PW_W2K, w1cf = PACK_X6_PW_W1C fragments;
+// slabs: mfma_pw_backward_slab_floats(D) floats
+int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
+                   const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, int D,
+                   hipStream_t s);
+
 }  // namespace probav

@@ -120,4 +120,255 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
     return check_launch("pw_fwd_x6");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fused backward of expConv + ReLU + decConv (1x1x1), x6 form.  Same decomposition as pw_bwd2_mfma_kernel (one wave
+// per 32-channel hidden chunk, chunk weights resident in registers, 8 waves on one 32-voxel tile, one slab per
+// workgroup), but no in-wave transposes: the chunk's hidden tile is produced in BOTH orientations,
+//     orientation 1 (hidden rows x voxel cols):  H1 = W1c^T X^T,  dH1 = W2c dT^T   -> gate -> B operand of  dX^T += W1c dH1'
+//     orientation 2 (voxel rows x hidden cols):  H2 = X W1c,      dH2 = dT W2c^T   -> gate -> B operands of
+//                                                dW1c += X^T dH2'   and   dW2c^T += dT^T H2'
+// because an accumulator tile is the next product's B operand exactly when that product contracts over the tile's ROW
+// index.  Two extra products (84 bf16 MFMAs per tile and chunk instead of 77 fp32 ones, at a sixth of the cycles
+// each) buy the removal of every LDS transpose.  The A and B lane maps of the 32x32x16 MFMA are the same, so the X / dT
+// fragments and the W1c / W2c fragments each serve both orientations.  X^T and dT^T (K = voxel) come out of the same
+// LDS piece images by ds_read_b64_tr_b16, whose 4-row blocks are exactly the accumulator k-order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PB_ROW = 80;                  // bytes per voxel row of a piece image: 32 bf16 + 16 (row reads conflict-free)
+constexpr int PB_IMG = 32 * PB_ROW;
+constexpr int PB_TILE = 3 * PB_IMG;         // one staged tile: three piece images
+constexpr int PB_TB = 32 * 33;              // floats of one dX partial
+
+__device__ __forceinline__ void tr_frag(const unsigned char* img, int lane, int kb, Frag& f)
+{
+    // A operand [row = channel lane&31][k-slot j of half h <-> voxel 16kb + 8(j>>2) + 4h + (j&3)] of a [voxel][channel] image
+    const int li = lane & 15, gcol = (lane >> 4) & 1, h = lane >> 5;
+    const unsigned char* p = img + (16 * kb + 4 * h + (li >> 2)) * PB_ROW + (16 * gcol + 4 * (li & 3)) * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 8 * PB_ROW));
+}
+
+__global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
+    const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
+    const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
+    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int D)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* XA = lds_raw;                                  // [2 buffers][3 pieces][32 voxels][80 B]
+    unsigned char* DA = XA + 2 * PB_TILE;                         // same for dT (channels D..31 stay zero)
+    float* TbAll = reinterpret_cast<float*>(DA + 2 * PB_TILE);   // [8 waves][32][33] dX partials
+    float* sB1 = TbAll + 8 * PB_TB;                               // 256 expand biases
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    float* Tb = TbAll + wave * PB_TB;
+    if (tid < 256) sB1[tid] = b1[tid];
+    const int c = wave;                                           // this wave's hidden chunk
+
+    Frag w1[2][3], w2[2][3], w3[2][3];                            // chunk-resident weight pieces
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            w1[kb][p].u = w1f[((c * 2 + kb) * 3 + p) * 64 + lane];
+            w2[kb][p].u = w2kf[((c * 2 + kb) * 3 + p) * 64 + lane];
+            w3[kb][p].u = w1cf[((c * 2 + kb) * 3 + p) * 64 + lane];
+        }
+    const float bcol = b1[32 * c + col];
+    f32x16 dW1, dW2t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; }
+    float bs1 = 0.f, bs2a = 0.f, bs2b = 0.f;
+
+    for (int i = tid; i < 2 * PB_TILE / 16; i += 512) reinterpret_cast<uint4*>(DA)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    const long ntiles = (nvox + 31) >> 5;
+    // staging: threads 0..255 move one float4 of the X tile, every thread one or two floats of the dT tile
+    // (element f = voxel * D + out, f = tid and tid + 512); clamped unconditional loads, zero selected afterwards
+    const int f0 = tid, f1 = tid + 512;
+    const int dv0 = f0 / D, do0i = f0 - dv0 * D, dv1 = f1 / D, do1i = f1 - dv1 * D;
+    const bool has1 = f1 < 32 * D;
+    auto stage_load = [&](long tile, float4& xv, float& d0, float& d1) {
+        const long v0 = tile * 32;
+        const long nrem = nvox - v0 < 32 ? nvox - v0 : 32;
+        if (tid < 256) {
+            const int vv = tid >> 3;
+            const long vsrc = vv < nrem ? v0 + vv : v0;
+            const float4 t = reinterpret_cast<const float4*>(x + vsrc * 32)[tid & 7];
+            xv = vv < nrem ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float a0 = dT[v0 * D + (f0 < nrem * D ? f0 : 0)];
+        const float a1 = dT[v0 * D + (f1 < nrem * D ? f1 : 0)];
+        d0 = f0 < nrem * D ? a0 : 0.f;
+        d1 = f1 < nrem * D ? a1 : 0.f;
+    };
+    auto stage_store = [&](int buf, const float4& xv, float d0, float d1) {
+        if (tid < 256) {
+            unsigned a[3], b[3];
+            split_pair(xv.x, xv.y, a[0], a[1], a[2]);
+            split_pair(xv.z, xv.w, b[0], b[1], b[2]);
+            unsigned char* d = XA + buf * PB_TILE + (tid >> 3) * PB_ROW + (tid & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * PB_IMG) = make_uint2(a[p], b[p]);
+        }
+        {
+            unsigned q[3];
+            pieces(d0, q[0], q[1], q[2]);
+            unsigned char* d = DA + buf * PB_TILE + dv0 * PB_ROW + do0i * 2;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned short*>(d + p * PB_IMG) = (unsigned short)(q[p] >> 16);
+        }
+        if (has1) {
+            unsigned q[3];
+            pieces(d1, q[0], q[1], q[2]);
+            unsigned char* d = DA + buf * PB_TILE + dv1 * PB_ROW + do1i * 2;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned short*>(d + p * PB_IMG) = (unsigned short)(q[p] >> 16);
+        }
+        bs2a += d0;
+        bs2b += d1;
+    };
+
+    long tile = blockIdx.x;
+    int buf = 0;
+    __syncthreads();                                   // DA pads are zero
+    {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d0 = 0.f, d1 = 0.f;
+        if (tile < ntiles) { stage_load(tile, xv, d0, d1); stage_store(0, xv, d0, d1); }
+    }
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        __syncthreads();                               // tile `tile` is staged in buffer `buf`; previous dX reduce is done
+        const long tnext = tile + gridDim.x;
+        float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd0 = 0.f, nd1 = 0.f;
+        if (tnext < ntiles) stage_load(tnext, nxv, nd0, nd1);          // in flight during this tile's MFMAs
+        const long v0 = tile * 32;
+        const int rv0 = 4 * wave + (lane >> 5), rv1 = rv0 + 2;       // this wave reduces voxels 4*wave .. 4*wave+3 of dX
+        const bool rok0 = v0 + rv0 < nvox, rok1 = v0 + rv1 < nvox;
+        const float do0 = dOut[(rok0 ? v0 + rv0 : v0) * 32 + col];
+        const float do1 = dOut[(rok1 ? v0 + rv1 : v0) * 32 + col];
+
+        const unsigned char* Xb = XA + buf * PB_TILE;
+        const unsigned char* Db = DA + buf * PB_TILE;
+        Frag xf[2][3], df[2][3];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
+                df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
+            }
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        // ---- orientation 1: rows = hidden (registers), cols = voxel (lanes) ----
+        {
+            f32x16 H = zero, dH = zero, dx = zero;
+            H = mac6(w1[0], xf[0], H); H = mac6(w1[1], xf[1], H);
+            dH = mac6(w2[0], df[0], dH); dH = mac6(w2[1], df[1], dH);
+            Frag g1[2][3];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float gs[8];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {                          // registers 4G .. 4G+3 <-> hidden 32c + 8G + 4h + (0..3)
+                    const float4 bb = *reinterpret_cast<const float4*>(sB1 + 32 * c + 8 * (2 * kb + g) + 4 * half);
+                    gs[4 * g + 0] = (H[8 * kb + 4 * g + 0] + bb.x) > 0.f ? dH[8 * kb + 4 * g + 0] : 0.f;
+                    gs[4 * g + 1] = (H[8 * kb + 4 * g + 1] + bb.y) > 0.f ? dH[8 * kb + 4 * g + 1] : 0.f;
+                    gs[4 * g + 2] = (H[8 * kb + 4 * g + 2] + bb.z) > 0.f ? dH[8 * kb + 4 * g + 2] : 0.f;
+                    gs[4 * g + 3] = (H[8 * kb + 4 * g + 3] + bb.w) > 0.f ? dH[8 * kb + 4 * g + 3] : 0.f;
+                }
+                split8(gs, g1[kb]);
+            }
+            dx = mac6(w3[0], g1[0], dx); dx = mac6(w3[1], g1[1], dx);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dx[r];
+        }
+        // ---- orientation 2: rows = voxel (registers), cols = hidden (lanes) ----
+        {
+            f32x16 H = zero, dH = zero;
+            H = mac6(xf[0], w1[0], H); H = mac6(xf[1], w1[1], H);
+            dH = mac6(df[0], w2[0], dH); dH = mac6(df[1], w2[1], dH);
+            Frag hf[2][3], gf[2][3];
+            float t1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float gs[8], hs[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float hv = H[8 * kb + j] + bcol;
+                    gs[j] = hv > 0.f ? dH[8 * kb + j] : 0.f;
+                    hs[j] = fmaxf(hv, 0.f);
+                    t1 += gs[j];
+                }
+                split8(gs, gf[kb]);
+                split8(hs, hf[kb]);
+            }
+            bs1 += t1;
+            Frag xt[3];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) tr_frag(Xb + p * PB_IMG, lane, kb, xt[p]);
+                dW1 = mac6(xt, gf[kb], dW1);                            // dW1c[cin][hidden] += X^T dH2'
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) tr_frag(Db + p * PB_IMG, lane, kb, xt[p]);
+                dW2t = mac6(xt, hf[kb], dW2t);                          // dW2c^T[out][hidden] += dT^T H2'
+            }
+        }
+        if (tnext < ntiles) stage_store(buf ^ 1, nxv, nd0, nd1);
+        __syncthreads();                               // all 8 dX partials (and the next tile) are in LDS
+        {
+            float s0 = do0, s1 = do1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* P = TbAll + j * PB_TB;
+                s0 += P[rv0 * 33 + col];
+                s1 += P[rv1 * 33 + col];
+            }
+            if (rok0) dX[(v0 + rv0) * 32 + col] = s0;
+            if (rok1) dX[(v0 + rv1) * 32 + col] = s1;
+        }
+    }
+    // one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    float* sl = slabs + (long)blockIdx.x * slab_floats;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rw = rowmap(r, half);
+        sl[(long)rw * 256 + 32 * c + col] = dW1[r];                                    // [cin][hidden]
+        if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = dW2t[r];                // [hidden][out]
+    }
+    const float b = bs1 + __shfl_xor(bs1, 32, 64);
+    if (half == 0) sl[8192 + 256 * (long)D + 32 * c + col] = b;
+    // db2[out] = sum of the staged dT values: thread t always staged out (t % D) and ((t + 512) % D); fixed-order sum
+    __syncthreads();
+    float* R = TbAll;
+    R[tid] = bs2a;
+    R[512 + tid] = has1 ? bs2b : 0.f;
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int j = tid; j < 1024; j += D) t += R[j];                                  // R[j] = column sum of staged element f = j
+        sl[8192 + 256 * (long)D + 256 + tid] = t;
+    }
+}
+
+int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
+                   const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, int D,
+                   hipStream_t s)
+{
+    static bool once = false;
+    const size_t lds = (size_t)4 * PB_TILE + ((size_t)8 * PB_TB + 256) * sizeof(float);
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(pw_bwd_x6_kernel, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
+                       (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D);
+    int rc = check_launch("pw_bwd_x6");
+    if (rc) return rc;
+    return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
+}
+
 }  // namespace probav

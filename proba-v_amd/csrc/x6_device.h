@@ -7,7 +7,8 @@ namespace probav {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-union Frag { uint4 u; bf16x8 v; };
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+union Frag { uint4 u; bf16x8 v; s16x4 hs[2]; };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).v, (b).v, (c), 0, 0, 0)
 

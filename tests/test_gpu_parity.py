@@ -319,16 +319,18 @@ def test_fused_pointwise_forward_backward(dev, nvox):
         assert err < 2e-6, (impl, err)
     nbytes = L.lib().probav_pw_backward_scratch_bytes(D)
     scratch = torch.empty(nbytes // 4 + 1, device=dev)
-    dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
-    dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
-    L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
-                                       L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, D, L.current_stream()))
     dH = (ddec.astype(np.float64) @ W2.T) * (Hpre > 0)
     refs = {"dx": dskip + dH @ W1.T, "dw1": X.T @ dH, "db1": dH.sum(0), "dw2": Hh.T @ ddec, "db2": ddec.astype(np.float64).sum(0)}
-    for name, got in (("dx", dx), ("dw1", dw1), ("db1", db1), ("dw2", dw2), ("db2", db2)):
-        r = refs[name]
-        err = np.abs(got.cpu().double().numpy() - r).max() / np.abs(r).max()
-        assert err < 5e-6, "%s rel err %.3e" % (name, err)
+    for impl in (2, 3):
+        dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
+        dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
+        L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
+                                           L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, D, impl, L.current_stream()))
+        for name, got in (("dx", dx), ("dw1", dw1), ("db1", db1), ("dw2", dw2), ("db2", db2)):
+            r = refs[name]
+            err = np.abs(got.cpu().double().numpy() - r).max() / np.abs(r).max()
+            print("pw_backward impl %d nvox %d %s: max err / max |ref| = %.3g" % (impl, nvox, name, err))
+            assert err < 5e-6, "impl %d %s rel err %.3e" % (impl, name, err)
 
 
 def test_mfma_engine_matches_direct_engine(dev):

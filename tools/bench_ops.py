@@ -38,5 +38,23 @@ def main():
                 impl, float((o - ref).abs().max() / ref.abs().max()), float((o - ref).pow(2).mean().sqrt() / ref.abs().max())))
 
 
+    if what == "pw_bwd":
+        ddec = torch.randn(nvox, D, generator=g).to(dev)
+        dskip = torch.randn(nvox, 32, generator=g).to(dev)
+        nbytes = L.lib().probav_pw_backward_scratch_bytes(D)
+        scratch = torch.empty(nbytes // 4 + 1, device=dev)
+        dx = torch.empty(nvox, 32, device=dev)
+        dw1, db1, dw2, db2 = (torch.empty(s, device=dev) for s in ((32, 256), (256,), (256, D), (D,)))
+        res = {}
+        for impl in (2, 3):
+            for _ in range(reps):
+                L.check(L.lib().probav_pw_backward(L.ptr(x), L.ptr(ddec), L.ptr(dskip), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(dx), L.ptr(dw1),
+                                                   L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, D, impl, L.current_stream()))
+            torch.cuda.synchronize()
+            res[impl] = [t.double().cpu().clone() for t in (dx, dw1, db1, dw2, db2)]
+        for a, b, name in zip(res[2], res[3], ("dx", "dw1", "db1", "dw2", "db2")):
+            print("%s: impl 3 vs impl 2 max diff / max = %.3g" % (name, float((a - b).abs().max() / a.abs().max())))
+
+
 if __name__ == "__main__":
     main()
