@@ -193,6 +193,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         for (auto& g : gs) {
             size_t q = wgrad_partial_floats(g);
             if (mfma_wgrad_supported(g)) { const size_t q2 = mfma_wgrad_partial_floats(g); if (q2 > q) q = q2; }
+            if (x6_wgrad_supported(g)) { const size_t q3 = x6_wgrad_partial_floats(g); if (q3 > q) q = q3; }
             if (q > pmax) pmax = q;
         }
         if (e->pw_mfma && mfma_pw_backward_slab_floats(D) > pmax) pmax = mfma_pw_backward_slab_floats(D);
@@ -221,6 +222,7 @@ static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x,
                       float* dw, float* db, float* partial, hipStream_t s)
 {
     ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : CLS_CONV3_WGRAD, geom_macs(g), s);
+    if (e->impl >= 3 && !gate && x6_wgrad_supported(g)) return x6_conv_wgrad(g, x, dy, dw, db, partial, s);
     if (e->impl >= 1 && mfma_wgrad_supported(g)) return mfma_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s);
 }
@@ -623,6 +625,7 @@ size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl)
 {
     if (!geom) return 0;
     const ConvGeom g = geom_from(geom);
+    if (impl == 3) return x6_wgrad_supported(g) ? x6_wgrad_partial_floats(g) * sizeof(float) : 0;
     if (impl == 1) return mfma_wgrad_supported(g) ? mfma_wgrad_partial_floats(g) * sizeof(float) : 0;
     return wgrad_partial_floats(g) * sizeof(float);
 }
@@ -633,6 +636,11 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
     if (!geom || !x || !dy || !dw || !scratch) { set_error("probav_conv3d_wgrad: null argument", hipSuccess); return PROBAV_EINVAL; }
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_wgrad: bad geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (impl == 3) {
+        if (gate || !x6_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the x6 kernel", hipSuccess); return PROBAV_EINVAL; }
+        if (scratch_bytes < x6_wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+        return x6_conv_wgrad(g, x, dy, dw, db, (float*)scratch, (hipStream_t)stream);
+    }
     if (impl == 1) {
         if (!mfma_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
         if (scratch_bytes < mfma_wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }

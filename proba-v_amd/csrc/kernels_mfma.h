@@ -48,6 +48,8 @@ int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const f
                      const float* w1khch, const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2,
                      float* slabs, long nvox, int D, hipStream_t s);
 
+// fixed-order fp64 sum of `slabs` backward-filter slabs ([nw] each at partial, [Cout] each at partial_b)
+int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, float* db, long nw, int Cout, int slabs, hipStream_t s);
 // fixed-order fp64 sum of the per-workgroup slabs of the fused pointwise backward (both the fp32 and the x6 kernel write them)
 int mfma_pw_backward_reduce(const float* slabs, int D, float* dW1, float* dW2, float* db1, float* db2, hipStream_t s);
 int mfma_pw_backward_grid();

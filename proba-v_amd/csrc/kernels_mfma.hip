@@ -1123,8 +1123,13 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
 #undef PROBAV_WGRAD
     int rc = check_launch("conv3_wgrad_mfma");
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, grid);
-    if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)g.Cout, grid);
+    return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);
+}
+
+int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, float* db, long nw, int Cout, int slabs, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, slabs);
+    if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)Cout, slabs);
     return check_launch("reduce_slabs");
 }
 

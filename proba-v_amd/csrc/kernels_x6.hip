@@ -371,4 +371,189 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward-filter of the 'same' 3x3x3 convolution, x6 form:  dW[tap][ci][co] = sum_v X[v + tap][ci] dY[v][co]
+// One GEMM per tap with M = ci (one 32-row tile; rows >= Cin are discarded), N = co, K = the voxels of one output
+// row in blocks of 16.  Per workgroup a three-row ring of the input lives in LDS as bf16 PIECE IMAGES
+// ([voxel][piece][channels], pads zero), cut once when a row is staged; ds_read_b64_tr_b16 then hands the
+// A operand (K = voxel) straight to the MFMA -- four voxel rows per read, each row's address supplied by its own
+// lanes, so the tap shift and the row wrap are address arithmetic.  The inner loop is 6 transposed reads + 6 MFMAs
+// per tap and k-block and has no VALU work beyond two address adds.  dY comes from HBM/L2 as the B operand
+// (8 coalesced loads per lane and k-block), cut into pieces once per k-block and reused by the wave's 7 taps.
+// 8 waves: wave w owns taps (w & 3) + 4j (accumulators: 7 x 16 registers) and the k-blocks of parity w >> 2; the two
+// parities are added in a fixed order at the end.  Workgroups walk contiguous (patch, row) runs, so consecutive rows
+// re-stage one row.  One slab per workgroup, summed by reduce_slabs_kernel (fp64, fixed order).
+// ---------------------------------------------------------------------------------------------------
+struct WgArgs {
+    int N, H, W, T, Cout;
+    int Wp, Tp, nv, total_tiles;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ partial, float* __restrict__ partial_b)
+{
+    constexpr int CB = CIN <= 28 ? 56 : 64;        // bytes of one piece of one voxel (channels padded to 28 / 32)
+    constexpr int VS = 3 * CB;                     // bytes per voxel
+    constexpr int NP = (CIN + 1) / 2;              // channel pairs staged per voxel
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int li = lane & 15, gcol = (lane >> 4) & 1;
+    const int tg = wave & 3, ksel = wave >> 2;
+    const int rowbytes = a.Wp * a.Tp * VS;
+    for (int i = tid; i < (3 * rowbytes + 16) / 8; i += 512) reinterpret_cast<uint2*>(lds_raw)[i] = make_uint2(0u, 0u);
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+
+    auto stage_row = [&](int n, int ih) {
+        unsigned char* slot = lds_raw + ((ih + 3) % 3) * rowbytes;
+        const bool ok = ih >= 0 && ih < a.H;
+        const float* src = x + ((long)n * a.H + (ok ? ih : 0)) * (long)a.W * a.T * CIN;
+        const int items = a.W * a.T * NP;
+        for (int i = tid; i < items; i += 512) {
+            const int vox = i / NP, cp = i - vox * NP;
+            const int w = vox / a.T, t = vox - w * a.T;
+            const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
+            float f0 = src[vox * CIN + c0], f1 = src[vox * CIN + c1];
+            f0 = ok ? f0 : 0.f;
+            f1 = (ok && c0 + 1 < CIN) ? f1 : 0.f;
+            unsigned q[3];
+            split_pair(f0, f1, q[0], q[1], q[2]);
+            unsigned char* d = slot + ((w + 1) * a.Tp + t + 1) * VS + cp * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
+        }
+    };
+
+    const int tbeg = (int)((long)blockIdx.x * a.total_tiles / gridDim.x), tend = (int)((long)(blockIdx.x + 1) * a.total_tiles / gridDim.x);
+    int prev_n = -1, prev_h = -1000;
+    const int nkb = (a.nv + 15) >> 4;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+#pragma unroll 1
+    for (int tile = tbeg; tile < tend; ++tile) {
+        const int n = tile / a.H, ho = tile - n * a.H;
+        __syncthreads();                                   // every wave is done with the rows of the previous tile
+        for (int rr = (n == prev_n && ho == prev_h + 1) ? 2 : 0; rr < 3; ++rr) stage_row(n, ho - 1 + rr);
+        __syncthreads();
+        prev_n = n; prev_h = ho;
+        const long out_base = ((long)n * a.H + ho) * a.nv;
+        int tapoff[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int tap = tg + 4 * j < 27 ? tg + 4 * j : 26;
+            const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
+            tapoff[j] = ((ho + dh + 2) % 3) * rowbytes + (dw * a.Tp + dt) * VS;      // slot of input row ho - 1 + dh
+        }
+#pragma unroll 1
+        for (int kb = ksel; kb < nkb; kb += 2) {
+            // B operand: dY[voxel 16kb + 8h + j][co = col]
+            float raw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int vi = 16 * kb + 8 * h + j;
+                const bool live = vi < a.nv && col < a.Cout;
+                const float d = dy[live ? (out_base + vi) * a.Cout + col : 0];
+                raw[j] = live ? d : 0.f;
+            }
+            // A operand addresses: block row q = li >> 2 of half h <-> voxel 16kb + 8h + 4jj + q, columns 16 gcol + 4 (li & 3)
+            int vaddr[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                int vi = 16 * kb + 8 * h + 4 * jj + (li >> 2);
+                vi = vi < a.nv ? vi : a.nv - 1;
+                const int w = vi / a.T, t = vi - w * a.T;
+                vaddr[jj] = (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
+            }
+            Frag bf[3];
+            split8(raw, bf);
+            if (tg == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += raw[j];
+            }
+            // taps one ahead: the transposed reads of tap j+1 are in flight under the MFMAs of tap j (barriers pin the order and
+            // keep the scheduler from hoisting all seven operand sets at once)
+            Frag af[2][3];
+            auto load_a = [&](int j, Frag (&f)[3]) {
+                const unsigned char* p0 = lds_raw + tapoff[j] + vaddr[0];
+                const unsigned char* p1 = lds_raw + tapoff[j] + vaddr[1];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * CB));
+                    f[p].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + p * CB));
+                }
+            };
+            load_a(0, af[0]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (tap 26 + tg's slot is clamped: harmless reread)
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < 6 || tg < 3) acc[j] = mac6(af[j & 1], bf, acc[j]);            // wave-uniform
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // slab of this workgroup: [27 * Cin][Cout] (+ bias sums); k-block parity 1 first, parity 0 adds to it
+    float* pp = partial + (long)blockIdx.x * 27 * CIN * a.Cout;
+    float* pb = partial_b + (long)blockIdx.x * a.Cout;
+    for (int pass = 1; pass >= 0; --pass) {
+        if (ksel == pass) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int tap = tg + 4 * j;
+                if (tap >= 27) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = rowmap(r, h);
+                    if (ci < CIN && col < a.Cout) {
+                        float* o = pp + ((long)tap * CIN + ci) * a.Cout + col;
+                        *o = pass == 1 ? acc[j][r] : acc[j][r] + *o;
+                    }
+                }
+            }
+            if (tg == 0) {
+                const float b = bsum + __shfl_xor(bsum, 32, 64);
+                if (h == 0 && col < a.Cout) pb[col] = pass == 1 ? b : b + pb[col];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool x6_wgrad_supported(const ConvGeom& g)
+{
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph != 1 || g.pw != 1 || g.pt != 1 || g.reflect_hw) return false;
+    if (g.Cin != 25 || g.Cout > 32 || g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return false;
+    const size_t lds = (size_t)3 * (g.Wi + 2) * (g.Ti + 2) * 168 + 16;
+    return lds <= 160 * 1024;
+}
+
+static int x6_wgrad_grid(const ConvGeom& g) { return g.N * g.Ho < 256 ? g.N * g.Ho : 256; }
+size_t x6_wgrad_partial_floats(const ConvGeom& g) { return (size_t)x6_wgrad_grid(g) * ((size_t)27 * g.Cin * g.Cout + g.Cout); }
+
+int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, hipStream_t s)
+{
+    if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    WgArgs a;
+    a.N = g.N; a.H = g.Hi; a.W = g.Wi; a.T = g.Ti; a.Cout = g.Cout; a.Wp = g.Wi + 2; a.Tp = g.Ti + 2;
+    a.nv = g.Wo * g.To; a.total_tiles = g.N * g.Ho;
+    const int grid = x6_wgrad_grid(g);
+    const long nw = (long)27 * g.Cin * g.Cout;
+    float* partial_b = partial + (size_t)grid * nw;
+    const size_t lds = (size_t)3 * a.Wp * a.Tp * 168 + 16;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL((conv3_wgrad_x6_kernel<25>), dim3(grid), dim3(512), lds, s, a, x, dy, partial, partial_b);
+    int rc = check_launch("conv3_wgrad_x6");
+    if (rc) return rc;
+    return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);
+}
+
 }  // namespace probav

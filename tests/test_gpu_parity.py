@@ -110,9 +110,11 @@ WGRAD_CASES = [c for c in CONV_CASES if not c[0].startswith("bwd-data")]
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
 def test_conv3d_wgrad_matches_autograd(dev, case, impl):
-    if impl >= 2:
-        pytest.skip("impl 2/3 only change the forward / backward-data kernels")
+    if impl == 2:
+        pytest.skip("impl 2 only changes the forward / backward-data kernels")
     name, N, hwt, Cin, Cout, k, pad, reflect, relu, _, _ = case
+    if impl == 3 and relu:
+        pytest.skip("the x6 backward-filter kernel covers the un-gated normConv layers")
     rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
     ho = _out_dims(hwt, k, pad, reflect)
     x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
@@ -132,8 +134,8 @@ def test_conv3d_wgrad_matches_autograd(dev, case, impl):
     L = _lib()
     g = _geom(N, hwt[0], hwt[1], hwt[2], Cin, ho[0], ho[1], ho[2], Cout, k, pad, reflect, relu)
     nbytes = L.lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(g), impl)
-    if impl == 1 and nbytes == 0:
-        pytest.skip("geometry not covered by the MFMA backward-filter kernel (engine falls back to the direct kernel)")
+    if impl in (1, 3) and nbytes == 0:
+        pytest.skip("geometry not covered by this MFMA backward-filter kernel (the engine falls back)")
     scratch = torch.empty(nbytes // 4 + 1, device=dev)
     dw = torch.full(k + (Cin, Cout), float("nan"), device=dev)
     db = torch.full((Cout,), float("nan"), device=dev)
@@ -141,6 +143,8 @@ def test_conv3d_wgrad_matches_autograd(dev, case, impl):
     L.check(L.lib().probav_conv3d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dyd), L.ptr(gd), L.ptr(dw), L.ptr(db),
                                         L.ptr(scratch), nbytes, impl, L.current_stream()))
     ref_w, ref_b = wt.grad.numpy(), dyg.sum(dim=(0, 1, 2, 3)).numpy()
+    print("conv3d_wgrad impl %d %s: dw err %.3g db err %.3g" % (impl, name, np.abs(dw.cpu().double().numpy() - ref_w).max() / np.abs(ref_w).max(),
+                                                                np.abs(db.cpu().double().numpy() - ref_b).max() / np.abs(ref_b).max()))
     assert np.abs(dw.cpu().double().numpy() - ref_w).max() / np.abs(ref_w).max() < 1e-5
     assert np.abs(db.cpu().double().numpy() - ref_b).max() / np.abs(ref_b).max() < 1e-5
     # bitwise reproducible (fixed-order partial sums, no float atomics)
