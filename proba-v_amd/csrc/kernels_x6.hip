@@ -19,6 +19,17 @@
 
 namespace probav {
 
+// per-wave phase stamps for tools/diag_x6.hip (diagnostic build only: -DPROBAV_STAMP; g_stamps lives in kernels_mfma.hip)
+#ifdef PROBAV_STAMP
+#define XS_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[8] = {xs_t, 0, 0, 0, 0, 0, 0, 0}
+#define XS_ACC(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[k] += t_ - xs_t; xs_t = t_; } while (0)
+#define XS_OUT do { xs_acc[7] = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 8; ++k_) g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k_] = xs_acc[k_]; } while (0)
+#else
+#define XS_DECL do { } while (0)
+#define XS_ACC(k) do { } while (0)
+#define XS_OUT do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // fused expConv + ReLU + decConv forward (1x1x1, 32 -> 256 -> D <= 32); one 32-voxel tile per wave and round.
 // Both weight sets live in LDS as pre-split fragments (2 x 48 KB); X comes straight from HBM into B fragments;
@@ -387,6 +398,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
 struct WgArgs {
     int N, H, W, T, Cout;
     int Wp, Tp, nv, total_tiles;
+    unsigned mT;                // ceil(2^32 / T): floor(v / T) = umulhi(v, mT) for the small v used here (T >= 2)
 };
 
 template <int CIN>
@@ -410,37 +422,66 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
 
-    auto stage_row = [&](int n, int ih) {
-        unsigned char* slot = lds_raw + ((ih + 3) % 3) * rowbytes;
+    // staging of one input row, split in two so that the HBM/L2 latency of the NEXT tile's row hides under this tile's MFMAs:
+    // stage_load leaves the row in registers (NST channel pairs per thread), stage_store cuts and stores it.
+    constexpr int NST = 6;                                 // x6_wgrad_supported(): W * T * NP <= 512 * NST
+    const int items = a.W * a.T * NP;
+    auto stage_load = [&](int n, int ih, float (&f)[NST][2]) {
         const bool ok = ih >= 0 && ih < a.H;
         const float* src = x + ((long)n * a.H + (ok ? ih : 0)) * (long)a.W * a.T * CIN;
-        const int items = a.W * a.T * NP;
-        for (int i = tid; i < items; i += 512) {
-            const int vox = i / NP, cp = i - vox * NP;
-            const int w = vox / a.T, t = vox - w * a.T;
-            const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
-            float f0 = src[vox * CIN + c0], f1 = src[vox * CIN + c1];
-            f0 = ok ? f0 : 0.f;
-            f1 = (ok && c0 + 1 < CIN) ? f1 : 0.f;
-            unsigned q[3];
-            split_pair(f0, f1, q[0], q[1], q[2]);
-            unsigned char* d = slot + ((w + 1) * a.Tp + t + 1) * VS + cp * 4;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + 512 * k;
+            const int ic = i < items ? i : 0;
+            const int vox = ic / NP, cp = ic - vox * NP;
+            const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
+            const float f0 = src[vox * CIN + c0], f1 = src[vox * CIN + c1];
+            f[k][0] = ok ? f0 : 0.f;
+            f[k][1] = (ok && c0 + 1 < CIN) ? f1 : 0.f;
+        }
+    };
+    auto stage_store = [&](int ih, const float (&f)[NST][2]) {
+        unsigned char* slot = lds_raw + ((ih + 3) % 3) * rowbytes;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + 512 * k;
+            if (i < items) {
+                const int vox = i / NP, cp = i - vox * NP;
+                const int w = vox / a.T, t = vox - w * a.T;
+                unsigned q[3];
+                split_pair(f[k][0], f[k][1], q[0], q[1], q[2]);
+                unsigned char* d = slot + ((w + 1) * a.Tp + t + 1) * VS + cp * 4;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
+            }
+        }
+    };
+    auto stage_three = [&](int n, int ho) {
+#pragma unroll 1
+        for (int rr = 0; rr < 3; ++rr) {
+            float f[NST][2];
+            stage_load(n, ho - 1 + rr, f);
+            stage_store(ho - 1 + rr, f);
         }
     };
 
     const int tbeg = (int)((long)blockIdx.x * a.total_tiles / gridDim.x), tend = (int)((long)(blockIdx.x + 1) * a.total_tiles / gridDim.x);
-    int prev_n = -1, prev_h = -1000;
     const int nkb = (a.nv + 15) >> 4;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    XS_DECL;
+    __syncthreads();                                       // ring zeroed
+    if (tbeg < tend) stage_three(tbeg / a.H, tbeg % a.H);
+    XS_ACC(1);
 #pragma unroll 1
     for (int tile = tbeg; tile < tend; ++tile) {
         const int n = tile / a.H, ho = tile - n * a.H;
-        __syncthreads();                                   // every wave is done with the rows of the previous tile
-        for (int rr = (n == prev_n && ho == prev_h + 1) ? 2 : 0; rr < 3; ++rr) stage_row(n, ho - 1 + rr);
-        __syncthreads();
-        prev_n = n; prev_h = ho;
+        __syncthreads();                                   // this tile's three rows are staged
+        XS_ACC(2);
+        const bool has_next = tile + 1 < tend;
+        const int nn = (tile + 1) / a.H, nho = (tile + 1) - nn * a.H;
+        const bool consecutive = has_next && nn == n;      // next tile = next row of the same patch: one new row
+        float nf[NST][2];
+        if (consecutive) stage_load(n, ho + 2, nf);        // in flight during this tile's MFMAs
         const long out_base = ((long)n * a.H + ho) * a.nv;
         int tapoff[7];
 #pragma unroll
@@ -449,38 +490,53 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
             tapoff[j] = ((ho + dh + 2) % 3) * rowbytes + (dw * a.Tp + dt) * VS;      // slot of input row ho - 1 + dh
         }
+        // B operand: dY[voxel 16kb + 8h + j][co = col].  Three-stage pipeline over this wave's k-blocks: loads of block i+2 |
+        // cutting block i+1 into pieces and its transposed-read addresses | MFMAs of block i.  The second stage is spread over
+        // the seven taps of the third so that its VALU work issues in the shadow of the MFMAs.
+        const float* dyrow = dy + out_base * 32 + col;
+        auto load_dy = [&](int kb, float (&r)[8]) {
+            const int v0 = 16 * kb + 8 * h;
+            if (16 * kb + 16 <= a.nv) {                                                 // wave-uniform fast path
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = dyrow[(v0 + j) * 32];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool live = v0 + j < a.nv;
+                    const float d = dyrow[live ? (v0 + j) * 32 : 0];
+                    r[j] = live ? d : 0.f;
+                }
+            }
+        };
+        auto tr_addr = [&](int kb, int jj) -> int {                                     // block row li >> 2 of half h, columns 16 gcol + 4 (li & 3)
+            int vi = 16 * kb + 8 * h + 4 * jj + (li >> 2);
+            vi = vi < a.nv ? vi : a.nv - 1;
+            const int w = (int)__umulhi((unsigned)vi, a.mT), t = vi - w * a.T;
+            return (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
+        };
+        Frag bf[3], bfn[3];
+        int va[2], van[2];
+        float rawn[8], rawnn[8];
+        {
+            float raw0[8];
+            load_dy(ksel, raw0);
+            load_dy(ksel + 2 < nkb ? ksel + 2 : ksel, rawn);
+            split8(raw0, bf);
+            va[0] = tr_addr(ksel, 0); va[1] = tr_addr(ksel, 1);
+            if (tg == 0 && ksel < nkb) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += raw0[j];
+            }
+        }
+        typedef const unsigned char* cptr;
 #pragma unroll 1
         for (int kb = ksel; kb < nkb; kb += 2) {
-            // B operand: dY[voxel 16kb + 8h + j][co = col]
-            float raw[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int vi = 16 * kb + 8 * h + j;
-                const bool live = vi < a.nv && col < a.Cout;
-                const float d = dy[live ? (out_base + vi) * a.Cout + col : 0];
-                raw[j] = live ? d : 0.f;
-            }
-            // A operand addresses: block row q = li >> 2 of half h <-> voxel 16kb + 8h + 4jj + q, columns 16 gcol + 4 (li & 3)
-            int vaddr[2];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                int vi = 16 * kb + 8 * h + 4 * jj + (li >> 2);
-                vi = vi < a.nv ? vi : a.nv - 1;
-                const int w = vi / a.T, t = vi - w * a.T;
-                vaddr[jj] = (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
-            }
-            Frag bf[3];
-            split8(raw, bf);
-            if (tg == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += raw[j];
-            }
-            // taps one ahead: the transposed reads of tap j+1 are in flight under the MFMAs of tap j (barriers pin the order and
-            // keep the scheduler from hoisting all seven operand sets at once)
+            const int kn = kb + 2 < nkb ? kb + 2 : kb, knn = kb + 4 < nkb ? kb + 4 : kb;
+            load_dy(knn, rawnn);
             Frag af[2][3];
             auto load_a = [&](int j, Frag (&f)[3]) {
-                const unsigned char* p0 = lds_raw + tapoff[j] + vaddr[0];
-                const unsigned char* p1 = lds_raw + tapoff[j] + vaddr[1];
+                cptr p0 = lds_raw + tapoff[j] + va[0];
+                cptr p1 = lds_raw + tapoff[j] + va[1];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * CB));
@@ -490,46 +546,95 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             load_a(0, af[0]);
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (tap 26 + tg's slot is clamped: harmless reread)
+                if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (slot j = 6 of tg = 3 is clamped: harmless reread)
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 6 || tg < 3) acc[j] = mac6(af[j & 1], bf, acc[j]);            // wave-uniform
+                // a seventh of the next block's preparation.  The empty volatile asm statements pin it between this tap's
+                // scheduling barriers (pure arithmetic would otherwise be sunk to the end of the loop body).
+                if (j < 4) {
+                    float ra = rawn[2 * j], rb = rawn[2 * j + 1];
+                    asm volatile("" : "+v"(ra), "+v"(rb));
+                    unsigned q0, q1, q2;
+                    split_pair(ra, rb, q0, q1, q2);
+                    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+                    if (j == 0) { bfn[0].u.x = q0; bfn[1].u.x = q1; bfn[2].u.x = q2; }
+                    if (j == 1) { bfn[0].u.y = q0; bfn[1].u.y = q1; bfn[2].u.y = q2; }
+                    if (j == 2) { bfn[0].u.z = q0; bfn[1].u.z = q1; bfn[2].u.z = q2; }
+                    if (j == 3) { bfn[0].u.w = q0; bfn[1].u.w = q1; bfn[2].u.w = q2; }
+                } else if (j < 6) {
+                    int kk = kn;
+                    asm volatile("" : "+v"(kk));
+                    int v = tr_addr(kk, j - 4);
+                    asm volatile("" : "+v"(v));
+                    van[j - 4] = v;
+                } else if (tg == 0 && kb + 2 < nkb) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bsum += rawn[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {                                         // one MFMA, then two VALU in its shadow
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[p] = bfn[p];
+            va[0] = van[0]; va[1] = van[1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rawn[i] = rawnn[i];
         }
+        XS_ACC(3);
+        __syncthreads();                                   // every wave is done with this tile's rows
+        XS_ACC(4);
+        if (consecutive) stage_store(ho + 2, nf);          // replaces row ho - 1
+        else if (has_next) stage_three(nn, nho);
+        XS_ACC(5);
     }
-    // slab of this workgroup: [27 * Cin][Cout] (+ bias sums); k-block parity 1 first, parity 0 adds to it
+    // slab of this workgroup: [27 * Cin][Cout] (+ bias sums).  The two k-block parities meet in LDS (the ring is dead now):
+    // parity 1 leaves its accumulators there, parity 0 adds them and writes the slab once.
     float* pp = partial + (long)blockIdx.x * 27 * CIN * a.Cout;
     float* pb = partial_b + (long)blockIdx.x * a.Cout;
-    for (int pass = 1; pass >= 0; --pass) {
-        if (ksel == pass) {
+    float* xch = reinterpret_cast<float*>(lds_raw) + tg * (7 * 16 + 1) * 64;             // [tg][7 taps x 16 registers + bias][64 lanes]
+    __syncthreads();
+    if (ksel == 1) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int tap = tg + 4 * j;
-                if (tap >= 27) continue;
+        for (int j = 0; j < 7; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ci = rowmap(r, h);
-                    if (ci < CIN && col < a.Cout) {
-                        float* o = pp + ((long)tap * CIN + ci) * a.Cout + col;
-                        *o = pass == 1 ? acc[j][r] : acc[j][r] + *o;
-                    }
-                }
-            }
-            if (tg == 0) {
-                const float b = bsum + __shfl_xor(bsum, 32, 64);
-                if (h == 0 && col < a.Cout) pb[col] = pass == 1 ? b : b + pb[col];
+            for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = acc[j][r];
+        xch[7 * 16 * 64 + lane] = bsum;
+    }
+    __syncthreads();
+    if (ksel == 0) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int tap = tg + 4 * j;
+            if (tap >= 27) continue;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[j][r] + xch[(j * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = rowmap(r, h);
+                if (ci < CIN) pp[((long)tap * CIN + ci) * 32 + col] = v[r];
             }
         }
-        __syncthreads();
+        if (tg == 0) {
+            float b = bsum + xch[7 * 16 * 64 + lane];
+            b += __shfl_xor(b, 32, 64);
+            if (h == 0) pb[col] = b;
+        }
     }
+    XS_ACC(6);
+    XS_OUT;
 }
 
 bool x6_wgrad_supported(const ConvGeom& g)
 {
     if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph != 1 || g.pw != 1 || g.pt != 1 || g.reflect_hw) return false;
-    if (g.Cin != 25 || g.Cout > 32 || g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return false;
+    if (g.Cin != 25 || g.Cout != 32 || g.Ti < 2 || g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return false;
     const size_t lds = (size_t)3 * (g.Wi + 2) * (g.Ti + 2) * 168 + 16;
-    return lds <= 160 * 1024;
+    return lds <= 160 * 1024 && g.Wi * g.Ti * 13 <= 512 * 6;
 }
 
 static int x6_wgrad_grid(const ConvGeom& g) { return g.N * g.Ho < 256 ? g.N * g.Ho : 256; }
@@ -541,10 +646,13 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw,
     WgArgs a;
     a.N = g.N; a.H = g.Hi; a.W = g.Wi; a.T = g.Ti; a.Cout = g.Cout; a.Wp = g.Wi + 2; a.Tp = g.Ti + 2;
     a.nv = g.Wo * g.To; a.total_tiles = g.N * g.Ho;
+    a.mT = (unsigned)((0x100000000ull + (unsigned)g.Ti - 1) / (unsigned)g.Ti);
     const int grid = x6_wgrad_grid(g);
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
-    const size_t lds = (size_t)3 * a.Wp * a.Tp * 168 + 16;
+    size_t lds = (size_t)3 * a.Wp * a.Tp * 168 + 16;
+    const size_t xch = (size_t)4 * (7 * 16 + 1) * 64 * sizeof(float);                 // exchange area of the epilogue
+    if (lds < xch) lds = xch;
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -56,5 +56,25 @@ def main():
             print("%s: impl 3 vs impl 2 max diff / max = %.3g" % (name, float((a - b).abs().max() / a.abs().max())))
 
 
+    if what == "wgrad":
+        import ctypes
+        N, H, W, T, Cin, Cout = 128, 22, 22, 9, 25, 32
+        gm = (ctypes.c_int32 * 17)(N, H, W, T, Cin, H, W, T, Cout, 3, 3, 3, 1, 1, 1, 0, 0)
+        xx = torch.randn(N, H, W, T, Cin, generator=g).to(dev)
+        dyy = torch.randn(N, H, W, T, Cout, generator=g).to(dev)
+        outs = {}
+        for impl in (1, 3):
+            nbytes = L.lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(gm), impl)
+            scratch = torch.empty(nbytes // 4 + 1, device=dev)
+            dw = torch.empty(3, 3, 3, Cin, Cout, device=dev)
+            db = torch.empty(Cout, device=dev)
+            for _ in range(reps):
+                L.check(L.lib().probav_conv3d_wgrad(ctypes.byref(gm), L.ptr(xx), L.ptr(dyy), None, L.ptr(dw), L.ptr(db), L.ptr(scratch), nbytes,
+                                                    impl, L.current_stream()))
+            torch.cuda.synchronize()
+            outs[impl] = dw.double().cpu()
+        print("wgrad impl 3 vs impl 1: max diff / max = %.3g" % float((outs[3] - outs[1]).abs().max() / outs[1].abs().max()))
+
+
 if __name__ == "__main__":
     main()

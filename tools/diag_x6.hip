@@ -1,0 +1,40 @@
+// Diagnostic (not part of the product): per-wave phase shares of the x6 backward-filter kernel.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -DPROBAV_STAMP -I proba-v_amd/csrc tools/diag_x6.hip -o /tmp/diag_x6 && /tmp/diag_x6
+// Never quote this build's run time: the stamps serialise; read the SHARES.
+#include "../proba-v_amd/csrc/kernels_small.hip"
+#include "../proba-v_amd/csrc/kernels_mfma.hip"
+#include "../proba-v_amd/csrc/kernels_x6.hip"
+#include <vector>
+#include <cstdio>
+using namespace probav;
+
+int main()
+{
+    const int B = 128, cin = 25, cout = 32;
+    ConvGeom g{B, 22, 22, 9, cin, 22, 22, 9, cout, 3, 3, 3, 1, 1, 1, 0, 0};
+    const size_t nin = (size_t)B * 22 * 22 * 9 * cin, nout = (size_t)B * 22 * 22 * 9 * cout;
+    float *x, *dy, *dw, *db, *part;
+    hipMalloc(&x, nin * 4); hipMalloc(&dy, nout * 4); hipMalloc(&dw, 27 * cin * cout * 4); hipMalloc(&db, cout * 4);
+    hipMalloc(&part, x6_wgrad_partial_floats(g) * 4);
+    std::vector<float> h(nout);
+    for (size_t i = 0; i < nout; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
+    hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dy, h.data(), nout * 4, hipMemcpyHostToDevice);
+    for (int it = 0; it < 3; ++it) x6_conv_wgrad(g, x, dy, dw, db, part, 0);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> st(8192 * 8);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+    const char* names[8] = {"t0", "prologue", "wait: rows staged", "k-loop", "wait: end of tile", "stage store", "epilogue", "t_end"};
+    for (int wave = 0; wave < 8; ++wave) {
+        double acc[8] = {0}; double life = 0;
+        for (int b = 0; b < 256; ++b) {
+            const unsigned long long* s = &st[(b * 8 + wave) * 8];
+            for (int k = 1; k < 7; ++k) acc[k] += (double)s[k];
+            life += (double)(s[7] - s[0]);
+        }
+        printf("wave %d (tg %d ksel %d): life %.0f cyc/WG |", wave, wave & 3, wave >> 2, life / 256);
+        for (int k = 1; k < 7; ++k) printf(" %s %.1f%%", names[k], 100.0 * acc[k] / life);
+        printf("\n");
+    }
+    return 0;
+}
