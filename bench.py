@@ -28,8 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CLASSES = ["weight_norm", "small", "conv3x3x3_fwd", "conv3x3x3_bwd_data", "conv3x3x3_wgrad",
-           "conv1x1x1_fwd", "conv1x1x1_bwd_data", "conv1x1x1_wgrad"]
+           "conv1x1x1_fwd", "conv1x1x1_bwd_data", "conv1x1x1_wgrad",
+           "conv3x3x3_fwd_x6", "conv3x3x3_bwd_data_x6", "conv3x3x3_wgrad_x6", "conv1x1x1_fwd_x6", "conv1x1x1_bwd_data_x6"]
 PEAK_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PF)
+X6_PRODUCTS = 6                    # bf16 MFMA products issued per fp32 product by the x6 kernels
 ALGO_GFLOP_PER_PATCH = 12.436      # SURVEY.md §8d / BASELINE.md §2: fwd + bwd, p16t9c85r12
 
 
@@ -73,7 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="patches per GPU (BASELINE.json: 128)")
     ap.add_argument("--frames", type=int, default=9, help="numImgLR: 9 (headline), 13 or 7")
-    ap.add_argument("--impl", type=int, default=2, help="2 = MFMA + strip convolution (default), 1 = MFMA row-tile kernels, 0 = generic direct kernels")
+    ap.add_argument("--impl", type=int, default=3, help="3 = x6 kernels: fp32 products as six bf16-piece products on the bf16 MFMA pipe (default), "
+                    "2 = native fp32 MFMA + strip convolution, 1 = fp32 MFMA row-tile kernels, 0 = generic direct kernels")
+    ap.add_argument("--no-fp32-mfma-leg", action="store_true", help="skip the short extra run on the native fp32-MFMA kernels (impl 2)")
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -165,6 +170,24 @@ def main():
         sync()
         full = (time.perf_counter() - t1) / args.steps * 1e3
 
+    fp32_leg = None
+    if args.impl == 3 and not args.no_fp32_mfma_leg:
+        model.set_impl(2)
+        for _ in range(2):
+            step()
+        sync()
+        k2 = max(3, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        sync()
+        t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        fp32_leg = {"value": round(world * B * k2 / float(t2), 2), "unit": "patches/s", "ms_per_step": round(float(t2) / k2 * 1e3, 4), "steps": k2,
+                    "note": "same step on the native fp32-MFMA kernels (--impl 2), for reference"}
+        model.set_impl(3)
+
     if rank == 0:
         value = world * B * args.steps / dt
         out = {
@@ -176,11 +199,16 @@ def main():
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
                                    (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16"}[args.impl],
+                       "arithmetic": ("fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as six exact bf16-piece products on the "
+                                      "bf16 MFMA pipe (x6 kernels, error of the order of fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 3
+                                      else "native fp32 MFMA / VALU"),
                        "loss": float(loss.detach()), "kernel_events": use_events},
             "algorithmic_tflops_whole_step": round(value * ALGO_GFLOP_PER_PATCH / 1e3, 3) if T == 9 else None,
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",
                                   "note": "derived from the reference's TensorBoard logs (BASELINE.md), not a published figure"},
         }
+        if fp32_leg is not None:
+            out["fp32_mfma_path"] = fp32_leg
         if full is not None:
             out["full_step"] = {"ms_per_step": round(full, 4), "patches_per_s": round(world * B / full * 1e3, 2),
                                 "includes": "fwd + L1 loss + bwd + Nadam update + cPSNR metric"}
@@ -190,11 +218,17 @@ def main():
                    for c, v in prof.items()}
             dom = max((c for c in prof if prof[c]["macs"] > 0), key=lambda c: prof[c]["ms"])
             ach = 2 * prof[dom]["macs"] / (prof[dom]["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+            x6 = dom.endswith("_x6")
+            peak = PEAK_BF16_TFLOPS / X6_PRODUCTS if x6 else PEAK_F32_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None,
                                "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["launches"]), 4),
                                "algorithmic_gflop_per_launch": round(2 * prof[dom]["macs"] / max(1, prof[dom]["launches"]) / 1e9, 3),
-                               "note": "rank 0, HIP events on the launch stream around every launch of the class during the timed steps"}
+                               "note": "rank 0, HIP events on the launch stream around every launch of the class during the timed steps; "
+                                       "achieved = algorithmic fp32 FLOP/s" + (
+                                           "; this class runs x6 kernels, which issue %d bf16 MFMA products per fp32 product, so its ceiling is "
+                                           "the dense bf16 MFMA peak (%.0f TFLOP/s) / %d" % (X6_PRODUCTS, PEAK_BF16_TFLOPS, X6_PRODUCTS) if x6 else
+                                           "; peak = dense fp32 MFMA")}
             out["kernel_classes"] = per
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -25,7 +25,7 @@ struct probav_engine {
     std::vector<LayerRec> layers;
     int64_t nparams = 0, weff_count = 0, cout_total = 0;
     WnLayer* d_layers = nullptr;
-    int impl = 2;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
+    int impl = 3;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
                               // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed, redReflect;
@@ -49,7 +49,9 @@ struct probav_engine {
     size_t prof_used = 0;
 };
 
-enum { CLS_WN = 0, CLS_SMALL, CLS_CONV3_FWD, CLS_CONV3_BWD_DATA, CLS_CONV3_WGRAD, CLS_PW_FWD, CLS_PW_BWD_DATA, CLS_PW_WGRAD, CLS_COUNT };
+enum { CLS_WN = 0, CLS_SMALL, CLS_CONV3_FWD, CLS_CONV3_BWD_DATA, CLS_CONV3_WGRAD, CLS_PW_FWD, CLS_PW_BWD_DATA, CLS_PW_WGRAD,
+       // launches served by an x6 kernel (bf16 MFMA pipe) are timed apart from the fp32-MFMA / VALU ones: they price against another peak
+       CLS_CONV3_FWD_X6, CLS_CONV3_BWD_DATA_X6, CLS_CONV3_WGRAD_X6, CLS_PW_FWD_X6, CLS_PW_BWD_DATA_X6, CLS_COUNT };
 
 struct ProfScope {
     probav_engine* e; hipStream_t s; bool live;
@@ -212,8 +214,9 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
     const float* wfrag = wf.f32;
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
-    ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD), geom_macs(g), s);
-    if (e->impl >= 3 && wf.x6 && mfma_conv_strip_supported(g)) return x6_conv_strip_forward(g, x, gate, wf.x6, bias, skip, y, s);
+    const bool x6 = e->impl >= 3 && wf.x6 && mfma_conv_strip_supported(g);
+    ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? (x6 ? CLS_CONV3_BWD_DATA_X6 : CLS_CONV3_BWD_DATA) : (x6 ? CLS_CONV3_FWD_X6 : CLS_CONV3_FWD)), geom_macs(g), s);
+    if (x6) return x6_conv_strip_forward(g, x, gate, wf.x6, bias, skip, y, s);
     if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, s);
     if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, s);
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
@@ -221,8 +224,9 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
                       float* dw, float* db, float* partial, hipStream_t s)
 {
-    ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : CLS_CONV3_WGRAD, geom_macs(g), s);
-    if (e->impl >= 3 && !gate && x6_wgrad_supported(g)) return x6_conv_wgrad(g, x, dy, dw, db, partial, s);
+    const bool x6 = e->impl >= 3 && !gate && x6_wgrad_supported(g);
+    ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : (x6 ? CLS_CONV3_WGRAD_X6 : CLS_CONV3_WGRAD), geom_macs(g), s);
+    if (x6) return x6_conv_wgrad(g, x, dy, dw, db, partial, s);
     if (e->impl >= 1 && mfma_wgrad_supported(g)) return mfma_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s);
 }
@@ -439,7 +443,7 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
         if (e->impl >= 1 && e->pw_mfma) {
             // fused expConv + ReLU + decConv: the 256-channel tensor never leaves the accumulators
             const long nvox = (long)B * Hin * Hin * T;
-            ProfScope ps(e, CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
+            ProfScope ps(e, e->impl >= 3 ? CLS_PW_FWD_X6 : CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
             if (e->impl >= 3)
                 CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                  W + p.dec[i], nvox, D, s));
@@ -535,7 +539,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         if (e->impl >= 1 && e->pw_mfma) {
             // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
             const long nvox = (long)B * Hin * Hin * T;
-            ProfScope ps(e, CLS_PW_BWD_DATA, (double)nvox * (3.0 * F * E + 2.0 * E * D), s);
+            ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (3.0 * F * E + 2.0 * E * D), s);
             if (e->impl >= 3)
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2Kx6[i], W + p.wpack + e->pkW1Cx6[i],
                                   params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
