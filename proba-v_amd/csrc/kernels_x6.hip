@@ -20,6 +20,11 @@
 namespace probav {
 
 // per-wave phase stamps for tools/diag_x6.hip (diagnostic build only: -DPROBAV_STAMP; g_stamps lives in kernels_mfma.hip)
+#ifdef PROBAV_STAMP2
+#define XS2(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs2[k] += t_ - xs2t; xs2t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define XS2(k) do { } while (0)
+#endif
 #ifdef PROBAV_STAMP
 #define XS_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[8] = {xs_t, 0, 0, 0, 0, 0, 0, 0}
 #define XS_ACC(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[k] += t_ - xs_t; xs_t = t_; } while (0)
@@ -132,31 +137,49 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
-// fused backward of expConv + ReLU + decConv (1x1x1), x6 form.  Same decomposition as pw_bwd2_mfma_kernel (one wave
-// per 32-channel hidden chunk, chunk weights resident in registers, 8 waves on one 32-voxel tile, one slab per
-// workgroup), but no in-wave transposes: the chunk's hidden tile is produced in BOTH orientations,
-//     orientation 1 (hidden rows x voxel cols):  H1 = W1c^T X^T,  dH1 = W2c dT^T   -> gate -> B operand of  dX^T += W1c dH1'
-//     orientation 2 (voxel rows x hidden cols):  H2 = X W1c,      dH2 = dT W2c^T   -> gate -> B operands of
-//                                                dW1c += X^T dH2'   and   dW2c^T += dT^T H2'
-// because an accumulator tile is the next product's B operand exactly when that product contracts over the tile's ROW
-// index.  Two extra products (84 bf16 MFMAs per tile and chunk instead of 77 fp32 ones, at a sixth of the cycles
-// each) buy the removal of every LDS transpose.  The A and B lane maps of the 32x32x16 MFMA are the same, so the X / dT
-// fragments and the W1c / W2c fragments each serve both orientations.  X^T and dT^T (K = voxel) come out of the same
-// LDS piece images by ds_read_b64_tr_b16, whose 4-row blocks are exactly the accumulator k-order.
+// fused backward of expConv + ReLU + decConv (1x1x1), x6 form.  Same decomposition as pw_bwd2_mfma_kernel: one wave per
+// 32-channel hidden chunk, chunk weights resident in registers (as bf16 pieces), 8 waves on one 32-voxel tile, one slab
+// per workgroup.  Per tile and chunk:
+//   (a) H^T  = W1c^T X^T (+ b1)          rows = hidden (registers), cols = voxel (lanes)
+//   (b) dH^T = W2c dT^T                  same layout -> gate dH' = dH [H > 0], H' = relu(H): elementwise
+//   (c) dX^T partial = W1c dH'^T         contracts over hidden = the ROW index: the cut accumulator registers are the B operand
+//   (d) dW1c += X^T dH'                  contracts over the voxel = the COLUMN (lane) index: one in-wave transpose --
+//   (e) dW2c^T += dT^T H'                the pieces are stored packed ([voxel][hidden], 8 bytes per lane and register quad) and
+//                                        read back with ds_read_b64_tr_b16; X^T and dT^T come out of the staged X / dT piece
+//                                        images the same way.
+// 60 bf16 MFMAs per tile and chunk.  (A first x6 version produced the hidden tile in both orientations instead of
+// transposing -- 84 MFMAs and three cuts per tile; it was bound by the vector issue port: 6.9 VALU instructions per MFMA.)
 // ---------------------------------------------------------------------------------------------------
 constexpr int PB_ROW = 80;                  // bytes per voxel row of a piece image: 32 bf16 + 16 (row reads conflict-free)
 constexpr int PB_IMG = 32 * PB_ROW;
 constexpr int PB_TILE = 3 * PB_IMG;         // one staged tile: three piece images
 constexpr int PB_TB = 32 * 33;              // floats of one dX partial
 
+constexpr int PT_ROW = 72;                  // row bytes of a wave's transpose image (only 8-byte accesses)
+constexpr int PT_IMG = 32 * PT_ROW;
+
+template <int ROW>
 __device__ __forceinline__ void tr_frag(const unsigned char* img, int lane, int kb, Frag& f)
 {
-    // A operand [row = channel lane&31][k-slot j of half h <-> voxel 16kb + 8(j>>2) + 4h + (j&3)] of a [voxel][channel] image
+    // operand [row|col = channel lane&31][k-slot j of half h <-> voxel 16kb + 8(j>>2) + 4h + (j&3)] of a [voxel][channel] image
     const int li = lane & 15, gcol = (lane >> 4) & 1, h = lane >> 5;
-    const unsigned char* p = img + (16 * kb + 4 * h + (li >> 2)) * PB_ROW + (16 * gcol + 4 * (li & 3)) * 2;
+    const unsigned char* p = img + (16 * kb + 4 * h + (li >> 2)) * ROW + (16 * gcol + 4 * (li & 3)) * 2;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
-    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 8 * PB_ROW));
+    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 8 * ROW));
+}
+// the transpose image of an accumulator tile whose rows (registers) are channels and whose columns (lanes) are voxels: lane
+// (voxel col, half h) owns channels 8G + 4h + (0..3) in registers 4G..4G+3, i.e. the dwords of its cut fragments in order
+__device__ __forceinline__ void store_pieces(unsigned char* img, int col, int h, const Frag (&f)[2][3])
+{
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        unsigned char* d = img + p * PT_IMG + col * PT_ROW + 8 * h;
+        *reinterpret_cast<uint2*>(d) = make_uint2(f[0][p].u.x, f[0][p].u.y);          // G = 0: channels 4h ..
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2(f[0][p].u.z, f[0][p].u.w);     // G = 1: channels 8 + 4h ..
+        *reinterpret_cast<uint2*>(d + 32) = make_uint2(f[1][p].u.x, f[1][p].u.y);     // G = 2
+        *reinterpret_cast<uint2*>(d + 48) = make_uint2(f[1][p].u.z, f[1][p].u.w);     // G = 3
+    }
 }
 
 __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
@@ -167,10 +190,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* XA = lds_raw;                                  // [2 buffers][3 pieces][32 voxels][80 B]
     unsigned char* DA = XA + 2 * PB_TILE;                         // same for dT (channels D..31 stay zero)
-    float* TbAll = reinterpret_cast<float*>(DA + 2 * PB_TILE);   // [8 waves][32][33] dX partials
-    float* sB1 = TbAll + 8 * PB_TB;                               // 256 expand biases
+    float* TbAll = reinterpret_cast<float*>(DA + 2 * PB_TILE);   // [2 tile parities][8 waves][32][33] dX partials
+    float* sB1 = TbAll + 16 * PB_TB;                              // 256 expand biases
+    unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 256);       // [8 waves][3 pieces][32 voxels][72 B] transpose images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    float* Tb = TbAll + wave * PB_TB;
     if (tid < 256) sB1[tid] = b1[tid];
     const int c = wave;                                           // this wave's hidden chunk
 
@@ -183,11 +206,12 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             w2[kb][p].u = w2kf[((c * 2 + kb) * 3 + p) * 64 + lane];
             w3[kb][p].u = w1cf[((c * 2 + kb) * 3 + p) * 64 + lane];
         }
-    const float bcol = b1[32 * c + col];
+    unsigned char* Ti = TiAll + wave * 3 * PT_IMG;
     f32x16 dW1, dW2t;
+    float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; }
-    float bs1 = 0.f, bs2a = 0.f, bs2b = 0.f;
+    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
+    float bs2a = 0.f, bs2b = 0.f;
 
     for (int i = tid; i < 2 * PB_TILE / 16; i += 512) reinterpret_cast<uint4*>(DA)[i] = make_uint4(0u, 0u, 0u, 0u);
 
@@ -240,21 +264,44 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 
     long tile = blockIdx.x;
     int buf = 0;
+    XS_DECL;
+#ifdef PROBAV_STAMP2
+    unsigned long long xs2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xs2t = 0;
+#endif
     __syncthreads();                                   // DA pads are zero
     {
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d0 = 0.f, d1 = 0.f;
         if (tile < ntiles) { stage_load(tile, xv, d0, d1); stage_store(0, xv, d0, d1); }
     }
+    // dX of a tile = dOut + the eight chunk partials.  The partials of tile t are reduced at the start of iteration t+1 (after the
+    // one barrier per tile), from the buffer of t's parity, while iteration t+1 fills the other one.
+    const int rv0 = 4 * wave + (lane >> 5), rv1 = rv0 + 2;           // this wave reduces voxels 4*wave .. 4*wave+3 of dX
+    long pv0 = -1; float pdo0 = 0.f, pdo1 = 0.f;                      // previous tile: first voxel, its dOut values
+    auto reduce_prev = [&](int pb) {
+        if (pv0 < 0) return;
+        float s0 = pdo0, s1 = pdo1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* P = TbAll + (pb * 8 + j) * PB_TB;
+            s0 += P[rv0 * 33 + col];
+            s1 += P[rv1 * 33 + col];
+        }
+        if (pv0 + rv0 < nvox) dX[(pv0 + rv0) * 32 + col] = s0;
+        if (pv0 + rv1 < nvox) dX[(pv0 + rv1) * 32 + col] = s1;
+    };
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        __syncthreads();                               // tile `tile` is staged in buffer `buf`; previous dX reduce is done
+        XS_ACC(5);
+        __syncthreads();                               // tile `tile` is staged in buffer `buf`; the previous tile's partials are complete
+        XS_ACC(1);
+        float* Tb = TbAll + (buf * 8 + wave) * PB_TB;
         const long tnext = tile + gridDim.x;
         float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd0 = 0.f, nd1 = 0.f;
         if (tnext < ntiles) stage_load(tnext, nxv, nd0, nd1);          // in flight during this tile's MFMAs
         const long v0 = tile * 32;
-        const int rv0 = 4 * wave + (lane >> 5), rv1 = rv0 + 2;       // this wave reduces voxels 4*wave .. 4*wave+3 of dX
         const bool rok0 = v0 + rv0 < nvox, rok1 = v0 + rv1 < nvox;
         const float do0 = dOut[(rok0 ? v0 + rv0 : v0) * 32 + col];
         const float do1 = dOut[(rok1 ? v0 + rv1 : v0) * 32 + col];
+        reduce_prev(buf ^ 1);
 
         const unsigned char* Xb = XA + buf * PB_TILE;
         const unsigned char* Db = DA + buf * PB_TILE;
@@ -269,78 +316,71 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         f32x16 zero;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-        // ---- orientation 1: rows = hidden (registers), cols = voxel (lanes) ----
+#ifdef PROBAV_STAMP2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        xs2t = __builtin_amdgcn_s_memtime();
+#endif
         {
             f32x16 H = zero, dH = zero, dx = zero;
-            H = mac6(w1[0], xf[0], H); H = mac6(w1[1], xf[1], H);
-            dH = mac6(w2[0], df[0], dH); dH = mac6(w2[1], df[1], dH);
-            Frag g1[2][3];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                float gs[8];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {                          // registers 4G .. 4G+3 <-> hidden 32c + 8G + 4h + (0..3)
-                    const float4 bb = *reinterpret_cast<const float4*>(sB1 + 32 * c + 8 * (2 * kb + g) + 4 * half);
-                    gs[4 * g + 0] = (H[8 * kb + 4 * g + 0] + bb.x) > 0.f ? dH[8 * kb + 4 * g + 0] : 0.f;
-                    gs[4 * g + 1] = (H[8 * kb + 4 * g + 1] + bb.y) > 0.f ? dH[8 * kb + 4 * g + 1] : 0.f;
-                    gs[4 * g + 2] = (H[8 * kb + 4 * g + 2] + bb.z) > 0.f ? dH[8 * kb + 4 * g + 2] : 0.f;
-                    gs[4 * g + 3] = (H[8 * kb + 4 * g + 3] + bb.w) > 0.f ? dH[8 * kb + 4 * g + 3] : 0.f;
-                }
-                split8(gs, g1[kb]);
-            }
-            dx = mac6(w3[0], g1[0], dx); dx = mac6(w3[1], g1[1], dx);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dx[r];
-        }
-        // ---- orientation 2: rows = voxel (registers), cols = hidden (lanes) ----
-        {
-            f32x16 H = zero, dH = zero;
-            H = mac6(xf[0], w1[0], H); H = mac6(xf[1], w1[1], H);
-            dH = mac6(df[0], w2[0], dH); dH = mac6(df[1], w2[1], dH);
-            Frag hf[2][3], gf[2][3];
-            float t1 = 0.f;
+            H = mac6(w1[0], xf[0], H); H = mac6(w1[1], xf[1], H);                     // (a)
+            dH = mac6(w2[0], df[0], dH); dH = mac6(w2[1], df[1], dH);                 // (b)
+            XS2(0);
+            Frag gf[2][3], hf[2][3];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 float gs[8], hs[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float hv = H[8 * kb + j] + bcol;
-                    gs[j] = hv > 0.f ? dH[8 * kb + j] : 0.f;
-                    hs[j] = fmaxf(hv, 0.f);
-                    t1 += gs[j];
+                for (int g = 0; g < 2; ++g) {                          // registers 4G .. 4G+3 <-> hidden 32c + 8G + 4h + (0..3)
+                    const float4 bb = *reinterpret_cast<const float4*>(sB1 + 32 * c + 8 * (2 * kb + g) + 4 * half);
+                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 8 * kb + 4 * g + i;
+                        const float hv = H[r] + bv[i];
+                        gs[4 * g + i] = hv > 0.f ? dH[r] : 0.f;
+                        hs[4 * g + i] = fmaxf(hv, 0.f);
+                        bs1v[r] += gs[4 * g + i];
+                    }
                 }
                 split8(gs, gf[kb]);
                 split8(hs, hf[kb]);
             }
-            bs1 += t1;
-            Frag xt[3];
+            XS2(1);
+            dx = mac6(w3[0], gf[0], dx); dx = mac6(w3[1], gf[1], dx);                 // (c)
+            XS2(2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dx[r];
+            // (d): dH' pieces through this wave's transpose image.  LDS operations of one wave execute in order; the empty asm
+            // statements only keep the COMPILER from moving reads above the writes they depend on.
+            store_pieces(Ti, col, half, gf);
+            asm volatile("" ::: "memory");
+            Frag at[3], bt[3];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) tr_frag(Xb + p * PB_IMG, lane, kb, xt[p]);
-                dW1 = mac6(xt, gf[kb], dW1);                            // dW1c[cin][hidden] += X^T dH2'
+                for (int p = 0; p < 3; ++p) { tr_frag<PB_ROW>(Xb + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
+                dW1 = mac6(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
             }
+            XS2(3);
+            asm volatile("" ::: "memory");
+            store_pieces(Ti, col, half, hf);                            // (e): H' pieces, same image
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) tr_frag(Db + p * PB_IMG, lane, kb, xt[p]);
-                dW2t = mac6(xt, hf[kb], dW2t);                          // dW2c^T[out][hidden] += dT^T H2'
+                for (int p = 0; p < 3; ++p) { tr_frag<PB_ROW>(Db + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
+                dW2t = mac6(at, bt, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
             }
+            asm volatile("" ::: "memory");
+            XS2(4);
         }
+        XS_ACC(2);
         if (tnext < ntiles) stage_store(buf ^ 1, nxv, nd0, nd1);
-        __syncthreads();                               // all 8 dX partials (and the next tile) are in LDS
-        {
-            float s0 = do0, s1 = do1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float* P = TbAll + j * PB_TB;
-                s0 += P[rv0 * 33 + col];
-                s1 += P[rv1 * 33 + col];
-            }
-            if (rok0) dX[(v0 + rv0) * 32 + col] = s0;
-            if (rok1) dX[(v0 + rv1) * 32 + col] = s1;
-        }
+        XS_ACC(3);
+        pv0 = v0; pdo0 = do0; pdo1 = do1;
     }
+    __syncthreads();
+    reduce_prev(buf ^ 1);
     // one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
     float* sl = slabs + (long)blockIdx.x * slab_floats;
@@ -350,8 +390,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         sl[(long)rw * 256 + 32 * c + col] = dW1[r];                                    // [cin][hidden]
         if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = dW2t[r];                // [hidden][out]
     }
-    const float b = bs1 + __shfl_xor(bs1, 32, 64);
-    if (half == 0) sl[8192 + 256 * (long)D + 32 * c + col] = b;
+    // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = bs1v[r];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+        if (col == 0) sl[8192 + 256 * (long)D + 32 * c + rowmap(r, half)] = v;
+    }
     // db2[out] = sum of the staged dT values: thread t always staged out (t % D) and ((t + 512) % D); fixed-order sum
     __syncthreads();
     float* R = TbAll;
@@ -363,6 +409,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         for (int j = tid; j < 1024; j += D) t += R[j];                                  // R[j] = column sum of staged element f = j
         sl[8192 + 256 * (long)D + 256 + tid] = t;
     }
+    XS_ACC(6);
+    XS_OUT;
+#ifdef PROBAV_STAMP2
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 5; ++k_) g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 1 + k_] = xs2[k_];
+#endif
 }
 
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
@@ -370,7 +421,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
                    hipStream_t s)
 {
     static bool once = false;
-    const size_t lds = (size_t)4 * PB_TILE + ((size_t)8 * PB_TB + 256) * sizeof(float);
+    const size_t lds = (size_t)4 * PB_TILE + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 3 * PT_IMG;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;

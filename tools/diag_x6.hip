@@ -36,5 +36,34 @@ int main()
         for (int k = 1; k < 7; ++k) printf(" %s %.1f%%", names[k], 100.0 * acc[k] / life);
         printf("\n");
     }
+    {   // fused pointwise backward
+        const long nvox = (long)B * 22 * 22 * 9;
+        const int D = 25;
+        float *xx, *dT, *dO, *dX, *w, *b1, *dW1, *dW2, *db1, *db2, *slabs;
+        hipMalloc(&xx, nvox * 32 * 4); hipMalloc(&dT, nvox * D * 4); hipMalloc(&dO, nvox * 32 * 4); hipMalloc(&dX, nvox * 32 * 4);
+        hipMalloc(&w, 3 * X6_PW_FRAG_WORDS * 4); hipMalloc(&b1, 256 * 4);
+        hipMalloc(&dW1, 8192 * 4); hipMalloc(&dW2, 256 * D * 4); hipMalloc(&db1, 256 * 4); hipMalloc(&db2, D * 4);
+        hipMalloc(&slabs, mfma_pw_backward_slab_floats(D) * 4);
+        hipMemcpy(xx, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dT, h.data(), nvox * D * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dO, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
+        hipMemset(w, 0x3c, 3 * X6_PW_FRAG_WORDS * 4); hipMemset(b1, 0, 256 * 4);
+        for (int it = 0; it < 3; ++it)
+            x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, D, 0);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+        const char* nm[8] = {"t0", "wait: tile staged", "compute", "stage store", "wait: partials", "dX reduce", "epilogue", "t_end"};
+        for (int wave = 0; wave < 8; wave += 3) {
+            double acc[8] = {0}; double life = 0;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned long long* s = &st[(b * 8 + wave) * 8];
+                for (int k = 1; k < 7; ++k) acc[k] += (double)s[k];
+                life += (double)(s[7] - s[0]);
+            }
+            printf("pw_bwd wave %d: life %.0f cyc/WG (%.0f per tile) |", wave, life / 256, life / 256 / 68.06);
+            for (int k = 1; k < 7; ++k) printf(" %s %.1f%%", nm[k], 100.0 * acc[k] / life);
+            printf("\n");
+        }
+    }
     return 0;
 }
