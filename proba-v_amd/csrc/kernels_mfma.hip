@@ -551,7 +551,7 @@ struct StripArgs {
 
 
 template <int CC, int KS>
-__device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds, const int (&base)[3], int tap0, int ntap,
+__device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds, int base0, int base1, int base2, int tap0, int ntap,
                                            const float4* __restrict__ wf, f32x16& acc, int ks)
 {
     // (CC == 32: the filter fragments are the two packed 16-channel chunks [chunk][tap][2][lane]; k-steps 0..7 come from
@@ -565,7 +565,8 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
     float acur[KS], anxt[KS];
     auto a_ptr = [&](int tap) -> const float* {
         const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;             // wave-uniform
-        const int b = dh == 0 ? base[0] : (dh == 1 ? base[1] : base[2]);
+        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);                  // (three scalars, not an array: an indexed
+                                                                                  //  array lands in scratch memory, one load per tap)
         return lds + b + (dw * a.Tp + dt) * CP;
     };
     auto b_load = [&](int tap, float4 (&dst)[KS4]) {
@@ -608,13 +609,14 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
 // floats past the voxel's channels (the next voxel's, finite) against zero filter pieces.
 // Three-stage software pipeline per tap: loads of tap i+1 | split of tap i+1's activations | MFMAs of tap i.
 template <int CC>
-__device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, const int (&base)[3], int tap0, int ntap,
+__device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, int base0, int base1, int base2, int tap0, int ntap,
                                               const uint4* __restrict__ wf, f32x16& acc)
 {
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     auto a_ptr = [&](int tap) -> const float* {
         const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;             // wave-uniform
-        const int b = dh == 0 ? base[0] : (dh == 1 ? base[1] : base[2]);
+        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);                  // (three scalars, not an array: an indexed
+                                                                                  //  array lands in scratch memory, one load per tap)
         return lds + b + (dw * a.Tp + dt) * CP;
     };
     float raw[2][8];
@@ -660,7 +662,8 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
     constexpr int V = (CC % 4 == 0) ? 4 : 1;        // floats per load when staging
     constexpr int CG = CC / V;
     const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                   // wave-uniform: keep tap arithmetic on the scalar unit
     const int tsel = wave & 3, grp = wave >> 2;     // tile of the round, tap group (0: taps 0..13, 1: taps 14..26)
     const int rowfloats = a.Wp * a.Tp * CP;
     float* part = lds + STRIP_SLOTS * rowfloats + 8; // [4 tiles][16 regs][64 lanes]
@@ -791,11 +794,11 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 vi = vi < NV ? vi : NV - 1;
                 const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
                 const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
-                int base[3];
-#pragma unroll
-                for (int dh = 0; dh < 3; ++dh) base[dh] = ((hrel + dh) % STRIP_SLOTS) * rowfloats + (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
-                if constexpr (X6) strip_taps_x6<CC>(a, lds, base, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc);
-                else strip_taps<CC, KS>(a, lds, base, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks);
+                const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
+                const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
+                          base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
+                if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc);
+                else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks);
                 if (grp == 1) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
