@@ -226,6 +226,65 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     out[i] = (float)t;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// backward-filter of the 2-D residual path (3x3x1 'valid' convolutions on [N, H, W, 1, C <= 9]: residConv1..3).  The generic
+// kernel above walks a few voxels per block with dependent global loads (latency-bound: 0.17 ms for 37 MFLOP).  Here one
+// workgroup takes half a patch: x rows and gated dy rows are staged in LDS once, thread (tap, ci, co) keeps ONE accumulator and
+// walks the half-patch's output voxels with two LDS reads (both broadcasts inside a (tap, ci) / co group) and one fma each.
+// One slab per workgroup, summed in fixed order by reduce_partials_kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void wgrad2d_small_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gate, float* __restrict__ partial,
+                                                            float* __restrict__ partial_b, int halves)
+{
+    extern __shared__ float lds2d[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int n = blockIdx.x / halves, part = blockIdx.x - n * halves;
+    const int r0 = part * g.Ho / halves, r1 = (part + 1) * g.Ho / halves;      // output rows of this workgroup
+    const int nrow_o = r1 - r0, nrow_i = nrow_o + 2;
+    float* xs = lds2d;                                       // [nrow_i][Wi][Cin]
+    float* ds = xs + nrow_i * g.Wi * g.Cin;                  // [nrow_o][Wo][Cout], already gated
+    const float* xsrc = x + ((long)n * g.Hi + r0) * g.Wi * g.Cin;
+    for (int i = tid; i < nrow_i * g.Wi * g.Cin; i += nthr) xs[i] = xsrc[i];
+    const long dbase = ((long)n * g.Ho + r0) * g.Wo * g.Cout;
+    for (int i = tid; i < nrow_o * g.Wo * g.Cout; i += nthr) {
+        float d = dy[dbase + i];
+        if (gate) d = gate[dbase + i] > 0.f ? d : 0.f;
+        ds[i] = d;
+    }
+    __syncthreads();
+    const int nout = 9 * g.Cin * g.Cout;
+    const long slab = (long)nout + g.Cout;
+    float* pp = partial + (long)blockIdx.x * nout;
+    if (tid < nout) {
+        const int co = tid % g.Cout, rest = tid / g.Cout, ci = rest % g.Cin, tap = rest / g.Cin;
+        const int a = tap / 3, b = tap - 3 * a;
+        const float* xp = xs + (a * g.Wi + b) * g.Cin + ci;
+        const float* dp = ds + co;
+        float acc = 0.f;
+        for (int h = 0; h < nrow_o; ++h)
+            for (int w = 0; w < g.Wo; ++w) acc = fmaf(xp[(h * g.Wi + w) * g.Cin], dp[(h * g.Wo + w) * g.Cout], acc);
+        pp[tid] = acc;                                       // == [(tap * Cin + ci) * Cout + co]
+    } else if (tid < nout + g.Cout) {
+        const int co = tid - nout;
+        float acc = 0.f;
+        for (int i = 0; i < nrow_o * g.Wo; ++i) acc += ds[i * g.Cout + co];
+        partial_b[(long)blockIdx.x * g.Cout + co] = acc;
+    }
+    (void)slab;
+}
+
+static bool small2d(const ConvGeom& g, int& halves, size_t& lds)
+{
+    if (g.kh != 3 || g.kw != 3 || g.kt != 1 || g.Ti != 1 || g.To != 1 || g.ph || g.pw || g.pt || g.reflect_hw) return false;
+    if (9 * g.Cin * g.Cout + g.Cout > 1024 || g.Ho < 2) return false;
+    halves = 2;
+    const int nrow_o = (g.Ho + 1) / 2 + 1;
+    lds = ((size_t)(nrow_o + 2) * g.Wi * g.Cin + (size_t)nrow_o * g.Wo * g.Cout) * sizeof(float);
+    return lds <= 64 * 1024;
+}
+
 static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& chunks, long& vpc)
 {
     const bool k3d = (g.kh == 3 && g.kw == 3 && g.kt == 3);
@@ -249,6 +308,8 @@ size_t wgrad_partial_floats(const ConvGeom& g)
     int ci_per, gy, gz, chunks; long vpc;
     wgrad_plan(g, ci_per, gy, gz, chunks, vpc);
     const size_t K = (size_t)g.kh * g.kw * g.kt * g.Cin;
+    int halves; size_t lds;
+    if (small2d(g, halves, lds) && g.N * halves > chunks) chunks = g.N * halves;
     return (size_t)chunks * (K * g.Cout + g.Cout);
 }
 
@@ -258,6 +319,21 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     int ci_per, gy, gz, chunks; long vpc;
     wgrad_plan(g, ci_per, gy, gz, chunks, vpc);
     const long K = (long)g.kh * g.kw * g.kt * g.Cin;
+    {
+        int halves; size_t lds;
+        if (small2d(g, halves, lds)) {
+            const int slabs = g.N * halves;
+            float* pb = partial + (size_t)slabs * K * g.Cout;
+            const int nthr = (int)((9 * g.Cin * g.Cout + g.Cout + 63) / 64 * 64);
+            hipLaunchKernelGGL(wgrad2d_small_kernel, dim3((unsigned)slabs), dim3((unsigned)nthr), lds, s, g, x, dy, gate, partial, pb, halves);
+            int rc = check_launch("wgrad2d_small");
+            if (rc) return rc;
+            const long nw = K * g.Cout;
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, s, partial, dw, nw, slabs);
+            if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), dim3(256), 0, s, pb, db, (long)g.Cout, slabs);
+            return check_launch("reduce_partials");
+        }
+    }
     float* partial_b = partial + (size_t)chunks * K * g.Cout;
     dim3 grid((unsigned)chunks, (unsigned)gy, (unsigned)gz), block(256);
     const bool k3d = (g.kh == 3 && g.kw == 3 && g.kt == 3);

@@ -550,9 +550,9 @@ struct StripArgs {
 };
 
 
-template <int CC, int KS>
+template <int CC, int KS, typename Mid>
 __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds, int base0, int base1, int base2, int tap0, int ntap,
-                                           const float4* __restrict__ wf, f32x16& acc, int ks)
+                                           const float4* __restrict__ wf, f32x16& acc, int ks, Mid mid)
 {
     // (CC == 32: the filter fragments are the two packed 16-channel chunks [chunk][tap][2][lane]; k-steps 0..7 come from
     //  chunk 0, 8..15 from chunk 1)
@@ -591,6 +591,8 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
         b_load(tn, bnxt);
 #pragma unroll
         for (int s = 0; s < KS; ++s) anxt[s] = pa[2 * s];
+        if (i == 1) mid();      // other global requests of the round go HERE: vmcnt retires in order, so behind the filters of tap 2
+                                // they get two taps of slack; in front of the loop they made the first tap wait for HBM
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -608,9 +610,9 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
 // pre-split from L2 ([tap][kb][piece][lane] x 16 B, X6_CONV packing).  For CC = 25 the second k-block reads seven
 // floats past the voxel's channels (the next voxel's, finite) against zero filter pieces.
 // Three-stage software pipeline per tap: loads of tap i+1 | split of tap i+1's activations | MFMAs of tap i.
-template <int CC>
+template <int CC, typename Mid>
 __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, int base0, int base1, int base2, int tap0, int ntap,
-                                              const uint4* __restrict__ wf, f32x16& acc)
+                                              const uint4* __restrict__ wf, f32x16& acc, Mid mid)
 {
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     auto a_ptr = [&](int tap) -> const float* {
@@ -638,6 +640,7 @@ __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* l
     for (int i = 0; i < ntap; ++i) {
         const int tn = (i + 1 < ntap) ? tap0 + i + 1 : tap0 + i;
         loads(tn, wnxt);
+        if (i == 1) mid();                       // see strip_taps
         __builtin_amdgcn_sched_barrier(0);
         acc = mac6(acur[0], wcur[0], acc);
         acc = mac6(acur[1], wcur[1], acc);
@@ -744,6 +747,7 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
         }
     };
 
+    XS_DECL;
     for (int pass = 0; pass < nchunk; ++pass) {
         const int c0 = pass * CC;
         const int cv = g.Cin - c0 < CC ? g.Cin - c0 : CC, ks = (cv + 1) >> 1;
@@ -763,6 +767,19 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
         }
         int hiq = 3;
         __syncthreads();
+        XS_ACC(1);
+        float skn[16];
+        auto load_skip = [&](int tl) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int vi = tl * 32 + rowmap(i, half);
+                const int o = (tl < NTL && vi < NV && col < g.Cout) ? vi * g.Cout + col : 0;
+                skn[i] = sbase[o];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) skn[i] = 0.f;
+        if (grp == 0 && sbase) load_skip(tsel);
 
         for (int r = 0; r < nrounds; ++r) {
             // does round r+1 need a row that is not resident yet?  (at most one new row per round: 128 <= voxels per row)
@@ -771,24 +788,18 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
             const bool do_load = r + 1 < nrounds && need_next > hiq;                 // wave-uniform
             constexpr bool ASYNC = STRIP_SLOTS >= 5;                                 // a spare slot lets the load overlap the MFMAs
             stage_t rv[RV];
-            if (ASYNC && do_load) stage_load(hiq + 1, c0, rv);                       // in flight during this round's MFMAs
+            auto mid = [&]() { if (ASYNC && do_load) stage_load(hiq + 1, c0, rv); };   // requested inside the tap loop
 
             const int tile = 4 * r + tsel;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            float sk[16];                                      // skip / previous-pass values of this wave's output rows,
-#pragma unroll                                                 // requested now so that their latency hides under the taps
-            for (int i = 0; i < 16; ++i) sk[i] = 0.f;
-            if (grp == 0 && tile < NTL && (sbase || pass > 0)) {
-                const float* src = (pass == nchunk - 1 && sbase && pass == 0) ? sbase : (pass > 0 ? (const float*)ybase : sbase);
+            // skip-connection values of this wave's output rows: requested a whole round ahead, AFTER the round's last filter
+            // load -- vmcnt retires in order, so a request placed in front of the tap loop made the first tap wait for HBM
+            // (single-pass layers only: strip_plan() never yields nchunk > 1)
+            float sk[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int vi = tile * 32 + rowmap(i, half);
-                    const int o = (vi < NV && col < g.Cout) ? vi * g.Cout + col : 0;
-                    sk[i] = src[o];
-                }
-            }
+            for (int i = 0; i < 16; ++i) sk[i] = skn[i];
             if (tile < NTL) {
                 int vi = tile * 32 + col;
                 vi = vi < NV ? vi : NV - 1;
@@ -797,15 +808,19 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
                 const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
                           base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
-                if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc);
-                else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks);
+                if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
+                else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks, mid);
                 if (grp == 1) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
                 }
             }
+            if (grp == 0 && sbase && r + 1 < nrounds) load_skip(4 * (r + 1) + tsel);
+            XS_ACC(2);
             if (ASYNC && do_load) { stage_store(hiq + 1, c0, rv); ++hiq; }
+            XS_ACC(3);
             __syncthreads();                                   // partials (+ the new row) are in LDS
+            XS_ACC(4);
             float pv[16];
             if (grp == 0 && tile < NTL) {
 #pragma unroll
@@ -816,7 +831,9 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 stage_store(hiq + 1, c0, rv);
                 ++hiq;
             }
+            XS_ACC(3);
             __syncthreads();                                   // partial buffer may be rewritten by the next round
+            XS_ACC(4);
             if (grp == 0 && tile < NTL) {
                 const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
                 int oo[16];
@@ -866,8 +883,10 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                     for (int i = 0; i < 16; ++i) if (oo[i] >= 0) ybase[oo[i]] = ov[i];
                 }
             }
+            XS_ACC(5);
         }
     }
+    XS_OUT;
 }
 
 struct StripPlan { bool ok; int CC, KS; size_t lds_bytes; int grid; StripArgs a; };

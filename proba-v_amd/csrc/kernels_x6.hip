@@ -19,21 +19,6 @@
 
 namespace probav {
 
-// per-wave phase stamps for tools/diag_x6.hip (diagnostic build only: -DPROBAV_STAMP; g_stamps lives in kernels_mfma.hip)
-#ifdef PROBAV_STAMP2
-#define XS2(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs2[k] += t_ - xs2t; xs2t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define XS2(k) do { } while (0)
-#endif
-#ifdef PROBAV_STAMP
-#define XS_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[8] = {xs_t, 0, 0, 0, 0, 0, 0, 0}
-#define XS_ACC(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[k] += t_ - xs_t; xs_t = t_; } while (0)
-#define XS_OUT do { xs_acc[7] = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 8; ++k_) g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k_] = xs_acc[k_]; } while (0)
-#else
-#define XS_DECL do { } while (0)
-#define XS_ACC(k) do { } while (0)
-#define XS_OUT do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // fused expConv + ReLU + decConv forward (1x1x1, 32 -> 256 -> D <= 32); one 32-voxel tile per wave and round.

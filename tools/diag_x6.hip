@@ -36,6 +36,26 @@ int main()
         for (int k = 1; k < 7; ++k) printf(" %s %.1f%%", names[k], 100.0 * acc[k] / life);
         printf("\n");
     }
+    {   // x6 strip convolution, forward 25 -> 32
+        float *y, *wf, *bias;
+        hipMalloc(&y, nout * 4); hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMalloc(&bias, 32 * 4);
+        hipMemset(wf, 0x3c, X6_CONV_FRAG_WORDS * 4); hipMemset(bias, 0, 32 * 4);
+        for (int it = 0; it < 3; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, dy, y, 0);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+        const char* nm[8] = {"t0", "prologue", "taps (+skip loads)", "stage store / exchange reads", "barrier waits", "epilogue", "-", "t_end"};
+        for (int wave = 0; wave < 8; wave += 2) {
+            double acc[8] = {0}; double life = 0;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned long long* s = &st[(b * 8 + wave) * 8];
+                for (int k = 1; k < 7; ++k) acc[k] += (double)s[k];
+                life += (double)(s[7] - s[0]);
+            }
+            printf("strip x6 wave %d: life %.0f cyc/WG |", wave, life / 256);
+            for (int k = 1; k < 6; ++k) printf(" %s %.1f%%", nm[k], 100.0 * acc[k] / life);
+            printf("\n");
+        }
+    }
     {   // fused pointwise backward
         const long nvox = (long)B * 22 * 22 * 9;
         const int D = 25;
