@@ -21,6 +21,7 @@
 #include "kernels_mfma.h"
 #include "x6_device.h"
 #include <type_traits>
+#include <cstdint>
 
 namespace probav {
 
@@ -1148,8 +1149,58 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
     return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);
 }
 
+// dw and db in ONE launch.  Filter blocks: 16 float4 columns x 16 interleaved slab groups (each thread: slabs/16 independent
+// 16-byte loads); the last block reduces the bias slabs (32 scalar columns x 8 groups; db need not be 16-byte aligned).  fp64
+// accumulation, fixed order => bitwise reproducible.
+__global__ __launch_bounds__(256) void reduce_slabs4_kernel(const float4* __restrict__ pw, float4* __restrict__ ow, long nw4, int nbw,
+                                                           const float* __restrict__ pb, float* __restrict__ ob, int nb, int slabs)
+{
+    __shared__ double red[16][16][4];
+    if ((int)blockIdx.x >= nbw) {
+        const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double a = 0.0;
+        if (e < nb)
+            for (int c = part; c < slabs; c += 8) a += (double)pb[(long)c * nb + e];
+        double* r = &red[0][0][0];
+        r[part * 32 + e] = a;
+        __syncthreads();
+        if (part != 0 || e >= nb) return;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += r[k * 32 + e];
+        ob[e] = (float)t;
+        return;
+    }
+    const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + e;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (i < nw4) {
+#pragma unroll 4
+        for (int c = part; c < slabs; c += 16) {
+            const float4 v = pw[(long)c * nw4 + i];
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+    }
+    red[part][e][0] = a0; red[part][e][1] = a1; red[part][e][2] = a2; red[part][e][3] = a3;
+    __syncthreads();
+    if (part != 0 || i >= nw4) return;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] += red[k][e][q];
+    ow[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+
 int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, float* db, long nw, int Cout, int slabs, hipStream_t s)
 {
+    const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0;
+    if ((nw & 3) == 0 && Cout <= 32 && al) {
+        const int nbw = (int)((nw / 4 + 15) / 16);
+        hipLaunchKernelGGL(reduce_slabs4_kernel, dim3((unsigned)(nbw + (db ? 1 : 0))), dim3(256), 0, s, (const float4*)partial, (float4*)dw, nw / 4, nbw,
+                           partial_b, db, Cout, slabs);
+        return check_launch("reduce_slabs4");
+    }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, slabs);
     if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)Cout, slabs);
     return check_launch("reduce_slabs");
