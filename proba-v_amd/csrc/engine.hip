@@ -214,9 +214,12 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
     const float* wfrag = wf.f32;
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
-    const bool x6 = e->impl >= 3 && wf.x6 && mfma_conv_strip_supported(g);
+    const bool x6s = e->impl >= 3 && wf.x6 && mfma_conv_strip_supported(g);
+    const bool x6r = e->impl >= 3 && wf.x6 && !x6s && x6_conv_rowtile_supported(g);
+    const bool x6 = x6s || x6r;
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? (x6 ? CLS_CONV3_BWD_DATA_X6 : CLS_CONV3_BWD_DATA) : (x6 ? CLS_CONV3_FWD_X6 : CLS_CONV3_FWD)), geom_macs(g), s);
-    if (x6) return x6_conv_strip_forward(g, x, gate, wf.x6, bias, skip, y, s);
+    if (x6s) return x6_conv_strip_forward(g, x, gate, wf.x6, bias, skip, y, s);
+    if (x6r) return x6_conv_rowtile_forward(g, x, gate, wf.x6, bias, skip, y, s);
     if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, s);
     if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, s);
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
@@ -614,10 +617,12 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
     if (impl < 0 || impl > 3) { set_error("probav_conv3d_forward: impl must be 0..3", hipSuccess); return PROBAV_EINVAL; }
     if (impl >= 1) {
-        const bool okk = impl >= 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g);
+        const bool x6row = impl == 3 && !mfma_conv_strip_supported(g) && x6_conv_rowtile_supported(g);
+        const bool okk = x6row || (impl >= 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g));
         if (!okk) { set_error("probav_conv3d_forward: geometry not supported by this MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
         int rc = op_pack(g, w, (hipStream_t)stream, impl == 3);
         if (rc) return rc;
+        if (x6row) return x6_conv_rowtile_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
         if (impl == 3) return x6_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
         if (impl == 2) return mfma_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
         return mfma_conv_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);

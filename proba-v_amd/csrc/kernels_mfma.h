@@ -29,7 +29,11 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
 bool mfma_conv_strip_supported(const ConvGeom& g);
 int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
                             const float* skip, float* y, hipStream_t s);
-// the same kernel with the x6 tap loop; wfrag6 = PACK_X6_CONV fragments
+// row-tile kernel with the x6 tap loop (32-channel inputs: reducers, upscale; any pads / reflect); wfrag6 = PACK_X6_CONV fragments
+bool x6_conv_rowtile_supported(const ConvGeom& g);
+int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
+                            const float* skip, float* y, hipStream_t s);
+// the strip kernel with the x6 tap loop; wfrag6 = PACK_X6_CONV fragments
 int x6_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
                           const float* skip, float* y, hipStream_t s);
 

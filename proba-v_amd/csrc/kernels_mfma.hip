@@ -366,7 +366,42 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
     }
 }
 
-template <int CC, int KS>
+// x6 form of conv_taps for 16-channel chunks (CP = 17): one k-block per tap and chunk.  The activation operand is read as fp32
+// from the halo tile (channels 8*half + j of the lane's voxel) and cut into bf16 pieces in registers; filters arrive pre-cut
+// ([tap][chunk][piece][lane] x 16 B, PACK_X6_CONV).  Two M tiles share every filter fragment.
+template <int MT>
+__device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
+                                             int chunk, f32x16& acc0, f32x16& acc1)
+{
+    constexpr int CP = 17;
+    float r0[8], r1[8];
+    Frag wcur[3], wnxt[3], a0[3], a1[3];
+    auto loads = [&](int tap, Frag (&w)[3]) {
+        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
+        const int toff = ((dh * a.Wp + dw) * a.Tp + dt) * CP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r0[j] = ldsA0[toff + j]; r1[j] = MT == 2 ? ldsA1[toff + j] : 0.f; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p].u = wf[((tap * 2 + chunk) * 3 + p) * 64];
+    };
+    loads(0, wcur);
+    split8(r0, a0);
+    if (MT == 2) split8(r1, a1);
+#pragma unroll 1
+    for (int tap = 0; tap < 27; ++tap) {
+        loads(tap + 1 < 27 ? tap + 1 : tap, wnxt);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mac6(a0, wcur, acc0);
+        if (MT == 2) acc1 = mac6(a1, wcur, acc1);
+        split8(r0, a0);
+        if (MT == 2) split8(r1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wcur[p] = wnxt[p];
+    }
+}
+
+template <int CC, int KS, bool X6>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                            const float4* __restrict__ wfrag, const float* __restrict__ bias,
                                                            const float* __restrict__ skip, float* __restrict__ y)
@@ -392,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         int vi0 = t0 * 32 + col, vi1 = t1 * 32 + col;
         vi0 = vi0 < nv ? vi0 : nv - 1; vi1 = vi1 < nv ? vi1 : nv - 1;
-        const float* ldsA0 = lds + tile_voxel_off(a, vi0, CP) + half;
-        const float* ldsA1 = lds + tile_voxel_off(a, vi1, CP) + half;
+        const float* ldsA0 = lds + tile_voxel_off(a, vi0, CP) + (X6 ? 8 * half : half);
+        const float* ldsA1 = lds + tile_voxel_off(a, vi1, CP) + (X6 ? 8 * half : half);
         for (int chunk = 0; chunk < nchunk; ++chunk) {
             if (pass == 0 || nchunk > 1) {
                 if (pass > 0 || chunk > 0) __syncthreads();
@@ -401,9 +436,15 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
                 STAMP(1 + 2 * chunk);
                 __syncthreads();
             }
-            const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
-            if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
-            else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1);
+            if constexpr (X6) {
+                const uint4* wf6 = reinterpret_cast<const uint4*>(wfrag) + lane;
+                if (v1) conv_taps_x6<2>(a, ldsA0, ldsA1, wf6, chunk, acc0, acc1);
+                else if (v0) conv_taps_x6<1>(a, ldsA0, ldsA1, wf6, chunk, acc0, acc1);
+            } else {
+                const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
+                if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
+                else if (v0) conv_taps<CC, KS, 1>(a, ldsA0, ldsA1, wf, acc0, acc1);
+            }
             STAMP(2 + 2 * chunk);
         }
         // epilogue: D row = output voxel, column = output channel.  All loads (bias, skip) and the arithmetic happen in
@@ -520,11 +561,29 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
     if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13>); allow_big_lds(conv3_mfma_kernel<16, 8>); allow_big_lds(conv3_mfma_kernel<1, 1>); once = true; }
-    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13, false>); allow_big_lds(conv3_mfma_kernel<16, 8, false>); allow_big_lds(conv3_mfma_kernel<1, 1, false>); once = true; }
+    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1, false>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13, false>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, false>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
     return check_launch("conv3_mfma");
+}
+
+// row-tile kernel with the x6 tap loop: 32-channel inputs (two 16-channel chunks), any pads / reflect (reducers, upscale)
+bool x6_conv_rowtile_supported(const ConvGeom& g)
+{
+    const ConvPlan p = conv_plan(g, false);
+    return p.ok && p.CC == 16 && g.Cin == 32;
+}
+int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
+                            const float* skip, float* y, hipStream_t s)
+{
+    const ConvPlan p = conv_plan(g, false);
+    if (!p.ok || p.CC != 16 || g.Cin != 32) { set_error("x6_conv_rowtile_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
+    static bool once = false;
+    if (!once) { allow_big_lds(conv3_mfma_kernel<16, 8, true>); once = true; }
+    hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, true>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y);
+    return check_launch("conv3_mfma_x6");
 }
 
 // ---------------------------------------------------------------------------------------------------
