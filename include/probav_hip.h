@@ -57,7 +57,10 @@ int probav_num_layers(const probav_engine* e);
 /* name, offsets (in floats) and kernel shape of layer i; shape is [kh,kw,kt,Cin,Cout]               */
 int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_off, int64_t* v_off,
                       int64_t* b_off, int32_t shape[5]);
-/* 0 = generic direct kernels everywhere, 1 = MFMA row-tile kernels, 2 = MFMA + strip convolution (default) */
+/* kernel family: 0 = generic direct (VALU) kernels everywhere, 1 = fp32-MFMA row-tile kernels, 2 = fp32 MFMA + strip convolution,
+ * 3 (default) = 2 with the x6 kernels where they exist: fp32 in / fp32 out / fp32 accumulate, every fp32 product evaluated as six
+ * exact bf16-piece products on the bf16 MFMA pipe (same tolerances as 2 in tests/test_gpu_parity.py).  Results of one family are
+ * bitwise reproducible run to run; different families differ by fp32 rounding.                                                      */
 int probav_engine_set_impl(probav_engine* e, int impl);
 size_t probav_workspace_bytes(const probav_engine* e, int batch, int training);
 /* per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
@@ -103,7 +106,7 @@ int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi,
 
 /* ---- single operators (what the engine is made of; exported for parity tests) ------------------- */
 /* geometry: int32[17] = N, Hi,Wi,Ti,Cin, Ho,Wo,To,Cout, kh,kw,kt, ph,pw,pt, reflect_hw, relu        */
-/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA row-tile, 2 = MFMA strip  */
+/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA row-tile, 2 = MFMA strip, 3 = x6 (strip or row-tile) */
 int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w,
                           const float* bias, const float* skip, float* y, int impl, void* stream);
 size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl);
