@@ -303,8 +303,8 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             e->jobs.push_back(J);
             if ((cin == 25 || cin == 32) && cout <= 32) {           // strip-kernel shapes: also the x6 fragments
                 PackJob X; memset(&X, 0, sizeof(X));
-                X.type = PACK_X6_CONV; X.src_is_T = dir; X.src_off = r.wn.w_off; X.dst_off = e->wpack_count;
-                X.count = X6_CONV_FRAG_WORDS; X.Cin = cin; X.Cout = cout; X.taps = 27;
+                X.type = cin == 25 ? PACK_X6_CONVK : PACK_X6_CONV; X.src_is_T = dir; X.src_off = r.wn.w_off; X.dst_off = e->wpack_count;
+                X.count = cin == 25 ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; X.Cin = cin; X.Cout = cout; X.taps = 27;
                 (dir ? e->pkBwd6 : e->pkFwd6)[li] = X.dst_off;
                 e->wpack_count += X.count;
                 e->jobs.push_back(X);
@@ -601,7 +601,7 @@ static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, bool x6 = f
     }
     if (n * sizeof(float) > ((size_t)4 << 20)) { set_error("probav_conv3d_forward: fragment scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     PackJob J; memset(&J, 0, sizeof(J));
-    if (x6) { J.type = PACK_X6_CONV; J.count = X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27; }
+    if (x6) { J.type = g.Cin == 25 ? PACK_X6_CONVK : PACK_X6_CONV; J.count = g.Cin == 25 ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27; }
     else mfma_conv_pack_job(J, g.Cin, g.Cout);
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(g_op_job, &J, sizeof(J), hipMemcpyHostToDevice);

@@ -6,9 +6,10 @@ namespace probav {
 
 enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4,
        // pre-split bf16 operand fragments of the x6 kernels (three truncation pieces per value, 16 B per lane and fragment)
-       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14 };
+       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14, PACK_X6_CONVK = 15 };
 constexpr long X6_PW_FRAG_WORDS = 8 * 2 * 3 * 64 * 4;      // [8 chunks][2 k-blocks][3 pieces][64 lanes] x 16 B
 constexpr long X6_CONV_FRAG_WORDS = 27 * 2 * 3 * 64 * 4;   // [27 taps][2 k-blocks][3 pieces][64 lanes] x 16 B
+constexpr long X6_CONVK_FRAG_WORDS = 9 * 5 * 3 * 64 * 4;   // Cin = 25, K = (dt, ci) concatenated: [9 (dh,dw)][5 k-blocks][3 pieces][64 lanes] x 16 B
 
 // One packing job: effective weights (weff / weffT, layout [tap][Cin][Cout]) -> MFMA operand fragments.
 struct PackJob {

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
         long q = i >> 8;                                   // float4 index (per lane)
         if (J.type >= PACK_X6_PW_W1) {
             // x6 fragments: this dword holds k-slots j = 2u, 2u+1 of lane `lane` in fragment q = (outer * 2 + kb) * 3 + piece
-            const int piece = (int)(q % 3), kb = (int)((q / 3) & 1), outer = (int)(q / 6);
+            int piece = (int)(q % 3), kb = (int)((q / 3) & 1), outer = (int)(q / 6);
+            if (J.type == PACK_X6_CONVK) { kb = (int)((q / 3) % 5); outer = (int)(q / 15); }       // fragment q = (group * 5 + kb) * 3 + piece
             float v2[2] = {0.f, 0.f};
             for (int e = 0; e < 2; ++e) {
                 const int j = 2 * u + e, kn = 16 * kb + 8 * half + j, kp = rowmap(8 * kb + j, half);   // natural / accumulator-order k
@@ -88,6 +89,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
                     if (kn < J.Cout) v2[e] = src[(long)(32 * outer + col) * J.Cout + kn];
                 } else if (J.type == PACK_X6_PW_W1C) {  // [row = cin col][k-slot = hidden 32c + kp]             W1 [cin 32][hidden 256]
                     v2[e] = src[(long)col * J.Cout + 32 * outer + kp];
+                } else if (J.type == PACK_X6_CONVK) {   // [k = dt * Cin + ci][col = cout] of (dh, dw) group `outer`: taps 3*outer + dt
+                    if (kn < 3 * J.Cin && col < J.Cout) v2[e] = src[((long)outer * 3 * J.Cin + kn) * J.Cout + col];
                 } else {                                // PACK_X6_CONV: [k = cin kn][col = cout] of tap `outer`
                     if (kn < J.Cin && col < J.Cout) v2[e] = src[((long)outer * J.Cin + kn) * J.Cout + col];
                 }
@@ -714,6 +717,55 @@ __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* l
     }
 }
 
+// x6 tap loop for Cin = 25 with the three dt taps of a (dh, dw) group CONCATENATED along K: with an unpadded channel stride of
+// 25 the voxels (w, t), (w, t+1), (w, t+2) are 75 contiguous floats, i.e. 5 k-blocks of 16 instead of 3 taps x 2 k-blocks of a
+// 25 -> 32 padded K (-17 % MFMAs and cuts).  k-blocks kbi = group * 5 + kb, kbi in [kb0, kb0 + nkb); filters: PACK_X6_CONVK.
+template <typename Mid>
+__device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* lds, int base0, int base1, int base2, int kb0, int nkb,
+                                               const uint4* __restrict__ wf, f32x16& acc, Mid mid)
+{
+    auto a_ptr = [&](int kbi) -> const float* {
+        const int grp = kbi / 5, kb = kbi - 5 * grp, dh = grp / 3, dw = grp - 3 * dh;      // wave-uniform
+        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);
+        return lds + b + dw * a.Tp * 25 + 16 * kb;
+    };
+    // A k-block is only 6 MFMAs (192 cycles): one block of lead covers neither the L2 latency of the filters nor the LDS latency
+    // of the activations.  Both are requested TWO blocks ahead; three filter buffers and two activation buffers rotate through a
+    // loop unrolled by six, so that no register copy sits between a load and its use.
+    float R[2][8];
+    Frag W[3][3], acur[3];
+    const int kend = kb0 + nkb - 1;
+    auto wload = [&](int kbi, Frag (&w)[3]) {
+        const int k = kbi < kend ? kbi : kend;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p].u = wf[(k * 3 + p) * 64];
+    };
+    auto aload = [&](int kbi, float (&r)[8]) {
+        const float* pa = a_ptr(kbi < kend ? kbi : kend);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = pa[j];
+    };
+    wload(kb0, W[0]);
+    wload(kb0 + 1, W[1]);
+    aload(kb0, R[0]);
+    aload(kb0 + 1, R[1]);
+    split8(R[0], acur);
+#pragma unroll 1
+    for (int i0 = 0; i0 < nkb; i0 += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int i = i0 + u;
+            wload(kb0 + i + 2, W[(u + 2) % 3]);
+            aload(kb0 + i + 2, R[u % 2]);                                // R[u % 2] was cut in the previous step
+            if (i == 2) mid();
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nkb) acc = mac6(acur, W[u % 3], acc);                 // wave-uniform
+            split8(R[(u + 1) % 2], acur);                                 // block i + 1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int CC, int KS, bool GATE, int STRIP_SLOTS, bool X6>
 __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                             const float4* __restrict__ wfrag, const float* __restrict__ bias,
@@ -868,7 +920,8 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
                 const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
                           base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
-                if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
+                if constexpr (X6 && CC == 25) strip_taps_x6k(a, lds, base0, base1, base2, grp == 0 ? 0 : 23, grp == 0 ? 23 : 22, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
+                else if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
                 else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks, mid);
                 if (grp == 1) {
 #pragma unroll
