@@ -3,10 +3,10 @@
 // Every fp32 operand x is cut into three bf16 pieces by truncation,
 //     x0 = x & 0xffff0000,  x1 = (x - x0) & 0xffff0000,  x2 = x - x0 - x1        (x == x0 + x1 + x2 EXACTLY: 8+8+8 bits)
 // and a product a*b is evaluated as the six largest of the nine piece products
-//     a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0)            (dropped: a1b2 + a2b1 + a2b2 <= 3 * 2^-24 |ab|)
+//     a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0)            (dropped: a1b2 + a2b1 + a2b2 < 2^-21 |ab|, ~2^-23 |ab| on average)
 // each of them EXACT in fp32 (8 x 8 significant bits) and summed in the MFMA's fp32 accumulator.  The error of one
-// product is therefore of the order of the fp32 rounding error of that product, and the result is fp32-grade; the
-// parity tests hold these kernels to the same tolerances as the native fp32-MFMA kernels.
+// product is therefore a few fp32 ulps at most (an fp32 fma rounds to 2^-24) and the result is fp32-grade; the parity tests
+// hold these kernels to the same tolerances as the native fp32-MFMA kernels (tests/test_x6_arith.py restates the arithmetic).
 // v_mfma_f32_32x32x16_bf16 retires 32*32*16 MACs in 32 cycles, v_mfma_f32_32x32x2_f32 32*32*2 in 64: six bf16
 // instructions replace sixteen fp32 ones, 2.67x less matrix-pipe time.
 //
