@@ -33,6 +33,10 @@ CLASSES = ["weight_norm", "small", "conv3x3x3_fwd", "conv3x3x3_bwd_data", "conv3
 PEAK_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PF)
 X6_PRODUCTS = 6                    # bf16 MFMA products issued per fp32 product by the x6 kernels
+PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
+ALGO_MB_PER_PATCH = 402.414        # layer-boundary byte model, fwd + bwd (un-fused)
+PLAN_MB_PER_PATCH = 81.0           # bytes the fused plan moves (256-channel tensor never reaches HBM)
+HBM_PROFILE = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
 ALGO_GFLOP_PER_PATCH = 12.436      # SURVEY.md §8d / BASELINE.md §2: fwd + bwd, p16t9c85r12
 
 
@@ -207,6 +211,21 @@ def main():
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",
                                   "note": "derived from the reference's TensorBoard logs (BASELINE.md), not a published figure"},
         }
+        if T == 9:
+            # the HBM view SURVEY.md §8d asks for next to the compute roofline: the un-fused layer-boundary byte model, the bytes the
+            # fused plan declares, and (when profiles/ holds the PMC passes of this workload) the bytes rocprofv3 counted
+            gbps = lambda mb: value * mb / 1e3
+            hv = {"peak_GBps": PEAK_HBM_GBPS,
+                  "layer_boundary_model": {"MB_per_patch": ALGO_MB_PER_PATCH, "GBps": round(gbps(ALGO_MB_PER_PATCH), 1),
+                                           "frac": round(gbps(ALGO_MB_PER_PATCH) / PEAK_HBM_GBPS, 4)},
+                  "fused_plan": {"MB_per_patch": PLAN_MB_PER_PATCH, "GBps": round(gbps(PLAN_MB_PER_PATCH), 1),
+                                 "frac": round(gbps(PLAN_MB_PER_PATCH) / PEAK_HBM_GBPS, 4)}}
+            if os.path.exists(HBM_PROFILE) and B == 128 and args.impl == 3:
+                with open(HBM_PROFILE) as fh:
+                    bps = json.load(fh)["bytes_per_step"]
+                hv["counted_by_rocprof"] = {"GB_per_step": round(bps / 1e9, 2), "GBps": round(bps / 1e9 / (dt / args.steps) / world, 1) if world == 1 else None,
+                                            "source": os.path.relpath(HBM_PROFILE, ROOT)}
+            out["hbm_view"] = hv
         if fp32_leg is not None:
             out["fp32_mfma_path"] = fp32_leg
         if full is not None:
@@ -230,6 +249,14 @@ def main():
                                            "the dense bf16 MFMA peak (%.0f TFLOP/s) / %d" % (X6_PRODUCTS, PEAK_BF16_TFLOPS, X6_PRODUCTS) if x6 else
                                            "; peak = dense fp32 MFMA")}
             out["kernel_classes"] = per
+            if os.path.exists(HBM_PROFILE) and T == 9 and B == 128 and args.impl == 3:
+                with open(HBM_PROFILE) as fh:
+                    hp = json.load(fh)
+                if dom in hp.get("per_class", {}):
+                    out["roofline"]["traffic"] = hp["per_class"][dom]["bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = ("HBM bytes per launch of %s from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                       "passes of this command; FETCH_SIZE doubled per the gfx950 note), not collected in this run"
+                                                       % (hp["per_class"][dom]["kernel"], os.path.relpath(HBM_PROFILE, ROOT)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
