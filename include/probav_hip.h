@@ -98,7 +98,9 @@ int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float
 /* replaces optimizer.apply_gradients with Keras Nadam                   models/trainClass.py:132, train.py:79-81
  * in place on the flat parameter buffer; m, v = first / second moment slots (n floats each).  The caller supplies the
  * step-dependent scalars of SURVEY.md A.5 (computed in double): c_g = (1-mu_t)/(1-Pi_t), c_m = mu_{t+1}/(1-Pi_t*mu_{t+1}),
- * c_v = 1/(1-beta2^t).                                                                                               */
+ * c_v = 1/(1-beta2^t).  The update is  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  theta -= lr (c_g g + c_m m) / (sqrt(c_v v) + eps),
+ * which also is Keras Adam (c_g = 0, c_m = sqrt(1-b2^t)/(1-b1^t), c_v = 1) and plain SGD (c_g = 1, c_m = 0, c_v = 0, eps = 1): the
+ * three optimizers of train.py:77-83 are one fused launch.                                                           */
 int probav_nadam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float c_g, float c_m, float c_v, void* stream);
 /* replaces tf.clip_by_value(sr, 0, 2**16); tf.round(sr)                 test.py:118-119             */

@@ -117,17 +117,73 @@ class HipNadam(torch.optim.Optimizer):
                                                         _lib.current_stream()), "probav_nadam_step")
 
 
+class HipAdam(torch.optim.Optimizer):
+    """Keras ``Adam`` (optimizer_v2 defaults, amsgrad off): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); theta -= lr_t m / (sqrt(v) + eps), eps
+    outside the bias correction.  Same fused launch as HipNadam (the kernel computes
+    theta -= lr (c_g g + c_m m) / (sqrt(c_v v) + eps); here c_g = 0, c_m = sqrt(1 - b2^t) / (1 - b1^t), c_v = 1)."""
+
+    def __init__(self, params, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        for group in self.param_groups:
+            b1, b2 = group["beta_1"], group["beta_2"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_device(p, "parameter")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                t = st["step"]
+                c_m = (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
+                _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(p), _lib.ptr(p.grad.contiguous()), _lib.ptr(st["m"]), _lib.ptr(st["v"]), p.numel(),
+                                                        group["lr"], b1, b2, group["epsilon"], 0.0, c_m, 1.0,
+                                                        _lib.current_stream()), "probav_nadam_step")
+
+
+class HipSGD(torch.optim.Optimizer):
+    """Keras ``SGD`` without momentum through the same fused launch (c_g = 1, c_m = 0, c_v = 0, eps = 1: theta -= lr g)."""
+
+    def __init__(self, params, lr=1e-2):
+        super().__init__(params, dict(lr=lr))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_device(p, "parameter")
+                st = self.state[p]
+                if not st:
+                    st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
+                _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(p), _lib.ptr(p.grad.contiguous()), _lib.ptr(st["m"]), _lib.ptr(st["v"]), p.numel(),
+                                                        group["lr"], 0.0, 0.0, 1.0, 1.0, 0.0, 0.0,
+                                                        _lib.current_stream()), "probav_nadam_step")
+
+
 def make_optimizer(name, model, learning_rate):
     """train.py:77-83: 'adam' -> Keras Adam, 'nadam' -> Keras Nadam, anything else -> SGD, with the Keras
     defaults restated (epsilon 1e-7; Nadam schedule_decay 0.004 -- SURVEY.md A.5).  On a HIP device Nadam is the
     fused kernel (`HipNadam`); on CPU (host-logic tests only) the algebraically identical torch.optim.NAdam."""
     params = list(model.parameters())
+    on_gpu = bool(params) and params[0].is_cuda
     if name == "adam":
+        if on_gpu:
+            return HipAdam(params, lr=learning_rate)
         return torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7)
     if name == "nadam":
         if params and params[0].is_cuda:
             return HipNadam(params, lr=learning_rate)
         return torch.optim.NAdam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
+    if on_gpu:
+        return HipSGD(params, lr=learning_rate)
     return torch.optim.SGD(params, lr=learning_rate)
 
 

@@ -249,6 +249,24 @@ def test_fused_nadam_matches_keras_restatement(dev):
     assert np.abs(p.detach().cpu().double().numpy() - th).max() < 2e-6 * np.abs(th).max()
 
 
+@pytest.mark.parametrize("name", ["adam", "sgd"])
+def test_fused_adam_sgd_match_keras_restatement(dev, name):
+    """train.py:77-83's other optimizers through the same fused launch, against the fp64 restatements of the Keras rules."""
+    from oracle import nadam_numpy as on_
+    from probav_amd.trainClass import HipAdam, HipSGD
+    rng = np.random.default_rng(2)
+    theta = rng.normal(size=100003).astype(np.float32)
+    p = torch.nn.Parameter(torch.as_tensor(theta).to(dev))
+    opt, ref = (HipAdam([p], lr=5e-4), on_.Adam(lr=5e-4)) if name == "adam" else (HipSGD([p], lr=1e-2), on_.SGD(lr=1e-2))
+    th = theta.astype(np.float64)
+    for _ in range(4):
+        g = (rng.normal(size=theta.shape) * (10.0 ** rng.integers(-3, 2))).astype(np.float32)
+        p.grad = torch.as_tensor(g).to(dev)
+        opt.step()
+        th = ref.step(th, g)
+    assert np.abs(p.detach().cpu().double().numpy() - th).max() < 2e-6 * np.abs(th).max()
+
+
 def test_clip_round_half_to_even(dev):
     L = _lib()
     x = torch.tensor([-3.2, 0.5, 1.5, 2.5, 65535.5, 65536.4, 70000.0, 123.49], device=dev)
