@@ -95,6 +95,14 @@ int probav_shift_loss_forward(const float* hr, const uint8_t* mask, const float*
 int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg,
                                int batch, int size, int border, int which, const float* upstream,
                                float* dpred, void* stream);
+/* cfg loss = sobel_l1_mix: Losses.shiftCompensatedL1EdgeLoss                     models/loss.py:86-97,126-137,214-219
+ * per sample min over the (2*border+1)^2 shifts of  pi * L1 + (1 - pi) * sum|sobel_edges(HR) - sobel_edges(corrected SR)| / n
+ * (tf.image.sobel_edges: REFLECT-padded 3x3 correlations; pi = Losses.pi = 0.7).  loss [batch], arg [batch],
+ * mean: TWO floats (mean over the batch, scratch).  The backward differentiates the arg-min shift, bias term included.   */
+int probav_shift_l1edge_forward(const float* hr, const uint8_t* mask, const float* pred, int batch, int size, int border,
+                                float pi, float* loss, int32_t* arg, float* mean, void* stream);
+int probav_shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg, int batch,
+                                 int size, int border, float pi, const float* upstream, float* dpred, void* stream);
 /* replaces optimizer.apply_gradients with Keras Nadam                   models/trainClass.py:132, train.py:79-81
  * in place on the flat parameter buffer; m, v = first / second moment slots (n floats each).  The caller supplies the
  * step-dependent scalars of SURVEY.md A.5 (computed in double): c_g = (1-mu_t)/(1-Pi_t), c_m = mu_{t+1}/(1-Pi_t*mu_{t+1}),

@@ -130,3 +130,33 @@ def train_step_grads(x, hr, mask, params, mean, std, **kw):
         grads[name] = {"g": gl[k], "v": gl[k + 1], "bias": gl[k + 2]}
         k += 3
     return pred.detach(), loss.detach(), grads
+
+
+def shift_l1edge_loss(hr, mask, pred, border=3, pi=0.7):
+    """cfg loss = sobel_l1_mix (models/loss.py:86-97, 126-137, 214-219): min over the shifts of
+    pi * L1 + (1 - pi) * sum |tf.image.sobel_edges(HR) - sobel_edges(corrected SR)| / n, batch mean.
+    tf.image.sobel_edges = depthwise 3x3 cross-correlation of the REFLECT-padded image with
+    [[-1,-2,-1],[0,0,0],[1,2,1]] (dy) and its transpose (dx)."""
+    import torch.nn.functional as F
+    hr, pred = hr.to(torch.float64), pred.to(torch.float64)
+    m = mask.to(torch.float64)
+    S = pred.shape[1]
+    L = S - 2 * border
+    ky = torch.tensor([[-1., -2., -1.], [0., 0., 0.], [1., 2., 1.]], dtype=torch.float64)
+    k = torch.stack([ky, ky.t()]).unsqueeze(1)                      # [2,1,3,3]
+
+    def sobel(img):                                                  # [B,L,L,1] -> [B,2,L,L]
+        return F.conv2d(F.pad(img.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect"), k)
+
+    cp = pred[:, border:border + L, border:border + L]
+    cands = []
+    for i in range(2 * border + 1):
+        for j in range(2 * border + 1):
+            h, mm = hr[:, i:i + L, j:j + L], m[:, i:i + L, j:j + L]
+            n = mm.sum(dim=(1, 2, 3))
+            b = ((h - cp * mm).sum(dim=(1, 2, 3)) / n).reshape(-1, 1, 1, 1)
+            c = (cp + b) * mm
+            l1 = (h - c).abs().sum(dim=(1, 2, 3)) / n
+            sob = (sobel(h) - sobel(c)).abs().sum(dim=(1, 2, 3)) / n
+            cands.append(pi * l1 + (1 - pi) * sob)
+    return torch.stack(cands).min(dim=0).values.mean()

@@ -41,6 +41,8 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_shift_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_void_p, c_void_p, c_void_p]),
+    "probav_shift_l1edge_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "probav_shift_l1edge_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "probav_clip_round": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
     "probav_nadam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                   c_float, c_float, c_float, c_void_p]),

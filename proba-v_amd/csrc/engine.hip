@@ -774,6 +774,18 @@ int probav_shift_loss_backward(const float* hr, const uint8_t* mask, const float
     if (!hr || !mask || !pred || !arg || !dpred || batch < 1) { set_error("probav_shift_loss_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
     return shift_loss_backward(hr, mask, pred, arg, batch, size, border, which, upstream, dpred, (hipStream_t)stream);
 }
+int probav_shift_l1edge_forward(const float* hr, const uint8_t* mask, const float* pred, int batch, int size, int border, float pi,
+                                float* loss, int32_t* arg, float* mean, void* stream)
+{
+    if (!hr || !mask || !pred || !loss || !arg || !mean || batch < 1) { set_error("probav_shift_l1edge_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    return shift_l1edge_forward(hr, mask, pred, batch, size, border, pi, loss, arg, mean, mean + 1, (hipStream_t)stream);
+}
+int probav_shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg, int batch, int size,
+                                 int border, float pi, const float* upstream, float* dpred, void* stream)
+{
+    if (!hr || !mask || !pred || !arg || !dpred || batch < 1) { set_error("probav_shift_l1edge_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    return shift_l1edge_backward(hr, mask, pred, arg, batch, size, border, pi, upstream, dpred, (hipStream_t)stream);
+}
 int probav_nadam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float c_g, float c_m, float c_v, void* stream)
 {

@@ -356,6 +356,187 @@ int shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cfg loss = sobel_l1_mix: shiftCompensatedL1EdgeLoss (models/loss.py:86-97, 126-137, 214-219).  Per sample and candidate shift
+//   D = H - (P + b) M   (b, M as above; H un-masked),  l1 = sum |D| / n,
+//   sob = sum (|Gy| + |Gx|) / n,  (Gy, Gx) = tf.image.sobel_edges(H) - sobel_edges(C) = sobel_edges(D): 3x3 cross-correlations
+//         [[-1,-2,-1],[0,0,0],[1,2,1]] and its transpose on the REFLECT-padded crop,
+//   loss = pi * l1 + (1 - pi) * sob;  minimum over the shifts, mean over the batch.
+// One 256-thread block per sample walks the shifts; D lives in LDS (the Sobel taps read it with mirrored indices).  fp64 sums.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mirror(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid)
+{
+    v = wave_sum(v);
+    __syncthreads();                       // red may still be read by the previous reduction
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void shift_l1edge_fwd_kernel(
+    const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred, int S, int border, float pi,
+    float* __restrict__ loss_out, int* __restrict__ arg_out)
+{
+    extern __shared__ float sD[];                                   // [L][L]
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = S - 2 * border, ns = 2 * border + 1, nshift = ns * ns;
+    const float* H = hr + (long)b * S * S;
+    const uint8_t* M = mask + (long)b * S * S;
+    const float* P = pred + (long)b * S * S;
+    double best = 1e300;
+    int abest = 0;
+    for (int sft = 0; sft < nshift; ++sft) {
+        const int i = sft / ns, j = sft - i * ns;
+        double cnt = 0.0, dsum = 0.0;
+        for (int k = tid; k < L * L; k += 256) {
+            const int r = k / L, c = k - r * L;
+            const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
+            cnt += (double)m;
+            dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+        }
+        cnt = block_sum(cnt, red, tid);
+        dsum = block_sum(dsum, red, tid);
+        const double bias = dsum / cnt;
+        double s1 = 0.0;
+        for (int k = tid; k < L * L; k += 256) {
+            const int r = k / L, c = k - r * L;
+            const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+            const double e = (double)H[(i + r) * S + j + c] - ((double)P[(border + r) * S + border + c] + bias) * m;
+            sD[k] = (float)e;
+            s1 += fabs(e);
+        }
+        s1 = block_sum(s1, red, tid);                               // (its barriers also publish sD)
+        double sg = 0.0;
+        for (int k = tid; k < L * L; k += 256) {
+            const int r = k / L, c = k - r * L;
+            const int r0 = mirror(r - 1, L) * L, r1 = r * L, r2 = mirror(r + 1, L) * L;
+            const int c0 = mirror(c - 1, L), c2 = mirror(c + 1, L);
+            const double gy = ((double)sD[r2 + c0] + 2.0 * sD[r2 + c] + sD[r2 + c2]) - ((double)sD[r0 + c0] + 2.0 * sD[r0 + c] + sD[r0 + c2]);
+            const double gx = ((double)sD[r0 + c2] + 2.0 * sD[r1 + c2] + sD[r2 + c2]) - ((double)sD[r0 + c0] + 2.0 * sD[r1 + c0] + sD[r2 + c0]);
+            sg += fabs(gy) + fabs(gx);
+        }
+        sg = block_sum(sg, red, tid);
+        const double loss = ((double)pi * s1 + (1.0 - (double)pi) * sg) / cnt;
+        if (loss < best) { best = loss; abest = sft; }              // first minimum in shift order wins ties
+    }
+    if (tid == 0) { loss_out[b] = (float)best; arg_out[b] = abest; }
+}
+
+// gradient of mean_B min_shift (pi l1 + (1-pi) sob) w.r.t. pred at the arg-min shift:
+//   G = dloss/dD = [pi sign(D) + (1-pi) Sobel^T(sign(Gy), sign(Gx))] / n      (Sobel^T folds the mirrored pad back onto the crop)
+//   dP_k = -M_k (G_k - sum(G M) / n)                                          (the second term is the brightness bias)
+__global__ __launch_bounds__(256) void shift_l1edge_bwd_kernel(
+    const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred, const int* __restrict__ arg,
+    int S, int border, float pi, const float* __restrict__ upstream, float inv_b, float* __restrict__ dpred)
+{
+    extern __shared__ float sm[];
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = S - 2 * border, ns = 2 * border + 1, Lp = L + 2;
+    float* sD = sm;                     // [L][L]
+    float* sY = sD + L * L;             // sign(Gy) [L][L]
+    float* sX = sY + L * L;             // sign(Gx)
+    float* sG = sX + L * L;             // gradient w.r.t. the padded crop [Lp][Lp], then folded
+    const float scale = (upstream ? upstream[0] : 1.f) * inv_b;
+    const float* H = hr + (long)b * S * S;
+    const uint8_t* M = mask + (long)b * S * S;
+    const float* P = pred + (long)b * S * S;
+    float* G = dpred + (long)b * S * S;
+    const int sft = arg[b], i = sft / ns, j = sft - i * ns;
+    double cnt = 0.0, dsum = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
+        cnt += (double)m;
+        dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+    }
+    cnt = block_sum(cnt, red, tid);
+    dsum = block_sum(dsum, red, tid);
+    const double bias = dsum / cnt;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+        sD[k] = (float)((double)H[(i + r) * S + j + c] - ((double)P[(border + r) * S + border + c] + bias) * m);
+    }
+    __syncthreads();
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const int r0 = mirror(r - 1, L) * L, r1 = r * L, r2 = mirror(r + 1, L) * L;
+        const int c0 = mirror(c - 1, L), c2 = mirror(c + 1, L);
+        const double gy = ((double)sD[r2 + c0] + 2.0 * sD[r2 + c] + sD[r2 + c2]) - ((double)sD[r0 + c0] + 2.0 * sD[r0 + c] + sD[r0 + c2]);
+        const double gx = ((double)sD[r0 + c2] + 2.0 * sD[r1 + c2] + sD[r2 + c2]) - ((double)sD[r0 + c0] + 2.0 * sD[r1 + c0] + sD[r2 + c0]);
+        sY[k] = gy > 0.0 ? 1.f : (gy < 0.0 ? -1.f : 0.f);
+        sX[k] = gx > 0.0 ? 1.f : (gx < 0.0 ? -1.f : 0.f);
+    }
+    __syncthreads();
+    // adjoint of the two correlations on the PADDED crop: position (u, v) in [-1, L] x [-1, L] collects the outputs q it feeds
+    for (int k = tid; k < Lp * Lp; k += 256) {
+        const int u = k / Lp - 1, v = k - (k / Lp) * Lp - 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                const int qr = u - (a - 1), qc = v - (bb - 1);      // output whose tap (a, bb) reads (u, v)
+                if (qr < 0 || qr >= L || qc < 0 || qc >= L) continue;
+                const float ky = (a == 0 ? -1.f : (a == 2 ? 1.f : 0.f)) * (bb == 1 ? 2.f : 1.f);
+                const float kx = (bb == 0 ? -1.f : (bb == 2 ? 1.f : 0.f)) * (a == 1 ? 2.f : 1.f);
+                acc += ky * sY[qr * L + qc] + kx * sX[qr * L + qc];
+            }
+        sG[k] = acc;
+    }
+    __syncthreads();
+    // fold the mirrored pad back (pad row -1 mirrors row 1, row L mirrors row L-2; same for columns) and mix with the L1 term
+    double gm = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        float acc = 0.f;
+        const int us[3] = {r, r == 1 ? -1 : -2, r == L - 2 ? L : -2};       // padded rows that mirror onto r (-2 = none)
+        const int vs[3] = {c, c == 1 ? -1 : -2, c == L - 2 ? L : -2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb)
+                if (us[a] != -2 && vs[bb] != -2) acc += sG[(us[a] + 1) * Lp + vs[bb] + 1];
+        const float d = sD[k];
+        const float g = pi * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + (1.f - pi) * acc;
+        sY[k] = g;                                                   // sY is dead: reuse for G * n
+        gm += (double)g * (M[(i + r) * S + j + c] ? 1.0 : 0.0);
+    }
+    gm = block_sum(gm, red, tid);
+    for (int k = tid; k < S * S; k += 256) {
+        const int Y = k / S, X = k - Y * S, r = Y - border, c = X - border;
+        float gk = 0.f;
+        if (r >= 0 && r < L && c >= 0 && c < L) {
+            const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+            gk = (float)(-(m / cnt) * ((double)sY[r * L + c] - gm / cnt) * (double)scale);
+        }
+        G[k] = gk;
+    }
+}
+
+int shift_l1edge_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border, float pi,
+                         float* loss, int* arg, float* mean, float* scratch_mean2, hipStream_t s)
+{
+    if (B <= 0 || S <= 2 * border + 2) { set_error("shift_l1edge_forward: bad shape", hipSuccess); return PROBAV_EINVAL; }
+    const int L = S - 2 * border;
+    hipLaunchKernelGGL(shift_l1edge_fwd_kernel, dim3(B), dim3(256), (size_t)L * L * sizeof(float), s, hr, mask, pred, S, border, pi, loss, arg);
+    hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, s, loss, loss, mean, scratch_mean2, B);
+    return check_launch("shift_l1edge_forward");
+}
+int shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, int B, int S, int border, float pi,
+                          const float* upstream, float* dpred, hipStream_t s)
+{
+    const int L = S - 2 * border;
+    const size_t lds = ((size_t)3 * L * L + (size_t)(L + 2) * (L + 2)) * sizeof(float);
+    if (B <= 0 || L < 3 || lds > 64 * 1024) { set_error("shift_l1edge_backward: bad shape", hipSuccess); return PROBAV_EINVAL; }
+    hipLaunchKernelGGL(shift_l1edge_bwd_kernel, dim3(B), dim3(256), lds, s, hr, mask, pred, arg, S, border, pi, upstream, 1.0f / (float)B, dpred);
+    return check_launch("shift_l1edge_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Keras Nadam (optimizer_v2; train.py:79-81) on the flat parameter buffer, one launch:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
 //   theta -= lr * ( (1-mu_t) g / (1-Pi_t) + mu_{t+1} m / (1-Pi_t mu_{t+1}) ) / ( sqrt(v / (1-b2^t)) + eps )

@@ -65,6 +65,11 @@ int shift_loss_backward(const float* hr, const uint8_t* mask, const float* pred,
                         int border, int which /*1 = L1, 2 = L2*/, const float* upstream /*device scalar or null*/,
                         float* dpred, hipStream_t s);
 
+int shift_l1edge_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border, float pi,
+                         float* loss, int* arg, float* mean, float* scratch_mean2, hipStream_t s);
+int shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, int B, int S, int border, float pi,
+                          const float* upstream, float* dpred, hipStream_t s);
+
 int nadam_step(float* theta, const float* grad, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                float c_g, float c_m, float c_v, hipStream_t s);
 

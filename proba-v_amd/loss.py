@@ -56,6 +56,33 @@ class _ShiftLoss(torch.autograd.Function):
         return dpred, None, None, None, None, None
 
 
+class _ShiftL1Edge(torch.autograd.Function):
+    """cfg loss = sobel_l1_mix (models/loss.py:86-97): one launch over all shifts, one for the gradient of the arg-min shift."""
+
+    @staticmethod
+    def forward(ctx, pred, hr, m, border, pi):
+        B, S = pred.shape[0], pred.shape[1]
+        loss = torch.empty(B, dtype=torch.float32, device=pred.device)
+        arg = torch.empty(B, dtype=torch.int32, device=pred.device)
+        mean = torch.empty(2, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.lib().probav_shift_l1edge_forward(_lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), B, S, border, pi, _lib.ptr(loss),
+                                                          _lib.ptr(arg), _lib.ptr(mean), _lib.current_stream()), "probav_shift_l1edge_forward")
+        ctx.save_for_backward(pred, hr, m, arg)
+        ctx.border, ctx.pi = border, pi
+        ctx.per_sample = loss
+        return mean[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, hr, m, arg = ctx.saved_tensors
+        g = g.contiguous().float().reshape(1)
+        dpred = torch.empty_like(pred)
+        _lib.check(_lib.lib().probav_shift_l1edge_backward(_lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), _lib.ptr(arg), pred.shape[0], pred.shape[1],
+                                                           ctx.border, ctx.pi, _lib.ptr(g), _lib.ptr(dpred), _lib.current_stream()),
+                   "probav_shift_l1edge_backward")
+        return dpred, None, None, None, None
+
+
 class Losses:
     """models/loss.py:8-35: all losses / metrics in one object; constants follow the reference."""
 
@@ -67,6 +94,7 @@ class Losses:
         self.numBytes = 2 ** bitDepth - 1
         self.cropSizeHeight = self.targetShapeHeight - self.maxPixelShift
         self.cropSizeWidth = self.targetShapeWidth - self.maxPixelShift
+        self.pi = 0.7                                     # SobelL1Mix weight (models/loss.py:21)
 
     def _check(self, pred):
         if pred.shape[1] != self.targetShapeHeight or pred.shape[2] != self.targetShapeWidth:
@@ -103,7 +131,10 @@ class Losses:
                 "mean_l1": means[0], "mean_l2": means[1]}
 
     def shiftCompensatedL1EdgeLoss(self, patchHR, maskHR, predPatchHR):
-        raise NotImplementedError("cfg loss=sobel_l1_mix (models/loss.py:86-97) is not on the hot path yet (SURVEY.md §8f-4)")
+        """models/loss.py:86-97 (cfg loss = sobel_l1_mix): pi * L1 + (1 - pi) * Sobel-edge L1, minimum over the shifts, batch mean."""
+        hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
+        self._check(pred)
+        return _ShiftL1Edge.apply(pred, hr, m, self.cropBorder, float(self.pi))
 
     def shiftCompensatedRevSSIM(self, patchHR, maskHR, predPatchHR):
         raise NotImplementedError("cfg loss=l1msssim (models/loss.py:99-110) is not on the hot path yet (SURVEY.md §8f-4)")

@@ -228,6 +228,25 @@ def test_shift_losses_match_oracle(dev, B, S, border):
         lo.shiftCompensatedL1Loss(hd[:, :-1], md, pd)
 
 
+def test_sobel_l1_mix_loss_and_gradient(dev):
+    """cfg loss = sobel_l1_mix: forward value and the gradient through the arg-min shift against the torch fp64 restatement."""
+    from oracle import wdsr_torch as ot_
+    from probav_amd.loss import Losses
+    rng = np.random.default_rng(7)
+    _, hr, mask = synth.synth_batch(5, seed=8)
+    pred = (hr + rng.normal(0, 300, hr.shape)).astype(np.float32)
+    lo = Losses(targetShape=(48, 48, 1))
+    pd = torch.tensor(pred, device=dev, requires_grad=True)
+    loss = lo.shiftCompensatedL1EdgeLoss(torch.tensor(hr).to(dev), torch.tensor(mask).to(dev), pd)
+    loss.backward()
+    pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    ref = ot_.shift_l1edge_loss(torch.tensor(hr), torch.tensor(mask), pt, border=3, pi=0.7)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    g, gr = pd.grad.cpu().double().numpy(), pt.grad.numpy()
+    assert np.abs(g - gr).max() < 1e-5 * np.abs(gr).max()
+
+
 def test_fused_nadam_matches_keras_restatement(dev):
     """HIP Nadam (probav_nadam_step) against the fp64 restatement of the Keras rule, incl. checkpoint round trip."""
     from oracle.nadam_numpy import Nadam

@@ -116,3 +116,22 @@ def test_nadam_restatement_equals_torch_nadam():
         opt_t.step()
         theta = opt_n.step(theta, g)
     np.testing.assert_allclose(p.detach().numpy(), theta, rtol=1e-7, atol=1e-10)     # same rule, different fp64 op order
+
+
+def test_sobel_l1_mix_restatement_conventions():
+    """oracle/wdsr_torch.py::shift_l1edge_loss: Sobel of a constant is 0 (reflect padding), of a unit ramp 8 in the interior;
+    with pred == hr and a full mask the loss is 0; pi = 1 reduces it to the shift-compensated L1."""
+    hr = np.tile(np.arange(48, dtype=np.float64).reshape(1, 1, 48, 1), (1, 48, 1, 1)) * 10.0     # ramp along W
+    mask = np.ones((1, 48, 48, 1), bool)
+    z = ot.shift_l1edge_loss(torch.tensor(hr), torch.tensor(mask), torch.tensor(hr))
+    assert float(z) == 0.0
+    rng = np.random.default_rng(3)
+    _, hr2, m2 = synth.synth_batch(2, seed=9)
+    pred = hr2 + rng.normal(0, 100, hr2.shape)
+    a = ot.shift_l1edge_loss(torch.tensor(hr2), torch.tensor(m2), torch.tensor(pred), pi=1.0)
+    b = ot.shift_l1_loss(torch.tensor(hr2), torch.tensor(m2), torch.tensor(pred))
+    assert abs(float(a) - float(b)) < 1e-9 * float(b)
+    # a flat +c offset is absorbed by the brightness bias: loss unchanged
+    c = ot.shift_l1edge_loss(torch.tensor(hr2), torch.tensor(m2), torch.tensor(pred + 37.0))
+    d = ot.shift_l1edge_loss(torch.tensor(hr2), torch.tensor(m2), torch.tensor(pred))
+    assert abs(float(c) - float(d)) < 1e-9 * float(d)
