@@ -404,6 +404,39 @@ __device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* lds
     }
 }
 
+// x6 tap loop of the row-tile kernel for 25-channel inputs, dt taps concatenated along K (see strip_taps_x6k): 45 k-blocks of 16,
+// filters PACK_X6_CONVK, two M tiles share every filter fragment.
+template <int MT>
+__device__ __forceinline__ void conv_taps_x6k(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
+                                              f32x16& acc0, f32x16& acc1)
+{
+    float r0[8], r1[8];
+    Frag wcur[3], wnxt[3], a0[3], a1[3];
+    auto loads = [&](int kbi, Frag (&w)[3]) {
+        const int grp = kbi / 5, kb = kbi - 5 * grp, dh = grp / 3, dw = grp - 3 * dh;
+        const int toff = (dh * a.Wp + dw) * a.Tp * 25 + 16 * kb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r0[j] = ldsA0[toff + j]; r1[j] = MT == 2 ? ldsA1[toff + j] : 0.f; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p].u = wf[(kbi * 3 + p) * 64];
+    };
+    loads(0, wcur);
+    split8(r0, a0);
+    if (MT == 2) split8(r1, a1);
+#pragma unroll 1
+    for (int kbi = 0; kbi < 45; ++kbi) {
+        loads(kbi + 1 < 45 ? kbi + 1 : kbi, wnxt);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mac6(a0, wcur, acc0);
+        if (MT == 2) acc1 = mac6(a1, wcur, acc1);
+        split8(r0, a0);
+        if (MT == 2) split8(r1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wcur[p] = wnxt[p];
+    }
+}
+
 template <int CC, int KS, bool X6>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                            const float4* __restrict__ wfrag, const float* __restrict__ bias,
@@ -439,7 +472,11 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
                 STAMP(1 + 2 * chunk);
                 __syncthreads();
             }
-            if constexpr (X6) {
+            if constexpr (X6 && CC == 25) {
+                const uint4* wf6 = reinterpret_cast<const uint4*>(wfrag) + lane;
+                if (v1) conv_taps_x6k<2>(a, ldsA0, ldsA1, wf6, acc0, acc1);
+                else if (v0) conv_taps_x6k<1>(a, ldsA0, ldsA1, wf6, acc0, acc1);
+            } else if constexpr (X6) {
                 const uint4* wf6 = reinterpret_cast<const uint4*>(wfrag) + lane;
                 if (v1) conv_taps_x6<2>(a, ldsA0, ldsA1, wf6, chunk, acc0, acc1);
                 else if (v0) conv_taps_x6<1>(a, ldsA0, ldsA1, wf6, chunk, acc0, acc1);
@@ -575,17 +612,18 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
 bool x6_conv_rowtile_supported(const ConvGeom& g)
 {
     const ConvPlan p = conv_plan(g, false);
-    return p.ok && p.CC == 16 && g.Cin == 32;
+    return p.ok && ((p.CC == 16 && g.Cin == 32) || (p.CC == 25 && g.Cin == 25));
 }
 int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
                             const float* skip, float* y, hipStream_t s)
 {
     const ConvPlan p = conv_plan(g, false);
-    if (!p.ok || p.CC != 16 || g.Cin != 32) { set_error("x6_conv_rowtile_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (!x6_conv_rowtile_supported(g)) { set_error("x6_conv_rowtile_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<16, 8, true>); once = true; }
-    hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, true>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y);
+    if (!once) { allow_big_lds(conv3_mfma_kernel<16, 8, true>); allow_big_lds(conv3_mfma_kernel<25, 13, true>); once = true; }
+    if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13, true>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y);
+    else hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, true>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y);
     return check_launch("conv3_mfma_x6");
 }
 
