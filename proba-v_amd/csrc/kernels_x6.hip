@@ -434,6 +434,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
 struct WgArgs {
     int N, H, W, T, Cout;
     int Wp, Tp, nv, total_tiles;
+    int nsplit, Wt;             // output rows are cut into nsplit column ranges of Wt columns when three full rows do not fit the LDS
     unsigned mT;                // ceil(2^32 / T): floor(v / T) = umulhi(v, mT) for the small v used here (T >= 2)
 };
 
@@ -460,65 +461,81 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
 
     // staging of one input row, split in two so that the HBM/L2 latency of the NEXT tile's row hides under this tile's MFMAs:
     // stage_load leaves the row in registers (NST channel pairs per thread), stage_store cuts and stores it.
-    constexpr int NST = 6;                                 // x6_wgrad_supported(): W * T * NP <= 512 * NST
-    const int items = a.W * a.T * NP;
-    auto stage_load = [&](int n, int ih, float (&f)[NST][2]) {
-        const bool ok = ih >= 0 && ih < a.H;
-        const float* src = x + ((long)n * a.H + (ok ? ih : 0)) * (long)a.W * a.T * CIN;
+    constexpr int NST = 6;                                 // x6_wgrad_supported(): (Wt + 2) * T * NP <= 512 * NST
+    // a tile = (patch n, column range sp, output row ho); its staged rows hold input columns ws0 - 1 .. ws0 + Wts (local 0 .. Wts + 1)
+    auto stage_load = [&](int n, int ih, int ws0, int Wts, float (&f)[NST][2]) {
+        const bool rok = ih >= 0 && ih < a.H;
+        const float* src = x + ((long)n * a.H + (rok ? ih : 0)) * (long)a.W * a.T * CIN;
+        const int items = (Wts + 2) * a.T * NP;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + 512 * k;
             const int ic = i < items ? i : 0;
             const int vox = ic / NP, cp = ic - vox * NP;
+            const int lw = (int)__umulhi((unsigned)vox, a.mT), t = vox - lw * a.T;
+            const int iw = ws0 - 1 + lw;
+            const bool ok = rok && iw >= 0 && iw < a.W;
             const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
-            const float f0 = src[vox * CIN + c0], f1 = src[vox * CIN + c1];
+            const long o = ((long)(ok ? iw : 0) * a.T + t) * CIN;
+            const float f0 = src[o + c0], f1 = src[o + c1];
             f[k][0] = ok ? f0 : 0.f;
             f[k][1] = (ok && c0 + 1 < CIN) ? f1 : 0.f;
         }
     };
-    auto stage_store = [&](int ih, const float (&f)[NST][2]) {
+    auto stage_store = [&](int ih, int Wts, const float (&f)[NST][2]) {
         unsigned char* slot = lds_raw + ((ih + 3) % 3) * rowbytes;
+        const int items = (Wts + 2) * a.T * NP;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + 512 * k;
             if (i < items) {
                 const int vox = i / NP, cp = i - vox * NP;
-                const int w = vox / a.T, t = vox - w * a.T;
+                const int lw = (int)__umulhi((unsigned)vox, a.mT), t = vox - lw * a.T;
                 unsigned q[3];
                 split_pair(f[k][0], f[k][1], q[0], q[1], q[2]);
-                unsigned char* d = slot + ((w + 1) * a.Tp + t + 1) * VS + cp * 4;
+                unsigned char* d = slot + (lw * a.Tp + t + 1) * VS + cp * 4;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
             }
         }
     };
-    auto stage_three = [&](int n, int ho) {
+    auto stage_three = [&](int n, int ho, int ws0, int Wts) {
 #pragma unroll 1
         for (int rr = 0; rr < 3; ++rr) {
             float f[NST][2];
-            stage_load(n, ho - 1 + rr, f);
-            stage_store(ho - 1 + rr, f);
+            stage_load(n, ho - 1 + rr, ws0, Wts, f);
+            stage_store(ho - 1 + rr, Wts, f);
         }
+    };
+    auto decode = [&](int tile, int& n, int& ws0, int& Wts, int& ho) {     // tile = (n * nsplit + sp) * H + ho
+        const int q = tile / a.H;
+        ho = tile - q * a.H;
+        n = q / a.nsplit;
+        const int sp = q - n * a.nsplit;
+        ws0 = sp * a.Wt;
+        Wts = a.W - ws0 < a.Wt ? a.W - ws0 : a.Wt;
     };
 
     const int tbeg = (int)((long)blockIdx.x * a.total_tiles / gridDim.x), tend = (int)((long)(blockIdx.x + 1) * a.total_tiles / gridDim.x);
-    const int nkb = (a.nv + 15) >> 4;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     XS_DECL;
     __syncthreads();                                       // ring zeroed
-    if (tbeg < tend) stage_three(tbeg / a.H, tbeg % a.H);
+    if (tbeg < tend) { int n, ws0, Wts, ho; decode(tbeg, n, ws0, Wts, ho); stage_three(n, ho, ws0, Wts); }
     XS_ACC(1);
 #pragma unroll 1
     for (int tile = tbeg; tile < tend; ++tile) {
-        const int n = tile / a.H, ho = tile - n * a.H;
+        int n, ws0, Wts, ho;
+        decode(tile, n, ws0, Wts, ho);
+        const int nv = Wts * a.T, nkb = (nv + 15) >> 4;
         __syncthreads();                                   // this tile's three rows are staged
         XS_ACC(2);
         const bool has_next = tile + 1 < tend;
-        const int nn = (tile + 1) / a.H, nho = (tile + 1) - nn * a.H;
-        const bool consecutive = has_next && nn == n;      // next tile = next row of the same patch: one new row
+        int nn = n, nws0 = ws0, nWts = Wts, nho = ho;
+        if (has_next) decode(tile + 1, nn, nws0, nWts, nho);
+        const bool consecutive = has_next && nn == n && nws0 == ws0 && nho == ho + 1;    // next tile = next row of the same column range
         float nf[NST][2];
-        if (consecutive) stage_load(n, ho + 2, nf);        // in flight during this tile's MFMAs
-        const long out_base = ((long)n * a.H + ho) * a.nv;
+        if (consecutive) stage_load(n, ho + 2, ws0, Wts, nf);   // in flight during this tile's MFMAs
+        const long out_base = (((long)n * a.H + ho) * a.W + ws0) * a.T;
         int tapoff[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -532,13 +549,13 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         const float* dyrow = dy + out_base * 32 + col;
         auto load_dy = [&](int kb, float (&r)[8]) {
             const int v0 = 16 * kb + 8 * h;
-            if (16 * kb + 16 <= a.nv) {                                                 // wave-uniform fast path
+            if (16 * kb + 16 <= nv) {                                                   // wave-uniform fast path
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = dyrow[(v0 + j) * 32];
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const bool live = v0 + j < a.nv;
+                    const bool live = v0 + j < nv;
                     const float d = dyrow[live ? (v0 + j) * 32 : 0];
                     r[j] = live ? d : 0.f;
                 }
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         };
         auto tr_addr = [&](int kb, int jj) -> int {                                     // block row li >> 2 of half h, columns 16 gcol + 4 (li & 3)
             int vi = 16 * kb + 8 * h + 4 * jj + (li >> 2);
-            vi = vi < a.nv ? vi : a.nv - 1;
+            vi = vi < nv ? vi : nv - 1;
             const int w = (int)__umulhi((unsigned)vi, a.mT), t = vi - w * a.T;
             return (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
         };
@@ -623,8 +640,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         XS_ACC(3);
         __syncthreads();                                   // every wave is done with this tile's rows
         XS_ACC(4);
-        if (consecutive) stage_store(ho + 2, nf);          // replaces row ho - 1
-        else if (has_next) stage_three(nn, nho);
+        if (consecutive) stage_store(ho + 2, Wts, nf);     // replaces row ho - 1
+        else if (has_next) stage_three(nn, nho, nws0, nWts);
         XS_ACC(5);
     }
     // slab of this workgroup: [27 * Cin][Cout] (+ bias sums).  The two k-block parities meet in LDS (the ring is dead now):
@@ -665,23 +682,33 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     XS_OUT;
 }
 
-bool x6_wgrad_supported(const ConvGeom& g)
+static int x6_wgrad_split(const ConvGeom& g)              // number of column ranges per row, 0 = unsupported
 {
-    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph != 1 || g.pw != 1 || g.pt != 1 || g.reflect_hw) return false;
-    if (g.Cin != 25 || g.Cout != 32 || g.Ti < 2 || g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return false;
-    const size_t lds = (size_t)3 * (g.Wi + 2) * (g.Ti + 2) * 168 + 16;
-    return lds <= 160 * 1024 && g.Wi * g.Ti * 13 <= 512 * 6;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph != 1 || g.pw != 1 || g.pt != 1 || g.reflect_hw) return 0;
+    if (g.Cin != 25 || g.Cout != 32 || g.Ti < 2 || g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return 0;
+    for (int ns = 1; ns <= 4 && ns <= g.Wi; ++ns) {
+        const int Wt = (g.Wi + ns - 1) / ns;
+        const size_t lds = (size_t)3 * (Wt + 2) * (g.Ti + 2) * 168 + 16;
+        if (lds <= 160 * 1024 && (Wt + 2) * g.Ti * 13 <= 512 * 6) return ns;
+    }
+    return 0;
 }
+bool x6_wgrad_supported(const ConvGeom& g) { return x6_wgrad_split(g) > 0; }
 
-static int x6_wgrad_grid(const ConvGeom& g) { return g.N * g.Ho < 256 ? g.N * g.Ho : 256; }
+static int x6_wgrad_grid(const ConvGeom& g)
+{
+    const int total = g.N * g.Ho * x6_wgrad_split(g);
+    return total < 256 ? total : 256;
+}
 size_t x6_wgrad_partial_floats(const ConvGeom& g) { return (size_t)x6_wgrad_grid(g) * ((size_t)27 * g.Cin * g.Cout + g.Cout); }
 
 int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, hipStream_t s)
 {
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     WgArgs a;
-    a.N = g.N; a.H = g.Hi; a.W = g.Wi; a.T = g.Ti; a.Cout = g.Cout; a.Wp = g.Wi + 2; a.Tp = g.Ti + 2;
-    a.nv = g.Wo * g.To; a.total_tiles = g.N * g.Ho;
+    a.nsplit = x6_wgrad_split(g); a.Wt = (g.Wi + a.nsplit - 1) / a.nsplit;
+    a.N = g.N; a.H = g.Hi; a.W = g.Wi; a.T = g.Ti; a.Cout = g.Cout; a.Wp = a.Wt + 2; a.Tp = g.Ti + 2;
+    a.nv = a.Wt * g.To; a.total_tiles = g.N * g.Ho * a.nsplit;
     a.mT = (unsigned)((0x100000000ull + (unsigned)g.Ti - 1) / (unsigned)g.Ti);
     const int grid = x6_wgrad_grid(g);
     const long nw = (long)27 * g.Cin * g.Cout;
