@@ -227,9 +227,9 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
                       float* dw, float* db, float* partial, hipStream_t s)
 {
-    const bool x6 = e->impl >= 3 && !gate && x6_wgrad_supported(g);
+    const bool x6 = e->impl >= 3 && x6_wgrad_supported(g);
     ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : (x6 ? CLS_CONV3_WGRAD_X6 : CLS_CONV3_WGRAD), geom_macs(g), s);
-    if (x6) return x6_conv_wgrad(g, x, dy, dw, db, partial, s);
+    if (x6) return x6_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
     if (e->impl >= 1 && mfma_wgrad_supported(g)) return mfma_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s);
 }
@@ -646,9 +646,9 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_wgrad: bad geometry", hipSuccess); return PROBAV_EINVAL; }
     if (impl == 3) {
-        if (gate || !x6_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the x6 kernel", hipSuccess); return PROBAV_EINVAL; }
+        if (!x6_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the x6 kernel", hipSuccess); return PROBAV_EINVAL; }
         if (scratch_bytes < x6_wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
-        return x6_conv_wgrad(g, x, dy, dw, db, (float*)scratch, (hipStream_t)stream);
+        return x6_conv_wgrad(g, x, dy, gate, dw, db, (float*)scratch, (hipStream_t)stream);
     }
     if (impl == 1) {
         if (!mfma_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }

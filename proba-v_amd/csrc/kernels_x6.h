@@ -14,9 +14,10 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
                    const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, int D,
                    hipStream_t s);
 
-// backward-filter of the 'same' 3x3x3 convolution with Cin = 25 (normConv); partial: x6_wgrad_partial_floats(g) floats
+// backward-filter of a 3x3x3 convolution with Cin = 25 or 32 and Cout = 32 (normConv, reducers; pads 0/1, reflect, ReLU gate);
+// partial: x6_wgrad_partial_floats(g) floats
 bool x6_wgrad_supported(const ConvGeom& g);
 size_t x6_wgrad_partial_floats(const ConvGeom& g);
-int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, hipStream_t s);
+int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial, hipStream_t s);
 
 }  // namespace probav

@@ -432,15 +432,20 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
 // re-stage one row.  One slab per workgroup, summed by reduce_slabs_kernel (fp64, fixed order).
 // ---------------------------------------------------------------------------------------------------
 struct WgArgs {
-    int N, H, W, T, Cout;
+    int N, H, W, T, Cout;       // OUTPUT extents (rows, columns, depth)
+    int Hi, Wi, Ti;             // input extents
+    int ph, pw, pt, reflect;    // pads (0 or 1 each); reflect: H/W pads mirror the input (tf.pad REFLECT) instead of zeros
     int Wp, Tp, nv, total_tiles;
     int nsplit, Wt;             // output rows are cut into nsplit column ranges of Wt columns when three full rows do not fit the LDS
-    unsigned mT;                // ceil(2^32 / T): floor(v / T) = umulhi(v, mT) for the small v used here (T >= 2)
+    unsigned mT, mTi;           // ceil(2^32 / T), ceil(2^32 / Ti): floor(v / d) = umulhi(v, m) for the small v used here (d >= 2)
 };
 
-template <int CIN>
+__device__ __forceinline__ int wg_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+template <int CIN, bool GATE>
 __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ partial, float* __restrict__ partial_b)
+                                                               const float* __restrict__ gate, float* __restrict__ partial,
+                                                               float* __restrict__ partial_b)
 {
     constexpr int CB = CIN <= 28 ? 56 : 64;        // bytes of one piece of one voxel (channels padded to 28 / 32)
     constexpr int VS = 3 * CB;                     // bytes per voxel
@@ -461,39 +466,43 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
 
     // staging of one input row, split in two so that the HBM/L2 latency of the NEXT tile's row hides under this tile's MFMAs:
     // stage_load leaves the row in registers (NST channel pairs per thread), stage_store cuts and stores it.
-    constexpr int NST = 6;                                 // x6_wgrad_supported(): (Wt + 2) * T * NP <= 512 * NST
-    // a tile = (patch n, column range sp, output row ho); its staged rows hold input columns ws0 - 1 .. ws0 + Wts (local 0 .. Wts + 1)
-    auto stage_load = [&](int n, int ih, int ws0, int Wts, float (&f)[NST][2]) {
-        const bool rok = ih >= 0 && ih < a.H;
-        const float* src = x + ((long)n * a.H + (rok ? ih : 0)) * (long)a.W * a.T * CIN;
-        const int items = (Wts + 2) * a.T * NP;
+    constexpr int NST = CIN <= 28 ? 6 : 7;                 // x6_wgrad_supported(): (Wt + 2) * Ti * NP <= 512 * NST
+    // a tile = (patch n, column range sp, output row ho).  Ring row `key` = ho + dh holds input row key - ph (mirrored / zero outside),
+    // local column lw <-> input column ws0 + lw - pw, local depth lt <-> input depth lt - pt (depth pads stay zero from the init).
+    auto stage_load = [&](int n, int key, int ws0, int Wts, float (&f)[NST][2]) {
+        int ih = key - a.ph;
+        if (a.reflect) ih = wg_reflect(ih, a.Hi);
+        const bool rok = ih >= 0 && ih < a.Hi;
+        const float* src = x + ((long)n * a.Hi + (rok ? ih : 0)) * (long)a.Wi * a.Ti * CIN;
+        const int items = (Wts + 2) * a.Ti * NP;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + 512 * k;
             const int ic = i < items ? i : 0;
             const int vox = ic / NP, cp = ic - vox * NP;
-            const int lw = (int)__umulhi((unsigned)vox, a.mT), t = vox - lw * a.T;
-            const int iw = ws0 - 1 + lw;
-            const bool ok = rok && iw >= 0 && iw < a.W;
+            const int lw = (int)__umulhi((unsigned)vox, a.mTi), t = vox - lw * a.Ti;
+            int iw = ws0 + lw - a.pw;
+            if (a.reflect) iw = wg_reflect(iw, a.Wi);
+            const bool ok = rok && iw >= 0 && iw < a.Wi;
             const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
-            const long o = ((long)(ok ? iw : 0) * a.T + t) * CIN;
+            const long o = ((long)(ok ? iw : 0) * a.Ti + t) * CIN;
             const float f0 = src[o + c0], f1 = src[o + c1];
             f[k][0] = ok ? f0 : 0.f;
             f[k][1] = (ok && c0 + 1 < CIN) ? f1 : 0.f;
         }
     };
-    auto stage_store = [&](int ih, int Wts, const float (&f)[NST][2]) {
-        unsigned char* slot = lds_raw + ((ih + 3) % 3) * rowbytes;
-        const int items = (Wts + 2) * a.T * NP;
+    auto stage_store = [&](int key, int Wts, const float (&f)[NST][2]) {
+        unsigned char* slot = lds_raw + (key % 3) * rowbytes;
+        const int items = (Wts + 2) * a.Ti * NP;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + 512 * k;
             if (i < items) {
                 const int vox = i / NP, cp = i - vox * NP;
-                const int lw = (int)__umulhi((unsigned)vox, a.mT), t = vox - lw * a.T;
+                const int lw = (int)__umulhi((unsigned)vox, a.mTi), t = vox - lw * a.Ti;
                 unsigned q[3];
                 split_pair(f[k][0], f[k][1], q[0], q[1], q[2]);
-                unsigned char* d = slot + (lw * a.Tp + t + 1) * VS + cp * 4;
+                unsigned char* d = slot + (lw * a.Tp + t + a.pt) * VS + cp * 4;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
             }
@@ -503,8 +512,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
 #pragma unroll 1
         for (int rr = 0; rr < 3; ++rr) {
             float f[NST][2];
-            stage_load(n, ho - 1 + rr, ws0, Wts, f);
-            stage_store(ho - 1 + rr, Wts, f);
+            stage_load(n, ho + rr, ws0, Wts, f);
+            stage_store(ho + rr, Wts, f);
         }
     };
     auto decode = [&](int tile, int& n, int& ws0, int& Wts, int& ho) {     // tile = (n * nsplit + sp) * H + ho
@@ -534,29 +543,34 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         if (has_next) decode(tile + 1, nn, nws0, nWts, nho);
         const bool consecutive = has_next && nn == n && nws0 == ws0 && nho == ho + 1;    // next tile = next row of the same column range
         float nf[NST][2];
-        if (consecutive) stage_load(n, ho + 2, ws0, Wts, nf);   // in flight during this tile's MFMAs
+        if (consecutive) stage_load(n, ho + 3, ws0, Wts, nf);   // ring row of the next tile's dh = 2, in flight during this tile's MFMAs
         const long out_base = (((long)n * a.H + ho) * a.W + ws0) * a.T;
         int tapoff[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int tap = tg + 4 * j < 27 ? tg + 4 * j : 26;
             const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
-            tapoff[j] = ((ho + dh + 2) % 3) * rowbytes + (dw * a.Tp + dt) * VS;      // slot of input row ho - 1 + dh
+            tapoff[j] = ((ho + dh) % 3) * rowbytes + (dw * a.Tp + dt) * VS;          // ring row ho + dh
         }
         // B operand: dY[voxel 16kb + 8h + j][co = col].  Three-stage pipeline over this wave's k-blocks: loads of block i+2 |
         // cutting block i+1 into pieces and its transposed-read addresses | MFMAs of block i.  The second stage is spread over
         // the seven taps of the third so that its VALU work issues in the shadow of the MFMAs.
         const float* dyrow = dy + out_base * 32 + col;
+        const float* gtrow = GATE ? gate + out_base * 32 + col : nullptr;       // the layer's own output: ReLU mask of dY
         auto load_dy = [&](int kb, float (&r)[8]) {
             const int v0 = 16 * kb + 8 * h;
             if (16 * kb + 16 <= nv) {                                                   // wave-uniform fast path
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = dyrow[(v0 + j) * 32];
+                for (int j = 0; j < 8; ++j) {
+                    r[j] = dyrow[(v0 + j) * 32];
+                    if constexpr (GATE) r[j] = gtrow[(v0 + j) * 32] > 0.f ? r[j] : 0.f;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool live = v0 + j < nv;
-                    const float d = dyrow[live ? (v0 + j) * 32 : 0];
+                    float d = dyrow[live ? (v0 + j) * 32 : 0];
+                    if constexpr (GATE) d = gtrow[live ? (v0 + j) * 32 : 0] > 0.f ? d : 0.f;
                     r[j] = live ? d : 0.f;
                 }
             }
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         XS_ACC(3);
         __syncthreads();                                   // every wave is done with this tile's rows
         XS_ACC(4);
-        if (consecutive) stage_store(ho + 2, Wts, nf);     // replaces row ho - 1
+        if (consecutive) stage_store(ho + 3, Wts, nf);     // replaces ring row ho
         else if (has_next) stage_three(nn, nho, nws0, nWts);
         XS_ACC(5);
     }
@@ -684,12 +698,15 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
 
 static int x6_wgrad_split(const ConvGeom& g)              // number of column ranges per row, 0 = unsupported
 {
-    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph != 1 || g.pw != 1 || g.pt != 1 || g.reflect_hw) return 0;
-    if (g.Cin != 25 || g.Cout != 32 || g.Ti < 2 || g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return 0;
-    for (int ns = 1; ns <= 4 && ns <= g.Wi; ++ns) {
-        const int Wt = (g.Wi + ns - 1) / ns;
-        const size_t lds = (size_t)3 * (Wt + 2) * (g.Ti + 2) * 168 + 16;
-        if (lds <= 160 * 1024 && (Wt + 2) * g.Ti * 13 <= 512 * 6) return ns;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph < 0 || g.ph > 1 || g.pw < 0 || g.pw > 1 || g.pt < 0 || g.pt > 1) return 0;
+    if (g.reflect_hw && (g.ph != 1 || g.pw != 1 || g.Hi < 2 || g.Wi < 2)) return 0;
+    if ((g.Cin != 25 && g.Cin != 32) || g.Cout != 32 || g.Ti < 2 || g.To < 2) return 0;
+    if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2 || g.Ho < 1 || g.Wo < 1) return 0;
+    const int vs = g.Cin == 25 ? 168 : 192, np = (g.Cin + 1) / 2, nst = g.Cin == 25 ? 6 : 7;
+    for (int ns = 1; ns <= 4 && ns <= g.Wo; ++ns) {
+        const int Wt = (g.Wo + ns - 1) / ns;
+        const size_t lds = (size_t)3 * (Wt + 2) * (g.Ti + 2 * g.pt) * vs + 16;
+        if (lds <= 160 * 1024 && (Wt + 2) * g.Ti * np <= 512 * nst) return ns;
     }
     return 0;
 }
@@ -702,26 +719,36 @@ static int x6_wgrad_grid(const ConvGeom& g)
 }
 size_t x6_wgrad_partial_floats(const ConvGeom& g) { return (size_t)x6_wgrad_grid(g) * ((size_t)27 * g.Cin * g.Cout + g.Cout); }
 
-int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, hipStream_t s)
+int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial, hipStream_t s)
 {
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     WgArgs a;
-    a.nsplit = x6_wgrad_split(g); a.Wt = (g.Wi + a.nsplit - 1) / a.nsplit;
-    a.N = g.N; a.H = g.Hi; a.W = g.Wi; a.T = g.Ti; a.Cout = g.Cout; a.Wp = a.Wt + 2; a.Tp = g.Ti + 2;
+    a.nsplit = x6_wgrad_split(g); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;
+    a.N = g.N; a.H = g.Ho; a.W = g.Wo; a.T = g.To; a.Cout = g.Cout; a.Hi = g.Hi; a.Wi = g.Wi; a.Ti = g.Ti;
+    a.ph = g.ph; a.pw = g.pw; a.pt = g.pt; a.reflect = g.reflect_hw;
+    a.Wp = a.Wt + 2; a.Tp = g.Ti + 2 * g.pt;
     a.nv = a.Wt * g.To; a.total_tiles = g.N * g.Ho * a.nsplit;
-    a.mT = (unsigned)((0x100000000ull + (unsigned)g.Ti - 1) / (unsigned)g.Ti);
+    a.mT = (unsigned)((0x100000000ull + (unsigned)g.To - 1) / (unsigned)g.To);
+    a.mTi = (unsigned)((0x100000000ull + (unsigned)g.Ti - 1) / (unsigned)g.Ti);
     const int grid = x6_wgrad_grid(g);
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
-    size_t lds = (size_t)3 * a.Wp * a.Tp * 168 + 16;
+    const int vs = g.Cin == 25 ? 168 : 192;
+    size_t lds = (size_t)3 * a.Wp * a.Tp * vs + 16;
     const size_t xch = (size_t)4 * (7 * 16 + 1) * 64 * sizeof(float);                 // exchange area of the epilogue
     if (lds < xch) lds = xch;
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    hipLaunchKernelGGL((conv3_wgrad_x6_kernel<25>), dim3(grid), dim3(512), lds, s, a, x, dy, partial, partial_b);
+#define PROBAV_WG6(C, G) hipLaunchKernelGGL((conv3_wgrad_x6_kernel<C, G>), dim3(grid), dim3(512), lds, s, a, x, dy, gate, partial, partial_b)
+    if (g.Cin == 25) { if (gate) PROBAV_WG6(25, true); else PROBAV_WG6(25, false); }
+    else             { if (gate) PROBAV_WG6(32, true); else PROBAV_WG6(32, false); }
+#undef PROBAV_WG6
     int rc = check_launch("conv3_wgrad_x6");
     if (rc) return rc;
     return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);

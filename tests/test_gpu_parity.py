@@ -113,8 +113,6 @@ def test_conv3d_wgrad_matches_autograd(dev, case, impl):
     if impl == 2:
         pytest.skip("impl 2 only changes the forward / backward-data kernels")
     name, N, hwt, Cin, Cout, k, pad, reflect, relu, _, _ = case
-    if impl == 3 and relu:
-        pytest.skip("the x6 backward-filter kernel covers the un-gated normConv layers")
     rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
     ho = _out_dims(hwt, k, pad, reflect)
     x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)

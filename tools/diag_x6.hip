@@ -20,7 +20,7 @@ int main()
     for (size_t i = 0; i < nout; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
     hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
     hipMemcpy(dy, h.data(), nout * 4, hipMemcpyHostToDevice);
-    for (int it = 0; it < 3; ++it) x6_conv_wgrad(g, x, dy, dw, db, part, 0);
+    for (int it = 0; it < 3; ++it) x6_conv_wgrad(g, x, dy, nullptr, dw, db, part, 0);
     hipDeviceSynchronize();
     std::vector<unsigned long long> st(8192 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
