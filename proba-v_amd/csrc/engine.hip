@@ -214,7 +214,8 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
     const float* wfrag = wf.f32;
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
-    const bool x6s = e->impl >= 3 && wf.x6 && mfma_conv_strip_supported(g);
+    static const bool no_strip = getenv("PROBAV_NO_STRIP") != nullptr;            // diagnostic: route strip-eligible layers to the row-tile kernel
+    const bool x6s = e->impl >= 3 && wf.x6 && !no_strip && mfma_conv_strip_supported(g);
     const bool x6r = e->impl >= 3 && wf.x6 && !x6s && x6_conv_rowtile_supported(g);
     const bool x6 = x6s || x6r;
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? (x6 ? CLS_CONV3_BWD_DATA_X6 : CLS_CONV3_BWD_DATA) : (x6 ? CLS_CONV3_FWD_X6 : CLS_CONV3_FWD)), geom_macs(g), s);

@@ -712,46 +712,50 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
 // floats past the voxel's channels (the next voxel's, finite) against zero filter pieces.
 // Three-stage software pipeline per tap: loads of tap i+1 | split of tap i+1's activations | MFMAs of tap i.
 template <int CC, typename Mid>
-__device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, int base0, int base1, int base2, int tap0, int ntap,
+__device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, int base0, int base1, int base2, int g0, int ng,
                                               const uint4* __restrict__ wf, f32x16& acc, Mid mid)
 {
+    // This wave's (dh, dw) groups g0 .. g0 + ng - 1; inside a group the three dt taps x two k-blocks are unrolled, so every LDS and
+    // filter offset of a step is a compile-time constant from one pointer per group (see strip_taps_x6k for why that matters).
+    // Operands are requested one step ahead (two buffers; six steps per group keep the buffer parity static).
     constexpr int CP = (CC & 1) ? CC : CC + 1;
-    auto a_ptr = [&](int tap) -> const float* {
-        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;             // wave-uniform
-        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);                  // (three scalars, not an array: an indexed
-                                                                                  //  array lands in scratch memory, one load per tap)
-        return lds + b + (dw * a.Tp + dt) * CP;
+    const int rowstep = a.Tp * CP;
+    const int glast = g0 + ng - 1;
+    auto group_ptr = [&](int g) -> const float* {
+        const int dh = g / 3, dw = g - 3 * dh;                                  // wave-uniform
+        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);
+        return lds + b + dw * rowstep;
     };
-    float raw[2][8];
-    Frag wcur[2][3], wnxt[2][3], acur[2][3];
-    auto loads = [&](int tap, Frag (&w)[2][3]) {
-        const float* pa = a_ptr(tap);
+    float R[2][8];
+    Frag W[2][3], acur[3];
+    auto request = [&](const float* pa, const uint4* pw, int st, Frag (&w)[3], float (&r)[8]) {   // st = dt * 2 + kb: compile-time
+        const int dt = st >> 1, kb = st & 1;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int j = 0; j < 8; ++j) r[j] = pa[dt * CP + 16 * kb + j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) raw[kb][j] = pa[16 * kb + j];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) w[kb][p].u = wf[((tap * 2 + kb) * 3 + p) * 64];
-        }
+        for (int p = 0; p < 3; ++p) w[p].u = pw[(st * 3 + p) * 64];
     };
-    loads(tap0, wcur);
-    split8(raw[0], acur[0]);
-    split8(raw[1], acur[1]);
+    const float* pa = group_ptr(g0);
+    const uint4* pw = wf + (long)g0 * 18 * 64;
+    request(pa, pw, 0, W[0], R[0]);
+    split8(R[0], acur);
+    bool did_mid = false;
 #pragma unroll 1
-    for (int i = 0; i < ntap; ++i) {
-        const int tn = (i + 1 < ntap) ? tap0 + i + 1 : tap0 + i;
-        loads(tn, wnxt);
-        if (i == 1) mid();                       // see strip_taps
-        __builtin_amdgcn_sched_barrier(0);
-        acc = mac6(acur[0], wcur[0], acc);
-        acc = mac6(acur[1], wcur[1], acc);
-        split8(raw[0], acur[0]);                 // the scheduler is free to slide these under the MFMAs above
-        split8(raw[1], acur[1]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int g = g0; g <= glast; ++g) {
+        const int gn = g + 1 <= glast ? g + 1 : glast;
+        const float* pan = group_ptr(gn);
+        const uint4* pwn = wf + (long)gn * 18 * 64;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wcur[kb][p] = wnxt[kb][p];
+        for (int st = 0; st < 6; ++st) {
+            if (st < 5) request(pa, pw, st + 1, W[(st + 1) & 1], R[(st + 1) & 1]);
+            else request(pan, pwn, 0, W[0], R[0]);                              // (after the last group: a harmless re-read)
+            if (st == 2 && !did_mid) { mid(); did_mid = true; }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mac6(acur, W[st & 1], acc);
+            split8(R[(st + 1) & 1], acur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pa = pan; pw = pwn;
     }
 }
 
@@ -759,47 +763,55 @@ __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* l
 // 25 the voxels (w, t), (w, t+1), (w, t+2) are 75 contiguous floats, i.e. 5 k-blocks of 16 instead of 3 taps x 2 k-blocks of a
 // 25 -> 32 padded K (-17 % MFMAs and cuts).  k-blocks kbi = group * 5 + kb, kbi in [kb0, kb0 + nkb); filters: PACK_X6_CONVK.
 template <typename Mid>
-__device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* lds, int base0, int base1, int base2, int kb0, int nkb,
+__device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* lds, int base0, int base1, int base2, int g0, int ng,
                                                const uint4* __restrict__ wf, f32x16& acc, Mid mid)
 {
-    auto a_ptr = [&](int kbi) -> const float* {
-        const int grp = kbi / 5, kb = kbi - 5 * grp, dh = grp / 3, dw = grp - 3 * dh;      // wave-uniform
+    // This wave's (dh, dw) groups g0 .. g0 + ng - 1, five k-blocks each.  The loop is NESTED -- groups at run time, the five blocks of
+    // a group unrolled -- so that everything inside a group is a compile-time offset from one LDS pointer and one filter pointer:
+    // decoding a flat block index (divisions by 5 and 3, clamps, 64-bit pointer arithmetic) cost ~25 dependent scalar instructions
+    // per block in the wave's in-order stream and was what bounded the loop (removing the MFMAs did not change its time).
+    // Operands are requested one block ahead (two buffers each); the group loop is unrolled by two so the buffer parity is static.
+    const int rowstep = a.Tp * 25;
+    const int glast = g0 + ng - 1;
+    auto group_ptr = [&](int g) -> const float* {
+        const int dh = g / 3, dw = g - 3 * dh;                                  // wave-uniform
         const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);
-        return lds + b + dw * a.Tp * 25 + 16 * kb;
+        return lds + b + dw * rowstep;
     };
-    // A k-block is only 6 MFMAs (192 cycles): one block of lead covers neither the L2 latency of the filters nor the LDS latency
-    // of the activations.  Both are requested TWO blocks ahead; three filter buffers and two activation buffers rotate through a
-    // loop unrolled by six, so that no register copy sits between a load and its use.
     float R[2][8];
-    Frag W[3][3], acur[3];
-    const int kend = kb0 + nkb - 1;
-    auto wload = [&](int kbi, Frag (&w)[3]) {
-        const int k = kbi < kend ? kbi : kend;
+    Frag W[2][3], acur[3];
+    auto request = [&](const float* pa, const uint4* pw, int kb, Frag (&w)[3], float (&r)[8]) {   // kb: compile-time
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = wf[(k * 3 + p) * 64];
-    };
-    auto aload = [&](int kbi, float (&r)[8]) {
-        const float* pa = a_ptr(kbi < kend ? kbi : kend);
+        for (int j = 0; j < 8; ++j) r[j] = pa[16 * kb + j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = pa[j];
+        for (int p = 0; p < 3; ++p) w[p].u = pw[(kb * 3 + p) * 64];
     };
-    wload(kb0, W[0]);
-    wload(kb0 + 1, W[1]);
-    aload(kb0, R[0]);
-    aload(kb0 + 1, R[1]);
+    const float* pa = group_ptr(g0);
+    const uint4* pw = wf + (long)g0 * 15 * 64;
+    request(pa, pw, 0, W[0], R[0]);
     split8(R[0], acur);
+    bool did_mid = false;
 #pragma unroll 1
-    for (int i0 = 0; i0 < nkb; i0 += 6) {
+    for (int g = g0; g <= glast; g += 2) {
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int i = i0 + u;
-            wload(kb0 + i + 2, W[(u + 2) % 3]);
-            aload(kb0 + i + 2, R[u % 2]);                                // R[u % 2] was cut in the previous step
-            if (i == 2) mid();
-            __builtin_amdgcn_sched_barrier(0);
-            if (i < nkb) acc = mac6(acur, W[u % 3], acc);                 // wave-uniform
-            split8(R[(u + 1) % 2], acur);                                 // block i + 1
-            __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 2; ++u) {
+            const int gg = g + u;                                               // this group (may be one past the end: skipped)
+            if (gg > glast) break;                                              // wave-uniform
+            const int gn = gg + 1 <= glast ? gg + 1 : glast;
+            const float* pan = group_ptr(gn);
+            const uint4* pwn = wf + (long)gn * 15 * 64;
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                const int s = 5 * u + kb;                                       // compile-time step parity (5 is odd: parity flips per group)
+                if (kb < 4) request(pa, pw, kb + 1, W[(s + 1) & 1], R[(s + 1) & 1]);
+                else request(pan, pwn, 0, W[(s + 1) & 1], R[(s + 1) & 1]);      // (after the last group: a harmless re-read)
+                if (kb == 2 && !did_mid) { mid(); did_mid = true; }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mac6(acur, W[s & 1], acc);
+                split8(R[(s + 1) & 1], acur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pa = pan; pw = pwn;
         }
     }
 }
@@ -958,8 +970,8 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
                 const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
                           base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
-                if constexpr (X6 && CC == 25) strip_taps_x6k(a, lds, base0, base1, base2, grp == 0 ? 0 : 23, grp == 0 ? 23 : 22, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
-                else if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
+                if constexpr (X6 && CC == 25) strip_taps_x6k(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);   // (the epilogue wave takes 4 of the 9 groups)
+                else if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
                 else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks, mid);
                 if (grp == 1) {
 #pragma unroll
