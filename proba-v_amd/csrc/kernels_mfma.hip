@@ -376,31 +376,44 @@ template <int MT>
 __device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
                                              int chunk, f32x16& acc0, f32x16& acc1)
 {
+    // groups (dh, dw) at run time, the three dt taps of a group unrolled: compile-time offsets inside a group (strip_taps_x6k)
     constexpr int CP = 17;
-    float r0[8], r1[8];
-    Frag wcur[3], wnxt[3], a0[3], a1[3];
-    auto loads = [&](int tap, Frag (&w)[3]) {
-        const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
-        const int toff = ((dh * a.Wp + dw) * a.Tp + dt) * CP;
+    float r0[2][8], r1[2][8];
+    Frag W[2][3], a0[3], a1[3];
+    auto group_off = [&](int g) -> int { const int dh = g / 3, dw = g - 3 * dh; return (dh * a.Wp + dw) * a.Tp * CP; };
+    auto request = [&](int goff, const uint4* pw, int dt, Frag (&w)[3], float (&q0)[8], float (&q1)[8]) {   // dt: compile-time
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { r0[j] = ldsA0[toff + j]; r1[j] = MT == 2 ? ldsA1[toff + j] : 0.f; }
+        for (int j = 0; j < 8; ++j) { q0[j] = ldsA0[goff + dt * CP + j]; q1[j] = MT == 2 ? ldsA1[goff + dt * CP + j] : 0.f; }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = wf[((tap * 2 + chunk) * 3 + p) * 64];
+        for (int p = 0; p < 3; ++p) w[p].u = pw[(dt * 6 + p) * 64];                 // fragment ((tap * 2 + chunk) * 3 + p), tap = 3 g + dt
     };
-    loads(0, wcur);
-    split8(r0, a0);
-    if (MT == 2) split8(r1, a1);
+    int goff = group_off(0);
+    const uint4* pw = wf + (long)chunk * 3 * 64;
+    request(goff, pw, 0, W[0], r0[0], r1[0]);
+    split8(r0[0], a0);
+    if (MT == 2) split8(r1[0], a1);
 #pragma unroll 1
-    for (int tap = 0; tap < 27; ++tap) {
-        loads(tap + 1 < 27 ? tap + 1 : tap, wnxt);
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = mac6(a0, wcur, acc0);
-        if (MT == 2) acc1 = mac6(a1, wcur, acc1);
-        split8(r0, a0);
-        if (MT == 2) split8(r1, a1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 9; g += 2) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wcur[p] = wnxt[p];
+        for (int u = 0; u < 2; ++u) {
+            if (g + u > 8) break;                                               // 9 groups: the second half of the last pair is empty
+            const int gn = g + u + 1 <= 8 ? g + u + 1 : 8;
+            const int goffn = group_off(gn);
+            const uint4* pwn = wf + ((long)gn * 18 + chunk * 3) * 64;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int s = 3 * u + dt;                                       // compile-time step parity (3 is odd)
+                if (dt < 2) request(goff, pw, dt + 1, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
+                else request(goffn, pwn, 0, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = mac6(a0, W[s & 1], acc0);
+                if (MT == 2) acc1 = mac6(a1, W[s & 1], acc1);
+                split8(r0[(s + 1) & 1], a0);
+                if (MT == 2) split8(r1[(s + 1) & 1], a1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            goff = goffn; pw = pwn;
+        }
     }
 }
 
@@ -410,30 +423,42 @@ template <int MT>
 __device__ __forceinline__ void conv_taps_x6k(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
                                               f32x16& acc0, f32x16& acc1)
 {
-    float r0[8], r1[8];
-    Frag wcur[3], wnxt[3], a0[3], a1[3];
-    auto loads = [&](int kbi, Frag (&w)[3]) {
-        const int grp = kbi / 5, kb = kbi - 5 * grp, dh = grp / 3, dw = grp - 3 * dh;
-        const int toff = (dh * a.Wp + dw) * a.Tp * 25 + 16 * kb;
+    float r0[2][8], r1[2][8];
+    Frag W[2][3], a0[3], a1[3];
+    auto group_off = [&](int g) -> int { const int dh = g / 3, dw = g - 3 * dh; return (dh * a.Wp + dw) * a.Tp * 25; };
+    auto request = [&](int goff, const uint4* pw, int kb, Frag (&w)[3], float (&q0)[8], float (&q1)[8]) {   // kb: compile-time
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { r0[j] = ldsA0[toff + j]; r1[j] = MT == 2 ? ldsA1[toff + j] : 0.f; }
+        for (int j = 0; j < 8; ++j) { q0[j] = ldsA0[goff + 16 * kb + j]; q1[j] = MT == 2 ? ldsA1[goff + 16 * kb + j] : 0.f; }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = wf[(kbi * 3 + p) * 64];
+        for (int p = 0; p < 3; ++p) w[p].u = pw[(kb * 3 + p) * 64];
     };
-    loads(0, wcur);
-    split8(r0, a0);
-    if (MT == 2) split8(r1, a1);
+    int goff = group_off(0);
+    const uint4* pw = wf;
+    request(goff, pw, 0, W[0], r0[0], r1[0]);
+    split8(r0[0], a0);
+    if (MT == 2) split8(r1[0], a1);
 #pragma unroll 1
-    for (int kbi = 0; kbi < 45; ++kbi) {
-        loads(kbi + 1 < 45 ? kbi + 1 : kbi, wnxt);
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = mac6(a0, wcur, acc0);
-        if (MT == 2) acc1 = mac6(a1, wcur, acc1);
-        split8(r0, a0);
-        if (MT == 2) split8(r1, a1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 9; g += 2) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wcur[p] = wnxt[p];
+        for (int u = 0; u < 2; ++u) {
+            if (g + u > 8) break;
+            const int gn = g + u + 1 <= 8 ? g + u + 1 : 8;
+            const int goffn = group_off(gn);
+            const uint4* pwn = wf + (long)gn * 15 * 64;
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                const int s = 5 * u + kb;
+                if (kb < 4) request(goff, pw, kb + 1, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
+                else request(goffn, pwn, 0, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = mac6(a0, W[s & 1], acc0);
+                if (MT == 2) acc1 = mac6(a1, W[s & 1], acc1);
+                split8(r0[(s + 1) & 1], a0);
+                if (MT == 2) split8(r1[(s + 1) & 1], a1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            goff = goffn; pw = pwn;
+        }
     }
 }
 
