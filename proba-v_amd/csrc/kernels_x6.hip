@@ -25,7 +25,7 @@ namespace probav {
 // Both weight sets live in LDS as pre-split fragments (2 x 48 KB); X comes straight from HBM into B fragments;
 // the 256-channel hidden tensor never leaves registers.
 // ---------------------------------------------------------------------------------------------------
-constexpr int PWF_WAVES = 8;
+constexpr int PWF_WAVES = 12;
 
 __global__ __launch_bounds__(64 * PWF_WAVES, 1) void pw_fwd_x6_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag,
                                                                      const uint4* __restrict__ w2frag, const float* __restrict__ b1,

@@ -32,11 +32,19 @@ union Frag { uint4 u; bf16x8 v; s16x4 hs[2]; };
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // the three truncation pieces of one value, as fp32 bit patterns whose low 16 bits are zero
+// (the mask lives in a scalar register: as a literal every v_and_b32 would be an 8-byte instruction)
+__device__ __forceinline__ unsigned hi_mask()
+{
+    unsigned m;
+    asm("s_mov_b32 %0, 0xffff0000" : "=s"(m));              // not volatile: one per kernel after CSE / hoisting
+    return m;
+}
 __device__ __forceinline__ void pieces(float x, unsigned& p0, unsigned& p1, unsigned& p2)
 {
-    p0 = __float_as_uint(x) & 0xffff0000u;
+    const unsigned M = hi_mask();
+    p0 = __float_as_uint(x) & M;
     const float r = x - __uint_as_float(p0);
-    p1 = __float_as_uint(r) & 0xffff0000u;
+    p1 = __float_as_uint(r) & M;
     p2 = __float_as_uint(r - __uint_as_float(p1));          // <= 8 significant bits left: already a bf16 value
 }
 // pieces of a pair, packed (a -> low half, b -> high half of each dword)
