@@ -286,7 +286,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         const bool rok0 = v0 + rv0 < nvox, rok1 = v0 + rv1 < nvox;
         const float do0 = dOut[(rok0 ? v0 + rv0 : v0) * 32 + col];
         const float do1 = dOut[(rok1 ? v0 + rv1 : v0) * 32 + col];
-        reduce_prev(buf ^ 1);
 
         const unsigned char* Xb = XA + buf * PB_TILE;
         const unsigned char* Db = DA + buf * PB_TILE;
@@ -309,6 +308,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             f32x16 H = zero, dH = zero, dx = zero;
             H = mac6(w1[0], xf[0], H); H = mac6(w1[1], xf[1], H);                     // (a)
             dH = mac6(w2[0], df[0], dH); dH = mac6(w2[1], df[1], dH);                 // (b)
+            __builtin_amdgcn_sched_barrier(0);
+            reduce_prev(buf ^ 1);                          // LDS reads, adds and two stores in the shadow of the 24 MFMAs just issued
+            __builtin_amdgcn_sched_barrier(0);
             XS2(0);
             Frag gf[2][3], hf[2][3];
 #pragma unroll
