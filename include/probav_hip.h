@@ -103,6 +103,16 @@ int probav_shift_l1edge_forward(const float* hr, const uint8_t* mask, const floa
                                 float pi, float* loss, int32_t* arg, float* mean, void* stream);
 int probav_shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg, int batch,
                                  int size, int border, float pi, const float* upstream, float* dpred, void* stream);
+/* cfg loss = l1msssim: Losses.shiftCompensatedRevSSIM                             models/loss.py:99-124,189-212
+ * ONE scalar for the batch: min over the shifts of  eta * (1 - sum_{scale,sample} luminance * prod_scale(contrast * structure) / B)
+ * + (1 - eta) * weighted L1 / (B * (2^bit_depth - 1)), with the reference's five exponential windows (its quirks restated in
+ * kernels_small.hip).  scratch: probav_revssim_scratch_bytes() bytes, written by the forward and read by the backward; loss and arg
+ * are one element each (the batch shares the shift).                                                                               */
+size_t probav_revssim_scratch_bytes(int batch, int border);
+int probav_revssim_forward(const float* hr, const uint8_t* mask, const float* pred, int batch, int size, int border, int bit_depth,
+                           float eta, void* scratch, size_t scratch_bytes, float* loss, int32_t* arg, void* stream);
+int probav_revssim_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg, const void* scratch,
+                            int batch, int size, int border, int bit_depth, float eta, const float* upstream, float* dpred, void* stream);
 /* replaces optimizer.apply_gradients with Keras Nadam                   models/trainClass.py:132, train.py:79-81
  * in place on the flat parameter buffer; m, v = first / second moment slots (n floats each).  The caller supplies the
  * step-dependent scalars of SURVEY.md A.5 (computed in double): c_g = (1-mu_t)/(1-Pi_t), c_m = mu_{t+1}/(1-Pi_t*mu_{t+1}),

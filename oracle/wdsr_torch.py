@@ -160,3 +160,43 @@ def shift_l1edge_loss(hr, mask, pred, border=3, pi=0.7):
             sob = (sobel(h) - sobel(c)).abs().sum(dim=(1, 2, 3)) / n
             cands.append(pi * l1 + (1 - pi) * sob)
     return torch.stack(cands).min(dim=0).values.mean()
+
+
+def shift_revssim_loss(hr, mask, pred, border=3, bit_depth=16, eta=0.25):
+    """cfg loss = l1msssim (models/loss.py:99-124, 189-212), with the reference's quirks: exponential (not Gaussian) windows
+    exp(-x / (2 sigma^2)) over x = linspace(-L/2, L/2, L); C1 in the contrast term; variances (not standard deviations) called sigma;
+    one scalar per shift for the WHOLE batch, minimum over the shifts."""
+    hr, pred = hr.to(torch.float64), pred.to(torch.float64)
+    m = mask.to(torch.float64)
+    B, S = pred.shape[0], pred.shape[1]
+    L = S - 2 * border
+    nb = 2.0 ** bit_depth - 1
+    C1, C3 = (0.01 * nb) ** 2, (0.03 * nb) ** 2 / 2
+    x = torch.linspace(-L / 2, L / 2, L, dtype=torch.float64)
+    cp = pred[:, border:border + L, border:border + L]
+    cands = []
+    for i in range(2 * border + 1):
+        for j in range(2 * border + 1):
+            h, mm = hr[:, i:i + L, j:j + L], m[:, i:i + L, j:j + L]
+            n = mm.sum(dim=(1, 2, 3))
+            b = ((h - cp * mm).sum(dim=(1, 2, 3)) / n).reshape(-1, 1, 1, 1)
+            c = (cp + b) * mm
+            ws = []
+            for sig in (0.5, 1.0, 2.0, 4.0, 8.0):
+                w1 = torch.exp(-x / (2 * sig ** 2))
+                w = torch.outer(w1, w1).reshape(1, L, L, 1) * mm
+                ws.append(w / w.sum(dim=(1, 2, 3), keepdim=True))
+            w = torch.stack(ws)                                          # [5,B,L,L,1]
+            mu_h = (w * h).sum(dim=(2, 3), keepdim=True)
+            mu_s = (w * c).sum(dim=(2, 3), keepdim=True)
+            s_h = (w * h ** 2).sum(dim=(2, 3), keepdim=True) - mu_h ** 2
+            s_s = (w * c ** 2).sum(dim=(2, 3), keepdim=True) - mu_s ** 2
+            cov = (w * h * c).sum(dim=(2, 3), keepdim=True) - mu_s * mu_h
+            lum = (2 * mu_h * mu_s + C1) / (mu_h ** 2 + mu_s ** 2 + C1)
+            con = (2 * s_h * s_s + C1) / (s_h ** 2 + s_s ** 2 + C1)
+            stc = (2 * cov + C3) / (s_h * s_s + C3)
+            pcs = (con * stc).prod(dim=0)
+            loss = 1 - (lum * pcs).sum() / B
+            l1w = ((h - c).abs() * w).sum() / B
+            cands.append(eta * loss + (1 - eta) * l1w / nb)
+    return torch.stack(cands).min()

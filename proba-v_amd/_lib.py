@@ -43,6 +43,9 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     "probav_shift_l1edge_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_shift_l1edge_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "probav_revssim_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "probav_revssim_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "probav_revssim_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "probav_clip_round": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
     "probav_nadam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                   c_float, c_float, c_float, c_void_p]),

@@ -787,6 +787,22 @@ int probav_shift_l1edge_backward(const float* hr, const uint8_t* mask, const flo
     if (!hr || !mask || !pred || !arg || !dpred || batch < 1) { set_error("probav_shift_l1edge_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
     return shift_l1edge_backward(hr, mask, pred, arg, batch, size, border, pi, upstream, dpred, (hipStream_t)stream);
 }
+size_t probav_revssim_scratch_bytes(int batch, int border) { return batch > 0 && border >= 0 ? revssim_scratch_bytes(batch, border) : 0; }
+int probav_revssim_forward(const float* hr, const uint8_t* mask, const float* pred, int batch, int size, int border, int bit_depth,
+                           float eta, void* scratch, size_t scratch_bytes, float* loss, int32_t* arg, void* stream)
+{
+    if (!hr || !mask || !pred || !scratch || !loss || !arg || batch < 1) { set_error("probav_revssim_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    if (scratch_bytes < revssim_scratch_bytes(batch, border)) { set_error("probav_revssim_forward: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+    const float maxv = (float)((1u << bit_depth) - 1u);
+    return revssim_forward(hr, mask, pred, batch, size, border, maxv, eta, (double*)scratch, loss, arg, (hipStream_t)stream);
+}
+int probav_revssim_backward(const float* hr, const uint8_t* mask, const float* pred, const int32_t* arg, const void* scratch, int batch,
+                            int size, int border, int bit_depth, float eta, const float* upstream, float* dpred, void* stream)
+{
+    if (!hr || !mask || !pred || !arg || !scratch || !dpred || batch < 1) { set_error("probav_revssim_backward: null argument", hipSuccess); return PROBAV_EINVAL; }
+    const float maxv = (float)((1u << bit_depth) - 1u);
+    return revssim_backward(hr, mask, pred, arg, (const double*)scratch, batch, size, border, maxv, eta, upstream, dpred, (hipStream_t)stream);
+}
 int probav_nadam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float c_g, float c_m, float c_v, void* stream)
 {

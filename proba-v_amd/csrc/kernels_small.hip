@@ -537,6 +537,234 @@ int shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pre
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cfg loss = l1msssim: shiftCompensatedRevSSIM (models/loss.py:99-124, 189-212), restated with the reference's quirks:
+//   weights of scale s: w1d = exp(-x / (2 sigma_s^2)), x = linspace(-L/2, L/2, L)  (NOT squared), w = outer(w1d, w1d) * M, normalised
+//   per sample;  mu, variance "sigma" and cov are w-weighted moments of H and C = (P + b) M;  luminance / contrast / structure use
+//   C1, C1, C3;  pcs = prod_s contrast_s structure_s;  ssim term = 1 - sum_{s,b} luminance_{s,b} pcs_b / B;
+//   mixed with the w-weighted L1: loss = eta * ssim + (1 - eta) * sum_{s,b,px} w |H - C| / (B * numBytes).
+// The loss is ONE scalar per shift for the whole batch, and the minimum over the shifts is taken of that scalar (the batch shares
+// the shift).  Kernel 1 (grid B x shifts) leaves 7 weighted sums per (shift, sample, scale); kernel 2 combines them and picks the
+// arg-min shift; the backward kernel differentiates that shift.  All sums in fp64.
+// ---------------------------------------------------------------------------------------------------
+#define RS_NS 5
+#define RS_NM 7          // Sw, SwH, SwC, SwHH, SwCC, SwHC, Sw|H-C|
+
+__device__ __forceinline__ double rs_w1d(int k, int L, int s)
+{
+    const double sig[RS_NS] = {0.5, 1.0, 2.0, 4.0, 8.0};
+    const double x = -0.5 * L + (double)k * (double)L / (double)(L - 1);      // tf.linspace(-L/2, L/2, L)
+    return exp(-x / (2.0 * sig[s] * sig[s]));
+}
+
+__global__ __launch_bounds__(256) void revssim_moments_kernel(
+    const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred, int S, int border,
+    double* __restrict__ mom /* [shift][B][5][7] */, int B)
+{
+    extern __shared__ double sW[];                                  // [5][L]
+    __shared__ double red[4];
+    const int b = blockIdx.x, sft = blockIdx.y, tid = threadIdx.x;
+    const int L = S - 2 * border, ns = 2 * border + 1;
+    const int i = sft / ns, j = sft - i * ns;
+    for (int k = tid; k < RS_NS * L; k += 256) sW[k] = rs_w1d(k % L, L, k / L);
+    const float* H = hr + (long)b * S * S;
+    const uint8_t* M = mask + (long)b * S * S;
+    const float* P = pred + (long)b * S * S;
+    double cnt = 0.0, dsum = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
+        cnt += (double)m;
+        dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+    }
+    cnt = block_sum(cnt, red, tid);
+    dsum = block_sum(dsum, red, tid);
+    const double bias = dsum / cnt;
+    double acc[RS_NS][RS_NM];
+#pragma unroll
+    for (int s = 0; s < RS_NS; ++s)
+#pragma unroll
+        for (int q = 0; q < RS_NM; ++q) acc[s][q] = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+        const double h = (double)H[(i + r) * S + j + c];
+        const double cc = ((double)P[(border + r) * S + border + c] + bias) * m;
+#pragma unroll
+        for (int s = 0; s < RS_NS; ++s) {
+            const double w = sW[s * L + r] * sW[s * L + c] * m;
+            acc[s][0] += w; acc[s][1] += w * h; acc[s][2] += w * cc; acc[s][3] += w * h * h; acc[s][4] += w * cc * cc;
+            acc[s][5] += w * h * cc; acc[s][6] += w * fabs(h - cc);
+        }
+    }
+    double* out = mom + ((long)sft * B + b) * RS_NS * RS_NM;
+#pragma unroll
+    for (int s = 0; s < RS_NS; ++s)
+#pragma unroll
+        for (int q = 0; q < RS_NM; ++q) {
+            const double v = block_sum(acc[s][q], red, tid);
+            if (tid == 0) out[s * RS_NM + q] = v;
+        }
+}
+
+struct RsTerms { double lum[RS_NS], con[RS_NS], str[RS_NS], muH[RS_NS], muS[RS_NS], sH[RS_NS], sS[RS_NS], cov[RS_NS], l1[RS_NS]; };
+
+__device__ __forceinline__ void rs_terms(const double* m, double C1, double C3, RsTerms& t)
+{
+#pragma unroll
+    for (int s = 0; s < RS_NS; ++s) {
+        const double* q = m + s * RS_NM;
+        const double iw = 1.0 / q[0];
+        t.muH[s] = q[1] * iw; t.muS[s] = q[2] * iw;
+        t.sH[s] = q[3] * iw - t.muH[s] * t.muH[s];
+        t.sS[s] = q[4] * iw - t.muS[s] * t.muS[s];
+        t.cov[s] = q[5] * iw - t.muS[s] * t.muH[s];
+        t.l1[s] = q[6] * iw;
+        t.lum[s] = (2.0 * t.muH[s] * t.muS[s] + C1) / (t.muH[s] * t.muH[s] + t.muS[s] * t.muS[s] + C1);
+        t.con[s] = (2.0 * t.sH[s] * t.sS[s] + C1) / (t.sH[s] * t.sH[s] + t.sS[s] * t.sS[s] + C1);
+        t.str[s] = (2.0 * t.cov[s] + C3) / (t.sH[s] * t.sS[s] + C3);
+    }
+}
+
+__global__ __launch_bounds__(64) void revssim_select_kernel(const double* __restrict__ mom, int B, int nshift, float max_val, float eta,
+                                                            float* __restrict__ loss_out, int* __restrict__ arg_out)
+{
+    const double C1 = (0.01 * max_val) * (0.01 * max_val), C3 = 0.5 * (0.03 * max_val) * (0.03 * max_val);
+    __shared__ double sl[64];
+    const int lane = threadIdx.x;
+    double mine = 1e300;
+    int marg = 0;
+    for (int sft = lane; sft < nshift; sft += 64) {                   // one lane per shift: a fixed-order sum over the batch
+        double ssim = 0.0, l1 = 0.0;
+        for (int b = 0; b < B; ++b) {
+            RsTerms t;
+            rs_terms(mom + ((long)sft * B + b) * RS_NS * RS_NM, C1, C3, t);
+            double pcs = 1.0, lsum = 0.0;
+#pragma unroll
+            for (int s = 0; s < RS_NS; ++s) { pcs *= t.con[s] * t.str[s]; lsum += t.lum[s]; l1 += t.l1[s]; }
+            ssim += lsum * pcs;
+        }
+        const double loss = (double)eta * (1.0 - ssim / B) + (1.0 - (double)eta) * (l1 / B) / (double)max_val;
+        if (loss < mine) { mine = loss; marg = sft; }
+    }
+    sl[lane] = mine;
+    __shared__ int sa[64];
+    sa[lane] = marg;
+    __syncthreads();
+    if (lane == 0) {
+        for (int k = 1; k < 64; ++k)
+            if (sl[k] < mine || (sl[k] == mine && sa[k] < marg)) { mine = sl[k]; marg = sa[k]; }
+        loss_out[0] = (float)mine;
+        arg_out[0] = marg;
+    }
+}
+
+__global__ __launch_bounds__(256) void revssim_bwd_kernel(
+    const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred, const int* __restrict__ arg,
+    const double* __restrict__ mom, int S, int border, int B, float max_val, float eta, const float* __restrict__ upstream,
+    float* __restrict__ dpred)
+{
+    extern __shared__ double sm2[];
+    double* sW = sm2;                                                // [5][L]
+    double* sG = sW + RS_NS * (S - 2 * border);                      // [L][L] dLoss/dC
+    __shared__ double red[4];
+    __shared__ double cA[RS_NS], cB[RS_NS], cC[RS_NS], cMuS[RS_NS], cMuH[RS_NS], cIw[RS_NS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = S - 2 * border, ns = 2 * border + 1;
+    const int sft = arg[0], i = sft / ns, j = sft - i * ns;
+    const double C1 = (0.01 * max_val) * (0.01 * max_val), C3 = 0.5 * (0.03 * max_val) * (0.03 * max_val);
+    const double up = upstream ? (double)upstream[0] : 1.0;
+    for (int k = tid; k < RS_NS * L; k += 256) sW[k] = rs_w1d(k % L, L, k / L);
+    if (tid == 0) {
+        RsTerms t;
+        const double* m = mom + ((long)sft * B + b) * RS_NS * RS_NM;
+        rs_terms(m, C1, C3, t);
+        double lsum = 0.0;
+#pragma unroll
+        for (int s = 0; s < RS_NS; ++s) lsum += t.lum[s];
+#pragma unroll
+        for (int s = 0; s < RS_NS; ++s) {
+            double pex = 1.0;                                        // product of contrast * structure over the OTHER scales
+#pragma unroll
+            for (int q = 0; q < RS_NS; ++q) if (q != s) pex *= t.con[q] * t.str[q];
+            const double pcs = pex * t.con[s] * t.str[s];
+            const double dl = t.muH[s] * t.muH[s] + t.muS[s] * t.muS[s] + C1;
+            const double dlum = (2.0 * t.muH[s] * dl - (2.0 * t.muH[s] * t.muS[s] + C1) * 2.0 * t.muS[s]) / (dl * dl);   // d lum / d muS
+            const double dc = t.sH[s] * t.sH[s] + t.sS[s] * t.sS[s] + C1;
+            const double dcon = (2.0 * t.sH[s] * dc - (2.0 * t.sH[s] * t.sS[s] + C1) * 2.0 * t.sS[s]) / (dc * dc);       // d con / d sS
+            const double ds = t.sH[s] * t.sS[s] + C3;
+            const double dstr_cov = 2.0 / ds, dstr_sS = -(2.0 * t.cov[s] + C3) * t.sH[s] / (ds * ds);
+            const double dT_con = lsum * pex * t.str[s], dT_str = lsum * pex * t.con[s];
+            cA[s] = pcs * dlum;                                      // dT / d muS
+            cB[s] = dT_con * dcon + dT_str * dstr_sS;                // dT / d sS
+            cC[s] = dT_str * dstr_cov;                               // dT / d cov
+            cMuS[s] = t.muS[s]; cMuH[s] = t.muH[s]; cIw[s] = 1.0 / m[s * RS_NM];
+        }
+    }
+    const float* H = hr + (long)b * S * S;
+    const uint8_t* M = mask + (long)b * S * S;
+    const float* P = pred + (long)b * S * S;
+    float* G = dpred + (long)b * S * S;
+    double cnt = 0.0, dsum = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
+        cnt += (double)m;
+        dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+    }
+    cnt = block_sum(cnt, red, tid);                                  // (barriers inside also publish sW and the c* scalars)
+    dsum = block_sum(dsum, red, tid);
+    const double bias = dsum / cnt;
+    double gm = 0.0;
+    for (int k = tid; k < L * L; k += 256) {
+        const int r = k / L, c = k - r * L;
+        const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+        const double h = (double)H[(i + r) * S + j + c];
+        const double cc = ((double)P[(border + r) * S + border + c] + bias) * m;
+        const double sg = h - cc > 0.0 ? 1.0 : (h - cc < 0.0 ? -1.0 : 0.0);
+        double g = 0.0;
+#pragma unroll
+        for (int s = 0; s < RS_NS; ++s) {
+            const double w = sW[s * L + r] * sW[s * L + c] * m * cIw[s];        // normalised weight
+            g += -((double)eta / B) * w * (cA[s] + 2.0 * cB[s] * (cc - cMuS[s]) + cC[s] * (h - cMuH[s]))
+                 - ((1.0 - (double)eta) / ((double)max_val * B)) * w * sg;
+        }
+        sG[k] = g;
+        gm += g * m;
+    }
+    gm = block_sum(gm, red, tid);
+    for (int k = tid; k < S * S; k += 256) {
+        const int Y = k / S, X = k - Y * S, r = Y - border, c = X - border;
+        float gk = 0.f;
+        if (r >= 0 && r < L && c >= 0 && c < L) {
+            const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
+            gk = (float)(m * (sG[r * L + c] - gm / cnt) * up);
+        }
+        G[k] = gk;
+    }
+}
+
+size_t revssim_scratch_bytes(int B, int border) { const int ns = 2 * border + 1; return (size_t)ns * ns * B * RS_NS * RS_NM * sizeof(double); }
+
+int revssim_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border, float max_val, float eta,
+                    double* scratch, float* loss, int* arg, hipStream_t s)
+{
+    const int L = S - 2 * border, ns = 2 * border + 1;
+    if (B <= 0 || L < 2) { set_error("revssim_forward: bad shape", hipSuccess); return PROBAV_EINVAL; }
+    hipLaunchKernelGGL(revssim_moments_kernel, dim3(B, ns * ns), dim3(256), (size_t)RS_NS * L * sizeof(double), s, hr, mask, pred, S, border, scratch, B);
+    hipLaunchKernelGGL(revssim_select_kernel, dim3(1), dim3(64), 0, s, scratch, B, ns * ns, max_val, eta, loss, arg);
+    return check_launch("revssim_forward");
+}
+int revssim_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, const double* scratch, int B, int S,
+                     int border, float max_val, float eta, const float* upstream, float* dpred, hipStream_t s)
+{
+    const int L = S - 2 * border;
+    const size_t lds = ((size_t)RS_NS * L + (size_t)L * L) * sizeof(double);
+    if (B <= 0 || L < 2 || lds > 64 * 1024) { set_error("revssim_backward: bad shape", hipSuccess); return PROBAV_EINVAL; }
+    hipLaunchKernelGGL(revssim_bwd_kernel, dim3(B), dim3(256), lds, s, hr, mask, pred, arg, scratch, S, border, B, max_val, eta, upstream, dpred);
+    return check_launch("revssim_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Keras Nadam (optimizer_v2; train.py:79-81) on the flat parameter buffer, one launch:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
 //   theta -= lr * ( (1-mu_t) g / (1-Pi_t) + mu_{t+1} m / (1-Pi_t mu_{t+1}) ) / ( sqrt(v / (1-b2^t)) + eps )

@@ -70,6 +70,12 @@ int shift_l1edge_forward(const float* hr, const uint8_t* mask, const float* pred
 int shift_l1edge_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, int B, int S, int border, float pi,
                           const float* upstream, float* dpred, hipStream_t s);
 
+size_t revssim_scratch_bytes(int B, int border);
+int revssim_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border, float max_val, float eta,
+                    double* scratch, float* loss, int* arg, hipStream_t s);
+int revssim_backward(const float* hr, const uint8_t* mask, const float* pred, const int* arg, const double* scratch, int B, int S,
+                     int border, float max_val, float eta, const float* upstream, float* dpred, hipStream_t s);
+
 int nadam_step(float* theta, const float* grad, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                float c_g, float c_m, float c_v, hipStream_t s);
 

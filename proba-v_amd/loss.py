@@ -83,6 +83,34 @@ class _ShiftL1Edge(torch.autograd.Function):
         return dpred, None, None, None, None
 
 
+class _RevSSIM(torch.autograd.Function):
+    """cfg loss = l1msssim (models/loss.py:99-124, 189-212): moments per (shift, sample, scale), one scalar per shift for the whole
+    batch, minimum over the shifts; the backward differentiates the arg-min shift."""
+
+    @staticmethod
+    def forward(ctx, pred, hr, m, border, bit_depth, eta):
+        B, S = pred.shape[0], pred.shape[1]
+        nbytes = _lib.lib().probav_revssim_scratch_bytes(B, border)
+        scratch = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=pred.device)
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        arg = torch.empty(1, dtype=torch.int32, device=pred.device)
+        _lib.check(_lib.lib().probav_revssim_forward(_lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), B, S, border, bit_depth, eta, _lib.ptr(scratch),
+                                                     nbytes, _lib.ptr(loss), _lib.ptr(arg), _lib.current_stream()), "probav_revssim_forward")
+        ctx.save_for_backward(pred, hr, m, arg, scratch)
+        ctx.border, ctx.bit_depth, ctx.eta = border, bit_depth, eta
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, hr, m, arg, scratch = ctx.saved_tensors
+        g = g.contiguous().float().reshape(1)
+        dpred = torch.empty_like(pred)
+        _lib.check(_lib.lib().probav_revssim_backward(_lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), _lib.ptr(arg), _lib.ptr(scratch), pred.shape[0],
+                                                      pred.shape[1], ctx.border, ctx.bit_depth, ctx.eta, _lib.ptr(g), _lib.ptr(dpred),
+                                                      _lib.current_stream()), "probav_revssim_backward")
+        return dpred, None, None, None, None, None
+
+
 class Losses:
     """models/loss.py:8-35: all losses / metrics in one object; constants follow the reference."""
 
@@ -95,6 +123,7 @@ class Losses:
         self.cropSizeHeight = self.targetShapeHeight - self.maxPixelShift
         self.cropSizeWidth = self.targetShapeWidth - self.maxPixelShift
         self.pi = 0.7                                     # SobelL1Mix weight (models/loss.py:21)
+        self.eta = 0.25                                   # SSIM share of the l1msssim mixture (models/loss.py:35)
 
     def _check(self, pred):
         if pred.shape[1] != self.targetShapeHeight or pred.shape[2] != self.targetShapeWidth:
@@ -137,4 +166,7 @@ class Losses:
         return _ShiftL1Edge.apply(pred, hr, m, self.cropBorder, float(self.pi))
 
     def shiftCompensatedRevSSIM(self, patchHR, maskHR, predPatchHR):
-        raise NotImplementedError("cfg loss=l1msssim (models/loss.py:99-110) is not on the hot path yet (SURVEY.md §8f-4)")
+        """models/loss.py:99-110 (cfg loss = l1msssim): the batch-level multi-scale SSIM / weighted-L1 mixture, minimum over the shifts."""
+        hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
+        self._check(pred)
+        return _RevSSIM.apply(pred, hr, m, self.cropBorder, self.bitDepth, float(self.eta))

@@ -245,6 +245,25 @@ def test_sobel_l1_mix_loss_and_gradient(dev):
     assert np.abs(g - gr).max() < 1e-5 * np.abs(gr).max()
 
 
+def test_l1msssim_loss_and_gradient(dev):
+    """cfg loss = l1msssim: batch-level value and the gradient through the arg-min shift against the torch fp64 restatement."""
+    from oracle import wdsr_torch as ot_
+    from probav_amd.loss import Losses
+    rng = np.random.default_rng(11)
+    _, hr, mask = synth.synth_batch(4, seed=12)
+    pred = (hr + rng.normal(0, 300, hr.shape)).astype(np.float32)
+    lo = Losses(targetShape=(48, 48, 1))
+    pd = torch.tensor(pred, device=dev, requires_grad=True)
+    loss = lo.shiftCompensatedRevSSIM(torch.tensor(hr).to(dev), torch.tensor(mask).to(dev), pd)
+    loss.backward()
+    pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    ref = ot_.shift_revssim_loss(torch.tensor(hr), torch.tensor(mask), pt)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    g, gr = pd.grad.cpu().double().numpy(), pt.grad.numpy()
+    assert np.abs(g - gr).max() < 1e-4 * np.abs(gr).max(), (np.abs(g - gr).max(), np.abs(gr).max())
+
+
 def test_fused_nadam_matches_keras_restatement(dev):
     """HIP Nadam (probav_nadam_step) against the fp64 restatement of the Keras rule, incl. checkpoint round trip."""
     from oracle.nadam_numpy import Nadam
