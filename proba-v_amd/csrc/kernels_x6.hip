@@ -196,55 +196,58 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
-    float bs2a = 0.f, bs2b = 0.f;
+
 
     for (int i = tid; i < 2 * PB_TILE / 16; i += 512) reinterpret_cast<uint4*>(DA)[i] = make_uint4(0u, 0u, 0u, 0u);
 
     const long ntiles = (nvox + 31) >> 5;
-    // staging: threads 0..255 move one float4 of the X tile, every thread one or two floats of the dT tile
-    // (element f = voxel * D + out, f = tid and tid + 512); clamped unconditional loads, zero selected afterwards
-    const int f0 = tid, f1 = tid + 512;
-    const int dv0 = f0 / D, do0i = f0 - dv0 * D, dv1 = f1 / D, do1i = f1 - dv1 * D;
-    const bool has1 = f1 < 32 * D;
-    auto stage_load = [&](long tile, float4& xv, float& d0, float& d1) {
+    // Staging belongs to the first-dispatched half of the workgroup (waves 0..3); the dX reduction is shared by both halves.  With the
+    // staging spread over all eight waves the second half (which loses the per-SIMD issue arbitration) was the pole wave of every tile
+    // while the first half waited ~20 % of a tile at the barrier; with staging AND reduction on the first half the roles flipped.
+    // Thread t < 256 moves one float4 of the X tile and the dT elements f = t + 256 k (k < 4, f < 32 D; element f = voxel * D + out);
+    // clamped unconditional loads, zero selected afterwards.
+    const bool stager = wave < 4;                                     // wave-uniform
+    int dvk[4], dok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int f = tid + 256 * k; dvk[k] = f / D; dok[k] = f - dvk[k] * D; }
+    float bs2[4] = {0.f, 0.f, 0.f, 0.f};
+    auto stage_load = [&](long tile, float4& xv, float (&d)[4]) {
+        if (!stager) return;
         const long v0 = tile * 32;
-        const long nrem = nvox - v0 < 32 ? nvox - v0 : 32;
-        if (tid < 256) {
-            const int vv = tid >> 3;
-            const long vsrc = vv < nrem ? v0 + vv : v0;
-            const float4 t = reinterpret_cast<const float4*>(x + vsrc * 32)[tid & 7];
-            xv = vv < nrem ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int nrem = (int)(nvox - v0 < 32 ? nvox - v0 : 32);
+        const int vv = tid >> 3;
+        const float4 t = reinterpret_cast<const float4*>(x + (v0 + (vv < nrem ? vv : 0)) * 32)[tid & 7];
+        xv = vv < nrem ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* dt0 = dT + v0 * D;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = tid + 256 * k;
+            const bool live = f < nrem * D;
+            const float a = dt0[live ? f : 0];
+            d[k] = live ? a : 0.f;
         }
-        const float a0 = dT[v0 * D + (f0 < nrem * D ? f0 : 0)];
-        const float a1 = dT[v0 * D + (f1 < nrem * D ? f1 : 0)];
-        d0 = f0 < nrem * D ? a0 : 0.f;
-        d1 = f1 < nrem * D ? a1 : 0.f;
     };
-    auto stage_store = [&](int buf, const float4& xv, float d0, float d1) {
-        if (tid < 256) {
+    auto stage_store = [&](int buf, const float4& xv, const float (&d)[4]) {
+        if (!stager) return;
+        {
             unsigned a[3], b[3];
             split_pair(xv.x, xv.y, a[0], a[1], a[2]);
             split_pair(xv.z, xv.w, b[0], b[1], b[2]);
-            unsigned char* d = XA + buf * PB_TILE + (tid >> 3) * PB_ROW + (tid & 7) * 8;
+            unsigned char* dst = XA + buf * PB_TILE + (tid >> 3) * PB_ROW + (tid & 7) * 8;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * PB_IMG) = make_uint2(a[p], b[p]);
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * PB_IMG) = make_uint2(a[p], b[p]);
         }
-        {
-            unsigned q[3];
-            pieces(d0, q[0], q[1], q[2]);
-            unsigned char* d = DA + buf * PB_TILE + dv0 * PB_ROW + do0i * 2;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned short*>(d + p * PB_IMG) = (unsigned short)(q[p] >> 16);
-        }
-        if (has1) {
-            unsigned q[3];
-            pieces(d1, q[0], q[1], q[2]);
-            unsigned char* d = DA + buf * PB_TILE + dv1 * PB_ROW + do1i * 2;
+        for (int k = 0; k < 4; ++k) {
+            if (tid + 256 * k < 32 * D) {
+                unsigned q[3];
+                pieces(d[k], q[0], q[1], q[2]);
+                unsigned char* dst = DA + buf * PB_TILE + dvk[k] * PB_ROW + dok[k] * 2;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned short*>(d + p * PB_IMG) = (unsigned short)(q[p] >> 16);
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned short*>(dst + p * PB_IMG) = (unsigned short)(q[p] >> 16);
+            }
+            bs2[k] += d[k];
         }
-        bs2a += d0;
-        bs2b += d1;
     };
 
     long tile = blockIdx.x;
@@ -255,24 +258,23 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #endif
     __syncthreads();                                   // DA pads are zero
     {
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d0 = 0.f, d1 = 0.f;
-        if (tile < ntiles) { stage_load(tile, xv, d0, d1); stage_store(0, xv, d0, d1); }
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tile < ntiles) { stage_load(tile, xv, d); stage_store(0, xv, d); }
     }
-    // dX of a tile = dOut + the eight chunk partials.  The partials of tile t are reduced at the start of iteration t+1 (after the
-    // one barrier per tile), from the buffer of t's parity, while iteration t+1 fills the other one.
-    const int rv0 = 4 * wave + (lane >> 5), rv1 = rv0 + 2;           // this wave reduces voxels 4*wave .. 4*wave+3 of dX
-    long pv0 = -1; float pdo0 = 0.f, pdo1 = 0.f;                      // previous tile: first voxel, its dOut values
+    // dX of a tile = dOut + the eight chunk partials.  The partials of tile t are reduced during iteration t+1 (after the one barrier
+    // per tile), from the buffer of t's parity, while iteration t+1 fills the other one.  Waves w and w+4 reduce voxels 8(w&3) .. 8(w&3)+7.
+    const int rk0 = wave < 4 ? 0 : 2;                                 // waves w and w+4 share the 8 voxels 8(w&3)..: two of the four lane slices each
+    long pv0 = -1; float pdo[4] = {0.f, 0.f, 0.f, 0.f};               // previous tile: first voxel, its dOut values
     auto reduce_prev = [&](int pb) {
         if (pv0 < 0) return;
-        float s0 = pdo0, s1 = pdo1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* P = TbAll + (pb * 8 + j) * PB_TB;
-            s0 += P[rv0 * 33 + col];
-            s1 += P[rv1 * 33 + col];
+        for (int k = 0; k < 2; ++k) {
+            const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
+            float sacc = pdo[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sacc += TbAll[(pb * 8 + j) * PB_TB + rv * 33 + col];
+            if (pv0 + rv < nvox) dX[(pv0 + rv) * 32 + col] = sacc;
         }
-        if (pv0 + rv0 < nvox) dX[(pv0 + rv0) * 32 + col] = s0;
-        if (pv0 + rv1 < nvox) dX[(pv0 + rv1) * 32 + col] = s1;
     };
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         XS_ACC(5);
@@ -280,13 +282,15 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         XS_ACC(1);
         float* Tb = TbAll + (buf * 8 + wave) * PB_TB;
         const long tnext = tile + gridDim.x;
-        float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd0 = 0.f, nd1 = 0.f;
-        if (tnext < ntiles) stage_load(tnext, nxv, nd0, nd1);          // in flight during this tile's MFMAs
+        float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tnext < ntiles) stage_load(tnext, nxv, nd);                 // in flight during this tile's MFMAs
         const long v0 = tile * 32;
-        const bool rok0 = v0 + rv0 < nvox, rok1 = v0 + rv1 < nvox;
-        const float do0 = dOut[(rok0 ? v0 + rv0 : v0) * 32 + col];
-        const float do1 = dOut[(rok1 ? v0 + rv1 : v0) * 32 + col];
-
+        float cdo[4] = {0.f, 0.f, 0.f, 0.f};                           // dOut of this tile's voxels, consumed by the next iteration's reduction
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
+            cdo[k] = dOut[(v0 + rv < nvox ? v0 + rv : v0) * 32 + col];
+        }
         const unsigned char* Xb = XA + buf * PB_TILE;
         const unsigned char* Db = DA + buf * PB_TILE;
         Frag xf[2][3], df[2][3];
@@ -362,9 +366,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             XS2(4);
         }
         XS_ACC(2);
-        if (tnext < ntiles) stage_store(buf ^ 1, nxv, nd0, nd1);
+        if (tnext < ntiles) stage_store(buf ^ 1, nxv, nd);
         XS_ACC(3);
-        pv0 = v0; pdo0 = do0; pdo1 = do1;
+        pv0 = v0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pdo[k] = cdo[k];
     }
     __syncthreads();
     reduce_prev(buf ^ 1);
@@ -387,13 +393,15 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     }
     // db2[out] = sum of the staged dT values: thread t always staged out (t % D) and ((t + 512) % D); fixed-order sum
     __syncthreads();
-    float* R = TbAll;
-    R[tid] = bs2a;
-    R[512 + tid] = has1 ? bs2b : 0.f;
+    float* R = TbAll;                                                 // R[f] = column sum of staged element f (f < 1024)
+    if (stager) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R[tid + 256 * k] = (tid + 256 * k < 32 * D) ? bs2[k] : 0.f;
+    }
     __syncthreads();
     if (tid < D) {
         float t = 0.f;
-        for (int j = tid; j < 1024; j += D) t += R[j];                                  // R[j] = column sum of staged element f = j
+        for (int j = tid; j < 1024; j += D) t += R[j];
         sl[8192 + 256 * (long)D + 256 + tid] = t;
     }
     XS_ACC(6);
