@@ -391,15 +391,16 @@ def test_fused_pointwise_forward_backward(dev, nvox):
             assert err < 5e-6, "impl %d %s rel err %.3e" % (impl, name, err)
 
 
-def test_mfma_engine_matches_direct_engine(dev):
-    """The two implementations of the engine (generic direct kernels / fp32-MFMA kernels) agree on a ragged batch."""
+@pytest.mark.parametrize("batch", [5, 1, 37])
+def test_mfma_engine_matches_direct_engine(dev, batch):
+    """The kernel families of the engine (generic direct kernels / fp32-MFMA kernels / x6 kernels) agree on ragged batches."""
     from probav_amd.loss import Losses
     params = synth.synth_params(seed=31, perturb=True)
     m = _model(dev, params=params)
     lo = Losses(targetShape=(48, 48, 1))
-    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(5, seed=32))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(batch, seed=32))
     res = []
-    for impl in (0, 2):
+    for impl in (0, 2, 3):
         m.set_impl(impl)
         m.flat.grad = None
         p = m(x, training=True)
@@ -409,13 +410,14 @@ def test_mfma_engine_matches_direct_engine(dev):
     with torch.no_grad():
         p1 = m(x, training=False)
     assert float((res[0][0] - p1).abs().max()) < 1e-5 * float(res[0][0].abs().max())
-    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
-    # two fp32 summation orders can flip a few of the ~10^8 ReLU gates whose pre-activation is ~0, which moves single
-    # filter-gradient entries by ~1/sqrt(#voxels): compare in relative L2 per tensor (the sharp per-kernel checks are
-    # the single-operator tests above)
-    for n, g0, g1 in zip(m.variable_names, res[0][1], res[1][1]):
-        tol = 2e-2 if n.endswith("/g") else 5e-3
-        assert float((g0 - g1).norm()) <= tol * float(g0.norm()) + 1e-12, n
+    for other in (1, 2):
+        assert float((res[0][0] - res[other][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
+        # two fp32 summation orders can flip a few of the ~10^8 ReLU gates whose pre-activation is ~0, which moves single
+        # filter-gradient entries by ~1/sqrt(#voxels): compare in relative L2 per tensor (the sharp per-kernel checks are
+        # the single-operator tests above); tiny batches have few voxels per gate, hence the looser bound there
+        for n, g0, g1 in zip(m.variable_names, res[0][1], res[other][1]):
+            tol = (2e-2 if n.endswith("/g") else 5e-3) * (1.0 if batch >= 5 else 4.0)
+            assert float((g0 - g1).norm()) <= tol * float(g0.norm()) + 1e-12, (n, other)
 
 
 def test_full_size_batch128_properties(dev):
