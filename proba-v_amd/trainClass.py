@@ -70,6 +70,71 @@ def shuffle_repeat_batch(n, epochs, batchSize, bufferSize, rng, repeat=True):
         yield np.asarray(batch)
 
 
+class BatchPrefetcher:
+    """The `.prefetch(AUTOTUNE)` of the reference's tf.data pipeline (utils/utils.py:32-39) for a HIP device: a background thread
+    gathers the next batches from the host arrays into PINNED staging buffers (`depth` rotating slots) and enqueues their
+    host-to-device copies on a side stream; the consumer's stream only waits on the copy's event.  Iterating yields tuples of
+    device tensors in exactly the order of `index_batches`.  On a CPU device it degrades to a plain gather (host-logic tests)."""
+
+    def __init__(self, arrays, dtypes, index_batches, device, depth=2):
+        import queue
+        import threading
+        self.arrays, self.dtypes, self.device, self.depth = arrays, dtypes, torch.device(device), max(1, int(depth))
+        self._it = iter(index_batches)
+        self._q = queue.Queue(maxsize=self.depth)
+        self._cuda = self.device.type == "cuda"
+        self._stream = torch.cuda.Stream(device=self.device) if self._cuda else None
+        self._slots = [None] * (self.depth + 1)               # one more slot than the queue holds: a slot is rewritten only after
+        self._thread = threading.Thread(target=self._work, daemon=True)     # its batch was handed out AND the next one produced
+        self._thread.start()
+
+    def _stage(self, k, idx):
+        outs = []
+        if self._slots[k] is None or self._slots[k][0].shape[0] < len(idx):
+            self._slots[k] = [torch.empty((len(idx),) + tuple(a.shape[1:]), dtype=dt, pin_memory=self._cuda)
+                              for a, dt in zip(self.arrays, self.dtypes)]
+        for a, dt, pin in zip(self.arrays, self.dtypes, self._slots[k]):
+            view = pin[:len(idx)]
+            view.copy_(torch.as_tensor(np.ascontiguousarray(a[idx])).to(dt))       # host gather + cast into the pinned slot
+            outs.append(view)
+        return outs
+
+    def _work(self):
+        try:
+            k = 0
+            for idx in self._it:
+                host = self._stage(k, idx)
+                if self._cuda:
+                    with torch.cuda.stream(self._stream):
+                        dev = [h.to(self.device, non_blocking=True) for h in host]
+                        ev = torch.cuda.Event()
+                        ev.record(self._stream)
+                    ev.synchronize()                          # the pinned slot may be rewritten once its copy has left the host
+                    self._q.put((dev, ev))
+                else:
+                    self._q.put(([h.clone() for h in host], None))
+                k = (k + 1) % len(self._slots)
+            self._q.put(None)
+        except BaseException as exc:                          # surface worker failures in the consumer
+            self._q.put(exc)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        dev, ev = item
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in dev:
+                t.record_stream(torch.cuda.current_stream(self.device))
+        return tuple(dev)
+
+
 def allreduce_mean_(flat_grad):
     """Average the flat gradient buffer over the data-parallel ranks: one collective per step
     (2.14 MB for p16t9c85r12).  No-op when torch.distributed is not initialised."""
@@ -320,7 +385,10 @@ class ModelTrainer:
         step = globalStep % totalSteps
         epoch = initEpoch
         logger.info("[ INFO ] Begin training...")
-        for idx in shuffle_repeat_batch(dataSetLength, epochs, globalBatchSize, bufferSize, rng):
+        mask_dtype = torch.as_tensor(np.asarray(yMask[:1])).dtype
+        batches = BatchPrefetcher((X, yHR, yMask), (torch.float32, torch.float32, mask_dtype),
+                                  shuffle_repeat_batch(dataSetLength, epochs, globalBatchSize, bufferSize, rng), self._device())
+        for xb, hb, mb in batches:
             if (totalSteps - step) == 0:
                 epoch += 1
                 step = self.step % totalSteps
@@ -329,7 +397,7 @@ class ModelTrainer:
                     m.reset_states()
             step += 1
             globalStep += 1
-            self.trainStep(self._to_dev(X[idx], torch.float32), self._to_dev(yHR[idx], torch.float32), self._to_dev(yMask[idx]))
+            self.trainStep(xb, hb, mb)
             self.step += 1
             logger.info(f"[ EPOCH {epoch}/{epochs} ] - [ STEP {step}/{int(totalSteps)} ] Loss: {self.trainLoss.result():.6f}, cPSNR: {self.trainPSNR.result():.3f}")
             self._scalar("Train PSNR", self.trainPSNR.result(), globalStep)
