@@ -19,20 +19,25 @@ F64 = np.float64
 # architecture tables
 # ----------------------------------------------------------------------------------------------
 def reducer_plan(numImgLR):
-    """Reflect-pad flags of the valid 3x3x3 `convReducer_i` layers, per temporal depth.
+    """(k, pad_hw, pad_t) of the valid k*k*k `convReducer_i` layers, per temporal depth; every pad is a
+    tf.pad(mode='reflect').
 
     models/modelsTF.py:62-69 selects the reducer by numImgLR:
       9  -> ConvReduceAndUpscale   (:152-164)  numImgLR//scale = 3 reducers, reflect pad H,W only before the first
       13 -> ConvReduceAndUpscalev3 (:123-150)  5 reducers, reflect pad before the first three
       7  -> ConvReduceAndUpscalev2 (:166-175)  2 reducers, no pad
-    (19 -> ConvReduceAndUpscaleEx uses 5x5x5 kernels and is marked EXPERIMENTAL; not restated.)
+      19 -> ConvReduceAndUpscaleEx (:76-121, EXPERIMENTAL there)  10 reducers; the first is 5x5x5 on a reflect pad of 2 on
+            H, W and T, the second pads (2,2,1), the third and fourth (2,2,0), the fifth (1,1,0), the rest none
     """
+    a, b = (3, 1, 0), (3, 0, 0)
     if numImgLR == 9:
-        return [True, False, False]
+        return [a, b, b]
     if numImgLR == 13:
-        return [True, True, True, False, False]
+        return [a, a, a, b, b]
     if numImgLR == 7:
-        return [False, False]
+        return [b, b]
+    if numImgLR == 19:
+        return [(5, 2, 2), (3, 2, 1), (3, 2, 0), (3, 2, 0), a, b, b, b, b, b]
     raise ValueError("reference defines reducers only for numImgLR in {7, 9, 13, 19}; got %r" % numImgLR)
 
 
@@ -47,9 +52,8 @@ def layer_specs(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImg
         specs.append(("expConv_%d" % i, (1, 1, 1, f, f * expRate)))
         specs.append(("decConv_%d" % i, (1, 1, 1, f * expRate, dec)))
         specs.append(("normConv_%d" % i, (3, 3, 3, dec, f)))
-    nred = len(reducer_plan(numImgLR))
-    for i in range(nred):                                       # :159-160
-        specs.append(("convReducer_%d" % (i + 1), (3, 3, 3, f, f)))
+    for i, (k, _, _) in enumerate(reducer_plan(numImgLR)):      # :159-160, :80
+        specs.append(("convReducer_%d" % (i + 1), (k, k, k, f, f)))
     s2 = scale * scale
     specs.append(("residConv1", (3, 3, 1, s2)))                 # :45-50 (depth-interleaved with main path)
     specs.append(("upscaleConv1", (3, 3, 3, f, s2)))            # :162-163
@@ -104,9 +108,9 @@ def wn_conv(x, p, padding, relu):
     return np.maximum(y, 0.0) if relu else y
 
 
-def reflect_pad_hw(x, n=1):
-    """tf.pad(x, [[0,0],[n,n],[n,n],[0,0],[0,0]], mode='reflect') (models/modelsTF.py:157-158)."""
-    return np.pad(x, [(0, 0), (n, n), (n, n), (0, 0), (0, 0)], mode="reflect")
+def reflect_pad_hw(x, n=1, nt=0):
+    """tf.pad(x, [[0,0],[n,n],[n,n],[nt,nt],[0,0]], mode='reflect') (models/modelsTF.py:157-158, :78-79)."""
+    return np.pad(x, [(0, 0), (n, n), (n, n), (nt, nt), (0, 0)], mode="reflect")
 
 
 def depth_to_space(x, s):
@@ -140,9 +144,9 @@ def wdsr_forward(x, params, mean, std, numResBlocks=12, numImgLR=9, scale=3, tap
         if taps is not None:
             taps["dec_%d" % i] = d
             taps["block_%d" % i] = h
-    for i, refl in enumerate(reducer_plan(numImgLR)):           # :152-164 / :123-150 / :166-175
-        if refl:
-            h = reflect_pad_hw(h, 1)
+    for i, (_, pad, pad_t) in enumerate(reducer_plan(numImgLR)):  # :152-164 / :123-150 / :166-175 / :76-121
+        if pad or pad_t:
+            h = reflect_pad_hw(h, pad, pad_t)
         h = wn_conv(h, params["convReducer_%d" % (i + 1)], "valid", True)
         if taps is not None:
             taps["reducer_%d" % (i + 1)] = h

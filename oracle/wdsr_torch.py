@@ -13,7 +13,9 @@ import torch.nn.functional as F
 
 def reducer_plan(numImgLR):
     """models/modelsTF.py:62-69, :123-175 (see oracle/wdsr_numpy.reducer_plan)."""
-    return {9: [True, False, False], 13: [True, True, True, False, False], 7: [False, False]}[numImgLR]
+    a, b = (3, 1, 0), (3, 0, 0)
+    return {9: [a, b, b], 13: [a, a, a, b, b], 7: [b, b],
+            19: [(5, 2, 2), (3, 2, 1), (3, 2, 0), (3, 2, 0), a, b, b, b, b, b]}[numImgLR]
 
 
 def weight_norm(v, g):
@@ -56,11 +58,9 @@ def wdsr_forward(x, params, mean, std, numResBlocks=12, numImgLR=9, scale=3):
         e = wn_conv(h, params["expConv_%d" % i], "same", True)
         d = wn_conv(e, params["decConv_%d" % i], "same", False)
         h = wn_conv(d, params["normConv_%d" % i], "same", False) + h
-    for i, refl in enumerate(reducer_plan(numImgLR)):          # :152-164
-        if refl:
-            N, H, W, T, C = h.shape
-            h2 = F.pad(h.permute(0, 3, 4, 1, 2).reshape(N, T * C, H, W), (1, 1, 1, 1), mode="reflect")
-            h = h2.reshape(N, T, C, H + 2, W + 2).permute(0, 3, 4, 1, 2)
+    for i, (_, pad, pad_t) in enumerate(reducer_plan(numImgLR)):   # :152-164, :76-121
+        if pad or pad_t:                                       # tf.pad(mode='reflect') on H, W (and T)
+            h = F.pad(h.permute(0, 4, 1, 2, 3), (pad_t, pad_t, pad, pad, pad, pad), mode="reflect").permute(0, 2, 3, 4, 1)
         h = wn_conv(h, params["convReducer_%d" % (i + 1)], "valid", True)
     h = wn_conv(h, params["upscaleConv1"], "valid", False)     # :162-163
     main = depth_to_space(h[:, :, :, 0, :], scale)             # :71-73

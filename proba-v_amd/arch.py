@@ -14,11 +14,19 @@ Layer = namedtuple("Layer", "name vshape cout g_off v_off b_off")
 
 
 def reducer_plan(numImgLR):
-    """Reflect-pad flags per valid `convReducer_i` (models/modelsTF.py:62-69, :123-175)."""
-    plans = {9: (True, False, False), 13: (True, True, True, False, False), 7: (False, False)}
+    """Per valid `convReducer_i`: (kernel size k, mirrored H/W pad, mirrored depth pad) -- models/modelsTF.py:62-69.
+
+      9  -> ConvReduceAndUpscale   (:152-164)  3 reducers, mirror pad 1 on H,W before the first
+      13 -> ConvReduceAndUpscalev3 (:123-150)  5 reducers, mirror pad 1 on H,W before the first three
+      7  -> ConvReduceAndUpscalev2 (:166-175)  2 reducers, no pad
+      19 -> ConvReduceAndUpscaleEx (:76-121, marked EXPERIMENTAL there)  10 reducers: 5x5x5 on a pad of 2 in H,W,T,
+            then 3x3x3 with pads (2,2,1), (2,2,0), (2,2,0), (1,1,0), then five unpadded
+    """
+    a, b = (3, 1, 0), (3, 0, 0)
+    plans = {9: (a, b, b), 13: (a, a, a, b, b), 7: (b, b),
+             19: ((5, 2, 2), (3, 2, 1), (3, 2, 0), (3, 2, 0), a, b, b, b, b, b)}
     if numImgLR not in plans:
-        raise ValueError("numImgLR=%r: the reference defines WDSRConv3D reducers for 7, 9, 13 (and an "
-                         "experimental 5x5x5 variant for 19 that is out of scope)" % (numImgLR,))
+        raise ValueError("numImgLR=%r: the reference defines WDSRConv3D reducers for 7, 9, 13 and 19 only" % (numImgLR,))
     return plans[numImgLR]
 
 
@@ -31,7 +39,7 @@ def layer_table(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImg
         shapes += [("expConv_%d" % i, (1, 1, 1, f, f * expRate)),
                    ("decConv_%d" % i, (1, 1, 1, f * expRate, dec)),
                    ("normConv_%d" % i, (3, 3, 3, dec, f))]
-    shapes += [("convReducer_%d" % (i + 1), (3, 3, 3, f, f)) for i in range(len(reducer_plan(numImgLR)))]
+    shapes += [("convReducer_%d" % (i + 1), (k, k, k, f, f)) for i, (k, _, _) in enumerate(reducer_plan(numImgLR))]
     shapes += [("residConv1", (3, 3, 1, s2)), ("upscaleConv1", (3, 3, 3, f, s2)),
                ("residConv2", (3, 3, s2, s2)), ("residConv3", (3, 3, s2, s2))]
     layers, off = [], 0

@@ -28,7 +28,9 @@ struct probav_engine {
     int impl = 3;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
                               // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
-    std::vector<int> iExp, iDec, iNorm, iRed, redReflect;
+    std::vector<int> iExp, iDec, iNorm, iRed;
+    struct RedSpec { int k, p, pt, refl, refl_t; };   // one valid convReducer: kernel size, H/W pad, depth pad, mirrored H/W pad, mirrored depth pad
+    std::vector<RedSpec> redSpec;
     int Hin = 0;
     // MFMA operand fragments: one packing job per (layer, use); offsets into the workspace's wpack region
     std::vector<PackJob> jobs;
@@ -108,7 +110,7 @@ static ConvGeom make_geom(int N, int Hi, int Ti, int Cin, int Ho, int To, int Co
 {
     ConvGeom g;
     g.N = N; g.Hi = Hi; g.Wi = Hi; g.Ti = Ti; g.Cin = Cin; g.Ho = Ho; g.Wo = Ho; g.To = To; g.Cout = Cout;
-    g.kh = kh; g.kw = kw; g.kt = kt; g.ph = ph; g.pw = ph; g.pt = pt; g.reflect_hw = reflect; g.relu = relu;
+    g.kh = kh; g.kw = kw; g.kt = kt; g.ph = ph; g.pw = ph; g.pt = pt; g.reflect_hw = reflect; g.relu = relu; g.reflect_t = 0;
     return g;
 }
 
@@ -117,22 +119,33 @@ static ConvGeom make_geom(int N, int Hi, int Ti, int Cin, int Ho, int To, int Co
 static ConvGeom bwd_data_geom(const ConvGeom& f)
 {
     ConvGeom b = f;
-    const int php = f.reflect_hw ? 0 : f.ph, pwp = f.reflect_hw ? 0 : f.pw;
+    const int php = f.reflect_hw ? 0 : f.ph, pwp = f.reflect_hw ? 0 : f.pw, ptp = f.reflect_t ? 0 : f.pt;
     b.Hi = f.Ho; b.Wi = f.Wo; b.Ti = f.To; b.Cin = f.Cout;
     b.Ho = f.reflect_hw ? f.Hi + 2 * f.ph : f.Hi;
     b.Wo = f.reflect_hw ? f.Wi + 2 * f.pw : f.Wi;
-    b.To = f.Ti; b.Cout = f.Cin;
-    b.ph = f.kh - 1 - php; b.pw = f.kw - 1 - pwp; b.pt = f.kt - 1 - f.pt;
-    b.reflect_hw = 0; b.relu = 0;
+    b.To = f.reflect_t ? f.Ti + 2 * f.pt : f.Ti;
+    b.Cout = f.Cin;
+    b.ph = f.kh - 1 - php; b.pw = f.kw - 1 - pwp; b.pt = f.kt - 1 - ptp;
+    b.reflect_hw = 0; b.reflect_t = 0; b.relu = 0;
     return b;
+}
+
+// geometry of reducer k on an input of extent h x h x t
+static ConvGeom red_geom(const probav_engine* e, int B, size_t k, int h, int t, int F)
+{
+    const probav_engine::RedSpec& r = e->redSpec[k];
+    ConvGeom g = make_geom(B, h, t, F, h + 2 * r.p - (r.k - 1), t + 2 * r.pt - (r.k - 1), F, r.k, r.k, r.k, r.p, r.pt, r.refl, 1);
+    g.reflect_t = r.refl_t;
+    return g;
 }
 
 static void reducer_extents(const probav_engine* e, std::vector<int>& hh, std::vector<int>& tt)
 {
     int h = e->Hin, t = e->cfg.num_img_lr;
     for (size_t k = 0; k < e->iRed.size(); ++k) {
-        if (!e->redReflect[k]) h -= 2;
-        t -= 2;
+        const probav_engine::RedSpec& r = e->redSpec[k];
+        h += 2 * r.p - (r.k - 1);
+        t += 2 * r.pt - (r.k - 1);
         hh.push_back(h); tt.push_back(t);
     }
 }
@@ -167,7 +180,16 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     p.H = take(V * E);
     p.dH = p.gA = p.gB = p.gDec = p.dtail = p.dr2 = p.dr1 = p.partial = 0;
     if (training) {
-        const size_t gmax = (size_t)B * (Hin + 2) * (Hin + 2) * T * F;
+        size_t gmax = (size_t)B * (Hin + 2) * (Hin + 2) * T * F;
+        {   // gradients of the (mirror-padded) reducer inputs
+            int h = Hin, t = T;
+            for (size_t k = 0; k < e->iRed.size(); ++k) {
+                const probav_engine::RedSpec& r = e->redSpec[k];
+                const size_t q = (size_t)B * (h + 2 * r.p) * (h + 2 * r.p) * (t + 2 * r.pt) * F;
+                if (q > gmax) gmax = q;
+                h = p.redH[k]; t = p.redT[k];
+            }
+        }
         p.gA = take(gmax); p.gB = take(gmax); p.gDec = take(V * D);
         p.dtail = take((size_t)B * P * P * s2);
         p.dr2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
@@ -182,8 +204,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         {
             int h = Hin, t = T;
             for (size_t k = 0; k < e->iRed.size(); ++k) {
-                const int refl = e->redReflect[k];
-                gs.push_back(make_geom(B, h, t, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1));
+                gs.push_back(red_geom(e, B, k, h, t, F));
                 h = p.redH[k]; t = p.redT[k];
             }
             gs.push_back(make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0));
@@ -214,6 +235,9 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
     const float* wfrag = wf.f32;
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
+    // the experimental 19-frame reducer: 5x5x5 kernels, pads of 2, mirrored depth pads (and their backward-data forms): generic kernels
+    const bool exotic = g.reflect_t || g.ph > 2 || g.pw > 2 || g.pt > 2 || (!pw && g.kh != 3) || (g.reflect_hw && g.ph > 1);
+    if (exotic) { ProfScope ps(e, bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD, geom_macs(g), s); return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s); }
     static const bool no_strip = getenv("PROBAV_NO_STRIP") != nullptr;            // diagnostic: route strip-eligible layers to the row-tile kernel
     const bool x6s = e->impl >= 3 && wf.x6 && !no_strip && mfma_conv_strip_supported(g);
     const bool x6r = e->impl >= 3 && wf.x6 && !x6s && x6_conv_rowtile_supported(g);
@@ -228,6 +252,8 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
                       float* dw, float* db, float* partial, hipStream_t s)
 {
+    const bool exotic = g.reflect_t || g.ph > 1 || g.pw > 1 || g.pt > 1 || (g.kh != 3 && g.kh != 1);
+    if (exotic) { ProfScope ps(e, CLS_CONV3_WGRAD, geom_macs(g), s); return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s); }
     const bool x6 = e->impl >= 3 && x6_wgrad_supported(g);
     ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : (x6 ? CLS_CONV3_WGRAD_X6 : CLS_CONV3_WGRAD), geom_macs(g), s);
     if (x6) return x6_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
@@ -250,8 +276,8 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
         set_error("probav_engine_create: the reference graph only closes for scale=3, maxShift=6 (models/modelsTF.py:45-53)", hipSuccess);
         return PROBAV_EINVAL;
     }
-    if (T != 7 && T != 9 && T != 13) {
-        set_error("probav_engine_create: numImgLR must be 7, 9 or 13 (models/modelsTF.py:62-69)", hipSuccess);
+    if (T != 7 && T != 9 && T != 13 && T != 19) {
+        set_error("probav_engine_create: numImgLR must be 7, 9, 13 or 19 (models/modelsTF.py:62-69)", hipSuccess);
         return PROBAV_EINVAL;
     }
     if (cfg->num_filters < 1 || cfg->num_res_blocks < 0 || cfg->exp_rate < 1 || cfg->dec_channels < 1 ||
@@ -269,11 +295,16 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
         e->iDec.push_back(add_layer(e, "decConv_" + std::to_string(i), 1, 1, 1, E, D));
         e->iNorm.push_back(add_layer(e, "normConv_" + std::to_string(i), 3, 3, 3, D, F));
     }
-    if (T == 9) e->redReflect = {1, 0, 0};
-    else if (T == 13) e->redReflect = {1, 1, 1, 0, 0};
-    else e->redReflect = {0, 0};
-    for (size_t k = 0; k < e->redReflect.size(); ++k)
-        e->iRed.push_back(add_layer(e, "convReducer_" + std::to_string(k + 1), 3, 3, 3, F, F));
+    typedef probav_engine::RedSpec RS;
+    if (T == 9) e->redSpec = {RS{3, 1, 0, 1, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}};
+    else if (T == 13) e->redSpec = {RS{3, 1, 0, 1, 0}, RS{3, 1, 0, 1, 0}, RS{3, 1, 0, 1, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}};
+    else if (T == 7) e->redSpec = {RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}};
+    else   // T == 19, ConvReduceAndUpscaleEx (models/modelsTF.py:76-121, marked EXPERIMENTAL there): a 5x5x5 layer on a fully mirrored pad of 2,
+           // four 3x3x3 layers on mirrored H/W pads of 2, 2, 2, 1 (the first also mirrors one frame of depth), five plain valid ones
+        e->redSpec = {RS{5, 2, 2, 1, 1}, RS{3, 2, 1, 1, 1}, RS{3, 2, 0, 1, 0}, RS{3, 2, 0, 1, 0}, RS{3, 1, 0, 1, 0},
+                      RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}};
+    for (size_t k = 0; k < e->redSpec.size(); ++k)
+        e->iRed.push_back(add_layer(e, "convReducer_" + std::to_string(k + 1), e->redSpec[k].k, e->redSpec[k].k, e->redSpec[k].k, F, F));
     e->iResid1 = add_layer(e, "residConv1", 3, 3, 1, 1, s2);
     e->iUp = add_layer(e, "upscaleConv1", 3, 3, 3, F, s2);
     e->iResid2 = add_layer(e, "residConv2", 3, 3, 1, s2, s2);
@@ -463,8 +494,7 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     const float* cur = W + p.act[R];
     int h = Hin, t = T;
     for (size_t k = 0; k < e->iRed.size(); ++k) {
-        const int refl = e->redReflect[k];
-        CK(conv_fwd(e, make_geom(B, h, t, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1), cur, nullptr,
+        CK(conv_fwd(e, red_geom(e, B, k, h, t, F), cur, nullptr,
                     weff(e->iRed[k]), frag(e->iRed[k]), bias(e->iRed[k]), nullptr, W + p.red[k], s));
         cur = W + p.red[k]; h = p.redH[k]; t = p.redT[k];
     }
@@ -516,14 +546,17 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, s));
     }
     for (int k = nred - 1; k >= 0; --k) {
-        const int refl = e->redReflect[k];
+        const probav_engine::RedSpec& rs = e->redSpec[k];
+        const int refl = rs.refl;
         const int hi = k ? p.redH[k - 1] : Hin, ti = k ? p.redT[k - 1] : T;
         const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
-        const ConvGeom gr = make_geom(B, hi, ti, F, p.redH[k], p.redT[k], F, 3, 3, 3, refl ? 1 : 0, 0, refl, 1);
+        const ConvGeom gr = red_geom(e, B, (size_t)k, hi, ti, F);
         CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, s));
         CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, s));
-        if (refl) {
+        if (refl && rs.p == 1 && !rs.refl_t) {
             CK(reflect_fold(oth, cur, B, hi, hi, ti * F, s));
+        } else if (refl) {
+            CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
         } else {
             float* tmp = cur; cur = oth; oth = tmp;
         }
@@ -575,7 +608,7 @@ static ConvGeom geom_from(const int32_t a[17])
 {
     ConvGeom g;
     g.N = a[0]; g.Hi = a[1]; g.Wi = a[2]; g.Ti = a[3]; g.Cin = a[4]; g.Ho = a[5]; g.Wo = a[6]; g.To = a[7]; g.Cout = a[8];
-    g.kh = a[9]; g.kw = a[10]; g.kt = a[11]; g.ph = a[12]; g.pw = a[13]; g.pt = a[14]; g.reflect_hw = a[15]; g.relu = a[16];
+    g.kh = a[9]; g.kw = a[10]; g.kt = a[11]; g.ph = a[12]; g.pw = a[13]; g.pt = a[14]; g.reflect_hw = a[15]; g.relu = a[16]; g.reflect_t = 0;
     return g;
 }
 static bool geom_ok(const ConvGeom& g)

@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(
             if (g.reflect_hw) iw = reflect_idx(iw, g.Wi);
             else if (iw < 0 || iw >= g.Wi) continue;
             for (int c = 0; c < g.kt; ++c) {
-                const int it = t + c - g.pt;
-                if (it < 0 || it >= g.Ti) continue;
+                int it = t + c - g.pt;
+                if (g.reflect_t) it = reflect_idx(it, g.Ti);
+                else if (it < 0 || it >= g.Ti) continue;
                 const long vin = (((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it;
                 const float* xp = x + vin * g.Cin;
                 const float* gp = gate ? gate + vin * g.Cin : nullptr;
@@ -165,8 +166,9 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(
                 else if (iw < 0 || iw >= g.Wi) continue;
 #pragma unroll
                 for (int c = 0; c < KT; ++c) {
-                    const int it = t + c - g.pt;
-                    if (it < 0 || it >= g.Ti) continue;
+                    int it = t + c - g.pt;
+                    if (g.reflect_t) it = reflect_idx(it, g.Ti);
+                    else if (it < 0 || it >= g.Ti) continue;
                     const float* xp = x + ((((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it) * g.Cin + ci0;
                     const int tp = (a * KW + b) * KT + c;
                     bool done = false;
@@ -289,7 +291,8 @@ static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& ch
 {
     const bool k3d = (g.kh == 3 && g.kw == 3 && g.kt == 3);
     const bool k2d = (g.kh == 3 && g.kw == 3 && g.kt == 1);
-    if (k3d) ci_per = g.Cin >= 4 ? 4 : 1;
+    if (g.kh == 5) ci_per = 1;
+    else if (k3d) ci_per = g.Cin >= 4 ? 4 : 1;
     else if (k2d) ci_per = g.Cin >= 4 ? 4 : 1;
     else ci_per = g.Cin >= 256 ? 32 : (g.Cin >= 4 ? 4 : 1);
     gy = (g.Cout + 31) / 32;
@@ -339,9 +342,11 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     const bool k3d = (g.kh == 3 && g.kw == 3 && g.kt == 3);
     const bool k2d = (g.kh == 3 && g.kw == 3 && g.kt == 1);
     const bool k1 = (g.kh == 1 && g.kw == 1 && g.kt == 1);
+    const bool k5d = (g.kh == 5 && g.kw == 5 && g.kt == 5);
 #define PROBAV_WG(KH, KW, KT, CP) \
     hipLaunchKernelGGL((conv_direct_wgrad_kernel<KH, KW, KT, CP>), grid, block, 0, s, g, x, dy, gate, partial, partial_b, vpc)
-    if (k3d && ci_per == 4) PROBAV_WG(3, 3, 3, 4);
+    if (k5d) PROBAV_WG(5, 5, 5, 1);
+    else if (k3d && ci_per == 4) PROBAV_WG(3, 3, 3, 4);
     else if (k3d) PROBAV_WG(3, 3, 3, 1);
     else if (k2d && ci_per == 4) PROBAV_WG(3, 3, 1, 4);
     else if (k2d) PROBAV_WG(3, 3, 1, 1);

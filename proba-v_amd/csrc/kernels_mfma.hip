@@ -479,6 +479,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
     const int nchunk = g.Cin / CC;
     const long out_base = ((long)n * g.Ho + h0) * g.Wo * g.To;
 
+    // K-concatenated taps read 80 floats where a (dh, dw) group holds 75: the tile's last voxel runs 5 floats into the slack
+    // words behind the tile.  Their filter rows are zero, but stale LDS bits that happen to spell Inf / NaN would still
+    // poison the sum, so the slack is cleared (made visible by the barrier after fill_tile).
+    if constexpr (X6 && CC == 25) { if (tid < 8) lds[a.rows * a.Wp * a.Tp * CP + tid] = 0.f; }
     STAMP(0);
     for (int pass = 0; pass * 8 < ntiles; ++pass) {
         const int t0 = pass * 8 + 2 * wave, t1 = t0 + 1;

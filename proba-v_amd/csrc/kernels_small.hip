@@ -202,6 +202,48 @@ int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, hipS
     return check_launch("reflect_fold");
 }
 
+// General fold: dx[i] = sum of dpad over every padded index that mirrors onto i, per dimension (pads 0..2; needs extent > 2 * pad).
+__device__ __forceinline__ int fold_srcs(int i, int n, int p, int (&u)[3])
+{
+    int c = 0;
+    u[c++] = i + p;
+    for (int j = 1; j <= p; ++j) {
+        if (i == j) u[c++] = p - j;                    // padded index p - j mirrors onto j
+        if (i == n - 1 - j) u[c++] = n - 1 + p + j;    // padded index n - 1 + p + j mirrors onto n - 1 - j
+    }
+    return c;
+}
+__global__ __launch_bounds__(256) void reflect_fold3_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int N, int H, int W,
+                                                           int T, int C, int ph, int pw, int pt)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W * T * C) return;
+    long r = i;
+    const int c = (int)(r % C); r /= C;
+    const int t = (int)(r % T); r /= T;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    int hs[3], ws[3], ts[3];
+    const int nh = fold_srcs(h, H, ph, hs), nw = fold_srcs(w, W, pw, ws), nt = fold_srcs(t, T, pt, ts);
+    const int Hp = H + 2 * ph, Wp = W + 2 * pw, Tp = T + 2 * pt;
+    float s = 0.f;
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b)
+            for (int d = 0; d < nt; ++d)
+                s += dpad[((((long)n * Hp + hs[a]) * Wp + ws[b]) * Tp + ts[d]) * C + c];
+    dx[i] = s;
+}
+int reflect_fold3(const float* dpad, float* dx, int N, int H, int W, int T, int C, int ph, int pw, int pt, hipStream_t s)
+{
+    if (ph < 0 || pw < 0 || pt < 0 || ph > 2 || pw > 2 || pt > 2 || H <= 2 * ph || W <= 2 * pw || T <= 2 * pt) {
+        set_error("reflect_fold3: pads must be 0..2 and smaller than half the extent", hipSuccess); return PROBAV_EINVAL;
+    }
+    const long n = (long)N * H * W * T * C;
+    hipLaunchKernelGGL(reflect_fold3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpad, dx, N, H, W, T, C, ph, pw, pt);
+    return check_launch("reflect_fold3");
+}
+
 // tf.clip_by_value(x, lo, hi) then tf.round (half to even == rintf in the default rounding mode)
 __global__ __launch_bounds__(256) void clip_round_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float lo, float hi)
 {

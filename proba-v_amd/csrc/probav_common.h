@@ -23,6 +23,7 @@ struct ConvGeom {
     int ph, pw, pt;
     int reflect_hw;
     int relu;
+    int reflect_t;      // the depth pad mirrors too (only the experimental 19-frame reducer, models/modelsTF.py:76-121; direct kernels only)
 };
 
 namespace probav {
@@ -57,6 +58,8 @@ int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, float
 int tail_forward(const float* up, const float* r3, float* y, int N, int P, int scale, float mean, float stdv, hipStream_t s);
 int tail_backward(const float* dy, float* dtail, int N, int P, int scale, float stdv, hipStream_t s);
 int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, hipStream_t s);
+// general form: gradient of tf.pad(x, [ph, pw, pt] 'reflect') folded back onto x [N,H,W,T,C]; pads <= 2
+int reflect_fold3(const float* dpad, float* dx, int N, int H, int W, int T, int C, int ph, int pw, int pt, hipStream_t s);
 int clip_round(const float* in, float* out, size_t n, float lo, float hi, hipStream_t s);
 int shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border,
                        float* l1_per_sample, float* l2_per_sample, float* cpsnr_per_sample,

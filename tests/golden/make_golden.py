@@ -20,6 +20,7 @@ from oracle import wdsr_torch as ot              # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FULL_GRADS = ["mainConv1", "expConv_0", "decConv_11", "normConv_5", "convReducer_1", "residConv1", "upscaleConv1", "residConv3"]
+EX_GRADS = {19: ["convReducer_2", "convReducer_5", "convReducer_10"]}   # convReducer_1 is 5x5x5 there (128 000 weights: norms only)
 
 
 def make(T, seed_w, seed_x, batch=2):
@@ -47,7 +48,7 @@ def make(T, seed_w, seed_x, batch=2):
         for key in ("g", "v", "bias"):
             a = g[key].numpy()
             norms.append([np.sqrt((a ** 2).sum()), np.abs(a).max()])
-            if name in FULL_GRADS and a.size <= 30000:
+            if name in FULL_GRADS + EX_GRADS.get(T, []) and a.size <= 30000:
                 out["grad/%s/%s" % (name, key)] = a
     out["grad_norms"] = np.array(norms)
     np.savez_compressed(os.path.join(HERE, "wdsr_t%d_b%d.npz" % (T, batch)), **out)
@@ -58,3 +59,4 @@ if __name__ == "__main__":
     make(9, 101, 102)
     make(13, 131, 132)
     make(7, 71, 72)
+    make(19, 191, 192)

@@ -32,12 +32,20 @@ def test_variable_inventory_matches_reference_checkpoint():
 
 
 def test_reducer_plans():
-    assert reducer_plan(9) == (True, False, False)          # models/modelsTF.py:152-164
-    assert reducer_plan(13) == (True, True, True, False, False)   # :123-150
-    assert reducer_plan(7) == (False, False)                 # :166-175
+    a, b = (3, 1, 0), (3, 0, 0)                              # (kernel, mirrored H/W pad, mirrored depth pad)
+    assert reducer_plan(9) == (a, b, b)                      # models/modelsTF.py:152-164
+    assert reducer_plan(13) == (a, a, a, b, b)               # :123-150
+    assert reducer_plan(7) == (b, b)                         # :166-175
+    assert reducer_plan(19) == ((5, 2, 2), (3, 2, 1), (3, 2, 0), (3, 2, 0), a, b, b, b, b, b)   # :76-121
     with pytest.raises(ValueError):
         reducer_plan(12)                                     # a literal 12-frame net is undefined
     assert layer_table(numImgLR=13)[1] == 535267 + 2 * 27712
+    # 19 frames: seven more reducers than t9, the first with a 5x5x5 kernel (125*32*32 weights + g + bias)
+    assert layer_table(numImgLR=19)[1] == 535267 + 6 * 27712 + (125 * 32 * 32 + 64)
+    h, t = 22, 19                                            # the 19-frame chain must end at P x P x 1 before the Reshape (:71)
+    for k, p, pt in reducer_plan(19) + ((3, 0, 0),):
+        h, t = h + 2 * p - k + 1, t + 2 * pt - k + 1
+    assert (h, t) == (16, 1)
 
 
 @pytest.mark.parametrize("name", ["p16t9c85r12", "p16t12c85r12"])

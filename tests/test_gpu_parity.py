@@ -312,12 +312,12 @@ def test_clip_round_half_to_even(dev):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("T", [9, 13, 7])
+@pytest.mark.parametrize("T", [9, 13, 7, 19])
 def test_end_to_end_against_golden(dev, T, impl):
-    """forward, loss, metric and all 132 (138 / 129) gradients against the committed fp64 fixtures."""
+    """forward, loss, metric and all 132 (138 / 129 / 153) gradients against the committed fp64 fixtures."""
     from probav_amd.loss import Losses
     z = np.load(os.path.join(GOLD, "wdsr_t%d_b2.npz" % T))
-    seeds = {9: (101, 102), 13: (131, 132), 7: (71, 72)}[T]
+    seeds = {9: (101, 102), 13: (131, 132), 7: (71, 72), 19: (191, 192)}[T]
     params = synth.synth_params(seed=seeds[0], perturb=True, numImgLR=T)
     m = _model(dev, T, params)
     m.set_impl(impl)

@@ -82,10 +82,10 @@ def test_depth_to_space_and_reflect_pad_conventions():
     assert p[0, 0, 0, 0, 0] == a[0, 1, 1, 0, 0] and p[0, 5, 2, 0, 0] == a[0, 2, 1, 0, 0]    # mirror without the edge
 
 
-@pytest.mark.parametrize("T", [9, 13, 7])
+@pytest.mark.parametrize("T", [9, 13, 7, 19])
 def test_golden_fixture_reproduced(T):
     z = np.load(os.path.join(GOLD, "wdsr_t%d_b2.npz" % T))
-    seeds = {9: (101, 102), 13: (131, 132), 7: (71, 72)}[T]
+    seeds = {9: (101, 102), 13: (131, 132), 7: (71, 72), 19: (191, 192)}[T]
     params = synth.synth_params(seed=seeds[0], perturb=True, numImgLR=T)
     x, hr, mask = synth.synth_batch(2, seed=seeds[1], numImgLR=T)
     flat = synth.flatten_params(params, numImgLR=T).astype(np.float64)
