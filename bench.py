@@ -202,7 +202,7 @@ def main():
             "config": {"workload": "cfg p16t%dc85r12: %d patches/GPU of [22,22,%d,1] -> [48,48,1], 12 WDSR-B blocks, 32 filters; "
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
                                    (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16"}[args.impl],
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16", 4: "h3-split-fp16"}[args.impl],
                        "arithmetic": ("fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as six exact bf16-piece products on the "
                                       "bf16 MFMA pipe (x6 kernels, error of the order of fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 3
                                       else "native fp32 MFMA / VALU"),

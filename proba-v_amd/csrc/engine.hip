@@ -26,7 +26,8 @@ struct probav_engine {
     int64_t nparams = 0, weff_count = 0, cout_total = 0;
     WnLayer* d_layers = nullptr;
     int impl = 3;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
-                              // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist
+                              // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist,
+                              // 4 = 3 with the H3 arithmetic (three products of scaled fp16 piece pairs) where it exists
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed;
     struct RedSpec { int k, p, pt, refl, refl_t; };   // one valid convReducer: kernel size, H/W pad, depth pad, mirrored H/W pad, mirrored depth pad
@@ -38,6 +39,8 @@ struct probav_engine {
     int64_t wpack_count = 0;
     std::vector<long> pkFwd, pkBwd;          // per layer: conv fragments for forward / backward-data (-1 = none)
     std::vector<long> pkFwd6, pkBwd6;        // per layer: x6 (pre-split bf16) conv fragments, impl 3
+    std::vector<long> pkFwdH, pkBwdH;        // per layer: H3 (scaled fp16 pieces) conv fragments, impl 4
+    std::vector<long> pkW1h, pkW2h, pkW2Kh, pkW1Ch;   // per block: H3 fragments of the fused expand/decay forward / backward
     std::vector<long> pkW1x6, pkW2x6;        // per block: x6 fragments of the fused expand/decay forward
     std::vector<long> pkW2Kx6, pkW1Cx6;      // per block: extra x6 fragments of the fused backward
     std::vector<long> pkW1, pkW2;            // per block: fused expand/decay forward fragments
@@ -100,6 +103,7 @@ static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }      // 64 f
 
 struct Plan {
     size_t weff, weffT, invn, dweff, xn, mn;
+    size_t amax; int n_amax, amax_bwd;        // amax slots (one 32-bit word each, x6_device.h): region offset, count, first backward slot
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
     size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
@@ -160,6 +164,12 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
     p.weff = take(e->weff_count); p.weffT = take(e->weff_count); p.invn = take(e->cout_total);
+    {   // slots: [weights | biases] per layer, act[0..R], dec[0..R-1], reducer outputs, then the backward pass's tensors in launch order
+        const int L = (int)e->layers.size(), nred = (int)e->iRed.size();
+        p.amax_bwd = 2 * L + 2 * R + 1 + nred;
+        p.n_amax = p.amax_bwd + 2 * R + 2 * nred + 8;
+        p.amax = take((size_t)p.n_amax);
+    }
     p.dweff = take(training ? e->weff_count : 0);
     p.wpack = take(e->wpack_count);
     p.xn = take(V); p.mn = take((size_t)B * Hin * Hin);
@@ -227,27 +237,52 @@ static Plan make_plan(const probav_engine* e, int B, int training)
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; };
+struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; const float* h3 = nullptr; };
 
-static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
-                    const Frags& wf, const float* bias, const float* skip, float* y, hipStream_t s)
+// amax slot addresses inside the workspace (layout: make_plan)
+struct AmaxSlots {
+    unsigned* base; int L, R, bwd;
+    AmaxSlots(const probav_engine* e, const Plan& p, float* W, int R_) : base(reinterpret_cast<unsigned*>(W + p.amax)), L((int)e->layers.size()), R(R_), bwd(p.amax_bwd) {}
+    unsigned* w(int li) const { return base + li; }
+    unsigned* b(int li) const { return base + L + li; }
+    unsigned* act(int i) const { return base + 2 * L + i; }
+    unsigned* dec(int i) const { return base + 2 * L + R + 1 + i; }
+    unsigned* red(int k) const { return base + 2 * L + 2 * R + 1 + k; }
+    unsigned* back(int j) const { return base + bwd + j; }     // j-th tensor produced by the backward pass
+};
+
+static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
+                           const Frags& wf, const float* bias, const float* skip, float* y, const Amax& am, bool& reported, hipStream_t s)
 {
     const float* wfrag = wf.f32;
     const bool pw = g.kh * g.kw * g.kt == 1;
     const bool bwd = (bias == nullptr);              // only backward-data launches run without a bias
+    reported = false;                                // does the kernel write am.y itself?
     // the experimental 19-frame reducer: 5x5x5 kernels, pads of 2, mirrored depth pads (and their backward-data forms): generic kernels
     const bool exotic = g.reflect_t || g.ph > 2 || g.pw > 2 || g.pt > 2 || (!pw && g.kh != 3) || (g.reflect_hw && g.ph > 1);
     if (exotic) { ProfScope ps(e, bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD, geom_macs(g), s); return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s); }
     static const bool no_strip = getenv("PROBAV_NO_STRIP") != nullptr;            // diagnostic: route strip-eligible layers to the row-tile kernel
-    const bool x6s = e->impl >= 3 && wf.x6 && !no_strip && mfma_conv_strip_supported(g);
-    const bool x6r = e->impl >= 3 && wf.x6 && !x6s && x6_conv_rowtile_supported(g);
+    const bool h3 = e->impl >= 4 && wf.h3 && am.x && am.w;
+    const float* wsplit = h3 ? wf.h3 : wf.x6;
+    const int arith = h3 ? 2 : 1;
+    const bool x6s = e->impl >= 3 && wsplit && !no_strip && mfma_conv_strip_supported(g);
+    const bool x6r = e->impl >= 3 && wsplit && !x6s && x6_conv_rowtile_supported(g);
     const bool x6 = x6s || x6r;
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? (x6 ? CLS_CONV3_BWD_DATA_X6 : CLS_CONV3_BWD_DATA) : (x6 ? CLS_CONV3_FWD_X6 : CLS_CONV3_FWD)), geom_macs(g), s);
-    if (x6s) return x6_conv_strip_forward(g, x, gate, wf.x6, bias, skip, y, s);
-    if (x6r) return x6_conv_rowtile_forward(g, x, gate, wf.x6, bias, skip, y, s);
-    if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, s);
-    if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, s);
+    if (x6s) { reported = true; return x6_conv_strip_forward(g, x, gate, wsplit, bias, skip, y, arith, am, s); }
+    if (x6r) { reported = true; return x6_conv_rowtile_forward(g, x, gate, wsplit, bias, skip, y, arith, am, s); }
+    if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) { reported = true; return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, am, s); }
+    if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) { reported = true; return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, am, s); }
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
+}
+// am.x / am.w: amax slots of x and of the layer's weights (H3 kernels); am.y: slot that must hold the output's amax afterwards
+static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
+                    const Frags& wf, const float* bias, const float* skip, float* y, const Amax& am, hipStream_t s)
+{
+    bool reported = false;
+    int rc = conv_fwd_launch(e, g, x, gate, w, wf, bias, skip, y, am, reported, s);
+    if (rc == PROBAV_OK && am.y && !reported) rc = amax_tensor(y, (size_t)g.N * g.Ho * g.Wo * g.To * g.Cout, am.y, s);
+    return rc;
 }
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
                       float* dw, float* db, float* partial, hipStream_t s)
@@ -320,6 +355,7 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
     // MFMA fragment-packing jobs
     e->pkFwd.assign(e->layers.size(), -1); e->pkBwd.assign(e->layers.size(), -1);
     e->pkFwd6.assign(e->layers.size(), -1); e->pkBwd6.assign(e->layers.size(), -1);
+    e->pkFwdH.assign(e->layers.size(), -1); e->pkBwdH.assign(e->layers.size(), -1);
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const LayerRec& r = e->layers[li];
         if (r.kh != 3 || r.kw != 3 || r.kt != 3) continue;
@@ -338,6 +374,11 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
                 X.type = cin == 25 ? PACK_X6_CONVK : PACK_X6_CONV; X.src_is_T = dir; X.src_off = r.wn.w_off; X.dst_off = e->wpack_count;
                 X.count = cin == 25 ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; X.Cin = cin; X.Cout = cout; X.taps = 27;
                 (dir ? e->pkBwd6 : e->pkFwd6)[li] = X.dst_off;
+                e->wpack_count += X.count;
+                e->jobs.push_back(X);
+                X.type += 10; X.dst_off = e->wpack_count; X.amax_slot = (int)li;      // PACK_H3_*
+                X.count = cin == 25 ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS;
+                (dir ? e->pkBwdH : e->pkFwdH)[li] = X.dst_off;
                 e->wpack_count += X.count;
                 e->jobs.push_back(X);
             }
@@ -370,6 +411,17 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             X.type = PACK_X6_PW_W1C; X.src_off = e->layers[e->iExp[i]].wn.w_off; X.dst_off = e->wpack_count;
             X.Cin = F; X.Cout = E;
             e->pkW1Cx6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.count = H3_PW_FRAG_WORDS;
+            X.type = PACK_H3_PW_W1; X.src_off = e->layers[e->iExp[i]].wn.w_off; X.dst_off = e->wpack_count;
+            X.Cin = F; X.Cout = E; X.amax_slot = e->iExp[i];
+            e->pkW1h.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.type = PACK_H3_PW_W1C; X.dst_off = e->wpack_count;
+            e->pkW1Ch.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.type = PACK_H3_PW_W2; X.src_off = e->layers[e->iDec[i]].wn.w_off; X.dst_off = e->wpack_count;
+            X.Cin = E; X.Cout = D; X.amax_slot = e->iDec[i];
+            e->pkW2h.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
+            X.type = PACK_H3_PW_W2K; X.dst_off = e->wpack_count;
+            e->pkW2Kh.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
         }
     }
     if (!e->jobs.empty()) {
@@ -444,7 +496,7 @@ int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_o
 
 int probav_engine_set_impl(probav_engine* e, int impl)
 {
-    if (!e || impl < 0 || impl > 3) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    if (!e || impl < 0 || impl > 4) { set_error("probav_engine_set_impl: bad argument", hipSuccess); return PROBAV_EINVAL; }
     e->impl = impl;
     return PROBAV_OK;
 }
@@ -468,40 +520,53 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
     auto weff = [&](int li) { return W + p.weff + e->layers[li].wn.w_off; };
     auto bias = [&](int li) { return params + e->layers[li].wn.b_off; };
-    auto frag = [&](int li) -> Frags { Frags f; if (e->pkFwd[li] >= 0) f.f32 = W + p.wpack + e->pkFwd[li]; if (e->pkFwd6[li] >= 0) f.x6 = W + p.wpack + e->pkFwd6[li]; return f; };
+    auto frag = [&](int li) -> Frags {
+        Frags f;
+        if (e->pkFwd[li] >= 0) f.f32 = W + p.wpack + e->pkFwd[li];
+        if (e->pkFwd6[li] >= 0) f.x6 = W + p.wpack + e->pkFwd6[li];
+        if (e->pkFwdH[li] >= 0) f.h3 = W + p.wpack + e->pkFwdH[li];
+        return f;
+    };
+    // amax slots (H3 arithmetic, impl 4): every tensor an H3 kernel reads has its largest magnitude in a slot by then
+    const bool h3 = e->impl >= 4;
+    const AmaxSlots A(e, p, W, R);
+    auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.w(li); m.y = ay; } return m; };
+    if (h3 && hipMemsetAsync(A.base, 0, (size_t)p.amax_bwd * sizeof(unsigned), s) != hipSuccess) { set_error("probav_forward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
 
-    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, s)); }
-    if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, s)); }
+    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
+    if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
-    CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], s));
+    CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
     for (int i = 0; i < R; ++i) {
         if (e->impl >= 1 && e->pw_mfma) {
             // fused expConv + ReLU + decConv: the 256-channel tensor never leaves the accumulators
             const long nvox = (long)B * Hin * Hin * T;
             ProfScope ps(e, e->impl >= 3 ? CLS_PW_FWD_X6 : CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
-            if (e->impl >= 3)
+            if (e->impl >= 3) {
                 CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                  W + p.dec[i], nvox, D, s));
-            else
+                if (h3) CK(amax_tensor(W + p.dec[i], (size_t)nvox * D, A.dec(i), s));
+            } else
                 CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                    W + p.dec[i], nvox, D, s));
         } else {
-            CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), frag(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, s));
-            CK(conv_fwd(e, make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0), W + p.H, nullptr, weff(e->iDec[i]), frag(e->iDec[i]), bias(e->iDec[i]), nullptr, W + p.dec[i], s));
+            CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), frag(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, Amax(), s));
+            CK(conv_fwd(e, make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0), W + p.H, nullptr, weff(e->iDec[i]), frag(e->iDec[i]), bias(e->iDec[i]), nullptr, W + p.dec[i], amx(nullptr, e->iDec[i], A.dec(i)), s));
         }
-        CK(conv_fwd(e, make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0), W + p.dec[i], nullptr, weff(e->iNorm[i]), frag(e->iNorm[i]), bias(e->iNorm[i]), W + p.act[i], W + p.act[i + 1], s));
+        CK(conv_fwd(e, make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0), W + p.dec[i], nullptr, weff(e->iNorm[i]), frag(e->iNorm[i]), bias(e->iNorm[i]), W + p.act[i], W + p.act[i + 1], amx(A.dec(i), e->iNorm[i], A.act(i + 1)), s));
     }
     const float* cur = W + p.act[R];
+    const unsigned* acur = A.act(R);
     int h = Hin, t = T;
     for (size_t k = 0; k < e->iRed.size(); ++k) {
         CK(conv_fwd(e, red_geom(e, B, k, h, t, F), cur, nullptr,
-                    weff(e->iRed[k]), frag(e->iRed[k]), bias(e->iRed[k]), nullptr, W + p.red[k], s));
-        cur = W + p.red[k]; h = p.redH[k]; t = p.redT[k];
+                    weff(e->iRed[k]), frag(e->iRed[k]), bias(e->iRed[k]), nullptr, W + p.red[k], amx(acur, e->iRed[k], A.red((int)k)), s));
+        cur = W + p.red[k]; acur = A.red((int)k); h = p.redH[k]; t = p.redT[k];
     }
-    CK(conv_fwd(e, make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0), cur, nullptr, weff(e->iUp), frag(e->iUp), bias(e->iUp), nullptr, W + p.up, s));
-    CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, s));
-    CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, s));
-    CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, s));
+    CK(conv_fwd(e, make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0), cur, nullptr, weff(e->iUp), frag(e->iUp), bias(e->iUp), nullptr, W + p.up, amx(acur, e->iUp, nullptr), s));
+    CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), s));
+    CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, Amax(), s));
+    CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, Amax(), s));
     CK(tail_forward(W + p.up, W + p.r3, y, B, P, c.scale, c.mean, c.std, s));
     return PROBAV_OK;
 }
@@ -518,7 +583,20 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
     auto weffT = [&](int li) { return W + p.weffT + e->layers[li].wn.w_off; };
-    auto fragT = [&](int li) -> Frags { Frags f; if (e->pkBwd[li] >= 0) f.f32 = W + p.wpack + e->pkBwd[li]; if (e->pkBwd6[li] >= 0) f.x6 = W + p.wpack + e->pkBwd6[li]; return f; };
+    auto fragT = [&](int li) -> Frags {
+        Frags f;
+        if (e->pkBwd[li] >= 0) f.f32 = W + p.wpack + e->pkBwd[li];
+        if (e->pkBwd6[li] >= 0) f.x6 = W + p.wpack + e->pkBwd6[li];
+        if (e->pkBwdH[li] >= 0) f.h3 = W + p.wpack + e->pkBwdH[li];
+        return f;
+    };
+    // amax slots of the gradient tensors, in launch order (the forward pass left those of the weights and activations)
+    const bool h3 = e->impl >= 4;
+    const AmaxSlots A(e, p, W, R);
+    int nback = 0;
+    auto new_slot = [&]() -> unsigned* { return h3 ? A.back(nback++) : nullptr; };
+    auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.w(li); m.y = ay; } return m; };
+    if (h3 && hipMemsetAsync(A.back(0), 0, (size_t)(p.n_amax - p.amax_bwd) * sizeof(unsigned), s) != hipSuccess) { set_error("probav_backward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
     auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     float* part = W + p.partial;
@@ -528,10 +606,10 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     {
         const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
         CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), part, s));
-        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, s));
+        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, Amax(), s));
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
         CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), part, s));
-        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, s));
+        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, Amax(), s));
         const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
         CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), part, s));
     }
@@ -539,11 +617,12 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     const int nred = (int)e->iRed.size();
     float* cur = W + p.gA;
     float* oth = W + p.gB;
+    unsigned* acur = new_slot();                    // amax slot of the tensor `cur` holds
     {
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
         CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, s));
+        CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
     }
     for (int k = nred - 1; k >= 0; --k) {
         const probav_engine::RedSpec& rs = e->redSpec[k];
@@ -552,13 +631,16 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
         const ConvGeom gr = red_geom(e, B, (size_t)k, hi, ti, F);
         CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, s));
-        if (refl && rs.p == 1 && !rs.refl_t) {
-            CK(reflect_fold(oth, cur, B, hi, hi, ti * F, s));
-        } else if (refl) {
-            CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
+        unsigned* aoth = new_slot();
+        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, amx(acur, e->iRed[k], aoth), s));
+        if (refl) {
+            if (rs.p == 1 && !rs.refl_t) CK(reflect_fold(oth, cur, B, hi, hi, ti * F, s));
+            else CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
+            acur = new_slot();                      // the folded gradient is a new tensor
+            if (h3) CK(amax_tensor(cur, (size_t)B * hi * hi * ti * F, acur, s));
         } else {
             float* tmp = cur; cur = oth; oth = tmp;
+            acur = aoth;
         }
     }
     // residual blocks (models/modelsTF.py:177-189), last first.  cur = d loss / d act[i+1]
@@ -572,7 +654,8 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
         // normConv_i: d loss/d w, then d loss/d dec_i
         CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, s));
+        unsigned* agdec = new_slot();
+        CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, amx(acur, ln, agdec), s));
         if (e->impl >= 1 && e->pw_mfma) {
             // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
             const long nvox = (long)B * Hin * Hin * T;
@@ -584,17 +667,21 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
                 CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
                                     params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
             float* tmp2 = cur; cur = oth; oth = tmp2;
+            acur = new_slot();
+            if (h3) CK(amax_tensor(cur, (size_t)nvox * F, acur, s));
             continue;
         }
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
-        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, s));
+        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, Amax(), s));
         // decConv_i
         CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, s));
-        CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, s));
+        CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, Amax(), s));
         // expConv_i: ReLU gate (H > 0) applied where dH is consumed; skip path adds d loss/d act[i+1]
         CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), part, s));
-        CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), fragT(le), nullptr, cur, oth, s));
+        unsigned* aoth = new_slot();
+        CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), fragT(le), nullptr, cur, oth, amx(nullptr, le, aoth), s));
         float* tmp = cur; cur = oth; oth = tmp;
+        acur = aoth;
     }
     // mainConv1 (input-facing: no backward-data)
     CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
@@ -624,23 +711,40 @@ static bool geom_ok(const ConvGeom& g)
 // weights into MFMA fragments needs a device buffer, allocated on first use -- the engine path never does this.
 static float* g_op_frag = nullptr;
 static PackJob* g_op_job = nullptr;
-static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, bool x6 = false)
+static unsigned* g_op_amax = nullptr;    // [0] activations, [1] weights (second weights: [2]), [4..] outputs / other operands
+static int op_scratch()
 {
-    const size_t n = x6 ? (size_t)X6_CONV_FRAG_WORDS : mfma_conv_wfrag_floats(g.Cin, g.Cout);
+    if (g_op_frag) return PROBAV_OK;
+    hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
+    if (err == hipSuccess) err = hipMalloc((void**)&g_op_job, 4 * sizeof(PackJob));
+    if (err == hipSuccess) err = hipMalloc((void**)&g_op_amax, 16 * sizeof(unsigned));
+    if (err != hipSuccess) { set_error("single-operator scratch allocation", err); return PROBAV_EHIP; }
+    return PROBAV_OK;
+}
+// amax of the operands of a single-operator call with H3 arithmetic (the engine gets them from the producing kernels)
+static int op_amax(const float* x, size_t nx, const float* w, size_t nw, hipStream_t s)
+{
+    if (hipMemsetAsync(g_op_amax, 0, 16 * sizeof(unsigned), s) != hipSuccess) { set_error("single-operator amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    int rc = amax_tensor(x, nx, g_op_amax + 0, s);
+    if (rc == PROBAV_OK && w) rc = amax_tensor(w, nw, g_op_amax + 1, s);
+    return rc;
+}
+static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split = 0)       // split: 0 fp32 fragments, 1 X6, 2 H3
+{
+    const size_t n = split ? (size_t)X6_CONV_FRAG_WORDS : mfma_conv_wfrag_floats(g.Cin, g.Cout);
     if (n == 0) { set_error("probav_conv3d_forward: channel configuration not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
-    if (!g_op_frag) {
-        hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
-        if (err == hipSuccess) err = hipMalloc((void**)&g_op_job, sizeof(PackJob));
-        if (err != hipSuccess) { set_error("probav_conv3d_forward: scratch allocation", err); return PROBAV_EHIP; }
-    }
+    int rc = op_scratch();
+    if (rc) return rc;
     if (n * sizeof(float) > ((size_t)4 << 20)) { set_error("probav_conv3d_forward: fragment scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     PackJob J; memset(&J, 0, sizeof(J));
-    if (x6) { J.type = g.Cin == 25 ? PACK_X6_CONVK : PACK_X6_CONV; J.count = g.Cin == 25 ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27; }
-    else mfma_conv_pack_job(J, g.Cin, g.Cout);
+    if (split) {
+        J.type = g.Cin == 25 ? PACK_X6_CONVK : PACK_X6_CONV; J.count = g.Cin == 25 ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27;
+        if (split == 2) { J.type += 10; J.count = g.Cin == 25 ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS; J.amax_slot = 1; }
+    } else mfma_conv_pack_job(J, g.Cin, g.Cout);
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(g_op_job, &J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_conv3d_forward: job upload", err); return PROBAV_EHIP; }
-    return mfma_pack(g_op_job, 1, w, w, g_op_frag, s);
+    return mfma_pack(g_op_job, 1, w, w, g_op_frag, g_op_amax, s);
 }
 
 int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w, const float* bias,
@@ -649,17 +753,25 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     if (!geom || !x || !w || !y) { set_error("probav_conv3d_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
-    if (impl < 0 || impl > 3) { set_error("probav_conv3d_forward: impl must be 0..3", hipSuccess); return PROBAV_EINVAL; }
+    if (impl < 0 || impl > 4) { set_error("probav_conv3d_forward: impl must be 0..4", hipSuccess); return PROBAV_EINVAL; }
     if (impl >= 1) {
-        const bool x6row = impl == 3 && !mfma_conv_strip_supported(g) && x6_conv_rowtile_supported(g);
+        const bool x6row = impl >= 3 && !mfma_conv_strip_supported(g) && x6_conv_rowtile_supported(g);
         const bool okk = x6row || (impl >= 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g));
         if (!okk) { set_error("probav_conv3d_forward: geometry not supported by this MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
-        int rc = op_pack(g, w, (hipStream_t)stream, impl == 3);
+        int rc = op_scratch();
         if (rc) return rc;
-        if (x6row) return x6_conv_rowtile_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
-        if (impl == 3) return x6_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
-        if (impl == 2) return mfma_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
-        return mfma_conv_forward(g, x, gate, g_op_frag, bias, skip, y, (hipStream_t)stream);
+        Amax am;
+        if (impl == 4) {
+            rc = op_amax(x, (size_t)g.N * g.Hi * g.Wi * g.Ti * g.Cin, w, (size_t)g.kh * g.kw * g.kt * g.Cin * g.Cout, (hipStream_t)stream);
+            if (rc) return rc;
+            am.x = g_op_amax; am.w = g_op_amax + 1; am.y = g_op_amax + 4;
+        }
+        rc = op_pack(g, w, (hipStream_t)stream, impl >= 3 ? impl - 2 : 0);
+        if (rc) return rc;
+        if (x6row) return x6_conv_rowtile_forward(g, x, gate, g_op_frag, bias, skip, y, impl - 2, am, (hipStream_t)stream);
+        if (impl >= 3) return x6_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, impl - 2, am, (hipStream_t)stream);
+        if (impl == 2) return mfma_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, am, (hipStream_t)stream);
+        return mfma_conv_forward(g, x, gate, g_op_frag, bias, skip, y, am, (hipStream_t)stream);
     }
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, (hipStream_t)stream);
 }
@@ -696,11 +808,7 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
 // fused pointwise pair, single-operator form (packs the Keras-layout weights into MFMA fragments in library scratch)
 static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2, const float** f2b, const float** f1c)
 {
-    if (!g_op_frag) {
-        hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
-        if (err == hipSuccess) err = hipMalloc((void**)&g_op_job, sizeof(PackJob));
-        if (err != hipSuccess) { set_error("probav_pw: scratch allocation", err); return PROBAV_EHIP; }
-    }
+    { int rc0 = op_scratch(); if (rc0) return rc0; }
     static PackJob* d_jobs4 = nullptr;
     if (!d_jobs4) { hipError_t err = hipMalloc((void**)&d_jobs4, 4 * sizeof(PackJob)); if (err != hipSuccess) { set_error("probav_pw: job allocation", err); return PROBAV_EHIP; } }
     PackJob J[4]; memset(J, 0, sizeof(J));
@@ -715,7 +823,7 @@ static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, co
     if (err == hipSuccess) err = hipMemcpy(d_jobs4, J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_pw: job upload", err); return PROBAV_EHIP; }
     *f1 = g_op_frag + J[0].dst_off; *f2 = g_op_frag + J[1].dst_off; *f2b = g_op_frag + J[2].dst_off; *f1c = g_op_frag + J[3].dst_off;
-    return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, s);
+    return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, nullptr, s);
 }
 
 static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2,
@@ -739,7 +847,7 @@ static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s,
     *f1 = frag; *f2 = frag + X6_PW_FRAG_WORDS;
     if (f2k) *f2k = frag + 2 * X6_PW_FRAG_WORDS;
     if (f1c) *f1c = frag + 3 * X6_PW_FRAG_WORDS;
-    return mfma_pack(d_jobs, 4, w1, w2, frag, s);
+    return mfma_pack(d_jobs, 4, w1, w2, frag, nullptr, s);
 }
 
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
@@ -784,7 +892,7 @@ int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, 
 int probav_wn_forward(probav_engine* e, const float* params, float* weff, float* weffT, float* inv_norm, void* stream)
 {
     if (!e || !params || !weff || !weffT || !inv_norm) { set_error("probav_wn_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
-    return wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, weff, weffT, inv_norm, (hipStream_t)stream);
+    return wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, weff, weffT, inv_norm, nullptr, (hipStream_t)stream);
 }
 int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm, float* grads, void* stream)
 {

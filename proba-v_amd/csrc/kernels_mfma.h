@@ -6,37 +6,45 @@ namespace probav {
 
 enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4,
        // pre-split bf16 operand fragments of the x6 kernels (three truncation pieces per value, 16 B per lane and fragment)
-       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14, PACK_X6_CONVK = 15 };
+       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14, PACK_X6_CONVK = 15,
+       // the same fragment orders with two scaled fp16 pieces per value (H3 arithmetic, x6_device.h): type = PACK_X6_* + 10
+       PACK_H3_PW_W1 = 20, PACK_H3_PW_W2 = 21, PACK_H3_CONV = 22, PACK_H3_PW_W2K = 23, PACK_H3_PW_W1C = 24, PACK_H3_CONVK = 25 };
 constexpr long X6_PW_FRAG_WORDS = 8 * 2 * 3 * 64 * 4;      // [8 chunks][2 k-blocks][3 pieces][64 lanes] x 16 B
 constexpr long X6_CONV_FRAG_WORDS = 27 * 2 * 3 * 64 * 4;   // [27 taps][2 k-blocks][3 pieces][64 lanes] x 16 B
 constexpr long X6_CONVK_FRAG_WORDS = 9 * 5 * 3 * 64 * 4;   // Cin = 25, K = (dt, ci) concatenated: [9 (dh,dw)][5 k-blocks][3 pieces][64 lanes] x 16 B
+constexpr long H3_PW_FRAG_WORDS = 8 * 2 * 2 * 64 * 4;      // two pieces instead of three
+constexpr long H3_CONV_FRAG_WORDS = 27 * 2 * 2 * 64 * 4;
+constexpr long H3_CONVK_FRAG_WORDS = 9 * 5 * 2 * 64 * 4;
 
 // One packing job: effective weights (weff / weffT, layout [tap][Cin][Cout]) -> MFMA operand fragments.
 struct PackJob {
     int type, src_is_T;
     long src_off, dst_off, count;     // offsets in floats; count = floats written (multiple of 256)
     int Cin, Cout, CC, KS, taps;
+    int amax_slot;                    // PACK_H3_*: index of the source tensor's amax in the array handed to mfma_pack
 };
 
-int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, hipStream_t s);
+// amax: per-tensor largest magnitudes (float bit patterns) of the weights, read by the PACK_H3_* jobs (may be null without such jobs)
+int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, const unsigned* amax, hipStream_t s);
 
 bool mfma_conv_supported(const ConvGeom& g);
 size_t mfma_conv_wfrag_floats(int Cin, int Cout);          // 0 = this channel configuration is not packed
 void mfma_conv_pack_job(PackJob& J, int Cin, int Cout);    // fills type/Cin/Cout/CC/KS/taps/count
 int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
-                      const float* skip, float* y, hipStream_t s);
+                      const float* skip, float* y, const Amax& am, hipStream_t s);
 
 // strip form (ring of input rows, flattened tiles, K split over wave pairs); same fragment layout as mfma_conv_forward
 bool mfma_conv_strip_supported(const ConvGeom& g);
 int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
-                            const float* skip, float* y, hipStream_t s);
-// row-tile kernel with the x6 tap loop (32-channel inputs: reducers, upscale; any pads / reflect); wfrag6 = PACK_X6_CONV fragments
+                            const float* skip, float* y, const Amax& am, hipStream_t s);
+// row-tile kernel with a split-operand tap loop (32-channel inputs: reducers, upscale; any pads / reflect).  arith 1: X6,
+// wfrag6 = PACK_X6_CONV / _CONVK fragments; arith 2: H3, PACK_H3_* fragments and am.x / am.w set (x6_device.h)
 bool x6_conv_rowtile_supported(const ConvGeom& g);
 int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
-                            const float* skip, float* y, hipStream_t s);
-// the strip kernel with the x6 tap loop; wfrag6 = PACK_X6_CONV fragments
+                            const float* skip, float* y, int arith, const Amax& am, hipStream_t s);
+// the strip kernel with a split-operand tap loop (same fragments)
 int x6_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
-                          const float* skip, float* y, hipStream_t s);
+                          const float* skip, float* y, int arith, const Amax& am, hipStream_t s);
 
 bool mfma_wgrad_supported(const ConvGeom& g);
 size_t mfma_wgrad_partial_floats(const ConvGeom& g);

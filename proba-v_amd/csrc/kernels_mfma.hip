@@ -66,38 +66,49 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // weight fragment packing (one launch per forward for all layers)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ weff,
-                                                  const float* __restrict__ weffT, float* __restrict__ wpack)
+                                                  const float* __restrict__ weffT, float* __restrict__ wpack,
+                                                  const unsigned* __restrict__ amax)
 {
     const PackJob J = jobs[blockIdx.y];
     const float* src = (J.src_is_T ? weffT : weff) + J.src_off;
     float* dst = wpack + J.dst_off;
+    const bool h3 = J.type >= PACK_H3_PW_W1;
+    const int type = h3 ? J.type - 10 : J.type;
+    const float wscale = h3 ? pow2i(h3_exp(amax[J.amax_slot])) : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < J.count; i += (long)gridDim.x * 256) {
         const int u = (int)(i & 3), lane = (int)((i >> 2) & 63), half = lane >> 5, col = lane & 31;
         long q = i >> 8;                                   // float4 index (per lane)
-        if (J.type >= PACK_X6_PW_W1) {
-            // x6 fragments: this dword holds k-slots j = 2u, 2u+1 of lane `lane` in fragment q = (outer * 2 + kb) * 3 + piece
-            int piece = (int)(q % 3), kb = (int)((q / 3) & 1), outer = (int)(q / 6);
-            if (J.type == PACK_X6_CONVK) { kb = (int)((q / 3) % 5); outer = (int)(q / 15); }       // fragment q = (group * 5 + kb) * 3 + piece
+        if (type >= PACK_X6_PW_W1) {
+            // split fragments: this dword holds k-slots j = 2u, 2u+1 of lane `lane` in fragment q = (outer * 2 + kb) * NP + piece
+            const int np = h3 ? 2 : 3;
+            int piece = (int)(q % np), kb = (int)((q / np) & 1), outer = (int)(q / (2 * np));
+            if (type == PACK_X6_CONVK) { kb = (int)((q / np) % 5); outer = (int)(q / (5 * np)); }       // fragment q = (group * 5 + kb) * NP + piece
             float v2[2] = {0.f, 0.f};
             for (int e = 0; e < 2; ++e) {
                 const int j = 2 * u + e, kn = 16 * kb + 8 * half + j, kp = rowmap(8 * kb + j, half);   // natural / accumulator-order k
-                if (J.type == PACK_X6_PW_W1) {          // [row|col = hidden 32c + col][k = cin kn]              W1 [cin 32][hidden 256]
+                if (type == PACK_X6_PW_W1) {          // [row|col = hidden 32c + col][k = cin kn]              W1 [cin 32][hidden 256]
                     v2[e] = src[(long)kn * J.Cout + 32 * outer + col];
-                } else if (J.type == PACK_X6_PW_W2) {   // [row = out col][k-slot = hidden 32c + kp]             W2 [hidden 256][out D]
+                } else if (type == PACK_X6_PW_W2) {   // [row = out col][k-slot = hidden 32c + kp]             W2 [hidden 256][out D]
                     if (col < J.Cout) v2[e] = src[(long)(32 * outer + kp) * J.Cout + col];
-                } else if (J.type == PACK_X6_PW_W2K) {  // [row|col = hidden 32c + col][k = out kn]              W2 [hidden 256][out D]
+                } else if (type == PACK_X6_PW_W2K) {  // [row|col = hidden 32c + col][k = out kn]              W2 [hidden 256][out D]
                     if (kn < J.Cout) v2[e] = src[(long)(32 * outer + col) * J.Cout + kn];
-                } else if (J.type == PACK_X6_PW_W1C) {  // [row = cin col][k-slot = hidden 32c + kp]             W1 [cin 32][hidden 256]
+                } else if (type == PACK_X6_PW_W1C) {  // [row = cin col][k-slot = hidden 32c + kp]             W1 [cin 32][hidden 256]
                     v2[e] = src[(long)col * J.Cout + 32 * outer + kp];
-                } else if (J.type == PACK_X6_CONVK) {   // [k = dt * Cin + ci][col = cout] of (dh, dw) group `outer`: taps 3*outer + dt
+                } else if (type == PACK_X6_CONVK) {   // [k = dt * Cin + ci][col = cout] of (dh, dw) group `outer`: taps 3*outer + dt
                     if (kn < 3 * J.Cin && col < J.Cout) v2[e] = src[((long)outer * 3 * J.Cin + kn) * J.Cout + col];
                 } else {                                // PACK_X6_CONV: [k = cin kn][col = cout] of tap `outer`
                     if (kn < J.Cin && col < J.Cout) v2[e] = src[((long)outer * J.Cin + kn) * J.Cout + col];
                 }
             }
-            unsigned pc[3];
-            split_pair(v2[0], v2[1], pc[0], pc[1], pc[2]);
-            reinterpret_cast<unsigned*>(dst)[i] = pc[piece];
+            if (h3) {
+                unsigned pc[2];
+                cut_pair<H3>(v2[0], v2[1], wscale, pc);
+                reinterpret_cast<unsigned*>(dst)[i] = pc[piece];
+            } else {
+                unsigned pc[3];
+                split_pair(v2[0], v2[1], pc[0], pc[1], pc[2]);
+                reinterpret_cast<unsigned*>(dst)[i] = pc[piece];
+            }
             continue;
         }
         float v = 0.f;
@@ -129,10 +140,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
     }
 }
 
-int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, hipStream_t s)
+int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, const unsigned* amax, hipStream_t s)
 {
     if (njobs <= 0) return PROBAV_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3(32, njobs), dim3(256), 0, s, d_jobs, weff, weffT, wpack);
+    hipLaunchKernelGGL(pack_kernel, dim3(32, njobs), dim3(256), 0, s, d_jobs, weff, weffT, wpack, amax);
     return check_launch("mfma_pack");
 }
 
@@ -372,26 +383,26 @@ __device__ __forceinline__ void conv_taps(const TileArgs& a, const float* ldsA0,
 // x6 form of conv_taps for 16-channel chunks (CP = 17): one k-block per tap and chunk.  The activation operand is read as fp32
 // from the halo tile (channels 8*half + j of the lane's voxel) and cut into bf16 pieces in registers; filters arrive pre-cut
 // ([tap][chunk][piece][lane] x 16 B, PACK_X6_CONV).  Two M tiles share every filter fragment.
-template <int MT>
+template <int MT, class AR>
 __device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
-                                             int chunk, f32x16& acc0, f32x16& acc1)
+                                             int chunk, float sa, f32x16& acc0, f32x16& acc1)
 {
     // groups (dh, dw) at run time, the three dt taps of a group unrolled: compile-time offsets inside a group (strip_taps_x6k)
-    constexpr int CP = 17;
+    constexpr int CP = 17, NP = AR::NP;
     float r0[2][8], r1[2][8];
-    Frag W[2][3], a0[3], a1[3];
+    Frag W[2][NP], a0[NP], a1[NP];
     auto group_off = [&](int g) -> int { const int dh = g / 3, dw = g - 3 * dh; return (dh * a.Wp + dw) * a.Tp * CP; };
-    auto request = [&](int goff, const uint4* pw, int dt, Frag (&w)[3], float (&q0)[8], float (&q1)[8]) {   // dt: compile-time
+    auto request = [&](int goff, const uint4* pw, int dt, Frag (&w)[NP], float (&q0)[8], float (&q1)[8]) {   // dt: compile-time
 #pragma unroll
         for (int j = 0; j < 8; ++j) { q0[j] = ldsA0[goff + dt * CP + j]; q1[j] = MT == 2 ? ldsA1[goff + dt * CP + j] : 0.f; }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = pw[(dt * 6 + p) * 64];                 // fragment ((tap * 2 + chunk) * 3 + p), tap = 3 g + dt
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(dt * 2 * NP + p) * 64];            // fragment ((tap * 2 + chunk) * NP + p), tap = 3 g + dt
     };
     int goff = group_off(0);
-    const uint4* pw = wf + (long)chunk * 3 * 64;
+    const uint4* pw = wf + (long)chunk * NP * 64;
     request(goff, pw, 0, W[0], r0[0], r1[0]);
-    split8(r0[0], a0);
-    if (MT == 2) split8(r1[0], a1);
+    cut8<AR>(r0[0], sa, a0);
+    if (MT == 2) cut8<AR>(r1[0], sa, a1);
 #pragma unroll 1
     for (int g = 0; g < 9; g += 2) {
 #pragma unroll
@@ -399,17 +410,17 @@ __device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* lds
             if (g + u > 8) break;                                               // 9 groups: the second half of the last pair is empty
             const int gn = g + u + 1 <= 8 ? g + u + 1 : 8;
             const int goffn = group_off(gn);
-            const uint4* pwn = wf + ((long)gn * 18 + chunk * 3) * 64;
+            const uint4* pwn = wf + ((long)gn * 6 * NP + chunk * NP) * 64;
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt) {
                 const int s = 3 * u + dt;                                       // compile-time step parity (3 is odd)
                 if (dt < 2) request(goff, pw, dt + 1, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
                 else request(goffn, pwn, 0, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc0 = mac6(a0, W[s & 1], acc0);
-                if (MT == 2) acc1 = mac6(a1, W[s & 1], acc1);
-                split8(r0[(s + 1) & 1], a0);
-                if (MT == 2) split8(r1[(s + 1) & 1], a1);
+                acc0 = mac<AR>(a0, W[s & 1], acc0);
+                if (MT == 2) acc1 = mac<AR>(a1, W[s & 1], acc1);
+                cut8<AR>(r0[(s + 1) & 1], sa, a0);
+                if (MT == 2) cut8<AR>(r1[(s + 1) & 1], sa, a1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             goff = goffn; pw = pwn;
@@ -419,24 +430,25 @@ __device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* lds
 
 // x6 tap loop of the row-tile kernel for 25-channel inputs, dt taps concatenated along K (see strip_taps_x6k): 45 k-blocks of 16,
 // filters PACK_X6_CONVK, two M tiles share every filter fragment.
-template <int MT>
+template <int MT, class AR>
 __device__ __forceinline__ void conv_taps_x6k(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
-                                              f32x16& acc0, f32x16& acc1)
+                                              float sa, f32x16& acc0, f32x16& acc1)
 {
+    constexpr int NP = AR::NP;
     float r0[2][8], r1[2][8];
-    Frag W[2][3], a0[3], a1[3];
+    Frag W[2][NP], a0[NP], a1[NP];
     auto group_off = [&](int g) -> int { const int dh = g / 3, dw = g - 3 * dh; return (dh * a.Wp + dw) * a.Tp * 25; };
-    auto request = [&](int goff, const uint4* pw, int kb, Frag (&w)[3], float (&q0)[8], float (&q1)[8]) {   // kb: compile-time
+    auto request = [&](int goff, const uint4* pw, int kb, Frag (&w)[NP], float (&q0)[8], float (&q1)[8]) {   // kb: compile-time
 #pragma unroll
         for (int j = 0; j < 8; ++j) { q0[j] = ldsA0[goff + 16 * kb + j]; q1[j] = MT == 2 ? ldsA1[goff + 16 * kb + j] : 0.f; }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = pw[(kb * 3 + p) * 64];
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(kb * NP + p) * 64];
     };
     int goff = group_off(0);
     const uint4* pw = wf;
     request(goff, pw, 0, W[0], r0[0], r1[0]);
-    split8(r0[0], a0);
-    if (MT == 2) split8(r1[0], a1);
+    cut8<AR>(r0[0], sa, a0);
+    if (MT == 2) cut8<AR>(r1[0], sa, a1);
 #pragma unroll 1
     for (int g = 0; g < 9; g += 2) {
 #pragma unroll
@@ -444,17 +456,17 @@ __device__ __forceinline__ void conv_taps_x6k(const TileArgs& a, const float* ld
             if (g + u > 8) break;
             const int gn = g + u + 1 <= 8 ? g + u + 1 : 8;
             const int goffn = group_off(gn);
-            const uint4* pwn = wf + (long)gn * 15 * 64;
+            const uint4* pwn = wf + (long)gn * 5 * NP * 64;
 #pragma unroll
             for (int kb = 0; kb < 5; ++kb) {
                 const int s = 5 * u + kb;
                 if (kb < 4) request(goff, pw, kb + 1, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
                 else request(goffn, pwn, 0, W[(s + 1) & 1], r0[(s + 1) & 1], r1[(s + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc0 = mac6(a0, W[s & 1], acc0);
-                if (MT == 2) acc1 = mac6(a1, W[s & 1], acc1);
-                split8(r0[(s + 1) & 1], a0);
-                if (MT == 2) split8(r1[(s + 1) & 1], a1);
+                acc0 = mac<AR>(a0, W[s & 1], acc0);
+                if (MT == 2) acc1 = mac<AR>(a1, W[s & 1], acc1);
+                cut8<AR>(r0[(s + 1) & 1], sa, a0);
+                if (MT == 2) cut8<AR>(r1[(s + 1) & 1], sa, a1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             goff = goffn; pw = pwn;
@@ -462,14 +474,20 @@ __device__ __forceinline__ void conv_taps_x6k(const TileArgs& a, const float* ld
     }
 }
 
-template <int CC, int KS, bool X6>
+// AM: arithmetic of the tap loop -- 0 fp32 MFMA, 1 X6 (bf16 pieces), 2 H3 (scaled fp16 pieces; am.x / am.w = amax slots of the
+// input tensor and of the filter, x6_device.h).  am.y (optional, any AM): slot that receives the largest output magnitude.
+template <int CC, int KS, int AM>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                            const float4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                           const float* __restrict__ skip, float* __restrict__ y)
+                                                           const float* __restrict__ skip, float* __restrict__ y, Amax am)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool X6 = AM != 0;
+    using AR = std::conditional_t<AM == 2, H3, probav::X6>;
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     constexpr int KS4 = (KS + 3) / 4;
+    float sa = 1.f; int eun = 0; float omax = 0.f;
+    if constexpr (AM == 2) { const int ea = h3_exp(*am.x), ew = h3_exp(*am.w); sa = pow2i(ea); eun = -(ea + ew); }
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -503,12 +521,12 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
             }
             if constexpr (X6 && CC == 25) {
                 const uint4* wf6 = reinterpret_cast<const uint4*>(wfrag) + lane;
-                if (v1) conv_taps_x6k<2>(a, ldsA0, ldsA1, wf6, acc0, acc1);
-                else if (v0) conv_taps_x6k<1>(a, ldsA0, ldsA1, wf6, acc0, acc1);
+                if (v1) conv_taps_x6k<2, AR>(a, ldsA0, ldsA1, wf6, sa, acc0, acc1);
+                else if (v0) conv_taps_x6k<1, AR>(a, ldsA0, ldsA1, wf6, sa, acc0, acc1);
             } else if constexpr (X6) {
                 const uint4* wf6 = reinterpret_cast<const uint4*>(wfrag) + lane;
-                if (v1) conv_taps_x6<2>(a, ldsA0, ldsA1, wf6, chunk, acc0, acc1);
-                else if (v0) conv_taps_x6<1>(a, ldsA0, ldsA1, wf6, chunk, acc0, acc1);
+                if (v1) conv_taps_x6<2, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
+                else if (v0) conv_taps_x6<1, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
             } else {
                 const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
                 if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
@@ -544,9 +562,12 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = (tsel ? acc1[r] : acc0[r]) + bv;
+                float v = tsel ? acc1[r] : acc0[r];
+                if constexpr (AM == 2) v = ldexpf(v, eun);                // back from the operands' power-of-two scales
+                v += bv;
                 if (g.relu) v = fmaxf(v, 0.f);
                 ov[r] += v;
+                omax = fmaxf(omax, oo[r] >= 0 ? fabsf(ov[r]) : 0.f);
             }
             if (full) {
 #pragma unroll
@@ -557,6 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
             }
         }
     }
+    if (am.y) amax_commit(omax, am.y);
     STAMP(7);
 }
 
@@ -624,35 +646,42 @@ static void allow_big_lds(K kernel)
 }
 
 int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
-                      const float* skip, float* y, hipStream_t s)
+                      const float* skip, float* y, const Amax& am, hipStream_t s)
 {
     const ConvPlan p = conv_plan(g, false);
     if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13, false>); allow_big_lds(conv3_mfma_kernel<16, 8, false>); allow_big_lds(conv3_mfma_kernel<1, 1, false>); once = true; }
-    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1, false>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13, false>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
-    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, false>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y);
+    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13, 0>); allow_big_lds(conv3_mfma_kernel<16, 8, 0>); allow_big_lds(conv3_mfma_kernel<1, 1, 0>); once = true; }
+    if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1, 0>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am);
+    else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13, 0>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am);
+    else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, 0>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am);
     return check_launch("conv3_mfma");
 }
 
-// row-tile kernel with the x6 tap loop: 32-channel inputs (two 16-channel chunks), any pads / reflect (reducers, upscale)
+// row-tile kernel with a split-operand tap loop: 32-channel inputs (two 16-channel chunks), any pads / reflect (reducers, upscale)
 bool x6_conv_rowtile_supported(const ConvGeom& g)
 {
     const ConvPlan p = conv_plan(g, false);
     return p.ok && ((p.CC == 16 && g.Cin == 32) || (p.CC == 25 && g.Cin == 25));
 }
 int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
-                            const float* skip, float* y, hipStream_t s)
+                            const float* skip, float* y, int arith, const Amax& am, hipStream_t s)
 {
     const ConvPlan p = conv_plan(g, false);
     if (!x6_conv_rowtile_supported(g)) { set_error("x6_conv_rowtile_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_rowtile_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
     static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<16, 8, true>); allow_big_lds(conv3_mfma_kernel<25, 13, true>); once = true; }
-    if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13, true>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y);
-    else hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, true>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y);
+    if (!once) {
+        allow_big_lds(conv3_mfma_kernel<16, 8, 1>); allow_big_lds(conv3_mfma_kernel<25, 13, 1>);
+        allow_big_lds(conv3_mfma_kernel<16, 8, 2>); allow_big_lds(conv3_mfma_kernel<25, 13, 2>);
+        once = true;
+    }
+#define PROBAV_RT(C, K, A) hipLaunchKernelGGL((conv3_mfma_kernel<C, K, A>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y, am)
+    if (arith == 2) { if (p.CC == 25) PROBAV_RT(25, 13, 2); else PROBAV_RT(16, 8, 2); }
+    else            { if (p.CC == 25) PROBAV_RT(25, 13, 1); else PROBAV_RT(16, 8, 1); }
+#undef PROBAV_RT
     return check_launch("conv3_mfma_x6");
 }
 
@@ -740,14 +769,14 @@ __device__ __forceinline__ void strip_taps(const StripArgs& a, const float* lds,
 // pre-split from L2 ([tap][kb][piece][lane] x 16 B, X6_CONV packing).  For CC = 25 the second k-block reads seven
 // floats past the voxel's channels (the next voxel's, finite) against zero filter pieces.
 // Three-stage software pipeline per tap: loads of tap i+1 | split of tap i+1's activations | MFMAs of tap i.
-template <int CC, typename Mid>
+template <int CC, class AR, typename Mid>
 __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* lds, int base0, int base1, int base2, int g0, int ng,
-                                              const uint4* __restrict__ wf, f32x16& acc, Mid mid)
+                                              const uint4* __restrict__ wf, float sa, f32x16& acc, Mid mid)
 {
     // This wave's (dh, dw) groups g0 .. g0 + ng - 1; inside a group the three dt taps x two k-blocks are unrolled, so every LDS and
     // filter offset of a step is a compile-time constant from one pointer per group (see strip_taps_x6k for why that matters).
     // Operands are requested one step ahead (two buffers; six steps per group keep the buffer parity static).
-    constexpr int CP = (CC & 1) ? CC : CC + 1;
+    constexpr int CP = (CC & 1) ? CC : CC + 1, NP = AR::NP;
     const int rowstep = a.Tp * CP;
     const int glast = g0 + ng - 1;
     auto group_ptr = [&](int g) -> const float* {
@@ -756,32 +785,32 @@ __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* l
         return lds + b + dw * rowstep;
     };
     float R[2][8];
-    Frag W[2][3], acur[3];
-    auto request = [&](const float* pa, const uint4* pw, int st, Frag (&w)[3], float (&r)[8]) {   // st = dt * 2 + kb: compile-time
+    Frag W[2][NP], acur[NP];
+    auto request = [&](const float* pa, const uint4* pw, int st, Frag (&w)[NP], float (&r)[8]) {   // st = dt * 2 + kb: compile-time
         const int dt = st >> 1, kb = st & 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = pa[dt * CP + 16 * kb + j];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = pw[(st * 3 + p) * 64];
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(st * NP + p) * 64];
     };
     const float* pa = group_ptr(g0);
-    const uint4* pw = wf + (long)g0 * 18 * 64;
+    const uint4* pw = wf + (long)g0 * 6 * NP * 64;
     request(pa, pw, 0, W[0], R[0]);
-    split8(R[0], acur);
+    cut8<AR>(R[0], sa, acur);
     bool did_mid = false;
 #pragma unroll 1
     for (int g = g0; g <= glast; ++g) {
         const int gn = g + 1 <= glast ? g + 1 : glast;
         const float* pan = group_ptr(gn);
-        const uint4* pwn = wf + (long)gn * 18 * 64;
+        const uint4* pwn = wf + (long)gn * 6 * NP * 64;
 #pragma unroll
         for (int st = 0; st < 6; ++st) {
             if (st < 5) request(pa, pw, st + 1, W[(st + 1) & 1], R[(st + 1) & 1]);
             else request(pan, pwn, 0, W[0], R[0]);                              // (after the last group: a harmless re-read)
             if (st == 2 && !did_mid) { mid(); did_mid = true; }
             __builtin_amdgcn_sched_barrier(0);
-            acc = mac6(acur, W[st & 1], acc);
-            split8(R[(st + 1) & 1], acur);
+            acc = mac<AR>(acur, W[st & 1], acc);
+            cut8<AR>(R[(st + 1) & 1], sa, acur);
             __builtin_amdgcn_sched_barrier(0);
         }
         pa = pan; pw = pwn;
@@ -791,10 +820,11 @@ __device__ __forceinline__ void strip_taps_x6(const StripArgs& a, const float* l
 // x6 tap loop for Cin = 25 with the three dt taps of a (dh, dw) group CONCATENATED along K: with an unpadded channel stride of
 // 25 the voxels (w, t), (w, t+1), (w, t+2) are 75 contiguous floats, i.e. 5 k-blocks of 16 instead of 3 taps x 2 k-blocks of a
 // 25 -> 32 padded K (-17 % MFMAs and cuts).  k-blocks kbi = group * 5 + kb, kbi in [kb0, kb0 + nkb); filters: PACK_X6_CONVK.
-template <typename Mid>
+template <class AR, typename Mid>
 __device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* lds, int base0, int base1, int base2, int g0, int ng,
-                                               const uint4* __restrict__ wf, f32x16& acc, Mid mid)
+                                               const uint4* __restrict__ wf, float sa, f32x16& acc, Mid mid)
 {
+    constexpr int NP = AR::NP;
     // This wave's (dh, dw) groups g0 .. g0 + ng - 1, five k-blocks each.  The loop is NESTED -- groups at run time, the five blocks of
     // a group unrolled -- so that everything inside a group is a compile-time offset from one LDS pointer and one filter pointer:
     // decoding a flat block index (divisions by 5 and 3, clamps, 64-bit pointer arithmetic) cost ~25 dependent scalar instructions
@@ -808,17 +838,17 @@ __device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* 
         return lds + b + dw * rowstep;
     };
     float R[2][8];
-    Frag W[2][3], acur[3];
-    auto request = [&](const float* pa, const uint4* pw, int kb, Frag (&w)[3], float (&r)[8]) {   // kb: compile-time
+    Frag W[2][NP], acur[NP];
+    auto request = [&](const float* pa, const uint4* pw, int kb, Frag (&w)[NP], float (&r)[8]) {   // kb: compile-time
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = pa[16 * kb + j];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p].u = pw[(kb * 3 + p) * 64];
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(kb * NP + p) * 64];
     };
     const float* pa = group_ptr(g0);
-    const uint4* pw = wf + (long)g0 * 15 * 64;
+    const uint4* pw = wf + (long)g0 * 5 * NP * 64;
     request(pa, pw, 0, W[0], R[0]);
-    split8(R[0], acur);
+    cut8<AR>(R[0], sa, acur);
     bool did_mid = false;
 #pragma unroll 1
     for (int g = g0; g <= glast; g += 2) {
@@ -828,7 +858,7 @@ __device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* 
             if (gg > glast) break;                                              // wave-uniform
             const int gn = gg + 1 <= glast ? gg + 1 : glast;
             const float* pan = group_ptr(gn);
-            const uint4* pwn = wf + (long)gn * 15 * 64;
+            const uint4* pwn = wf + (long)gn * 5 * NP * 64;
 #pragma unroll
             for (int kb = 0; kb < 5; ++kb) {
                 const int s = 5 * u + kb;                                       // compile-time step parity (5 is odd: parity flips per group)
@@ -836,8 +866,8 @@ __device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* 
                 else request(pan, pwn, 0, W[(s + 1) & 1], R[(s + 1) & 1]);      // (after the last group: a harmless re-read)
                 if (kb == 2 && !did_mid) { mid(); did_mid = true; }
                 __builtin_amdgcn_sched_barrier(0);
-                acc = mac6(acur, W[s & 1], acc);
-                split8(R[(s + 1) & 1], acur);
+                acc = mac<AR>(acur, W[s & 1], acc);
+                cut8<AR>(R[(s + 1) & 1], sa, acur);
                 __builtin_amdgcn_sched_barrier(0);
             }
             pa = pan; pw = pwn;
@@ -845,12 +875,16 @@ __device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* 
     }
 }
 
-template <int CC, int KS, bool GATE, int STRIP_SLOTS, bool X6>
+template <int CC, int KS, bool GATE, int STRIP_SLOTS, int AM>            // AM / am: see conv3_mfma_kernel
 __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                             const float4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                            const float* __restrict__ skip, float* __restrict__ y)
+                                                            const float* __restrict__ skip, float* __restrict__ y, Amax am)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool X6 = AM != 0;
+    using AR = std::conditional_t<AM == 2, H3, probav::X6>;
+    float sa = 1.f; int eun = 0; float omax = 0.f;
+    if constexpr (AM == 2) { const int ea = h3_exp(*am.x), ew = h3_exp(*am.w); sa = pow2i(ea); eun = -(ea + ew); }
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     constexpr int KS4 = (KS + 3) / 4;
     constexpr int V = (CC % 4 == 0) ? 4 : 1;        // floats per load when staging
@@ -999,8 +1033,8 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
                 const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
                           base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
-                if constexpr (X6 && CC == 25) strip_taps_x6k(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);   // (the epilogue wave takes 4 of the 9 groups)
-                else if constexpr (X6) strip_taps_x6<CC>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, acc, mid);
+                if constexpr (X6 && CC == 25) strip_taps_x6k<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);   // (the epilogue wave takes 4 of the 9 groups)
+                else if constexpr (X6) strip_taps_x6<CC, AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
                 else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks, mid);
                 if (grp == 1) {
 #pragma unroll
@@ -1035,6 +1069,7 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                     const int vi = tile * 32 + rowmap(i, half);
                     oo[i] = (vi < NV && col < g.Cout) ? vi * g.Cout + col : -1;
                     ov[i] = acc[i] + pv[i];
+                    if constexpr (AM == 2) ov[i] = ldexpf(ov[i], eun);      // back from the operands' power-of-two scales
                 }
                 // single-pass layers (the only ones routed here): sk = skip connection.  Multi-pass: pass 0 stores the raw
                 // partial, later passes add the previous partial (sk), the last one finishes with bias / ReLU / skip.
@@ -1067,6 +1102,8 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                         }
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) omax = fmaxf(omax, oo[i] >= 0 ? fabsf(ov[i]) : 0.f);
                 if (full) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) ybase[oo[i]] = ov[i];
@@ -1078,6 +1115,7 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
             XS_ACC(5);
         }
     }
+    if (am.y) amax_commit(omax, am.y);
     XS_OUT;
 }
 
@@ -1116,39 +1154,42 @@ static StripPlan strip_plan(const ConvGeom& g)
 bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
 
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
-                        const float* skip, float* y, bool x6, hipStream_t s)
+                        const float* skip, float* y, int arith, const Amax& am, hipStream_t s)
 {
     const StripPlan p = strip_plan(g);
     if (!p.ok) { set_error("mfma_conv_strip_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_strip_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
     static bool once = false;
     if (!once) {
-        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, false>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, false>);
-        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, false>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, false>);
-        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, true>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, true>);
-        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, true>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, true>);
+        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 0>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 0>);
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 0>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 0>);
+        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 1>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 1>);
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 1>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 1>);
+        allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 2>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 2>);
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 2>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 2>);
         once = true;
     }
-#define PROBAV_STRIP(C, K, G, S, X) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G, S, X>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y)
-    if (x6) {
-        if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5, true); else PROBAV_STRIP(25, 13, false, 5, true); }
-        else            { if (gate) PROBAV_STRIP(32, 16, true, 4, true); else PROBAV_STRIP(32, 16, false, 4, true); }
-    } else {
-        if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5, false); else PROBAV_STRIP(25, 13, false, 5, false); }
-        else            { if (gate) PROBAV_STRIP(32, 16, true, 4, false); else PROBAV_STRIP(32, 16, false, 4, false); }
-    }
+#define PROBAV_STRIP(C, K, G, S, X) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G, S, X>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am)
+#define PROBAV_STRIP_A(X) do { \
+        if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5, X); else PROBAV_STRIP(25, 13, false, 5, X); } \
+        else            { if (gate) PROBAV_STRIP(32, 16, true, 4, X); else PROBAV_STRIP(32, 16, false, 4, X); } } while (0)
+    if (arith == 2) PROBAV_STRIP_A(2);
+    else if (arith == 1) PROBAV_STRIP_A(1);
+    else PROBAV_STRIP_A(0);
+#undef PROBAV_STRIP_A
 #undef PROBAV_STRIP
     return check_launch("conv3_strip");
 }
 
 int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
-                            const float* skip, float* y, hipStream_t s)
+                            const float* skip, float* y, const Amax& am, hipStream_t s)
 {
-    return strip_launch(g, x, gate, wfrag, bias, skip, y, false, s);
+    return strip_launch(g, x, gate, wfrag, bias, skip, y, 0, am, s);
 }
 int x6_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
-                          const float* skip, float* y, hipStream_t s)
+                          const float* skip, float* y, int arith, const Amax& am, hipStream_t s)
 {
-    return strip_launch(g, x, gate, wfrag6, bias, skip, y, true, s);
+    return strip_launch(g, x, gate, wfrag6, bias, skip, y, arith, am, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -55,10 +55,12 @@ __device__ __forceinline__ int find_layer(const WnLayer* L, int nl, int chan, in
 
 __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restrict__ layers, int nl,
                                                        const float* __restrict__ params, float* __restrict__ weff,
-                                                       float* __restrict__ weffT, float* __restrict__ inv_norm)
+                                                       float* __restrict__ weffT, float* __restrict__ inv_norm,
+                                                       unsigned* __restrict__ amax)
 {
     int co;
-    const WnLayer L = layers[find_layer(layers, nl, blockIdx.x, co)];
+    const int li = find_layer(layers, nl, blockIdx.x, co);
+    const WnLayer L = layers[li];
     const float* v = params + L.v_off;
     const int lane = threadIdx.x;
     float ss = 0.f;
@@ -67,12 +69,41 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
     const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));            // tf.nn.l2_normalize epsilon
     const float scale = params[L.g_off + co] * inv;
     if (lane == 0) inv_norm[L.n_off + co] = inv;
+    float wmax = 0.f;
     for (int k = lane; k < L.K; k += 64) {
         const float q = v[(long)k * L.Cout + co] * scale;
         weff[L.w_off + (long)k * L.Cout + co] = q;
         const int tap = k / L.Cin, ci = k - tap * L.Cin;
         weffT[L.w_off + ((long)(L.taps - 1 - tap) * L.Cout + co) * L.Cin + ci] = q;
+        wmax = fmaxf(wmax, fabsf(q));
     }
+    if (amax) {     // largest |effective weight| and |bias| of the layer: operand scales of the H3 kernels (slots li and nl + li)
+#pragma unroll
+        for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+        if (lane == 0) { atomicMax(amax + li, __float_as_uint(wmax)); atomicMax(amax + nl + li, __float_as_uint(fabsf(params[L.b_off + co]))); }
+    }
+}
+
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ slot)
+{
+    float m = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+int amax_tensor(const float* x, size_t n, unsigned* slot, hipStream_t s)
+{
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, slot);
+    return check_launch("amax");
 }
 
 // d loss/d g = sum(dw * v) / ||v|| ;  d loss/d v = g/||v|| * (dw - v * sum(dw * v) / ||v||^2)
@@ -100,9 +131,9 @@ __global__ __launch_bounds__(64) void wn_backward_kernel(const WnLayer* __restri
 }
 
 int wn_forward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,
-               float* weff, float* weffT, float* inv_norm, hipStream_t s)
+               float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s)
 {
-    hipLaunchKernelGGL(wn_forward_kernel, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm);
+    hipLaunchKernelGGL(wn_forward_kernel, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm, amax);
     return check_launch("wn_forward");
 }
 int wn_backward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,

@@ -28,6 +28,13 @@ struct ConvGeom {
 
 namespace probav {
 
+// amax slots of one launch (H3 arithmetic, x6_device.h): the bit pattern of the largest |value| of a tensor (a non-negative
+// float), kept in device memory.  x / w: slots of the activation operand and of the filter, read by an H3 kernel to choose its
+// power-of-two operand scales; y: slot that receives (atomicMax) the largest output magnitude, written by any kernel when set.
+struct Amax { const unsigned* x = nullptr; const unsigned* w = nullptr; unsigned* y = nullptr; };
+// largest |x[i]| -> *slot (atomicMax; the slot must have been zeroed), for tensors whose producer does not report it
+int amax_tensor(const float* x, size_t n, unsigned* slot, hipStream_t s);
+
 void set_error(const char* what, hipError_t e);
 int check_launch(const char* what);
 const char* last_error();
@@ -50,8 +57,9 @@ struct WnLayer {            // one weight-normalised layer inside the flat param
     int K;                      // taps * Cin
     int Cin, Cout, taps;
 };
+// amax (optional): 2 * nlayers zeroed slots; receives the largest |effective weight| (slot l) and |bias| (slot nlayers + l) per layer
 int wn_forward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
-               float* weff, float* weffT, float* inv_norm, hipStream_t s);
+               float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s);
 int wn_backward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
                 const float* dweff, const float* inv_norm, float* grads, hipStream_t s);
 int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, float mean, float stdv, hipStream_t s);

@@ -1,5 +1,12 @@
-// Device helpers of the "x6" kernels (kernels_x6.hip, and the x6 variants inside kernels_mfma.hip): an fp32 value
-// as three bf16 truncation pieces, and a product of two such triples as the six largest piece products.
+// Device helpers of the split-operand kernels (kernels_x6.hip, and the split variants inside kernels_mfma.hip).
+//
+// Two arithmetics evaluate an fp32 product on the 16-bit matrix pipe; a kernel is written once against the `AR` tag:
+//   X6  three bf16 truncation pieces per value, the six largest piece products (v_mfma_f32_32x32x16_bf16).  No scaling.
+//   H3  two fp16 round-to-nearest pieces per value (a = a0 + a1 to 2^-24 |a|: the sign of a1 is the 23rd bit), three piece
+//       products a1 b0 + a0 b1 + a0 b0 (v_mfma_f32_32x32x16_f16; dropped a1 b1 <= 2^-24 |ab|) -- half the MFMAs of X6.  fp16 has
+//       5 exponent bits, so every operand TENSOR is multiplied by a power of two that puts its largest magnitude (or a bound
+//       on it) into [2^14, 2^15); the product is scaled back once, in the epilogue.  Elements down to 2^-17 of the tensor
+//       maximum keep full relative precision, smaller ones an absolute error of 2^-40 of the maximum.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,15 +30,40 @@ namespace probav {
 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-union Frag { uint4 u; bf16x8 v; s16x4 hs[2]; };
+union Frag { uint4 u; bf16x8 v; f16x8 h; s16x4 hs[2]; };
+
+struct X6 { static constexpr int NP = 3; static constexpr bool SCALED = false; };
+struct H3 { static constexpr int NP = 2; static constexpr bool SCALED = true; };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).v, (b).v, (c), 0, 0, 0)
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a).h, (b).h, (c), 0, 0, 0)
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// the three truncation pieces of one value, as fp32 bit patterns whose low 16 bits are zero
+// ---- H3 scaling: amax slots hold the bit pattern of a non-negative float (atomicMax on the bits orders them) ----
+// exponent e with amax * 2^e in [2^14, 2^15); 0 for an all-zero tensor; clamped so that 2^e stays a normal float
+__device__ __forceinline__ int h3_exp(unsigned amax_bits)
+{
+    const int E = (int)((amax_bits >> 23) & 0xffu);
+    const int e = E == 0 ? 0 : 141 - E;
+    return e > 126 ? 126 : e;
+}
+__device__ __forceinline__ int h3_exp(float bound) { return h3_exp(__float_as_uint(bound)); }
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }      // -126 <= e <= 127
+// the largest |value| a wave has produced -> its tensor's slot (one atomic per wave)
+__device__ __forceinline__ void amax_commit(float m, unsigned* slot)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+
+// ---- X6: the three truncation pieces of one value, as fp32 bit patterns whose low 16 bits are zero
 // (the mask lives in a scalar register: as a literal every v_and_b32 would be an 8-byte instruction)
 __device__ __forceinline__ unsigned hi_mask()
 {
@@ -57,24 +89,69 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& q0, unsig
     q1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
     q2 = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
 }
-// eight consecutive k-slots -> three fragments
-__device__ __forceinline__ void split8(const float (&x)[8], Frag (&f)[3])
+
+// ---- arithmetic-generic forms: `s` is the operand tensor's power-of-two scale (ignored by X6) ----
+// pieces of a pair, packed (a -> low half, b -> high half of each dword); q[p] = piece p
+template <class AR>
+__device__ __forceinline__ void cut_pair(float a, float b, float s, unsigned (&q)[AR::NP])
 {
-    split_pair(x[0], x[1], f[0].u.x, f[1].u.x, f[2].u.x);
-    split_pair(x[2], x[3], f[0].u.y, f[1].u.y, f[2].u.y);
-    split_pair(x[4], x[5], f[0].u.z, f[1].u.z, f[2].u.z);
-    split_pair(x[6], x[7], f[0].u.w, f[1].u.w, f[2].u.w);
+    if constexpr (AR::SCALED) {
+        const f32x2 v = {a * s, b * s};
+        const f16x2 h0 = __builtin_convertvector(v, f16x2);                 // v_cvt_pk_f16_f32: round to nearest even
+        const f32x2 r = v - __builtin_convertvector(h0, f32x2);             // exact
+        const f16x2 h1 = __builtin_convertvector(r, f16x2);
+        q[0] = __builtin_bit_cast(unsigned, h0);
+        q[1] = __builtin_bit_cast(unsigned, h1);
+    } else {
+        split_pair(a, b, q[0], q[1], q[2]);
+    }
+}
+// 16-bit pieces of one value
+template <class AR>
+__device__ __forceinline__ void cut_one(float a, float s, unsigned short (&q)[AR::NP])
+{
+    if constexpr (AR::SCALED) {
+        const float v = a * s;
+        const _Float16 h0 = (_Float16)v;
+        const _Float16 h1 = (_Float16)(v - (float)h0);
+        q[0] = __builtin_bit_cast(unsigned short, h0);
+        q[1] = __builtin_bit_cast(unsigned short, h1);
+    } else {
+        unsigned p0, p1, p2;
+        pieces(a, p0, p1, p2);
+        q[0] = (unsigned short)(p0 >> 16); q[1] = (unsigned short)(p1 >> 16); q[2] = (unsigned short)(p2 >> 16);
+    }
+}
+// eight consecutive k-slots -> NP fragments
+template <class AR>
+__device__ __forceinline__ void cut8(const float (&x)[8], float s, Frag (&f)[AR::NP])
+{
+    unsigned q[4][AR::NP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cut_pair<AR>(x[2 * i], x[2 * i + 1], s, q[i]);
+#pragma unroll
+    for (int p = 0; p < AR::NP; ++p) { f[p].u.x = q[0][p]; f[p].u.y = q[1][p]; f[p].u.z = q[2][p]; f[p].u.w = q[3][p]; }
 }
 // acc += A * B over one k-block of 16, smallest terms first
-__device__ __forceinline__ f32x16 mac6(const Frag (&a)[3], const Frag (&b)[3], f32x16 acc)
+template <class AR>
+__device__ __forceinline__ f32x16 mac(const Frag (&a)[AR::NP], const Frag (&b)[AR::NP], f32x16 acc)
 {
-    acc = MFMA16(a[2], b[0], acc);
-    acc = MFMA16(a[1], b[1], acc);
-    acc = MFMA16(a[0], b[2], acc);
-    acc = MFMA16(a[1], b[0], acc);
-    acc = MFMA16(a[0], b[1], acc);
-    acc = MFMA16(a[0], b[0], acc);
+    if constexpr (AR::SCALED) {
+        acc = MFMA16H(a[1], b[0], acc);
+        acc = MFMA16H(a[0], b[1], acc);
+        acc = MFMA16H(a[0], b[0], acc);
+    } else {
+        acc = MFMA16(a[2], b[0], acc);
+        acc = MFMA16(a[1], b[1], acc);
+        acc = MFMA16(a[0], b[2], acc);
+        acc = MFMA16(a[1], b[0], acc);
+        acc = MFMA16(a[0], b[1], acc);
+        acc = MFMA16(a[0], b[0], acc);
+    }
     return acc;
 }
+// X6 spellings used by the kernels written before the tag existed
+__device__ __forceinline__ void split8(const float (&x)[8], Frag (&f)[3]) { cut8<X6>(x, 1.f, f); }
+__device__ __forceinline__ f32x16 mac6(const Frag (&a)[3], const Frag (&b)[3], f32x16 acc) { return mac<X6>(a, b, acc); }
 
 }  // namespace probav
