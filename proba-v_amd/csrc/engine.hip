@@ -284,14 +284,15 @@ static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, c
     if (rc == PROBAV_OK && am.y && !reported) rc = amax_tensor(y, (size_t)g.N * g.Ho * g.Wo * g.To * g.Cout, am.y, s);
     return rc;
 }
+// am.x / am.w: amax slots of x and of dy (H3 backward-filter kernel)
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
-                      float* dw, float* db, float* partial, hipStream_t s)
+                      float* dw, float* db, float* partial, const Amax& am, hipStream_t s)
 {
     const bool exotic = g.reflect_t || g.ph > 1 || g.pw > 1 || g.pt > 1 || (g.kh != 3 && g.kh != 1);
     if (exotic) { ProfScope ps(e, CLS_CONV3_WGRAD, geom_macs(g), s); return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s); }
     const bool x6 = e->impl >= 3 && x6_wgrad_supported(g);
     ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : (x6 ? CLS_CONV3_WGRAD_X6 : CLS_CONV3_WGRAD), geom_macs(g), s);
-    if (x6) return x6_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
+    if (x6) { const bool h3 = e->impl >= 4 && am.x && am.w; return x6_conv_wgrad(g, x, dy, gate, dw, db, partial, h3 ? 2 : 1, am, s); }
     if (e->impl >= 1 && mfma_wgrad_supported(g)) return mfma_conv_wgrad(g, x, dy, gate, dw, db, partial, s);
     return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s);
 }
@@ -542,10 +543,13 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
             // fused expConv + ReLU + decConv: the 256-channel tensor never leaves the accumulators
             const long nvox = (long)B * Hin * Hin * T;
             ProfScope ps(e, e->impl >= 3 ? CLS_PW_FWD_X6 : CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
-            if (e->impl >= 3) {
+            if (h3) {
+                PwAmax m; m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.b1 = A.b(e->iExp[i]); m.y = A.dec(i);
+                CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1h[i], W + p.wpack + e->pkW2h[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                                 W + p.dec[i], nvox, D, 2, m, s));
+            } else if (e->impl >= 3) {
                 CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
-                                 W + p.dec[i], nvox, D, s));
-                if (h3) CK(amax_tensor(W + p.dec[i], (size_t)nvox * D, A.dec(i), s));
+                                 W + p.dec[i], nvox, D, 1, PwAmax(), s));
             } else
                 CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                    W + p.dec[i], nvox, D, s));
@@ -605,13 +609,13 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first
     {
         const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), part, s));
+        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), part, Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, Amax(), s));
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), part, s));
+        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), part, Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, Amax(), s));
         const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
-        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), part, s));
+        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), part, Amax(), s));
     }
     // upscale + reducers (models/modelsTF.py:152-164)
     const int nred = (int)e->iRed.size();
@@ -621,7 +625,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     {
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
-        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), part, s));
+        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), part, Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
     }
     for (int k = nred - 1; k >= 0; --k) {
@@ -630,7 +634,8 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         const int hi = k ? p.redH[k - 1] : Hin, ti = k ? p.redT[k - 1] : T;
         const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
         const ConvGeom gr = red_geom(e, B, (size_t)k, hi, ti, F);
-        CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, s));
+        { Amax m; if (h3) { m.x = k ? A.red(k - 1) : A.act(R); m.w = acur; }
+          CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, m, s)); }
         unsigned* aoth = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, amx(acur, e->iRed[k], aoth), s));
         if (refl) {
@@ -653,31 +658,36 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         float* dH = W + p.dH;
         const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
         // normConv_i: d loss/d w, then d loss/d dec_i
-        CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, s));
+        { Amax m; if (h3) { m.x = A.dec(i); m.w = acur; }
+          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, m, s)); }
         unsigned* agdec = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, amx(acur, ln, agdec), s));
         if (e->impl >= 1 && e->pw_mfma) {
             // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
             const long nvox = (long)B * Hin * Hin * T;
             ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (3.0 * F * E + 2.0 * E * D), s);
-            if (e->impl >= 3)
+            unsigned* anew = new_slot();                     // amax slot of dX
+            if (h3) {
+                PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.b1 = A.b(le); m.dt = agdec; m.y = anew;
+                CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1h[i], W + p.wpack + e->pkW2Kh[i], W + p.wpack + e->pkW1Ch[i],
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, 2, m, s));
+            } else if (e->impl >= 3)
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2Kx6[i], W + p.wpack + e->pkW1Cx6[i],
-                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, 1, PwAmax(), s));
             else
                 CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
                                     params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
             float* tmp2 = cur; cur = oth; oth = tmp2;
-            acur = new_slot();
-            if (h3) CK(amax_tensor(cur, (size_t)nvox * F, acur, s));
+            acur = anew;
             continue;
         }
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
         CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, Amax(), s));
         // decConv_i
-        CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, s));
+        CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, Amax(), s));
         // expConv_i: ReLU gate (H > 0) applied where dH is consumed; skip path adds d loss/d act[i+1]
-        CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), part, s));
+        CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), part, Amax(), s));
         unsigned* aoth = new_slot();
         CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), fragT(le), nullptr, cur, oth, amx(nullptr, le, aoth), s));
         float* tmp = cur; cur = oth; oth = tmp;
@@ -685,7 +695,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     }
     // mainConv1 (input-facing: no backward-data)
     CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
-                  dweff(e->iMain), dbias(e->iMain), part, s));
+                  dweff(e->iMain), dbias(e->iMain), part, Amax(), s));
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.dweff, W + p.invn, grads, s)); }
     return PROBAV_OK;
 }
@@ -780,7 +790,7 @@ size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl)
 {
     if (!geom) return 0;
     const ConvGeom g = geom_from(geom);
-    if (impl == 3) return x6_wgrad_supported(g) ? x6_wgrad_partial_floats(g) * sizeof(float) : 0;
+    if (impl == 3 || impl == 4) return x6_wgrad_supported(g) ? x6_wgrad_partial_floats(g) * sizeof(float) : 0;
     if (impl == 1) return mfma_wgrad_supported(g) ? mfma_wgrad_partial_floats(g) * sizeof(float) : 0;
     return wgrad_partial_floats(g) * sizeof(float);
 }
@@ -791,10 +801,17 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
     if (!geom || !x || !dy || !dw || !scratch) { set_error("probav_conv3d_wgrad: null argument", hipSuccess); return PROBAV_EINVAL; }
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_wgrad: bad geometry", hipSuccess); return PROBAV_EINVAL; }
-    if (impl == 3) {
+    if (impl == 3 || impl == 4) {
         if (!x6_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the x6 kernel", hipSuccess); return PROBAV_EINVAL; }
         if (scratch_bytes < x6_wgrad_partial_floats(g) * sizeof(float)) { set_error("probav_conv3d_wgrad: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
-        return x6_conv_wgrad(g, x, dy, gate, dw, db, (float*)scratch, (hipStream_t)stream);
+        Amax am;
+        if (impl == 4) {
+            int rc = op_scratch();
+            if (!rc) rc = op_amax(x, (size_t)g.N * g.Hi * g.Wi * g.Ti * g.Cin, dy, (size_t)g.N * g.Ho * g.Wo * g.To * g.Cout, (hipStream_t)stream);
+            if (rc) return rc;
+            am.x = g_op_amax; am.w = g_op_amax + 1;
+        }
+        return x6_conv_wgrad(g, x, dy, gate, dw, db, (float*)scratch, impl == 4 ? 2 : 1, am, (hipStream_t)stream);
     }
     if (impl == 1) {
         if (!mfma_wgrad_supported(g)) { set_error("probav_conv3d_wgrad: geometry not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
@@ -826,8 +843,9 @@ static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, co
     return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, nullptr, s);
 }
 
+// h3: PACK_H3_* fragments; the weights' amax must already be in g_op_amax[1] (w1) and [2] (w2)
 static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2,
-                         const float** f2k = nullptr, const float** f1c = nullptr)
+                         const float** f2k = nullptr, const float** f1c = nullptr, bool h3 = false)
 {
     static float* frag = nullptr;
     static PackJob* d_jobs = nullptr;
@@ -841,25 +859,50 @@ static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s,
     J[3].type = PACK_X6_PW_W1C; J[3].src_is_T = 0; J[3].dst_off = 3 * X6_PW_FRAG_WORDS; J[3].count = X6_PW_FRAG_WORDS; J[3].Cin = 32; J[3].Cout = 256;
     J[0].type = PACK_X6_PW_W1; J[0].src_is_T = 0; J[0].dst_off = 0; J[0].count = X6_PW_FRAG_WORDS; J[0].Cin = 32; J[0].Cout = 256;
     J[1].type = PACK_X6_PW_W2; J[1].src_is_T = 1; J[1].dst_off = X6_PW_FRAG_WORDS; J[1].count = X6_PW_FRAG_WORDS; J[1].Cin = 256; J[1].Cout = D;
+    if (h3) for (int k = 0; k < 4; ++k) { J[k].type += 10; J[k].count = H3_PW_FRAG_WORDS; J[k].amax_slot = J[k].src_is_T ? 2 : 1; }
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(d_jobs, J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_pw (x6): job upload", err); return PROBAV_EHIP; }
     *f1 = frag; *f2 = frag + X6_PW_FRAG_WORDS;
     if (f2k) *f2k = frag + 2 * X6_PW_FRAG_WORDS;
     if (f1c) *f1c = frag + 3 * X6_PW_FRAG_WORDS;
-    return mfma_pack(d_jobs, 4, w1, w2, frag, nullptr, s);
+    return mfma_pack(d_jobs, 4, w1, w2, frag, g_op_amax, s);
+}
+// amax of the operands of a single-operator call of the fused pointwise pair: [0] x, [1] w1, [2] w2, [3] b1, [5] d_dec
+static int op_amax_pw(const float* x, const float* w1, const float* w2, const float* b1, const float* d_dec, long nvox, int D, hipStream_t s)
+{
+    int rc = op_scratch();
+    if (rc) return rc;
+    if (hipMemsetAsync(g_op_amax, 0, 16 * sizeof(unsigned), s) != hipSuccess) { set_error("single-operator amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    rc = amax_tensor(x, (size_t)nvox * 32, g_op_amax + 0, s);
+    if (!rc) rc = amax_tensor(w1, 32 * 256, g_op_amax + 1, s);
+    if (!rc) rc = amax_tensor(w2, (size_t)256 * D, g_op_amax + 2, s);
+    if (!rc) rc = amax_tensor(b1, 256, g_op_amax + 3, s);
+    if (!rc && d_dec) rc = amax_tensor(d_dec, (size_t)nvox * D, g_op_amax + 5, s);
+    return rc;
+}
+static PwAmax op_pw_slots()
+{
+    PwAmax m; m.x = g_op_amax; m.w1 = g_op_amax + 1; m.w2 = g_op_amax + 2; m.b1 = g_op_amax + 3; m.dt = g_op_amax + 5; m.y = g_op_amax + 4;
+    return m;
 }
 
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
                       int64_t nvox, int D, int impl, void* stream)
 {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !dec || nvox < 1 || (impl != 2 && impl != 3)) { set_error("probav_pw_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    if (!x || !w1 || !b1 || !w2 || !b2 || !dec || nvox < 1 || impl < 2 || impl > 4) { set_error("probav_pw_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_forward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
-    if (impl == 3) {
+    if (impl >= 3) {
         const float *g1, *g2;
-        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &g1, &g2);
+        PwAmax am;
+        if (impl == 4) {
+            int rc = op_amax_pw(x, w1, w2, b1, nullptr, (long)nvox, D, (hipStream_t)stream);
+            if (rc) return rc;
+            am = op_pw_slots();
+        }
+        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &g1, &g2, nullptr, nullptr, impl == 4);
         if (rc) return rc;
-        return x6_pw_forward(x, g1, g2, b1, b2, dec, (long)nvox, D, (hipStream_t)stream);
+        return x6_pw_forward(x, g1, g2, b1, b2, dec, (long)nvox, D, impl - 2, am, (hipStream_t)stream);
     }
     const float *f1, *f2, *f2b, *f1c;
     int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
@@ -873,16 +916,22 @@ int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, 
                        float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
                        int64_t nvox, int D, int impl, void* stream)
 {
-    if (!x || !d_dec || !d_skip || !w1 || !b1 || !w2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch || nvox < 1 || (impl != 2 && impl != 3)) {
+    if (!x || !d_dec || !d_skip || !w1 || !b1 || !w2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch || nvox < 1 || impl < 2 || impl > 4) {
         set_error("probav_pw_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL;
     }
     if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_backward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
     if (scratch_bytes < probav_pw_backward_scratch_bytes(D)) { set_error("probav_pw_backward: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     const float *f1, *f2, *f2b, *f1c;
-    if (impl == 3) {
-        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
+    if (impl >= 3) {
+        PwAmax am;
+        if (impl == 4) {
+            int rc = op_amax_pw(x, w1, w2, b1, d_dec, (long)nvox, D, (hipStream_t)stream);
+            if (rc) return rc;
+            am = op_pw_slots();
+        }
+        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c, impl == 4);
         if (rc) return rc;
-        return x6_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, D, (hipStream_t)stream);
+        return x6_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, D, impl - 2, am, (hipStream_t)stream);
     }
     int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
     if (rc) return rc;

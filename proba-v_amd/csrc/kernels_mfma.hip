@@ -875,6 +875,101 @@ __device__ __forceinline__ void strip_taps_x6k(const StripArgs& a, const float* 
     }
 }
 
+// The same loop with operands requested PF k-blocks ahead, used by the H3 arithmetic: with half the MFMAs and half the cutting per
+// k-block a wave's step became shorter than the L2 latency of its filter fragments, and with one block of look-ahead every step
+// ended up waiting for them (709 cycles per step, 96 of them MFMA).  Five buffers = the five k-blocks of a group, so a buffer's
+// index is its k-block (static) and the loop body is one branch-free group: hipcc's s_waitcnt insertion keeps exact counts only
+// inside a basic block (the partly unrolled form with an early exit per group waited for lgkmcnt(0) / vmcnt(0) after every branch).
+template <class AR, typename Mid>
+__device__ __forceinline__ void strip_taps_k2(const StripArgs& a, const float* lds, int base0, int base1, int base2, int g0, int ng,
+                                              const uint4* __restrict__ wf, float sa, f32x16& acc, Mid mid)
+{
+    constexpr int NP = AR::NP, PF = 3;
+    const int rowstep = a.Tp * 25;
+    const int glast = g0 + ng - 1;
+    auto group_ptr = [&](int g) -> const float* {
+        const int dh = g / 3, dw = g - 3 * dh;                                  // wave-uniform
+        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);
+        return lds + b + dw * rowstep;
+    };
+    float R[5][8];
+    Frag W[5][NP], acur[NP];
+    auto request = [&](const float* pa, const uint4* pw, int kb, Frag (&w)[NP], float (&r)[8]) {   // kb: compile-time
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = pa[16 * kb + j];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(kb * NP + p) * 64];
+    };
+    const float* pa = group_ptr(g0);
+    const uint4* pw = wf + (long)g0 * 5 * NP * 64;
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb) request(pa, pw, kb, W[kb], R[kb]);
+    mid();
+    cut8<AR>(R[0], sa, acur);
+#pragma unroll 1
+    for (int g = g0; g <= glast; ++g) {
+        const int gn = g + 1 <= glast ? g + 1 : glast;
+        const float* pan = group_ptr(gn);
+        const uint4* pwn = wf + (long)gn * 5 * NP * 64;
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) {
+            if (kb + PF < 5) request(pa, pw, kb + PF, W[kb + PF], R[kb + PF]);
+            else request(pan, pwn, kb + PF - 5, W[kb + PF - 5], R[kb + PF - 5]);  // (after the last group: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mac<AR>(acur, W[kb], acc);
+            cut8<AR>(R[(kb + 1) % 5], sa, acur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pa = pan; pw = pwn;
+    }
+}
+
+// 32-channel form of strip_taps_k2: six steps (dt, k-block) per group = six buffers, look-ahead 3
+template <class AR, typename Mid>
+__device__ __forceinline__ void strip_taps_c2(const StripArgs& a, const float* lds, int base0, int base1, int base2, int g0, int ng,
+                                              const uint4* __restrict__ wf, float sa, f32x16& acc, Mid mid)
+{
+    constexpr int NP = AR::NP, PF = 3, CP = 33;
+    const int rowstep = a.Tp * CP;
+    const int glast = g0 + ng - 1;
+    auto group_ptr = [&](int g) -> const float* {
+        const int dh = g / 3, dw = g - 3 * dh;                                  // wave-uniform
+        const int b = dh == 0 ? base0 : (dh == 1 ? base1 : base2);
+        return lds + b + dw * rowstep;
+    };
+    float R[6][8];
+    Frag W[6][NP], acur[NP];
+    auto request = [&](const float* pa, const uint4* pw, int st, Frag (&w)[NP], float (&r)[8]) {   // st = dt * 2 + kb: compile-time
+        const int dt = st >> 1, kb = st & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = pa[dt * CP + 16 * kb + j];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(st * NP + p) * 64];
+    };
+    const float* pa = group_ptr(g0);
+    const uint4* pw = wf + (long)g0 * 6 * NP * 64;
+#pragma unroll
+    for (int st = 0; st < PF; ++st) request(pa, pw, st, W[st], R[st]);
+    mid();
+    cut8<AR>(R[0], sa, acur);
+#pragma unroll 1
+    for (int g = g0; g <= glast; ++g) {
+        const int gn = g + 1 <= glast ? g + 1 : glast;
+        const float* pan = group_ptr(gn);
+        const uint4* pwn = wf + (long)gn * 6 * NP * 64;
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            if (st + PF < 6) request(pa, pw, st + PF, W[st + PF], R[st + PF]);
+            else request(pan, pwn, st + PF - 6, W[st + PF - 6], R[st + PF - 6]);  // (after the last group: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mac<AR>(acur, W[st], acc);
+            cut8<AR>(R[(st + 1) % 6], sa, acur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pa = pan; pw = pwn;
+    }
+}
+
 template <int CC, int KS, bool GATE, int STRIP_SLOTS, int AM>            // AM / am: see conv3_mfma_kernel
 __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                             const float4* __restrict__ wfrag, const float* __restrict__ bias,
@@ -1033,7 +1128,9 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
                 const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
                           base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
-                if constexpr (X6 && CC == 25) strip_taps_x6k<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);   // (the epilogue wave takes 4 of the 9 groups)
+                if constexpr (AM == 2 && CC == 25) strip_taps_k2<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
+                else if constexpr (X6 && CC == 25) strip_taps_x6k<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);   // (the epilogue wave takes 4 of the 9 groups)
+                else if constexpr (AM == 2) strip_taps_c2<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
                 else if constexpr (X6) strip_taps_x6<CC, AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
                 else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks, mid);
                 if (grp == 1) {

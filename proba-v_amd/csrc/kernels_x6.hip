@@ -27,22 +27,35 @@ namespace probav {
 // ---------------------------------------------------------------------------------------------------
 constexpr int PWF_WAVES = 12;
 
+template <class AR>
 __global__ __launch_bounds__(64 * PWF_WAVES, 1) void pw_fwd_x6_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag,
                                                                      const uint4* __restrict__ w2frag, const float* __restrict__ b1,
                                                                      const float* __restrict__ b2, float* __restrict__ dec,
-                                                                     long nvox, int D)
+                                                                     long nvox, int D, PwAmax am)
 {
+    constexpr int NP = AR::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint4* sW1 = reinterpret_cast<uint4*>(lds_raw);             // [8 chunks][2 kb][3 pieces][64 lanes]  48 KB
-    uint4* sW2 = sW1 + 8 * 6 * 64;                               // same
-    float* sB1 = reinterpret_cast<float*>(sW2 + 8 * 6 * 64);    // 256
+    uint4* sW1 = reinterpret_cast<uint4*>(lds_raw);             // [8 chunks][2 kb][NP pieces][64 lanes]  48 / 32 KB
+    uint4* sW2 = sW1 + 8 * 2 * NP * 64;                          // same
+    float* sB1 = reinterpret_cast<float*>(sW2 + 8 * 2 * NP * 64);    // 256
     float* sB2 = sB1 + 256;                                      // 32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    for (int i = tid; i < 8 * 6 * 64; i += 64 * PWF_WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
-    if (tid < 256) sB1[tid] = b1[tid];
+    // H3 scales.  The hidden tensor exists only in registers, so its scale comes from a bound: |h| <= 32 amax(x) amax(w1) + amax(b1).
+    float sx = 1.f; int k1 = 0, k2 = 0; float sbias = 1.f;
+    if constexpr (AR::SCALED) {
+        const unsigned ax = *am.x, aw1 = *am.w1;
+        const int ex = h3_exp(ax), ew1 = h3_exp(aw1), ew2 = h3_exp(*am.w2);
+        const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(*am.b1));
+        sx = pow2i(ex); sbias = pow2i(eh);
+        k1 = eh - ex - ew1;                                      // accumulator of the first product -> hidden at its own scale
+        k2 = -(ew2 + eh);                                        // accumulator of the second product -> true values
+    }
+    for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * PWF_WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
+    if (tid < 256) sB1[tid] = b1[tid] * sbias;
     if (tid < 32) sB2[tid] = tid < D ? b2[tid] : 0.f;
     __syncthreads();
 
+    float omax = 0.f;
     const long ntiles = (nvox + 31) >> 5;
     const long wstride = (long)gridDim.x * PWF_WAVES;
     for (long tile = (long)blockIdx.x * PWF_WAVES + wave; tile < ntiles; tile += wstride) {
@@ -50,13 +63,13 @@ __global__ __launch_bounds__(64 * PWF_WAVES, 1) void pw_fwd_x6_kernel(const floa
         const bool vok = v < nvox;
         if (!vok) v = nvox - 1;
         // B operand of the first product: X^T, k = cin 16kb + 8h + j
-        Frag xb[2][3];
+        Frag xb[2][NP];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 16 * kb + 8 * h);
             const float4 t0 = xp[0], t1 = xp[1];
             const float xs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            split8(xs, xb[kb]);
+            cut8<AR>(xs, sx, xb[kb]);
         }
         f32x16 T;
 #pragma unroll
@@ -68,32 +81,35 @@ __global__ __launch_bounds__(64 * PWF_WAVES, 1) void pw_fwd_x6_kernel(const floa
             for (int r = 0; r < 16; ++r) H[r] = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                Frag a[3];
+                Frag a[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p].u = sW1[((c * 2 + kb) * 3 + p) * 64 + lane];
-                H = mac6(a, xb[kb], H);
+                for (int p = 0; p < NP; ++p) a[p].u = sW1[((c * 2 + kb) * NP + p) * 64 + lane];
+                H = mac<AR>(a, xb[kb], H);
             }
             // bias + ReLU, then split the hidden tile: registers 8kb .. 8kb+7 are k-block kb of the second product
-            Frag hb[2][3];
+            Frag hb[2][NP];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 float hs[8];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const float4 bb = *reinterpret_cast<const float4*>(sB1 + 32 * c + 8 * (2 * kb + g) + 4 * h);
-                    hs[4 * g + 0] = fmaxf(H[8 * kb + 4 * g + 0] + bb.x, 0.f);
-                    hs[4 * g + 1] = fmaxf(H[8 * kb + 4 * g + 1] + bb.y, 0.f);
-                    hs[4 * g + 2] = fmaxf(H[8 * kb + 4 * g + 2] + bb.z, 0.f);
-                    hs[4 * g + 3] = fmaxf(H[8 * kb + 4 * g + 3] + bb.w, 0.f);
+                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float hv = H[8 * kb + 4 * g + i];
+                        if constexpr (AR::SCALED) hv = ldexpf(hv, k1);
+                        hs[4 * g + i] = fmaxf(hv + bv[i], 0.f);
+                    }
                 }
-                split8(hs, hb[kb]);
+                cut8_scaled<AR>(hs, hb[kb]);
             }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                Frag a[3];
+                Frag a[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p].u = sW2[((c * 2 + kb) * 3 + p) * 64 + lane];
-                T = mac6(a, hb[kb], T);
+                for (int p = 0; p < NP; ++p) a[p].u = sW2[((c * 2 + kb) * NP + p) * 64 + lane];
+                T = mac<AR>(a, hb[kb], T);
             }
         }
         if (vok) {
@@ -101,23 +117,35 @@ __global__ __launch_bounds__(64 * PWF_WAVES, 1) void pw_fwd_x6_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = rowmap(r, h);
-                if (ch < D) o[ch] = T[r] + sB2[ch];
+                float t = T[r];
+                if constexpr (AR::SCALED) t = ldexpf(t, k2);
+                t += sB2[ch];
+                if (ch < D) { o[ch] = t; omax = fmaxf(omax, fabsf(t)); }
             }
         }
     }
+    if (am.y) amax_commit(omax, am.y);
 }
 
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
-                  long nvox, int D, hipStream_t s)
+                  long nvox, int D, int arith, const PwAmax& am, hipStream_t s)
 {
     static bool once = false;
-    const size_t lds = (size_t)2 * 8 * 6 * 64 * 16 + (256 + 32) * sizeof(float);
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    hipLaunchKernelGGL(pw_fwd_x6_kernel, dim3(256), dim3(64 * PWF_WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
-                       b1, b2, dec, nvox, D);
+    if (arith == 2) {
+        if (!am.x || !am.w1 || !am.w2 || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+        const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32) * sizeof(float);
+        hipLaunchKernelGGL(pw_fwd_x6_kernel<H3>, dim3(256), dim3(64 * PWF_WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+                           b1, b2, dec, nvox, D, am);
+    } else {
+        const size_t lds = (size_t)2 * 8 * 2 * X6::NP * 64 * 16 + (256 + 32) * sizeof(float);
+        hipLaunchKernelGGL(pw_fwd_x6_kernel<X6>, dim3(256), dim3(64 * PWF_WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+                           b1, b2, dec, nvox, D, am);
+    }
     return check_launch("pw_fwd_x6");
 }
 
@@ -137,7 +165,6 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
 // ---------------------------------------------------------------------------------------------------
 constexpr int PB_ROW = 80;                  // bytes per voxel row of a piece image: 32 bf16 + 16 (row reads conflict-free)
 constexpr int PB_IMG = 32 * PB_ROW;
-constexpr int PB_TILE = 3 * PB_IMG;         // one staged tile: three piece images
 constexpr int PB_TB = 32 * 33;              // floats of one dX partial
 
 constexpr int PT_ROW = 72;                  // row bytes of a wave's transpose image (only 8-byte accesses)
@@ -155,10 +182,11 @@ __device__ __forceinline__ void tr_frag(const unsigned char* img, int lane, int 
 }
 // the transpose image of an accumulator tile whose rows (registers) are channels and whose columns (lanes) are voxels: lane
 // (voxel col, half h) owns channels 8G + 4h + (0..3) in registers 4G..4G+3, i.e. the dwords of its cut fragments in order
-__device__ __forceinline__ void store_pieces(unsigned char* img, int col, int h, const Frag (&f)[2][3])
+template <int NP>
+__device__ __forceinline__ void store_pieces(unsigned char* img, int col, int h, const Frag (&f)[2][NP])
 {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
         unsigned char* d = img + p * PT_IMG + col * PT_ROW + 8 * h;
         *reinterpret_cast<uint2*>(d) = make_uint2(f[0][p].u.x, f[0][p].u.y);          // G = 0: channels 4h ..
         *reinterpret_cast<uint2*>(d + 16) = make_uint2(f[0][p].u.z, f[0][p].u.w);     // G = 1: channels 8 + 4h ..
@@ -167,31 +195,50 @@ __device__ __forceinline__ void store_pieces(unsigned char* img, int col, int h,
     }
 }
 
+template <class AR>
 __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
     const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
-    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int D)
+    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int D, PwAmax am)
 {
+    constexpr int NP = AR::NP;
+    constexpr int PB_TILE = NP * PB_IMG;                          // one staged tile: NP piece images
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned char* XA = lds_raw;                                  // [2 buffers][3 pieces][32 voxels][80 B]
+    unsigned char* XA = lds_raw;                                  // [2 buffers][NP pieces][32 voxels][80 B]
     unsigned char* DA = XA + 2 * PB_TILE;                         // same for dT (channels D..31 stay zero)
     float* TbAll = reinterpret_cast<float*>(DA + 2 * PB_TILE);   // [2 tile parities][8 waves][32][33] dX partials
     float* sB1 = TbAll + 16 * PB_TB;                              // 256 expand biases
-    unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 256);       // [8 waves][3 pieces][32 voxels][72 B] transpose images
+    unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 256);       // [8 waves][NP pieces][32 voxels][72 B] transpose images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    if (tid < 256) sB1[tid] = b1[tid];
+    // H3 scales.  Tensors that exist only in registers are scaled from bounds: |H| <= 32 amax(x) amax(w1) + amax(b1) (as in the
+    // forward kernel) and |dH| <= D amax(dT) amax(w2).
+    float sx = 1.f, sd = 1.f, sbias = 1.f;
+    int kh = 0, kg = 0, kdx = 0, kdw1 = 0, kdw2 = 0, kdb1 = 0;
+    if constexpr (AR::SCALED) {
+        const unsigned ax = *am.x, aw1 = *am.w1, aw2 = *am.w2, ad = *am.dt;
+        const int ex = h3_exp(ax), ew1 = h3_exp(aw1), ew2 = h3_exp(aw2), ed = h3_exp(ad);
+        const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(*am.b1));
+        const int eg = h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2));
+        sx = pow2i(ex); sd = pow2i(ed); sbias = pow2i(eh);
+        kh = eh - ex - ew1;           // accumulator (a) -> hidden values at their own scale
+        kg = eg - ew2 - ed;           // accumulator (b) -> hidden gradients at their own scale
+        kdx = -(ew1 + eg);            // (c) partials -> true values
+        kdw1 = -(ex + eg); kdw2 = -(ed + eh); kdb1 = -eg;
+    }
+    if (tid < 256) sB1[tid] = b1[tid] * sbias;
     const int c = wave;                                           // this wave's hidden chunk
 
-    Frag w1[2][3], w2[2][3], w3[2][3];                            // chunk-resident weight pieces
+    Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            w1[kb][p].u = w1f[((c * 2 + kb) * 3 + p) * 64 + lane];
-            w2[kb][p].u = w2kf[((c * 2 + kb) * 3 + p) * 64 + lane];
-            w3[kb][p].u = w1cf[((c * 2 + kb) * 3 + p) * 64 + lane];
+        for (int p = 0; p < NP; ++p) {
+            w1[kb][p].u = w1f[((c * 2 + kb) * NP + p) * 64 + lane];
+            w2[kb][p].u = w2kf[((c * 2 + kb) * NP + p) * 64 + lane];
+            w3[kb][p].u = w1cf[((c * 2 + kb) * NP + p) * 64 + lane];
         }
-    unsigned char* Ti = TiAll + wave * 3 * PT_IMG;
+    unsigned char* Ti = TiAll + wave * NP * PT_IMG;
+    float omax = 0.f;
     f32x16 dW1, dW2t;
     float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
 #pragma unroll
@@ -230,21 +277,21 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     auto stage_store = [&](int buf, const float4& xv, const float (&d)[4]) {
         if (!stager) return;
         {
-            unsigned a[3], b[3];
-            split_pair(xv.x, xv.y, a[0], a[1], a[2]);
-            split_pair(xv.z, xv.w, b[0], b[1], b[2]);
+            unsigned a[NP], b[NP];
+            cut_pair<AR>(xv.x, xv.y, sx, a);
+            cut_pair<AR>(xv.z, xv.w, sx, b);
             unsigned char* dst = XA + buf * PB_TILE + (tid >> 3) * PB_ROW + (tid & 7) * 8;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * PB_IMG) = make_uint2(a[p], b[p]);
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(dst + p * PB_IMG) = make_uint2(a[p], b[p]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (tid + 256 * k < 32 * D) {
-                unsigned q[3];
-                pieces(d[k], q[0], q[1], q[2]);
+                unsigned short q[NP];
+                cut_one<AR>(d[k], sd, q);
                 unsigned char* dst = DA + buf * PB_TILE + dvk[k] * PB_ROW + dok[k] * 2;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned short*>(dst + p * PB_IMG) = (unsigned short)(q[p] >> 16);
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<unsigned short*>(dst + p * PB_IMG) = q[p];
             }
             bs2[k] += d[k];
         }
@@ -270,10 +317,18 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
-            float sacc = pdo[k];
+            float sacc;
+            if constexpr (AR::SCALED) {
+                sacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sacc += TbAll[(pb * 8 + j) * PB_TB + rv * 33 + col];
-            if (pv0 + rv < nvox) dX[(pv0 + rv) * 32 + col] = sacc;
+                for (int j = 0; j < 8; ++j) sacc += TbAll[(pb * 8 + j) * PB_TB + rv * 33 + col];
+                sacc = ldexpf(sacc, kdx) + pdo[k];
+            } else {
+                sacc = pdo[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sacc += TbAll[(pb * 8 + j) * PB_TB + rv * 33 + col];
+            }
+            if (pv0 + rv < nvox) { dX[(pv0 + rv) * 32 + col] = sacc; omax = fmaxf(omax, fabsf(sacc)); }
         }
     };
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
@@ -293,11 +348,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         }
         const unsigned char* Xb = XA + buf * PB_TILE;
         const unsigned char* Db = DA + buf * PB_TILE;
-        Frag xf[2][3], df[2][3];
+        Frag xf[2][NP], df[2][NP];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
                 df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
             }
@@ -310,13 +365,13 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #endif
         {
             f32x16 H = zero, dH = zero, dx = zero;
-            H = mac6(w1[0], xf[0], H); H = mac6(w1[1], xf[1], H);                     // (a)
-            dH = mac6(w2[0], df[0], dH); dH = mac6(w2[1], df[1], dH);                 // (b)
+            H = mac<AR>(w1[0], xf[0], H); H = mac<AR>(w1[1], xf[1], H);               // (a)
+            dH = mac<AR>(w2[0], df[0], dH); dH = mac<AR>(w2[1], df[1], dH);           // (b)
             __builtin_amdgcn_sched_barrier(0);
             reduce_prev(buf ^ 1);                          // LDS reads, adds and two stores in the shadow of the 24 MFMAs just issued
             __builtin_amdgcn_sched_barrier(0);
             XS2(0);
-            Frag gf[2][3], hf[2][3];
+            Frag gf[2][NP], hf[2][NP];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 float gs[8], hs[8];
@@ -327,40 +382,42 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 8 * kb + 4 * g + i;
-                        const float hv = H[r] + bv[i];
-                        gs[4 * g + i] = hv > 0.f ? dH[r] : 0.f;
+                        float hv = H[r], dv = dH[r];
+                        if constexpr (AR::SCALED) { hv = ldexpf(hv, kh); dv = ldexpf(dv, kg); }
+                        hv += bv[i];
+                        gs[4 * g + i] = hv > 0.f ? dv : 0.f;
                         hs[4 * g + i] = fmaxf(hv, 0.f);
                         bs1v[r] += gs[4 * g + i];
                     }
                 }
-                split8(gs, gf[kb]);
-                split8(hs, hf[kb]);
+                cut8_scaled<AR>(gs, gf[kb]);
+                cut8_scaled<AR>(hs, hf[kb]);
             }
             XS2(1);
-            dx = mac6(w3[0], gf[0], dx); dx = mac6(w3[1], gf[1], dx);                 // (c)
+            dx = mac<AR>(w3[0], gf[0], dx); dx = mac<AR>(w3[1], gf[1], dx);           // (c)
             XS2(2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dx[r];
             // (d): dH' pieces through this wave's transpose image.  LDS operations of one wave execute in order; the empty asm
             // statements only keep the COMPILER from moving reads above the writes they depend on.
-            store_pieces(Ti, col, half, gf);
+            store_pieces<NP>(Ti, col, half, gf);
             asm volatile("" ::: "memory");
-            Frag at[3], bt[3];
+            Frag at[NP], bt[NP];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { tr_frag<PB_ROW>(Xb + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
-                dW1 = mac6(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
+                for (int p = 0; p < NP; ++p) { tr_frag<PB_ROW>(Xb + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
+                dW1 = mac<AR>(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
             }
             XS2(3);
             asm volatile("" ::: "memory");
-            store_pieces(Ti, col, half, hf);                            // (e): H' pieces, same image
+            store_pieces<NP>(Ti, col, half, hf);                            // (e): H' pieces, same image
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { tr_frag<PB_ROW>(Db + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
-                dW2t = mac6(at, bt, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
+                for (int p = 0; p < NP; ++p) { tr_frag<PB_ROW>(Db + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
+                dW2t = mac<AR>(at, bt, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
             }
             asm volatile("" ::: "memory");
             XS2(4);
@@ -374,14 +431,17 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     }
     __syncthreads();
     reduce_prev(buf ^ 1);
+    if (am.y) amax_commit(omax, am.y);
     // one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
     float* sl = slabs + (long)blockIdx.x * slab_floats;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rw = rowmap(r, half);
-        sl[(long)rw * 256 + 32 * c + col] = dW1[r];                                    // [cin][hidden]
-        if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = dW2t[r];                // [hidden][out]
+        float a1 = dW1[r], a2 = dW2t[r];
+        if constexpr (AR::SCALED) { a1 = ldexpf(a1, kdw1); a2 = ldexpf(a2, kdw2); }
+        sl[(long)rw * 256 + 32 * c + col] = a1;                                        // [cin][hidden]
+        if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = a2;                     // [hidden][out]
     }
     // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
 #pragma unroll
@@ -389,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         float v = bs1v[r];
 #pragma unroll
         for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+        if constexpr (AR::SCALED) v = ldexpf(v, kdb1);
         if (col == 0) sl[8192 + 256 * (long)D + 32 * c + rowmap(r, half)] = v;
     }
     // db2[out] = sum of the staged dT values: thread t always staged out (t % D) and ((t + 512) % D); fixed-order sum
@@ -413,16 +474,24 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
                    const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, int D,
-                   hipStream_t s)
+                   int arith, const PwAmax& am, hipStream_t s)
 {
     static bool once = false;
-    const size_t lds = (size_t)4 * PB_TILE + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 3 * PT_IMG;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    hipLaunchKernelGGL(pw_bwd_x6_kernel, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
-                       (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D);
+    if (arith == 2) {
+        if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+        const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * H3::NP * PT_IMG;
+        hipLaunchKernelGGL(pw_bwd_x6_kernel<H3>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
+                           (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D, am);
+    } else {
+        const size_t lds = (size_t)4 * X6::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * X6::NP * PT_IMG;
+        hipLaunchKernelGGL(pw_bwd_x6_kernel<X6>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
+                           (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D, am);
+    }
     int rc = check_launch("pw_bwd_x6");
     if (rc) return rc;
     return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
@@ -452,14 +521,17 @@ struct WgArgs {
 
 __device__ __forceinline__ int wg_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-template <int CIN, bool GATE>
+template <int CIN, bool GATE, class AR>
 __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ gate, float* __restrict__ partial,
-                                                               float* __restrict__ partial_b)
+                                                               float* __restrict__ partial_b, Amax am)
 {
+    constexpr int NPC = AR::NP;                    // pieces per value
     constexpr int CB = CIN <= 28 ? 56 : 64;        // bytes of one piece of one voxel (channels padded to 28 / 32)
-    constexpr int VS = 3 * CB;                     // bytes per voxel
+    constexpr int VS = NPC * CB;                   // bytes per voxel
     constexpr int NP = (CIN + 1) / 2;              // channel pairs staged per voxel
+    float sx = 1.f, sd = 1.f; int kun = 0;         // H3: scales of x (am.x) and dY (am.w), exponent that undoes both
+    if constexpr (AR::SCALED) { const int ex = h3_exp(*am.x), ed = h3_exp(*am.w); sx = pow2i(ex); sd = pow2i(ed); kun = -(ex + ed); }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const int li = lane & 15, gcol = (lane >> 4) & 1;
@@ -510,11 +582,11 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             if (i < items) {
                 const int vox = i / NP, cp = i - vox * NP;
                 const int lw = (int)__umulhi((unsigned)vox, a.mTi), t = vox - lw * a.Ti;
-                unsigned q[3];
-                split_pair(f[k][0], f[k][1], q[0], q[1], q[2]);
+                unsigned q[NPC];
+                cut_pair<AR>(f[k][0], f[k][1], sx, q);
                 unsigned char* d = slot + (lw * a.Tp + t + a.pt) * VS + cp * 4;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
+                for (int p = 0; p < NPC; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
             }
         }
     };
@@ -591,14 +663,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             const int w = (int)__umulhi((unsigned)vi, a.mT), t = vi - w * a.T;
             return (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
         };
-        Frag bf[3], bfn[3];
+        Frag bf[NPC], bfn[NPC];
         int va[2], van[2];
         float rawn[8], rawnn[8];
         {
             float raw0[8];
             load_dy(ksel, raw0);
             load_dy(ksel + 2 < nkb ? ksel + 2 : ksel, rawn);
-            split8(raw0, bf);
+            cut8<AR>(raw0, sd, bf);
             va[0] = tr_addr(ksel, 0); va[1] = tr_addr(ksel, 1);
             if (tg == 0 && ksel < nkb) {
 #pragma unroll
@@ -610,12 +682,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         for (int kb = ksel; kb < nkb; kb += 2) {
             const int kn = kb + 2 < nkb ? kb + 2 : kb, knn = kb + 4 < nkb ? kb + 4 : kb;
             load_dy(knn, rawnn);
-            Frag af[2][3];
-            auto load_a = [&](int j, Frag (&f)[3]) {
+            Frag af[2][NPC];
+            auto load_a = [&](int j, Frag (&f)[NPC]) {
                 cptr p0 = lds_raw + tapoff[j] + va[0];
                 cptr p1 = lds_raw + tapoff[j] + va[1];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NPC; ++p) {
                     f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * CB));
                     f[p].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + p * CB));
                 }
@@ -625,19 +697,22 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             for (int j = 0; j < 7; ++j) {
                 if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (slot j = 6 of tg = 3 is clamped: harmless reread)
                 __builtin_amdgcn_sched_barrier(0);
-                if (j < 6 || tg < 3) acc[j] = mac6(af[j & 1], bf, acc[j]);            // wave-uniform
+                if (j < 6 || tg < 3) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);         // wave-uniform
                 // a seventh of the next block's preparation.  The empty volatile asm statements pin it between this tap's
                 // scheduling barriers (pure arithmetic would otherwise be sunk to the end of the loop body).
                 if (j < 4) {
                     float ra = rawn[2 * j], rb = rawn[2 * j + 1];
                     asm volatile("" : "+v"(ra), "+v"(rb));
-                    unsigned q0, q1, q2;
-                    split_pair(ra, rb, q0, q1, q2);
-                    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
-                    if (j == 0) { bfn[0].u.x = q0; bfn[1].u.x = q1; bfn[2].u.x = q2; }
-                    if (j == 1) { bfn[0].u.y = q0; bfn[1].u.y = q1; bfn[2].u.y = q2; }
-                    if (j == 2) { bfn[0].u.z = q0; bfn[1].u.z = q1; bfn[2].u.z = q2; }
-                    if (j == 3) { bfn[0].u.w = q0; bfn[1].u.w = q1; bfn[2].u.w = q2; }
+                    unsigned q[NPC];
+                    cut_pair<AR>(ra, rb, sd, q);
+#pragma unroll
+                    for (int p = 0; p < NPC; ++p) {
+                        asm volatile("" : "+v"(q[p]));
+                        if (j == 0) bfn[p].u.x = q[p];
+                        if (j == 1) bfn[p].u.y = q[p];
+                        if (j == 2) bfn[p].u.z = q[p];
+                        if (j == 3) bfn[p].u.w = q[p];
+                    }
                 } else if (j < 6) {
                     int kk = kn;
                     asm volatile("" : "+v"(kk));
@@ -649,14 +724,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
                     for (int i = 0; i < 8; ++i) bsum += rawn[i];
                 }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {                                         // one MFMA, then two VALU in its shadow
+                for (int i = 0; i < (AR::SCALED ? 3 : 6); ++i) {                      // one MFMA, then two VALU in its shadow
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p] = bfn[p];
+            for (int p = 0; p < NPC; ++p) bf[p] = bfn[p];
             va[0] = van[0]; va[1] = van[1];
 #pragma unroll
             for (int i = 0; i < 8; ++i) rawn[i] = rawnn[i];
@@ -689,7 +764,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             if (tap >= 27) continue;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[j][r] + xch[(j * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[j][r] + xch[(j * 16 + r) * 64 + lane];
+                if constexpr (AR::SCALED) v[r] = ldexpf(v[r], kun);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = rowmap(r, h);
@@ -706,13 +784,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     XS_OUT;
 }
 
-static int x6_wgrad_split(const ConvGeom& g)              // number of column ranges per row, 0 = unsupported
+static int x6_wgrad_split(const ConvGeom& g, int arith = 1)              // number of column ranges per row, 0 = unsupported
 {
     if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.ph < 0 || g.ph > 1 || g.pw < 0 || g.pw > 1 || g.pt < 0 || g.pt > 1) return 0;
     if (g.reflect_hw && (g.ph != 1 || g.pw != 1 || g.Hi < 2 || g.Wi < 2)) return 0;
     if ((g.Cin != 25 && g.Cin != 32) || g.Cout != 32 || g.Ti < 2 || g.To < 2) return 0;
     if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2 || g.Ho < 1 || g.Wo < 1) return 0;
-    const int vs = g.Cin == 25 ? 168 : 192, np = (g.Cin + 1) / 2, nst = g.Cin == 25 ? 6 : 7;
+    const int np_ = arith == 2 ? 2 : 3;
+    const int vs = (g.Cin == 25 ? 56 : 64) * np_, np = (g.Cin + 1) / 2, nst = g.Cin == 25 ? 6 : 7;
     for (int ns = 1; ns <= 4 && ns <= g.Wo; ++ns) {
         const int Wt = (g.Wo + ns - 1) / ns;
         const size_t lds = (size_t)3 * (Wt + 2) * (g.Ti + 2 * g.pt) * vs + 16;
@@ -720,44 +799,52 @@ static int x6_wgrad_split(const ConvGeom& g)              // number of column ra
     }
     return 0;
 }
-bool x6_wgrad_supported(const ConvGeom& g) { return x6_wgrad_split(g) > 0; }
+bool x6_wgrad_supported(const ConvGeom& g) { return x6_wgrad_split(g) > 0; }     // (whatever X6 fits, H3 fits)
 
-static int x6_wgrad_grid(const ConvGeom& g)
+static int x6_wgrad_grid(const ConvGeom& g, int arith = 1)
 {
-    const int total = g.N * g.Ho * x6_wgrad_split(g);
+    const int total = g.N * g.Ho * x6_wgrad_split(g, arith);
     return total < 256 ? total : 256;
 }
+// scratch for either arithmetic (H3 never cuts a row into more column ranges than X6, so its grid is not larger)
 size_t x6_wgrad_partial_floats(const ConvGeom& g) { return (size_t)x6_wgrad_grid(g) * ((size_t)27 * g.Cin * g.Cout + g.Cout); }
 
-int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial, hipStream_t s)
+int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial,
+                  int arith, const Amax& am, hipStream_t s)
 {
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_wgrad: H3 arithmetic needs the amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
     WgArgs a;
-    a.nsplit = x6_wgrad_split(g); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;
+    a.nsplit = x6_wgrad_split(g, arith); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;
     a.N = g.N; a.H = g.Ho; a.W = g.Wo; a.T = g.To; a.Cout = g.Cout; a.Hi = g.Hi; a.Wi = g.Wi; a.Ti = g.Ti;
     a.ph = g.ph; a.pw = g.pw; a.pt = g.pt; a.reflect = g.reflect_hw;
     a.Wp = a.Wt + 2; a.Tp = g.Ti + 2 * g.pt;
     a.nv = a.Wt * g.To; a.total_tiles = g.N * g.Ho * a.nsplit;
     a.mT = (unsigned)((0x100000000ull + (unsigned)g.To - 1) / (unsigned)g.To);
     a.mTi = (unsigned)((0x100000000ull + (unsigned)g.Ti - 1) / (unsigned)g.Ti);
-    const int grid = x6_wgrad_grid(g);
+    const int grid = x6_wgrad_grid(g, arith);
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
-    const int vs = g.Cin == 25 ? 168 : 192;
+    const int vs = (g.Cin == 25 ? 56 : 64) * (arith == 2 ? 2 : 3);
     size_t lds = (size_t)3 * a.Wp * a.Tp * vs + 16;
     const size_t xch = (size_t)4 * (7 * 16 + 1) * 64 * sizeof(float);                 // exchange area of the epilogue
     if (lds < xch) lds = xch;
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<25, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define PROBAV_WGA(C, G, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<C, G, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        PROBAV_WGA(25, false, X6); PROBAV_WGA(25, true, X6); PROBAV_WGA(32, false, X6); PROBAV_WGA(32, true, X6);
+        PROBAV_WGA(25, false, H3); PROBAV_WGA(25, true, H3); PROBAV_WGA(32, false, H3); PROBAV_WGA(32, true, H3);
+#undef PROBAV_WGA
         once = true;
     }
-#define PROBAV_WG6(C, G) hipLaunchKernelGGL((conv3_wgrad_x6_kernel<C, G>), dim3(grid), dim3(512), lds, s, a, x, dy, gate, partial, partial_b)
-    if (g.Cin == 25) { if (gate) PROBAV_WG6(25, true); else PROBAV_WG6(25, false); }
-    else             { if (gate) PROBAV_WG6(32, true); else PROBAV_WG6(32, false); }
+#define PROBAV_WG6(C, G, A) hipLaunchKernelGGL((conv3_wgrad_x6_kernel<C, G, A>), dim3(grid), dim3(512), lds, s, a, x, dy, gate, partial, partial_b, am)
+    if (arith == 2) {
+        if (g.Cin == 25) { if (gate) PROBAV_WG6(25, true, H3); else PROBAV_WG6(25, false, H3); }
+        else             { if (gate) PROBAV_WG6(32, true, H3); else PROBAV_WG6(32, false, H3); }
+    } else {
+        if (g.Cin == 25) { if (gate) PROBAV_WG6(25, true, X6); else PROBAV_WG6(25, false, X6); }
+        else             { if (gate) PROBAV_WG6(32, true, X6); else PROBAV_WG6(32, false, X6); }
+    }
 #undef PROBAV_WG6
     int rc = check_launch("conv3_wgrad_x6");
     if (rc) return rc;

@@ -60,7 +60,8 @@ __device__ __forceinline__ void amax_commit(float m, unsigned* slot)
 {
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+    // (a stale read only costs a redundant atomic: the slot never decreases while its tensor is being produced)
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, __float_as_uint(m));
 }
 
 // ---- X6: the three truncation pieces of one value, as fp32 bit patterns whose low 16 bits are zero
@@ -106,6 +107,21 @@ __device__ __forceinline__ void cut_pair(float a, float b, float s, unsigned (&q
         split_pair(a, b, q[0], q[1], q[2]);
     }
 }
+// the same for values that already carry their tensor's scale
+template <class AR>
+__device__ __forceinline__ void cut_pair_scaled(float a, float b, unsigned (&q)[AR::NP])
+{
+    if constexpr (AR::SCALED) {
+        const f32x2 v = {a, b};
+        const f16x2 h0 = __builtin_convertvector(v, f16x2);
+        const f32x2 r = v - __builtin_convertvector(h0, f32x2);
+        const f16x2 h1 = __builtin_convertvector(r, f16x2);
+        q[0] = __builtin_bit_cast(unsigned, h0);
+        q[1] = __builtin_bit_cast(unsigned, h1);
+    } else {
+        split_pair(a, b, q[0], q[1], q[2]);
+    }
+}
 // 16-bit pieces of one value
 template <class AR>
 __device__ __forceinline__ void cut_one(float a, float s, unsigned short (&q)[AR::NP])
@@ -129,6 +145,15 @@ __device__ __forceinline__ void cut8(const float (&x)[8], float s, Frag (&f)[AR:
     unsigned q[4][AR::NP];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cut_pair<AR>(x[2 * i], x[2 * i + 1], s, q[i]);
+#pragma unroll
+    for (int p = 0; p < AR::NP; ++p) { f[p].u.x = q[0][p]; f[p].u.y = q[1][p]; f[p].u.z = q[2][p]; f[p].u.w = q[3][p]; }
+}
+template <class AR>
+__device__ __forceinline__ void cut8_scaled(const float (&x)[8], Frag (&f)[AR::NP])
+{
+    unsigned q[4][AR::NP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cut_pair_scaled<AR>(x[2 * i], x[2 * i + 1], q[i]);
 #pragma unroll
     for (int p = 0; p < AR::NP; ++p) { f[p].u.x = q[0][p]; f[p].u.y = q[1][p]; f[p].u.z = q[2][p]; f[p].u.w = q[3][p]; }
 }

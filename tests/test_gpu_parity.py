@@ -110,7 +110,7 @@ WGRAD_CASES = [c for c in CONV_CASES if not c[0].startswith("bwd-data")]
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
 def test_conv3d_wgrad_matches_autograd(dev, case, impl):
-    if impl in (2, 4):
+    if impl == 2:
         pytest.skip("impl 2 only changes the forward / backward-data kernels")
     name, N, hwt, Cin, Cout, k, pad, reflect, relu, _, _ = case
     rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
@@ -132,7 +132,7 @@ def test_conv3d_wgrad_matches_autograd(dev, case, impl):
     L = _lib()
     g = _geom(N, hwt[0], hwt[1], hwt[2], Cin, ho[0], ho[1], ho[2], Cout, k, pad, reflect, relu)
     nbytes = L.lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(g), impl)
-    if impl in (1, 3) and nbytes == 0:
+    if impl in (1, 3, 4) and nbytes == 0:
         pytest.skip("geometry not covered by this MFMA backward-filter kernel (the engine falls back)")
     scratch = torch.empty(nbytes // 4 + 1, device=dev)
     dw = torch.full(k + (Cin, Cout), float("nan"), device=dev)
@@ -368,7 +368,7 @@ def test_fused_pointwise_forward_backward(dev, nvox):
     Hpre = X @ W1 + b1
     Hh = np.maximum(Hpre, 0)
     ref = Hh @ W2 + b2
-    for impl in (2, 3):                       # native fp32 MFMA and the six-product bf16 split: one tolerance for both
+    for impl in (2, 3, 4):                    # native fp32 MFMA, the six-product bf16 split and the three-product fp16 split: one tolerance
         dec = torch.full((nvox, D), float("nan"), device=dev)
         L.check(L.lib().probav_pw_forward(L.ptr(xd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(dec), nvox, D, impl,
                                           L.current_stream()))
@@ -379,7 +379,7 @@ def test_fused_pointwise_forward_backward(dev, nvox):
     scratch = torch.empty(nbytes // 4 + 1, device=dev)
     dH = (ddec.astype(np.float64) @ W2.T) * (Hpre > 0)
     refs = {"dx": dskip + dH @ W1.T, "dw1": X.T @ dH, "db1": dH.sum(0), "dw2": Hh.T @ ddec, "db2": ddec.astype(np.float64).sum(0)}
-    for impl in (2, 3):
+    for impl in (2, 3, 4):
         dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
         dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
         L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
@@ -400,7 +400,7 @@ def test_mfma_engine_matches_direct_engine(dev, batch):
     lo = Losses(targetShape=(48, 48, 1))
     x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(batch, seed=32))
     res = []
-    for impl in (0, 2, 3):
+    for impl in (0, 2, 3, 4):
         m.set_impl(impl)
         m.flat.grad = None
         p = m(x, training=True)
@@ -410,7 +410,7 @@ def test_mfma_engine_matches_direct_engine(dev, batch):
     with torch.no_grad():
         p1 = m(x, training=False)
     assert float((res[0][0] - p1).abs().max()) < 1e-5 * float(res[0][0].abs().max())
-    for other in (1, 2):
+    for other in (1, 2, 3):
         assert float((res[0][0] - res[other][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
         # two fp32 summation orders can flip a few of the ~10^8 ReLU gates whose pre-activation is ~0, which moves single
         # filter-gradient entries by ~1/sqrt(#voxels): compare in relative L2 per tensor (the sharp per-kernel checks are
