@@ -32,7 +32,7 @@ CLASSES = ["weight_norm", "small", "conv3x3x3_fwd", "conv3x3x3_bwd_data", "conv3
            "conv3x3x3_fwd_x6", "conv3x3x3_bwd_data_x6", "conv3x3x3_wgrad_x6", "conv1x1x1_fwd_x6", "conv1x1x1_bwd_data_x6"]
 PEAK_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PF)
-X6_PRODUCTS = 6                    # bf16 MFMA products issued per fp32 product by the x6 kernels
+SPLIT_PRODUCTS = {3: 6, 4: 3}      # 16-bit MFMA products issued per fp32 product: x6 kernels (bf16 pieces) / H3 kernels (scaled fp16 pieces)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
 ALGO_MB_PER_PATCH = 402.414        # layer-boundary byte model, fwd + bwd (un-fused)
 PLAN_MB_PER_PATCH = 81.0           # bytes the fused plan moves (256-channel tensor never reaches HBM)
@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="patches per GPU (BASELINE.json: 128)")
     ap.add_argument("--frames", type=int, default=9, help="numImgLR: 9 (headline), 13 or 7")
-    ap.add_argument("--impl", type=int, default=3, help="3 = x6 kernels: fp32 products as six bf16-piece products on the bf16 MFMA pipe (default), "
+    ap.add_argument("--impl", type=int, default=4, help="4 = H3 kernels: fp32 products as three products of scaled fp16 piece pairs on the 16-bit MFMA pipe (default), "
+                    "3 = x6 kernels: six bf16-piece products, "
                     "2 = native fp32 MFMA + strip convolution, 1 = fp32 MFMA row-tile kernels, 0 = generic direct kernels")
     ap.add_argument("--no-fp32-mfma-leg", action="store_true", help="skip the short extra run on the native fp32-MFMA kernels (impl 2)")
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
@@ -175,7 +176,7 @@ def main():
         full = (time.perf_counter() - t1) / args.steps * 1e3
 
     fp32_leg = None
-    if args.impl == 3 and not args.no_fp32_mfma_leg:
+    if args.impl >= 3 and not args.no_fp32_mfma_leg:
         model.set_impl(2)
         for _ in range(2):
             step()
@@ -190,7 +191,7 @@ def main():
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         fp32_leg = {"value": round(world * B * k2 / float(t2), 2), "unit": "patches/s", "ms_per_step": round(float(t2) / k2 * 1e3, 4), "steps": k2,
                     "note": "same step on the native fp32-MFMA kernels (--impl 2), for reference"}
-        model.set_impl(3)
+        model.set_impl(args.impl)
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -203,7 +204,10 @@ def main():
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
                                    (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16", 4: "h3-split-fp16"}[args.impl],
-                       "arithmetic": ("fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as six exact bf16-piece products on the "
+                       "arithmetic": ("fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as three exact products of fp16 piece pairs "
+                                      "(a = a0 + a1 to 2^-24, per-tensor power-of-two scaling) on the fp16 MFMA pipe (H3 kernels, error of the order of "
+                                      "fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 4 else
+                                      "fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as six exact bf16-piece products on the "
                                       "bf16 MFMA pipe (x6 kernels, error of the order of fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 3
                                       else "native fp32 MFMA / VALU"),
                        "loss": float(loss.detach()), "kernel_events": use_events},
@@ -220,7 +224,7 @@ def main():
                                            "frac": round(gbps(ALGO_MB_PER_PATCH) / PEAK_HBM_GBPS, 4)},
                   "fused_plan": {"MB_per_patch": PLAN_MB_PER_PATCH, "GBps": round(gbps(PLAN_MB_PER_PATCH), 1),
                                  "frac": round(gbps(PLAN_MB_PER_PATCH) / PEAK_HBM_GBPS, 4)}}
-            if os.path.exists(HBM_PROFILE) and B == 128 and args.impl == 3:
+            if os.path.exists(HBM_PROFILE) and B == 128 and args.impl == 4:
                 with open(HBM_PROFILE) as fh:
                     bps = json.load(fh)["bytes_per_step"]
                 hv["counted_by_rocprof"] = {"GB_per_step": round(bps / 1e9, 2), "GBps": round(bps / 1e9 / (dt / args.steps) / world, 1) if world == 1 else None,
@@ -237,19 +241,20 @@ def main():
                    for c, v in prof.items()}
             dom = max((c for c in prof if prof[c]["macs"] > 0), key=lambda c: prof[c]["ms"])
             ach = 2 * prof[dom]["macs"] / (prof[dom]["ms"] * 1e-3) / 1e12
-            x6 = dom.endswith("_x6")
-            peak = PEAK_BF16_TFLOPS / X6_PRODUCTS if x6 else PEAK_F32_TFLOPS
+            x6 = dom.endswith("_x6")              # a split-operand class (x6 or H3 kernels, by --impl)
+            nprod = SPLIT_PRODUCTS.get(args.impl, 6)
+            peak = PEAK_BF16_TFLOPS / nprod if x6 else PEAK_F32_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
                                "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["launches"]), 4),
                                "algorithmic_gflop_per_launch": round(2 * prof[dom]["macs"] / max(1, prof[dom]["launches"]) / 1e9, 3),
                                "note": "rank 0, HIP events on the launch stream around every launch of the class during the timed steps; "
                                        "achieved = algorithmic fp32 FLOP/s" + (
-                                           "; this class runs x6 kernels, which issue %d bf16 MFMA products per fp32 product, so its ceiling is "
-                                           "the dense bf16 MFMA peak (%.0f TFLOP/s) / %d" % (X6_PRODUCTS, PEAK_BF16_TFLOPS, X6_PRODUCTS) if x6 else
+                                           "; this class runs split-operand kernels, which issue %d 16-bit MFMA products per fp32 product, so its "
+                                           "ceiling is the dense bf16/fp16 MFMA peak (%.0f TFLOP/s) / %d" % (nprod, PEAK_BF16_TFLOPS, nprod) if x6 else
                                            "; peak = dense fp32 MFMA")}
             out["kernel_classes"] = per
-            if os.path.exists(HBM_PROFILE) and T == 9 and B == 128 and args.impl == 3:
+            if os.path.exists(HBM_PROFILE) and T == 9 and B == 128 and args.impl == 4:
                 with open(HBM_PROFILE) as fh:
                     hp = json.load(fh)
                 if dom in hp.get("per_class", {}):

@@ -25,7 +25,7 @@ struct probav_engine {
     std::vector<LayerRec> layers;
     int64_t nparams = 0, weff_count = 0, cout_total = 0;
     WnLayer* d_layers = nullptr;
-    int impl = 3;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
+    int impl = 4;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
                               // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist,
                               // 4 = 3 with the H3 arithmetic (three products of scaled fp16 piece pairs) where it exists
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
