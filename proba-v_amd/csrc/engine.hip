@@ -639,10 +639,12 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         unsigned* aoth = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, amx(acur, e->iRed[k], aoth), s));
         if (refl) {
-            if (rs.p == 1 && !rs.refl_t) CK(reflect_fold(oth, cur, B, hi, hi, ti * F, s));
-            else CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
             acur = new_slot();                      // the folded gradient is a new tensor
-            if (h3) CK(amax_tensor(cur, (size_t)B * hi * hi * ti * F, acur, s));
+            if (rs.p == 1 && !rs.refl_t) CK(reflect_fold(oth, cur, B, hi, hi, ti * F, acur, s));
+            else {
+                CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
+                if (h3) CK(amax_tensor(cur, (size_t)B * hi * hi * ti * F, acur, s));
+            }
         } else {
             float* tmp = cur; cur = oth; oth = tmp;
             acur = aoth;

@@ -428,6 +428,48 @@ __device__ __forceinline__ void conv_taps_x6(const TileArgs& a, const float* lds
     }
 }
 
+// conv_taps_x6 with operands requested two steps ahead (three buffers = the three dt steps of a group: static indices, a
+// branch-free group body; see strip_taps_k2), used by the H3 arithmetic
+template <int MT, class AR>
+__device__ __forceinline__ void conv_taps_c2(const TileArgs& a, const float* ldsA0, const float* ldsA1, const uint4* __restrict__ wf,
+                                             int chunk, float sa, f32x16& acc0, f32x16& acc1)
+{
+    constexpr int CP = 17, NP = AR::NP;
+    float r0[3][8], r1[3][8];
+    Frag W[3][NP], a0[NP], a1[NP];
+    auto group_off = [&](int g) -> int { const int dh = g / 3, dw = g - 3 * dh; return (dh * a.Wp + dw) * a.Tp * CP; };
+    auto request = [&](int goff, const uint4* pw, int dt, Frag (&w)[NP], float (&q0)[8], float (&q1)[8]) {   // dt: compile-time
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q0[j] = ldsA0[goff + dt * CP + j]; q1[j] = MT == 2 ? ldsA1[goff + dt * CP + j] : 0.f; }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) w[p].u = pw[(dt * 2 * NP + p) * 64];
+    };
+    int goff = group_off(0);
+    const uint4* pw = wf + (long)chunk * NP * 64;
+    request(goff, pw, 0, W[0], r0[0], r1[0]);
+    request(goff, pw, 1, W[1], r0[1], r1[1]);
+    cut8<AR>(r0[0], sa, a0);
+    if (MT == 2) cut8<AR>(r1[0], sa, a1);
+#pragma unroll 1
+    for (int g = 0; g < 9; ++g) {
+        const int gn = g + 1 <= 8 ? g + 1 : 8;
+        const int goffn = group_off(gn);
+        const uint4* pwn = wf + ((long)gn * 6 * NP + chunk * NP) * 64;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            if (dt == 0) request(goff, pw, 2, W[2], r0[2], r1[2]);
+            else request(goffn, pwn, dt - 1, W[dt - 1], r0[dt - 1], r1[dt - 1]);     // (after the last group: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = mac<AR>(a0, W[dt], acc0);
+            if (MT == 2) acc1 = mac<AR>(a1, W[dt], acc1);
+            cut8<AR>(r0[(dt + 1) % 3], sa, a0);
+            if (MT == 2) cut8<AR>(r1[(dt + 1) % 3], sa, a1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        goff = goffn; pw = pwn;
+    }
+}
+
 // x6 tap loop of the row-tile kernel for 25-channel inputs, dt taps concatenated along K (see strip_taps_x6k): 45 k-blocks of 16,
 // filters PACK_X6_CONVK, two M tiles share every filter fragment.
 template <int MT, class AR>
@@ -525,8 +567,13 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
                 else if (v0) conv_taps_x6k<1, AR>(a, ldsA0, ldsA1, wf6, sa, acc0, acc1);
             } else if constexpr (X6) {
                 const uint4* wf6 = reinterpret_cast<const uint4*>(wfrag) + lane;
-                if (v1) conv_taps_x6<2, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
-                else if (v0) conv_taps_x6<1, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
+                if constexpr (AM == 2) {
+                    if (v1) conv_taps_c2<2, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
+                    else if (v0) conv_taps_c2<1, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
+                } else {
+                    if (v1) conv_taps_x6<2, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
+                    else if (v0) conv_taps_x6<1, AR>(a, ldsA0, ldsA1, wf6, chunk, sa, acc0, acc1);
+                }
             } else {
                 const float4* wf = wfrag + (long)chunk * 27 * KS4 * 64 + lane;
                 if (v1) conv_taps<CC, KS, 2>(a, ldsA0, ldsA1, wf, acc0, acc1);
@@ -1128,9 +1175,10 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
                 const int voff = (w * a.Tp + t) * CP + (X6 ? 8 * half : half);
                 const int base0 = (hrel % STRIP_SLOTS) * rowfloats + voff, base1 = ((hrel + 1) % STRIP_SLOTS) * rowfloats + voff,
                           base2 = ((hrel + 2) % STRIP_SLOTS) * rowfloats + voff;
-                if constexpr (AM == 2 && CC == 25) strip_taps_k2<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
+                // (H3: the first-dispatched half -- which also writes the tile -- takes 5 of the 9 groups: the younger half is the slower one per k-block)
+                if constexpr (AM == 2 && CC == 25) strip_taps_k2<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 5, grp == 0 ? 5 : 4, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
                 else if constexpr (X6 && CC == 25) strip_taps_x6k<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);   // (the epilogue wave takes 4 of the 9 groups)
-                else if constexpr (AM == 2) strip_taps_c2<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
+                else if constexpr (AM == 2) strip_taps_c2<AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 5, grp == 0 ? 5 : 4, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
                 else if constexpr (X6) strip_taps_x6<CC, AR>(a, lds, base0, base1, base2, grp == 0 ? 0 : 4, grp == 0 ? 4 : 5, reinterpret_cast<const uint4*>(wfrag) + lane, sa, acc, mid);
                 else strip_taps<CC, KS>(a, lds, base0, base1, base2, grp == 0 ? 0 : 14, grp == 0 ? 14 : 13, wf, acc, ks, mid);
                 if (grp == 1) {

@@ -87,15 +87,28 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ slot)
 {
     float m = 0.f;
-    const size_t n4 = n >> 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {                  // four independent loads in flight
+        const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(x)[i + stride];
+        const float4 c = reinterpret_cast<const float4*>(x)[i + 2 * stride], d = reinterpret_cast<const float4*>(x)[i + 3 * stride];
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                          // one atomic per workgroup, skipped when the slot already holds more
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, __float_as_uint(m));
+    }
 }
 int amax_tensor(const float* x, size_t n, unsigned* slot, hipStream_t s)
 {
@@ -204,32 +217,48 @@ int tail_backward(const float* dy, float* dtail, int N, int P, int sc, float std
 
 // Gradient of tf.pad(x, 1 on H and W, 'reflect'): padded row 0 mirrors row 1, padded row H+1 mirrors row H-2.
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx,
-                                                          int N, int H, int W, int TC)
+                                                          int N, int H, int W, int TC, unsigned* __restrict__ amax)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)N * H * W * TC) return;
-    const int e = (int)(i % TC);
-    long r = i / TC;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
-    int hs[2], ws[2], nh = 1, nw = 1;
-    hs[0] = h + 1; ws[0] = w + 1;
-    if (h == 1) hs[nh++] = 0;
-    if (h == H - 2) hs[nh++] = H + 1;          // H >= 4, so h == 1 and h == H-2 never coincide
-    if (w == 1) ws[nw++] = 0;
-    if (w == W - 2) ws[nw++] = W + 1;
-    float s = 0.f;
-    for (int a = 0; a < nh; ++a)
-        for (int b = 0; b < nw; ++b)
-            s += dpad[(((long)n * (H + 2) + hs[a]) * (W + 2) + ws[b]) * TC + e];
-    dx[i] = s;
+    const long total = (long)N * H * W * TC;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int e = (int)(i % TC);
+        long r = i / TC;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        int hs[2], ws[2], nh = 1, nw = 1;
+        hs[0] = h + 1; ws[0] = w + 1;
+        if (h == 1) hs[nh++] = 0;
+        if (h == H - 2) hs[nh++] = H + 1;          // H >= 4, so h == 1 and h == H-2 never coincide
+        if (w == 1) ws[nw++] = 0;
+        if (w == W - 2) ws[nw++] = W + 1;
+        float s = 0.f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b)
+                s += dpad[(((long)n * (H + 2) + hs[a]) * (W + 2) + ws[b]) * TC + e];
+        dx[i] = s;
+        m = fmaxf(m, fabsf(s));
+    }
+    if (amax) {                                 // largest |dx| (H3 operand scale of the next layer's kernels): one guarded atomic per workgroup
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __shared__ float wm[4];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+            if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(m));
+        }
+    }
 }
-int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, hipStream_t s)
+int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax, hipStream_t s)
 {
     if (H < 4 || W < 4) { set_error("reflect_fold: H, W must be >= 4", hipSuccess); return PROBAV_EINVAL; }
     const long n = (long)N * H * W * TC;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpad, dx, N, H, W, TC);
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dpad, dx, N, H, W, TC, amax);
     return check_launch("reflect_fold");
 }
 

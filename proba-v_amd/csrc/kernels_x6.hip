@@ -25,15 +25,18 @@ namespace probav {
 // Both weight sets live in LDS as pre-split fragments (2 x 48 KB); X comes straight from HBM into B fragments;
 // the 256-channel hidden tensor never leaves registers.
 // ---------------------------------------------------------------------------------------------------
-constexpr int PWF_WAVES = 12;
+// Workgroup shape: the X6 weight images (2 x 48 KB) leave room for one workgroup per CU, so it is 12 waves wide; the H3 images
+// (2 x 32 KB) fit twice: two workgroups of 8 waves = 4 waves per SIMD instead of 3.
+template <class AR> struct PwfShape { static constexpr int WAVES = 12, WGS = 1; };
+template <> struct PwfShape<H3> { static constexpr int WAVES = 8, WGS = 2; };
 
 template <class AR>
-__global__ __launch_bounds__(64 * PWF_WAVES, 1) void pw_fwd_x6_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag,
+__global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void pw_fwd_x6_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag,
                                                                      const uint4* __restrict__ w2frag, const float* __restrict__ b1,
                                                                      const float* __restrict__ b2, float* __restrict__ dec,
                                                                      long nvox, int D, PwAmax am)
 {
-    constexpr int NP = AR::NP;
+    constexpr int NP = AR::NP, PWF_WAVES = PwfShape<AR>::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* sW1 = reinterpret_cast<uint4*>(lds_raw);             // [8 chunks][2 kb][NP pieces][64 lanes]  48 / 32 KB
     uint4* sW2 = sW1 + 8 * 2 * NP * 64;                          // same
@@ -139,11 +142,11 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
         const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32) * sizeof(float);
-        hipLaunchKernelGGL(pw_fwd_x6_kernel<H3>, dim3(256), dim3(64 * PWF_WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+        hipLaunchKernelGGL(pw_fwd_x6_kernel<H3>, dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                            b1, b2, dec, nvox, D, am);
     } else {
         const size_t lds = (size_t)2 * 8 * 2 * X6::NP * 64 * 16 + (256 + 32) * sizeof(float);
-        hipLaunchKernelGGL(pw_fwd_x6_kernel<X6>, dim3(256), dim3(64 * PWF_WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+        hipLaunchKernelGGL(pw_fwd_x6_kernel<X6>, dim3(256 * PwfShape<X6>::WGS), dim3(64 * PwfShape<X6>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                            b1, b2, dec, nvox, D, am);
     }
     return check_launch("pw_fwd_x6");

@@ -65,7 +65,7 @@ int wn_backward(const WnLayer* d_layers, int nlayers, int max_cout_total, const 
 int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, float mean, float stdv, hipStream_t s);
 int tail_forward(const float* up, const float* r3, float* y, int N, int P, int scale, float mean, float stdv, hipStream_t s);
 int tail_backward(const float* dy, float* dtail, int N, int P, int scale, float stdv, hipStream_t s);
-int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, hipStream_t s);
+int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax /* optional: receives max |dx| */, hipStream_t s);
 // general form: gradient of tf.pad(x, [ph, pw, pt] 'reflect') folded back onto x [N,H,W,T,C]; pads <= 2
 int reflect_fold3(const float* dpad, float* dx, int N, int H, int W, int T, int C, int ph, int pw, int pt, hipStream_t s);
 int clip_round(const float* in, float* out, size_t n, float lo, float hi, hipStream_t s);
