@@ -58,9 +58,12 @@ int probav_num_layers(const probav_engine* e);
 int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_off, int64_t* v_off,
                       int64_t* b_off, int32_t shape[5]);
 /* kernel family: 0 = generic direct (VALU) kernels everywhere, 1 = fp32-MFMA row-tile kernels, 2 = fp32 MFMA + strip convolution,
- * 3 (default) = 2 with the x6 kernels where they exist: fp32 in / fp32 out / fp32 accumulate, every fp32 product evaluated as six
- * exact bf16-piece products on the bf16 MFMA pipe (same tolerances as 2 in tests/test_gpu_parity.py).  Results of one family are
- * bitwise reproducible run to run; different families differ by fp32 rounding.                                                      */
+ * 3 = 2 with the x6 kernels where they exist: fp32 in / fp32 out / fp32 accumulate, every fp32 product evaluated as six exact
+ * bf16-piece products on the bf16 MFMA pipe, 4 (default) = the same kernels with the H3 arithmetic: three exact products of fp16 piece
+ * pairs, every operand tensor scaled by a power of two chosen from its largest magnitude (amax slots in the workspace, filled by the
+ * producing kernels).  3 and 4 are held to the tolerances of 2 in tests/test_gpu_parity.py.  Results of one family are bitwise
+ * reproducible run to run; different families differ by fp32 rounding; with 4 a sample's result also depends on its batch mates at
+ * that level (the scales are batch-wide maxima).                                                                                    */
 int probav_engine_set_impl(probav_engine* e, int impl);
 size_t probav_workspace_bytes(const probav_engine* e, int batch, int training);
 /* per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
@@ -126,7 +129,8 @@ int probav_clip_round(const float* in, float* out, size_t n, float lo, float hi,
 
 /* ---- single operators (what the engine is made of; exported for parity tests) ------------------- */
 /* geometry: int32[17] = N, Hi,Wi,Ti,Cin, Ho,Wo,To,Cout, kh,kw,kt, ph,pw,pt, reflect_hw, relu        */
-/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA row-tile, 2 = MFMA strip, 3 = x6 (strip or row-tile) */
+/* y = act(conv(x * [gate>0], w) + bias) + skip; impl 0 = direct, 1 = MFMA row-tile, 2 = MFMA strip, 3 = x6 (strip or row-tile),
+ * 4 = H3 (the same kernels with three products of scaled fp16 piece pairs; operand maxima are measured by the library) */
 int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* gate, const float* w,
                           const float* bias, const float* skip, float* y, int impl, void* stream);
 size_t probav_conv3d_wgrad_scratch_bytes(const int32_t geom[17], int impl);
@@ -134,7 +138,8 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
                         float* dw, float* db, void* scratch, size_t scratch_bytes, int impl, void* stream);
 /* fused expConv_i (1x1x1, 32->256) + ReLU + decConv_i (1x1x1, 256->D<=26)      models/modelsTF.py:179-183
  * x [nvox,32], w1 [32,256], b1 [256], w2 [256,D], b2 [D] -> dec [nvox,D]; the 256-channel tensor never reaches HBM
- * impl 2 = fp32 MFMA, 3 = fp32 products as six bf16-piece products on the bf16 MFMA pipe ("x6", same accuracy class) */
+ * impl 2 = fp32 MFMA, 3 = fp32 products as six bf16-piece products on the bf16 MFMA pipe ("x6", same accuracy class),
+ * 4 = three products of scaled fp16 piece pairs ("H3", same accuracy class) */
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
                       int64_t nvox, int D, int impl, void* stream);
 /* its reverse pass: d_dec [nvox,D], d_skip [nvox,32] (gradient arriving over the residual connection)

@@ -11,7 +11,12 @@ using namespace probav;
 int main()
 {
     const int B = 128, cin = 25, cout = 32;
-    ConvGeom g{B, 22, 22, 9, cin, 22, 22, 9, cout, 3, 3, 3, 1, 1, 1, 0, 0};
+    ConvGeom g{B, 22, 22, 9, cin, 22, 22, 9, cout, 3, 3, 3, 1, 1, 1, 0, 0, 0};
+    unsigned* am_; hipMalloc(&am_, 64);
+    { const unsigned one = 0x3f800000u; unsigned hv[8] = {one, one, one, one, one, one, 0, 0}; hipMemcpy(am_, hv, 32, hipMemcpyHostToDevice); }
+    Amax am; am.x = am_; am.w = am_ + 1; am.y = am_ + 6;
+    PwAmax pam; pam.x = am_; pam.w1 = am_ + 1; pam.w2 = am_ + 2; pam.b1 = am_ + 3; pam.dt = am_ + 4; pam.y = am_ + 7;
+    const int ARITH = 2;
     const size_t nin = (size_t)B * 22 * 22 * 9 * cin, nout = (size_t)B * 22 * 22 * 9 * cout;
     float *x, *dy, *dw, *db, *part;
     hipMalloc(&x, nin * 4); hipMalloc(&dy, nout * 4); hipMalloc(&dw, 27 * cin * cout * 4); hipMalloc(&db, cout * 4);
@@ -20,7 +25,7 @@ int main()
     for (size_t i = 0; i < nout; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
     hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
     hipMemcpy(dy, h.data(), nout * 4, hipMemcpyHostToDevice);
-    for (int it = 0; it < 3; ++it) x6_conv_wgrad(g, x, dy, nullptr, dw, db, part, 0);
+    for (int it = 0; it < 3; ++it) x6_conv_wgrad(g, x, dy, nullptr, dw, db, part, ARITH, am, 0);
     hipDeviceSynchronize();
     std::vector<unsigned long long> st(8192 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
@@ -40,7 +45,7 @@ int main()
         float *y, *wf, *bias;
         hipMalloc(&y, nout * 4); hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMalloc(&bias, 32 * 4);
         hipMemset(wf, 0x3c, X6_CONV_FRAG_WORDS * 4); hipMemset(bias, 0, 32 * 4);
-        for (int it = 0; it < 3; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, dy, y, 0);
+        for (int it = 0; it < 3; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, dy, y, ARITH, am, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
         const char* nm[8] = {"t0", "prologue", "taps (+skip loads)", "stage store / exchange reads", "barrier waits", "epilogue", "-", "t_end"};
@@ -69,7 +74,7 @@ int main()
         hipMemcpy(dO, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
         hipMemset(w, 0x3c, 3 * X6_PW_FRAG_WORDS * 4); hipMemset(b1, 0, 256 * 4);
         for (int it = 0; it < 3; ++it)
-            x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, D, 0);
+            x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, D, ARITH, pam, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
         const char* nm[8] = {"t0", "wait: tile staged", "compute", "stage store", "wait: partials", "dX reduce", "epilogue", "t_end"};
