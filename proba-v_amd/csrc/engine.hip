@@ -40,6 +40,7 @@ struct probav_engine {
     std::vector<long> pkFwd, pkBwd;          // per layer: conv fragments for forward / backward-data (-1 = none)
     std::vector<long> pkFwd6, pkBwd6;        // per layer: x6 (pre-split bf16) conv fragments, impl 3
     std::vector<long> pkFwdH, pkBwdH;        // per layer: H3 (scaled fp16 pieces) conv fragments, impl 4
+    std::vector<long> pkFwdHt, pkBwdHt;      // per layer, 25 input channels only: the per-tap (not K-concatenated) H3 fragments of the piece-ring strip kernel
     std::vector<long> pkW1h, pkW2h, pkW2Kh, pkW1Ch;   // per block: H3 fragments of the fused expand/decay forward / backward
     std::vector<long> pkW1x6, pkW2x6;        // per block: x6 fragments of the fused expand/decay forward
     std::vector<long> pkW2Kx6, pkW1Cx6;      // per block: extra x6 fragments of the fused backward
@@ -237,7 +238,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; const float* h3 = nullptr; };
+struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; const float* h3 = nullptr; const float* h3t = nullptr; };   // h3t: per-tap H3 fragments of a 25-channel layer
 
 // amax slot addresses inside the workspace (layout: make_plan)
 struct AmaxSlots {
@@ -269,7 +270,11 @@ static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const floa
     const bool x6r = e->impl >= 3 && wsplit && !x6s && x6_conv_rowtile_supported(g);
     const bool x6 = x6s || x6r;
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? (x6 ? CLS_CONV3_BWD_DATA_X6 : CLS_CONV3_BWD_DATA) : (x6 ? CLS_CONV3_FWD_X6 : CLS_CONV3_FWD)), geom_macs(g), s);
-    if (x6s) { reported = true; return x6_conv_strip_forward(g, x, gate, wsplit, bias, skip, y, arith, am, s); }
+    if (x6s) {
+        reported = true;
+        const float* wq = (h3 && g.Cin == 25 && wf.h3t && x6_strip_wants_tap_fragments(g, 2)) ? wf.h3t : wsplit;
+        return x6_conv_strip_forward(g, x, gate, wq, bias, skip, y, arith, am, s);
+    }
     if (x6r) { reported = true; return x6_conv_rowtile_forward(g, x, gate, wsplit, bias, skip, y, arith, am, s); }
     if (e->impl >= 2 && wfrag && mfma_conv_strip_supported(g)) { reported = true; return mfma_conv_strip_forward(g, x, gate, wfrag, bias, skip, y, am, s); }
     if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) { reported = true; return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, am, s); }
@@ -357,6 +362,7 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
     e->pkFwd.assign(e->layers.size(), -1); e->pkBwd.assign(e->layers.size(), -1);
     e->pkFwd6.assign(e->layers.size(), -1); e->pkBwd6.assign(e->layers.size(), -1);
     e->pkFwdH.assign(e->layers.size(), -1); e->pkBwdH.assign(e->layers.size(), -1);
+    e->pkFwdHt.assign(e->layers.size(), -1); e->pkBwdHt.assign(e->layers.size(), -1);
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const LayerRec& r = e->layers[li];
         if (r.kh != 3 || r.kw != 3 || r.kt != 3) continue;
@@ -382,6 +388,12 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
                 (dir ? e->pkBwdH : e->pkFwdH)[li] = X.dst_off;
                 e->wpack_count += X.count;
                 e->jobs.push_back(X);
+                if (cin == 25) {
+                    X.type = PACK_H3_CONV; X.count = H3_CONV_FRAG_WORDS; X.dst_off = e->wpack_count;
+                    (dir ? e->pkBwdHt : e->pkFwdHt)[li] = X.dst_off;
+                    e->wpack_count += X.count;
+                    e->jobs.push_back(X);
+                }
             }
         }
     }
@@ -526,6 +538,7 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
         if (e->pkFwd[li] >= 0) f.f32 = W + p.wpack + e->pkFwd[li];
         if (e->pkFwd6[li] >= 0) f.x6 = W + p.wpack + e->pkFwd6[li];
         if (e->pkFwdH[li] >= 0) f.h3 = W + p.wpack + e->pkFwdH[li];
+        if (e->pkFwdHt[li] >= 0) f.h3t = W + p.wpack + e->pkFwdHt[li];
         return f;
     };
     // amax slots (H3 arithmetic, impl 4): every tensor an H3 kernel reads has its largest magnitude in a slot by then
@@ -592,6 +605,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         if (e->pkBwd[li] >= 0) f.f32 = W + p.wpack + e->pkBwd[li];
         if (e->pkBwd6[li] >= 0) f.x6 = W + p.wpack + e->pkBwd6[li];
         if (e->pkBwdH[li] >= 0) f.h3 = W + p.wpack + e->pkBwdH[li];
+        if (e->pkBwdHt[li] >= 0) f.h3t = W + p.wpack + e->pkBwdHt[li];
         return f;
     };
     // amax slots of the gradient tensors, in launch order (the forward pass left those of the weights and activations)
@@ -741,7 +755,7 @@ static int op_amax(const float* x, size_t nx, const float* w, size_t nw, hipStre
     if (rc == PROBAV_OK && w) rc = amax_tensor(w, nw, g_op_amax + 1, s);
     return rc;
 }
-static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split = 0)       // split: 0 fp32 fragments, 1 X6, 2 H3
+static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split = 0, bool per_tap = false)   // split: 0 fp32 fragments, 1 X6, 2 H3
 {
     const size_t n = split ? (size_t)X6_CONV_FRAG_WORDS : mfma_conv_wfrag_floats(g.Cin, g.Cout);
     if (n == 0) { set_error("probav_conv3d_forward: channel configuration not supported by the MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
@@ -750,8 +764,9 @@ static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split =
     if (n * sizeof(float) > ((size_t)4 << 20)) { set_error("probav_conv3d_forward: fragment scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
     PackJob J; memset(&J, 0, sizeof(J));
     if (split) {
-        J.type = g.Cin == 25 ? PACK_X6_CONVK : PACK_X6_CONV; J.count = g.Cin == 25 ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27;
-        if (split == 2) { J.type += 10; J.count = g.Cin == 25 ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS; J.amax_slot = 1; }
+        const bool kc = g.Cin == 25 && !per_tap;                            // K-concatenated form (per_tap: the H3 piece-ring strip kernel)
+        J.type = kc ? PACK_X6_CONVK : PACK_X6_CONV; J.count = kc ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27;
+        if (split == 2) { J.type += 10; J.count = kc ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS; J.amax_slot = 1; }
     } else mfma_conv_pack_job(J, g.Cin, g.Cout);
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(g_op_job, &J, sizeof(J), hipMemcpyHostToDevice);
@@ -778,7 +793,7 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
             if (rc) return rc;
             am.x = g_op_amax; am.w = g_op_amax + 1; am.y = g_op_amax + 4;
         }
-        rc = op_pack(g, w, (hipStream_t)stream, impl >= 3 ? impl - 2 : 0);
+        rc = op_pack(g, w, (hipStream_t)stream, impl >= 3 ? impl - 2 : 0, !x6row && impl == 4 && x6_strip_wants_tap_fragments(g, 2));
         if (rc) return rc;
         if (x6row) return x6_conv_rowtile_forward(g, x, gate, g_op_frag, bias, skip, y, impl - 2, am, (hipStream_t)stream);
         if (impl >= 3) return x6_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, impl - 2, am, (hipStream_t)stream);

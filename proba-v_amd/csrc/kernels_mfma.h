@@ -42,7 +42,9 @@ int mfma_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate
 bool x6_conv_rowtile_supported(const ConvGeom& g);
 int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
                             const float* skip, float* y, int arith, const Amax& am, hipStream_t s);
-// the strip kernel with a split-operand tap loop (same fragments)
+// the strip kernel with a split-operand tap loop (same fragments; when x6_strip_wants_tap_fragments(g, arith) the filters of a
+// 25-channel layer must be the per-tap PACK_H3_CONV form, not PACK_H3_CONVK: the H3 piece-ring kernel serves the call)
+bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith);
 int x6_conv_strip_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag6, const float* bias,
                           const float* skip, float* y, int arith, const Amax& am, hipStream_t s);
 

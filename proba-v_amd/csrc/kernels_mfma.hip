@@ -1266,6 +1266,245 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
 
 struct StripPlan { bool ok; int CC, KS; size_t lds_bytes; int grid; StripArgs a; };
 
+// ---------------------------------------------------------------------------------------------------
+// Strip convolution with a ring of fp16 PIECE records (H3 arithmetic only).  Same decomposition as conv3_strip_kernel (strip of
+// output rows per workgroup, flattened 32-voxel tiles, the taps of a tile split over a wave pair), but a staged row is cut ONCE,
+// when it is written to LDS, instead of once per (dh, dw) group in the tap loop -- in the fp32 ring that cutting and the four
+// ds_read2_b32 feeding it were ~25 % of the kernel (tools/diag_strip.hip: 135 -> 100 us with them stubbed out).
+// Record of one voxel: 128 B = 8 chunks of 16 B, logical chunk p * 4 + cc = piece p of channels 8cc .. 8cc+7 (channels >= Cin are
+// zero), stored at chunk (p * 4 + cc) ^ (voxel & 7): a wave's ds_read_b128 of one logical chunk of 32 consecutive voxels then
+// touches all 32 banks evenly (a plain 128-byte stride would put every lane on the same four banks).  A k-block of 16 channels of
+// one tap is one ds_read_b128 per piece; no VALU work in the loop beyond the record address.  Four slots (135 KB at 24 x 11 voxels),
+// so the next row is REQUESTED under the taps but stored between the round's two barriers, when the oldest row is dead.
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, bool GATE>
+__global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
+                                                             const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                             const float* __restrict__ skip, float* __restrict__ y, Amax am)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    using AR = H3;
+    constexpr int NP = 2, SLOTS = 4, REC = 128, PF = 3;
+    const ConvGeom& g = a.g;
+    const int ea = h3_exp(*am.x), ew = h3_exp(*am.w);
+    const float sa = pow2i(ea);
+    const int eun = -(ea + ew);
+    float omax = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tsel = wave & 3, grp = wave >> 2;
+    const int rowbytes = a.Wp * a.Tp * REC;
+    float* part = reinterpret_cast<float*>(plds + SLOTS * rowbytes);          // [4 tiles][16 regs][64 lanes]
+    const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
+    const int hb = strip * a.SR;
+    const int SRr = g.Ho - hb < a.SR ? g.Ho - hb : a.SR;
+    const int nvr = g.Wo * g.To;
+    const int NV = SRr * nvr, NTL = (NV + 31) >> 5, nrounds = (NTL + 3) >> 2;
+    const long out_base = ((long)n * g.Ho + hb) * nvr;
+    float* ybase = y + out_base * g.Cout;
+    const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
+    const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+
+    // staging: item i of a row = (input voxel i >> 2, channel chunk i & 3); RVP items per thread
+    const int items = g.Wi * g.Ti * 4;
+    constexpr int RVP = 2;                                                   // strip_plan(): Wi * Ti * 4 <= 512 * RVP
+    auto stage_load = [&](int q, float (&v)[RVP][8]) {
+        const int ih = hb - g.ph + q;
+        const bool rok = ih >= 0 && ih < g.Hi;
+        const long rbase = (((long)n * g.Hi + (rok ? ih : 0)) * g.Wi) * (long)g.Ti * CIN;
+        const float* xrow = x + rbase;
+        const float* grow = GATE ? gate + rbase : nullptr;
+#pragma unroll
+        for (int k = 0; k < RVP; ++k) {
+            const int i = tid + 512 * k;
+            const bool live = rok && i < items;
+            const int ic = i < items ? i : 0;
+            const int vox = ic >> 2, cc = ic & 3;
+            const float* src = xrow + vox * CIN + 8 * cc;
+            const float* gsr = GATE ? grow + vox * CIN + 8 * cc : nullptr;
+            if constexpr (CIN % 8 == 0) {
+                const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
+                float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                if constexpr (GATE) {
+                    const float4 m0 = reinterpret_cast<const float4*>(gsr)[0], m1 = reinterpret_cast<const float4*>(gsr)[1];
+                    const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = m[j] > 0.f ? f[j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = live ? f[j] : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool cok = 8 * cc + j < CIN;                       // (clamped unconditional load, zero selected afterwards)
+                    float f = src[cok ? j : 0];
+                    if constexpr (GATE) f = gsr[cok ? j : 0] > 0.f ? f : 0.f;
+                    v[k][j] = (live && cok) ? f : 0.f;
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int q, const float (&v)[RVP][8]) {
+        unsigned char* slot = plds + (q % SLOTS) * rowbytes;
+#pragma unroll
+        for (int k = 0; k < RVP; ++k) {
+            const int i = tid + 512 * k;
+            if (i < items) {
+                const int vox = i >> 2, cc = i & 3;
+                const int w = fdiv(vox, g.Ti, a.mTi), t = vox - w * g.Ti;
+                const int vd = (w + g.pw) * a.Tp + t + g.pt;
+                Frag f[NP];
+                cut8<AR>(v[k], sa, f);
+                unsigned char* rec = slot + vd * REC;
+                const int sw = (int)((rec - plds) >> 7) & 7;                 // swizzle = absolute record index & 7 (the readers use the same)
+                *reinterpret_cast<uint4*>(rec + ((cc ^ sw) << 4)) = f[0].u;
+                *reinterpret_cast<uint4*>(rec + (((4 + cc) ^ sw) << 4)) = f[1].u;
+            }
+        }
+    };
+
+    {   // zero the whole ring (pads stay zero), then rows q = 0..3
+        uint4* z = reinterpret_cast<uint4*>(plds);
+        for (int i = tid; i < SLOTS * rowbytes / 16; i += 512) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        float v[RVP][8];
+        stage_load(q, v);
+        stage_store(q, v);
+    }
+    int hiq = 3;
+    __syncthreads();
+
+    float skn[16];
+    auto load_skip = [&](int tl) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int vi = tl * 32 + rowmap(i, half);
+            const int o = (tl < NTL && vi < NV && col < g.Cout) ? vi * g.Cout + col : 0;
+            skn[i] = sbase[o];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) skn[i] = 0.f;
+    if (grp == 0 && sbase) load_skip(tsel);
+
+    const uint4* wf = wfrag + lane;                                         // PACK_H3_CONV: fragment ((tap * 2 + kb) * NP + piece) * 64 + lane
+    for (int r = 0; r < nrounds; ++r) {
+        const int vlast_next = (r + 2) * 128 - 1 < NV - 1 ? (r + 2) * 128 - 1 : NV - 1;
+        const int need_next = fdiv(vlast_next, nvr, a.mNvr) + 2;
+        const bool do_load = r + 1 < nrounds && need_next > hiq;                 // wave-uniform
+        float nv_[RVP][8];
+        const int tile = 4 * r + tsel;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float sk[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sk[i] = skn[i];
+        if (tile < NTL) {
+            int vi = tile * 32 + col;
+            vi = vi < NV ? vi : NV - 1;
+            const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+            const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+            const int vox0 = w * a.Tp + t;                                   // record index of tap (dw, dt) = (0, 0) inside a slot
+            const int sb0 = (hrel % SLOTS) * rowbytes, sb1 = ((hrel + 1) % SLOTS) * rowbytes, sb2 = ((hrel + 2) % SLOTS) * rowbytes;
+            const int g0 = grp == 0 ? 0 : 5, glast = grp == 0 ? 4 : 8;      // the first-dispatched half takes 5 of the 9 (dh, dw) groups
+            // operand address of step st = dt * 2 + kb of group gg: record vox0 + dw * Tp + dt of ring row hrel + dh, logical chunks 2 kb + half (+4)
+            auto rec_addr = [&](int gg, int dt) -> int {
+                const int dh = gg / 3, dw = gg - 3 * dh;                     // wave-uniform
+                const int sb = dh == 0 ? sb0 : (dh == 1 ? sb1 : sb2);
+                return sb + (vox0 + dw * a.Tp + dt) * REC;
+            };
+            Frag A[6][NP], W[6][NP];
+            auto request = [&](int gg, int st, Frag (&af)[NP], Frag (&wq)[NP]) {   // st: compile-time
+                const int dt = st >> 1, kb = st & 1;
+                const int ra = rec_addr(gg, dt);
+                const int sw = (ra >> 7) & 7;                                // absolute record index & 7, as stored
+                const int c0 = (2 * kb + half) ^ sw;
+                af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (c0 << 4));
+                af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((c0 ^ 4) << 4));
+                const uint4* pw = wf + ((long)gg * 6 + st) * NP * 64;
+                wq[0].u = pw[0]; wq[1].u = pw[64];
+            };
+#pragma unroll
+            for (int st = 0; st < PF; ++st) request(g0, st, A[st], W[st]);
+            if (do_load) stage_load(hiq + 1, nv_);                           // in flight during the taps
+#pragma unroll 1
+            for (int gg = g0; gg <= glast; ++gg) {
+                const int gn = gg + 1 <= glast ? gg + 1 : glast;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    if (st + PF < 6) request(gg, st + PF, A[st + PF], W[st + PF]);
+                    else request(gn, st + PF - 6, A[st + PF - 6], W[st + PF - 6]);   // (after the last group: a harmless re-read)
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = mac<AR>(A[st], W[st], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (grp == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
+            }
+        } else if (do_load) stage_load(hiq + 1, nv_);
+        if (grp == 0 && sbase && r + 1 < nrounds) load_skip(4 * (r + 1) + tsel);
+        __syncthreads();                                   // partials are in LDS; every wave is past its taps
+        float pv[16];
+        if (grp == 0 && tile < NTL) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pv[i] = part[(tsel * 16 + i) * 64 + lane];
+        }
+        if (do_load) { stage_store(hiq + 1, nv_); ++hiq; }  // replaces the oldest row, which no tile of the next round reads
+        __syncthreads();                                   // partial buffer may be rewritten, the new row is visible
+        if (grp == 0 && tile < NTL) {
+            const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
+            int oo[16];
+            float ov[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int vi = tile * 32 + rowmap(i, half);
+                oo[i] = (vi < NV && col < g.Cout) ? vi * g.Cout + col : -1;
+                float v = ldexpf(acc[i] + pv[i], eun) + bv;
+                if (g.relu) v = fmaxf(v, 0.f);
+                ov[i] = v + sk[i];
+                omax = fmaxf(omax, oo[i] >= 0 ? fabsf(ov[i]) : 0.f);
+            }
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ybase[oo[i]] = ov[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (oo[i] >= 0) ybase[oo[i]] = ov[i];
+            }
+        }
+    }
+    if (am.y) amax_commit(omax, am.y);
+}
+
+// plan of the piece-ring form: 3x3x3, zero pads, Cin 25 / 32, Cout <= 32, >= 128 voxels per output row
+static bool pstrip_plan(const ConvGeom& g, StripPlan& p)
+{
+    p.ok = false;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.Cout > 32 || (g.Cin != 25 && g.Cin != 32)) return false;
+    if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return false;
+    const int nvr = g.Wo * g.To;
+    if (nvr < 128 || g.Ho < 3 || g.Wi * g.Ti * 4 > 512 * 2) return false;
+    const int Wp = g.Wo + 2, Tp = g.To + 2;
+    const size_t lds = (size_t)4 * Wp * Tp * 128 + (size_t)4 * 16 * 64 * sizeof(float);
+    if (lds > 163840) return false;
+    int nstrips = (256 + g.N - 1) / g.N;
+    if (nstrips < 1) nstrips = 1;
+    if (nstrips > g.Ho / 4) nstrips = g.Ho / 4 > 0 ? g.Ho / 4 : 1;
+    const int SR = (g.Ho + nstrips - 1) / nstrips;
+    nstrips = (g.Ho + SR - 1) / SR;
+    p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = lds; p.grid = g.N * nstrips;
+    p.a.g = g; p.a.Wp = Wp; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips;
+    p.a.mTo = magic(g.To); p.a.mNvr = magic(nvr); p.a.mTi = magic(g.Ti); p.a.mSrcCol = 0;
+    return true;
+}
+
+
 static StripPlan strip_plan(const ConvGeom& g)
 {
     StripPlan p;
@@ -1297,13 +1536,35 @@ static StripPlan strip_plan(const ConvGeom& g)
 }
 
 bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
+// does x6_conv_strip_forward(g, ..., arith) read per-tap fragments (PACK_*_CONV) even for 25 input channels?  (the H3 piece-ring kernel does;
+// the other 25-channel split kernels read the K-concatenated PACK_*_CONVK form)
+bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith)
+{
+    StripPlan pp;
+    return arith == 2 && strip_plan(g).ok && pstrip_plan(g, pp);
+}
 
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
                         const float* skip, float* y, int arith, const Amax& am, hipStream_t s)
 {
+    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_strip_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+    if (arith == 2 && x6_strip_wants_tap_fragments(g, arith)) {               // H3: the piece-ring kernel (filters: PACK_H3_CONV)
+        StripPlan pp;
+        (void)pstrip_plan(g, pp);
+        static bool oncep = false;
+        if (!oncep) {
+            allow_big_lds(conv3_pstrip_kernel<25, false>); allow_big_lds(conv3_pstrip_kernel<25, true>);
+            allow_big_lds(conv3_pstrip_kernel<32, false>); allow_big_lds(conv3_pstrip_kernel<32, true>);
+            oncep = true;
+        }
+#define PROBAV_PSTRIP(C, G) hipLaunchKernelGGL((conv3_pstrip_kernel<C, G>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
+        if (g.Cin == 25) { if (gate) PROBAV_PSTRIP(25, true); else PROBAV_PSTRIP(25, false); }
+        else             { if (gate) PROBAV_PSTRIP(32, true); else PROBAV_PSTRIP(32, false); }
+#undef PROBAV_PSTRIP
+        return check_launch("conv3_pstrip");
+    }
     const StripPlan p = strip_plan(g);
     if (!p.ok) { set_error("mfma_conv_strip_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
-    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_strip_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
     static bool once = false;
     if (!once) {
         allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 0>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 0>);
