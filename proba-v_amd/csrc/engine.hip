@@ -389,7 +389,7 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
                 e->wpack_count += X.count;
                 e->jobs.push_back(X);
                 if (cin == 25) {
-                    X.type = PACK_H3_CONV; X.count = H3_CONV_FRAG_WORDS; X.dst_off = e->wpack_count;
+                    X.type = PACK_H3_CONVP; X.count = H3_CONVK_FRAG_WORDS; X.dst_off = e->wpack_count;
                     (dir ? e->pkBwdHt : e->pkFwdHt)[li] = X.dst_off;
                     e->wpack_count += X.count;
                     e->jobs.push_back(X);
@@ -767,6 +767,7 @@ static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split =
         const bool kc = g.Cin == 25 && !per_tap;                            // K-concatenated form (per_tap: the H3 piece-ring strip kernel)
         J.type = kc ? PACK_X6_CONVK : PACK_X6_CONV; J.count = kc ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27;
         if (split == 2) { J.type += 10; J.count = kc ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS; J.amax_slot = 1; }
+        if (split == 2 && g.Cin == 25 && per_tap) { J.type = PACK_H3_CONVP; J.count = H3_CONVK_FRAG_WORDS; }
     } else mfma_conv_pack_job(J, g.Cin, g.Cout);
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(g_op_job, &J, sizeof(J), hipMemcpyHostToDevice);

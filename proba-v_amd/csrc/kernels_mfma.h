@@ -6,9 +6,12 @@ namespace probav {
 
 enum { PACK_CONV = 0, PACK_PW_A_KCIN = 1, PACK_PW_A_KHCH = 2, PACK_PW_A_KOUT = 3, PACK_PW_A_CIN_KHCH = 4,
        // pre-split bf16 operand fragments of the x6 kernels (three truncation pieces per value, 16 B per lane and fragment)
-       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14, PACK_X6_CONVK = 15,
+       PACK_X6_PW_W1 = 10, PACK_X6_PW_W2 = 11, PACK_X6_CONV = 12, PACK_X6_PW_W2K = 13, PACK_X6_PW_W1C = 14, PACK_X6_CONVK = 15, PACK_X6_CONVP = 16,
        // the same fragment orders with two scaled fp16 pieces per value (H3 arithmetic, x6_device.h): type = PACK_X6_* + 10
-       PACK_H3_PW_W1 = 20, PACK_H3_PW_W2 = 21, PACK_H3_CONV = 22, PACK_H3_PW_W2K = 23, PACK_H3_PW_W1C = 24, PACK_H3_CONVK = 25 };
+       PACK_H3_PW_W1 = 20, PACK_H3_PW_W2 = 21, PACK_H3_CONV = 22, PACK_H3_PW_W2K = 23, PACK_H3_PW_W1C = 24, PACK_H3_CONVK = 25,
+       // Cin = 25, K of a (dh, dw) group as ten 8-channel chunks: (dt, channels 8c .. 8c+7) for dt, c < 3, then [ch 24 of dt = 0, 1, 2 | 0 x 5]
+       // (the operand order of the piece-ring strip kernel); same size as the K-concatenated form
+       PACK_H3_CONVP = 26 };
 constexpr long X6_PW_FRAG_WORDS = 8 * 2 * 3 * 64 * 4;      // [8 chunks][2 k-blocks][3 pieces][64 lanes] x 16 B
 constexpr long X6_CONV_FRAG_WORDS = 27 * 2 * 3 * 64 * 4;   // [27 taps][2 k-blocks][3 pieces][64 lanes] x 16 B
 constexpr long X6_CONVK_FRAG_WORDS = 9 * 5 * 3 * 64 * 4;   // Cin = 25, K = (dt, ci) concatenated: [9 (dh,dw)][5 k-blocks][3 pieces][64 lanes] x 16 B

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
             // split fragments: this dword holds k-slots j = 2u, 2u+1 of lane `lane` in fragment q = (outer * 2 + kb) * NP + piece
             const int np = h3 ? 2 : 3;
             int piece = (int)(q % np), kb = (int)((q / np) & 1), outer = (int)(q / (2 * np));
-            if (type == PACK_X6_CONVK) { kb = (int)((q / np) % 5); outer = (int)(q / (5 * np)); }       // fragment q = (group * 5 + kb) * NP + piece
+            if (type == PACK_X6_CONVK || type == PACK_X6_CONVP) { kb = (int)((q / np) % 5); outer = (int)(q / (5 * np)); }   // fragment q = (group * 5 + kb) * NP + piece
             float v2[2] = {0.f, 0.f};
             for (int e = 0; e < 2; ++e) {
                 const int j = 2 * u + e, kn = 16 * kb + 8 * half + j, kp = rowmap(8 * kb + j, half);   // natural / accumulator-order k
@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
                     if (kn < J.Cout) v2[e] = src[(long)(32 * outer + col) * J.Cout + kn];
                 } else if (type == PACK_X6_PW_W1C) {  // [row = cin col][k-slot = hidden 32c + kp]             W1 [cin 32][hidden 256]
                     v2[e] = src[(long)col * J.Cout + 32 * outer + kp];
+                } else if (type == PACK_X6_CONVP) {   // chunk c = 2 kb + half of group `outer`: (dt, ci) = (c / 3, 8 (c % 3) + j), chunk 9 = channel 24 of dt = j
+                    const int c = 2 * kb + half;
+                    const int dt = c < 9 ? c / 3 : j, ci = c < 9 ? 8 * (c % 3) + j : 24;
+                    if ((c < 9 || j < 3) && col < J.Cout) v2[e] = src[((long)(outer * 3 + dt) * J.Cin + ci) * J.Cout + col];
                 } else if (type == PACK_X6_CONVK) {   // [k = dt * Cin + ci][col = cout] of (dh, dw) group `outer`: taps 3*outer + dt
                     if (kn < 3 * J.Cin && col < J.Cout) v2[e] = src[((long)outer * 3 * J.Cin + kn) * J.Cout + col];
                 } else {                                // PACK_X6_CONV: [k = cin kn][col = cout] of tap `outer`
@@ -1334,11 +1338,17 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[k][j] = live ? f[j] : 0.f;
             } else {
+                // 25 channels: chunks 0..2 = channels 0..23 of the voxel; chunk 3 of the record at PADDED depth t' (the item's `vox`
+                // is then (w, t')) gathers channel 24 of padded depths t', t'+1, t'+2 = input depths t'-1, t', t'+1 (pt = 1): the
+                // tenth K chunk of a (dh, dw) group, so that a group is 5 k-blocks instead of 6
+                const int w = fdiv(vox, g.Ti, a.mTi), t = vox - w * g.Ti;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const bool cok = 8 * cc + j < CIN;                       // (clamped unconditional load, zero selected afterwards)
-                    float f = src[cok ? j : 0];
-                    if constexpr (GATE) f = gsr[cok ? j : 0] > 0.f ? f : 0.f;
+                    const int tj = t - 1 + j;                                 // (cc == 3 only)
+                    const bool cok = cc < 3 || (j < 3 && tj >= 0 && tj < g.Ti);
+                    const int o = cc < 3 ? 8 * cc + j : (cok ? (j - 1) * CIN + 24 : 8 * cc);    // relative to the voxel's channel 0 (clamped when dead)
+                    float f = (xrow + vox * CIN)[o];
+                    if constexpr (GATE) f = (grow + vox * CIN)[o] > 0.f ? f : 0.f;
                     v[k][j] = (live && cok) ? f : 0.f;
                 }
             }
@@ -1352,7 +1362,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
             if (i < items) {
                 const int vox = i >> 2, cc = i & 3;
                 const int w = fdiv(vox, g.Ti, a.mTi), t = vox - w * g.Ti;
-                const int vd = (w + g.pw) * a.Tp + t + g.pt;
+                const int vd = (w + g.pw) * a.Tp + t + ((CIN == 25 && cc == 3) ? 0 : g.pt);   // (the gathered chunk is indexed by padded depth)
                 Frag f[NP];
                 cut8<AR>(v[k], sa, f);
                 unsigned char* rec = slot + vd * REC;
@@ -1376,6 +1386,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     }
     int hiq = 3;
     __syncthreads();
+    XS_DECL;
+    XS_ACC(1);
 
     float skn[16];
     auto load_skip = [&](int tl) {
@@ -1390,7 +1402,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     for (int i = 0; i < 16; ++i) skn[i] = 0.f;
     if (grp == 0 && sbase) load_skip(tsel);
 
-    const uint4* wf = wfrag + lane;                                         // PACK_H3_CONV: fragment ((tap * 2 + kb) * NP + piece) * 64 + lane
+    const uint4* wf = wfrag + lane;                                         // PACK_H3_CONV (32 channels) / PACK_H3_CONVP (25): fragment ((group * NST + st) * NP + piece) * 64 + lane
     for (int r = 0; r < nrounds; ++r) {
         const int vlast_next = (r + 2) * 128 - 1 < NV - 1 ? (r + 2) * 128 - 1 : NV - 1;
         const int need_next = fdiv(vlast_next, nvr, a.mNvr) + 2;
@@ -1417,15 +1429,26 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 const int sb = dh == 0 ? sb0 : (dh == 1 ? sb1 : sb2);
                 return sb + (vox0 + dw * a.Tp + dt) * REC;
             };
-            Frag A[6][NP], W[6][NP];
+            constexpr int NST = CIN == 25 ? 5 : 6;                           // k-blocks per (dh, dw) group
+            Frag A[NST][NP], W[NST][NP];
             auto request = [&](int gg, int st, Frag (&af)[NP], Frag (&wq)[NP]) {   // st: compile-time
-                const int dt = st >> 1, kb = st & 1;
-                const int ra = rec_addr(gg, dt);
+                int ra, cc;
+                if constexpr (CIN == 25) {
+                    // chunk c = 2 st + half of the group's ten: c < 9 -> (dt, cc) = (c / 3, c % 3); c = 9 -> the gathered channel-24 chunk of dt = 0
+                    const int c0 = 2 * st, c1 = 2 * st + 1;                 // (constants after unrolling)
+                    const int dt0 = c0 / 3, cc0 = c0 % 3, dt1 = c1 < 9 ? c1 / 3 : 0, cc1 = c1 < 9 ? c1 % 3 : 3;
+                    ra = rec_addr(gg, 0) + (half ? dt1 : dt0) * REC;
+                    cc = half ? cc1 : cc0;
+                } else {
+                    const int dt = st >> 1, kb = st & 1;
+                    ra = rec_addr(gg, dt);
+                    cc = 2 * kb + half;
+                }
                 const int sw = (ra >> 7) & 7;                                // absolute record index & 7, as stored
-                const int c0 = (2 * kb + half) ^ sw;
-                af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (c0 << 4));
-                af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((c0 ^ 4) << 4));
-                const uint4* pw = wf + ((long)gg * 6 + st) * NP * 64;
+                const int cp = cc ^ sw;
+                af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
+                af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
+                const uint4* pw = wf + ((long)gg * NST + st) * NP * 64;
                 wq[0].u = pw[0]; wq[1].u = pw[64];
             };
 #pragma unroll
@@ -1435,9 +1458,9 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
             for (int gg = g0; gg <= glast; ++gg) {
                 const int gn = gg + 1 <= glast ? gg + 1 : glast;
 #pragma unroll
-                for (int st = 0; st < 6; ++st) {
-                    if (st + PF < 6) request(gg, st + PF, A[st + PF], W[st + PF]);
-                    else request(gn, st + PF - 6, A[st + PF - 6], W[st + PF - 6]);   // (after the last group: a harmless re-read)
+                for (int st = 0; st < NST; ++st) {
+                    if (st + PF < NST) request(gg, st + PF, A[st + PF], W[st + PF]);
+                    else request(gn, st + PF - NST, A[st + PF - NST], W[st + PF - NST]);   // (after the last group: a harmless re-read)
                     __builtin_amdgcn_sched_barrier(0);
                     acc = mac<AR>(A[st], W[st], acc);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1449,14 +1472,18 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
             }
         } else if (do_load) stage_load(hiq + 1, nv_);
         if (grp == 0 && sbase && r + 1 < nrounds) load_skip(4 * (r + 1) + tsel);
+        XS_ACC(2);
         __syncthreads();                                   // partials are in LDS; every wave is past its taps
+        XS_ACC(4);
         float pv[16];
         if (grp == 0 && tile < NTL) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) pv[i] = part[(tsel * 16 + i) * 64 + lane];
         }
         if (do_load) { stage_store(hiq + 1, nv_); ++hiq; }  // replaces the oldest row, which no tile of the next round reads
+        XS_ACC(3);
         __syncthreads();                                   // partial buffer may be rewritten, the new row is visible
+        XS_ACC(4);
         if (grp == 0 && tile < NTL) {
             const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
             int oo[16];
@@ -1478,8 +1505,10 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 for (int i = 0; i < 16; ++i) if (oo[i] >= 0) ybase[oo[i]] = ov[i];
             }
         }
+        XS_ACC(5);
     }
     if (am.y) amax_commit(omax, am.y);
+    XS_OUT;
 }
 
 // plan of the piece-ring form: 3x3x3, zero pads, Cin 25 / 32, Cout <= 32, >= 128 voxels per output row
@@ -1490,6 +1519,7 @@ static bool pstrip_plan(const ConvGeom& g, StripPlan& p)
     if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return false;
     const int nvr = g.Wo * g.To;
     if (nvr < 128 || g.Ho < 3 || g.Wi * g.Ti * 4 > 512 * 2) return false;
+    if (g.Cin == 25 && (g.pt != 1 || g.To != g.Ti)) return false;            // (the gathered channel-24 chunk is written for depth pad 1)
     const int Wp = g.Wo + 2, Tp = g.To + 2;
     const size_t lds = (size_t)4 * Wp * Tp * 128 + (size_t)4 * 16 * 64 * sizeof(float);
     if (lds > 163840) return false;
