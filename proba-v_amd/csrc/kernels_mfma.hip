@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
             const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
             const int vox0 = w * a.Tp + t;                                   // record index of tap (dw, dt) = (0, 0) inside a slot
             const int sb0 = (hrel % SLOTS) * rowbytes, sb1 = ((hrel + 1) % SLOTS) * rowbytes, sb2 = ((hrel + 2) % SLOTS) * rowbytes;
-            const int g0 = grp == 0 ? 0 : 5, glast = grp == 0 ? 4 : 8;      // the first-dispatched half takes 5 of the 9 (dh, dw) groups
+            const int g0 = grp == 0 ? 0 : 5, glast = grp == 0 ? 4 : 8;      // the first-dispatched half takes 5 of the 9 (dh, dw) groups (4 : 5 measures the same)
             // operand address of step st = dt * 2 + kb of group gg: record vox0 + dw * Tp + dt of ring row hrel + dh, logical chunks 2 kb + half (+4)
             auto rec_addr = [&](int gg, int dt) -> int {
                 const int dh = gg / 3, dw = gg - 3 * dh;                     // wave-uniform
