@@ -294,7 +294,7 @@ static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x,
                       float* dw, float* db, float* partial, const Amax& am, hipStream_t s)
 {
     const bool exotic = g.reflect_t || g.ph > 1 || g.pw > 1 || g.pt > 1 || (g.kh != 3 && g.kh != 1);
-    if (exotic) { ProfScope ps(e, CLS_CONV3_WGRAD, geom_macs(g), s); return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s); }
+    if (exotic || (e->impl >= 1 && conv3d_direct_wgrad_is_tuned(g))) { ProfScope ps(e, CLS_CONV3_WGRAD, geom_macs(g), s); return conv3d_direct_wgrad(g, x, dy, gate, dw, db, partial, s); }
     const bool x6 = e->impl >= 3 && x6_wgrad_supported(g);
     ProfScope ps(e, g.kh * g.kw * g.kt == 1 ? CLS_PW_WGRAD : (x6 ? CLS_CONV3_WGRAD_X6 : CLS_CONV3_WGRAD), geom_macs(g), s);
     if (x6) { const bool h3 = e->impl >= 4 && am.x && am.w; return x6_conv_wgrad(g, x, dy, gate, dw, db, partial, h3 ? 2 : 1, am, s); }

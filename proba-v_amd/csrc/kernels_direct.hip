@@ -306,6 +306,76 @@ static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& ch
     chunks = (int)((nvox + vpc - 1) / vpc);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Backward-filter of a ONE-input-channel 'same' 3x3x3 layer with 32 outputs (mainConv1): dw[tap][co] = sum_v x[v + tap] dy[v][co].
+// Too thin for a matrix kernel (K = 27 rows, one of them per tap): the fp32-MFMA backward-filter kernel took 132 us on it, the
+// 142 MB of dY + ReLU mask it reads cost ~35 us.  Persistent workgroups walk (patch, row) tiles: the three input rows of a tile sit
+// zero-padded in LDS (3 KB), 16 voxel streams (8 waves x 2 half-waves) run over the row's voxels with lane = output channel, so
+// dY / mask loads are 128-byte rows and every x value is an LDS broadcast; 27 + 1 accumulators per thread, one slab per workgroup.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void wgrad_cin1_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ gate, float* __restrict__ partial,
+                                                        float* __restrict__ partial_b)
+{
+    extern __shared__ float sx[];                                  // [3 rows][W + 2][T + 2], then the exchange area [8 waves][28][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, co = lane & 31;
+    const int Wp = g.Wi + 2, Tp = g.Ti + 2, rowf = Wp * Tp;
+    float* xch = sx + 3 * rowf;
+    float acc[27], bsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+    const int nvr = g.Wo * g.To, ntile = g.N * g.Ho;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int n = tile / g.Ho, h = tile - n * g.Ho;
+        __syncthreads();
+        for (int i = tid; i < 3 * rowf; i += 512) {
+            const int r = i / rowf, rem = i - r * rowf, w = rem / Tp - 1, t = rem - (rem / Tp) * Tp - 1, ih = h + r - 1;
+            const bool ok = ih >= 0 && ih < g.Hi && w >= 0 && w < g.Wi && t >= 0 && t < g.Ti;
+            sx[i] = ok ? x[(((long)n * g.Hi + ih) * g.Wi + w) * g.Ti + t] : 0.f;
+        }
+        __syncthreads();
+        const long ob = ((long)n * g.Ho + h) * nvr;
+        for (int vi = 2 * wave + half; vi < nvr; vi += 16) {
+            const int w = vi / g.To, t = vi - w * g.To;
+            float d = dy[(ob + vi) * 32 + co];
+            if (gate) d = gate[(ob + vi) * 32 + co] > 0.f ? d : 0.f;
+            bsum += d;
+            const float* px = sx + w * Tp + t;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) acc[(dh * 3 + dw) * 3 + dt] = fmaf(px[dh * rowf + dw * Tp + dt], d, acc[(dh * 3 + dw) * 3 + dt]);
+        }
+    }
+    // the 16 streams of an output channel meet in a fixed order: half-waves by shuffle, waves through LDS
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (half == 0) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) xch[(wave * 28 + k) * 32 + co] = acc[k];
+        xch[(wave * 28 + 27) * 32 + co] = bsum;
+    }
+    __syncthreads();
+    for (int i = tid; i < 28 * 32; i += 512) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += xch[w * 28 * 32 + i];
+        if (i < 27 * 32) partial[(long)blockIdx.x * 27 * 32 + i] = v;
+        else partial_b[(long)blockIdx.x * 32 + (i - 27 * 32)] = v;
+    }
+}
+static bool cin1_wgrad(const ConvGeom& g)
+{
+    return g.Cin == 1 && g.Cout == 32 && g.kh == 3 && g.kw == 3 && g.kt == 3 && g.ph == 1 && g.pw == 1 && g.pt == 1 && !g.reflect_hw && !g.reflect_t &&
+           g.Ho == g.Hi && g.Wo == g.Wi && g.To == g.Ti && (size_t)(3 * (g.Wi + 2) * (g.Ti + 2) + 8 * 28 * 32) * sizeof(float) <= 64 * 1024;
+}
+static int cin1_grid(const ConvGeom& g) { const int nt = g.N * g.Ho; return nt < 512 ? nt : 512; }
+bool conv3d_direct_wgrad_is_tuned(const ConvGeom& g) { return cin1_wgrad(g); }
+
 size_t wgrad_partial_floats(const ConvGeom& g)
 {
     int ci_per, gy, gz, chunks; long vpc;
@@ -313,6 +383,7 @@ size_t wgrad_partial_floats(const ConvGeom& g)
     const size_t K = (size_t)g.kh * g.kw * g.kt * g.Cin;
     int halves; size_t lds;
     if (small2d(g, halves, lds) && g.N * halves > chunks) chunks = g.N * halves;
+    if (cin1_wgrad(g) && cin1_grid(g) > chunks) chunks = cin1_grid(g);
     return (size_t)chunks * (K * g.Cout + g.Cout);
 }
 
@@ -322,6 +393,17 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     int ci_per, gy, gz, chunks; long vpc;
     wgrad_plan(g, ci_per, gy, gz, chunks, vpc);
     const long K = (long)g.kh * g.kw * g.kt * g.Cin;
+    if (cin1_wgrad(g)) {
+        const int slabs = cin1_grid(g);
+        float* pb = partial + (size_t)slabs * 27 * 32;
+        const size_t lds = (size_t)(3 * (g.Wi + 2) * (g.Ti + 2) + 8 * 28 * 32) * sizeof(float);
+        hipLaunchKernelGGL(wgrad_cin1_kernel, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
+        int rc = check_launch("wgrad_cin1");
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((27 * 32 + 31) / 32)), dim3(256), 0, s, partial, dw, (long)27 * 32, slabs);
+        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, pb, db, (long)32, slabs);
+        return check_launch("reduce_partials");
+    }
     {
         int halves; size_t lds;
         if (small2d(g, halves, lds)) {

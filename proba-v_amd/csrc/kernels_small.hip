@@ -324,20 +324,20 @@ int clip_round(const float* in, float* out, size_t n, float lo, float hi, hipStr
 //   n = sum M ; b = sum(H - P*M)/n ; C = (P + b)*M ; l1 = sum|H - C|/n ; l2 = sum (H - C)^2/n
 // (HR is NOT masked -- reference quirk, models/loss.py:146,151)
 // ---------------------------------------------------------------------------------------------------
+// One workgroup per (sample, shift row i): its four waves take the shifts (i, j), j = wave, wave + 4.  Candidates go to a scratch
+// table [B][49][2] (fp64); shift_select_kernel picks the per-sample minima (first minimum in shift order wins ties), batch_mean_kernel
+// the batch means.  (One workgroup per sample looping over all 49 shifts left half of the CUs idle: 131 us at batch 128.)
 __global__ __launch_bounds__(256) void shift_loss_fwd_kernel(
     const float* __restrict__ hr, const uint8_t* __restrict__ mask, const float* __restrict__ pred, int S, int border,
-    float* __restrict__ l1_out, float* __restrict__ l2_out, float* __restrict__ cpsnr_out,
-    int* __restrict__ arg_l1, int* __restrict__ arg_l2, float max_val)
+    double* __restrict__ cand)
 {
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, i = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = S - 2 * border, ns = 2 * border + 1, nshift = ns * ns;
     const float* H = hr + (long)b * S * S;
     const uint8_t* M = mask + (long)b * S * S;
     const float* P = pred + (long)b * S * S;
-    double best1 = 1e300, best2 = 1e300;
-    int a1 = 0, a2 = 0;
-    for (int sft = wave; sft < nshift; sft += 4) {
-        const int i = sft / ns, j = sft - i * ns;
+    for (int j = wave; j < ns; j += 4) {
+        const int sft = i * ns + j;
         double cnt = 0.0, dsum = 0.0;
         for (int k = lane; k < L * L; k += 64) {
             const int r = k / L, c = k - r * L;
@@ -356,23 +356,7 @@ __global__ __launch_bounds__(256) void shift_loss_fwd_kernel(
             s2 += e * e;
         }
         s1 = wave_sum(s1) / cnt; s2 = wave_sum(s2) / cnt;
-        if (s1 < best1) { best1 = s1; a1 = sft; }
-        if (s2 < best2) { best2 = s2; a2 = sft; }
-    }
-    __shared__ double sb1[4], sb2[4];
-    __shared__ int sa1[4], sa2[4];
-    if (lane == 0) { sb1[wave] = best1; sb2[wave] = best2; sa1[wave] = a1; sa2[wave] = a2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {          // first minimum in shift order wins ties (shift ids ascend per wave)
-            if (sb1[w] < best1 || (sb1[w] == best1 && sa1[w] < a1)) { best1 = sb1[w]; a1 = sa1[w]; }
-            if (sb2[w] < best2 || (sb2[w] == best2 && sa2[w] < a2)) { best2 = sb2[w]; a2 = sa2[w]; }
-        }
-        l1_out[b] = (float)best1;
-        l2_out[b] = (float)best2;
-        cpsnr_out[b] = (float)(10.0 * log10((double)max_val * (double)max_val / best2));
-        arg_l1[b] = a1;
-        arg_l2[b] = a2;
+        if (lane == 0) { cand[((long)b * nshift + sft) * 2] = s1; cand[((long)b * nshift + sft) * 2 + 1] = s2; }
     }
 }
 
@@ -385,12 +369,48 @@ __global__ __launch_bounds__(64) void batch_mean_kernel(const float* __restrict_
     if (threadIdx.x == 0) { *ma = (float)(s1 / n); *mb = (float)(s2 / n); }
 }
 
+// per-sample minima over the shifts (ascending shift order, strict <: the first minimum wins ties); one thread per sample
+__global__ __launch_bounds__(64) void shift_select_kernel(const double* __restrict__ cand, int B, int nshift, float max_val,
+                                                         float* __restrict__ l1_out, float* __restrict__ l2_out, float* __restrict__ cpsnr_out,
+                                                         int* __restrict__ arg_l1, int* __restrict__ arg_l2)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const double2* c = reinterpret_cast<const double2*>(cand) + (long)b * nshift;
+    double best1 = 1e300, best2 = 1e300;
+    int a1 = 0, a2 = 0;
+#pragma unroll 7
+    for (int sft = 0; sft < nshift; ++sft) {
+        const double2 v = c[sft];
+        if (v.x < best1) { best1 = v.x; a1 = sft; }
+        if (v.y < best2) { best2 = v.y; a2 = sft; }
+    }
+    l1_out[b] = (float)best1;
+    l2_out[b] = (float)best2;
+    cpsnr_out[b] = (float)(10.0 * log10((double)max_val * (double)max_val / best2));
+    arg_l1[b] = a1;
+    arg_l2[b] = a2;
+}
+
 int shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, int B, int S, int border,
                        float* l1, float* l2, float* cpsnr, int* arg_l1, int* arg_l2, float* mean_l1, float* mean_l2,
                        float max_val, hipStream_t s)
 {
     if (B <= 0 || S <= 2 * border) { set_error("shift_loss_forward: bad shape", hipSuccess); return PROBAV_EINVAL; }
-    hipLaunchKernelGGL(shift_loss_fwd_kernel, dim3(B), dim3(256), 0, s, hr, mask, pred, S, border, l1, l2, cpsnr, arg_l1, arg_l2, max_val);
+    const int ns = 2 * border + 1;
+    // candidate table owned by the library, grown on demand (never inside a captured region: the first call of a shape allocates)
+    static double* cand = nullptr;
+    static size_t cand_n = 0;
+    const size_t need = (size_t)B * ns * ns * 2;
+    if (need > cand_n) {
+        if (cand) (void)hipFree(cand);
+        cand = nullptr; cand_n = 0;
+        hipError_t err = hipMalloc((void**)&cand, need * sizeof(double));
+        if (err != hipSuccess) { set_error("shift_loss_forward: scratch allocation", err); return PROBAV_EHIP; }
+        cand_n = need;
+    }
+    hipLaunchKernelGGL(shift_loss_fwd_kernel, dim3(B, ns), dim3(256), 0, s, hr, mask, pred, S, border, cand);
+    hipLaunchKernelGGL(shift_select_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, cand, B, ns * ns, max_val, l1, l2, cpsnr, arg_l1, arg_l2);
     hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, s, l1, l2, mean_l1, mean_l2, B);
     return check_launch("shift_loss_forward");
 }

@@ -48,6 +48,8 @@ int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, 
 size_t wgrad_partial_floats(const ConvGeom& g);
 int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate,
                         float* dw, float* db, float* partial, hipStream_t s);
+// geometries for which conv3d_direct_wgrad runs a dedicated kernel that beats the matrix kernels (one input channel: mainConv1)
+bool conv3d_direct_wgrad_is_tuned(const ConvGeom& g);
 
 // ---- kernels_small.hip ---------------------------------------------------------------------------
 struct WnLayer {            // one weight-normalised layer inside the flat parameter buffer
