@@ -44,13 +44,14 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
     float* sB2 = sB1 + 256;                                      // 32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     // H3 scales.  The hidden tensor exists only in registers, so its scale comes from a bound: |h| <= 32 amax(x) amax(w1) + amax(b1).
-    float sx = 1.f; int k1 = 0, k2 = 0; float sbias = 1.f;
+    float sx = 1.f; int k1 = 0, k2 = 0; float sbias = 1.f, c1 = 1.f;
     if constexpr (AR::SCALED) {
         const unsigned ax = *am.x, aw1 = *am.w1;
         const int ex = h3_exp(ax), ew1 = h3_exp(aw1), ew2 = h3_exp(*am.w2);
         const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(*am.b1));
         sx = pow2i(ex); sbias = pow2i(eh);
         k1 = eh - ex - ew1;                                      // accumulator of the first product -> hidden at its own scale
+        c1 = pow2i(k1 < -126 ? -126 : k1);                       // (k1 <= -17 always: the bound is at least 32 amax(x) amax(w1); as a float factor it fuses with the bias add)
         k2 = -(ew2 + eh);                                        // accumulator of the second product -> true values
     }
     for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * PWF_WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
@@ -100,9 +101,7 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
                     const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float hv = H[8 * kb + 4 * g + i];
-                        if constexpr (AR::SCALED) hv = ldexpf(hv, k1);
-                        hs[4 * g + i] = fmaxf(hv + bv[i], 0.f);
+                        hs[4 * g + i] = fmaxf(fmaf(H[8 * kb + 4 * g + i], c1, bv[i]), 0.f);      // (c1 = 1 without scaling)
                     }
                 }
                 cut8_scaled<AR>(hs, hb[kb]);
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     // H3 scales.  Tensors that exist only in registers are scaled from bounds: |H| <= 32 amax(x) amax(w1) + amax(b1) (as in the
     // forward kernel) and |dH| <= D amax(dT) amax(w2).
-    float sx = 1.f, sd = 1.f, sbias = 1.f;
+    float sx = 1.f, sd = 1.f, sbias = 1.f, ch = 1.f, cg = 1.f;
     int kh = 0, kg = 0, kdx = 0, kdw1 = 0, kdw2 = 0, kdb1 = 0;
     if constexpr (AR::SCALED) {
         const unsigned ax = *am.x, aw1 = *am.w1, aw2 = *am.w2, ad = *am.dt;
@@ -225,6 +224,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         sx = pow2i(ex); sd = pow2i(ed); sbias = pow2i(eh);
         kh = eh - ex - ew1;           // accumulator (a) -> hidden values at their own scale
         kg = eg - ew2 - ed;           // accumulator (b) -> hidden gradients at their own scale
+        ch = pow2i(kh < -126 ? -126 : kh);                          // (kh, kg <= -17 always, see the bounds: float factors that fuse with the bias add)
+        cg = pow2i(kg < -126 ? -126 : kg);
         kdx = -(ew1 + eg);            // (c) partials -> true values
         kdw1 = -(ex + eg); kdw2 = -(ed + eh); kdb1 = -eg;
     }
@@ -385,9 +386,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 8 * kb + 4 * g + i;
-                        float hv = H[r], dv = dH[r];
-                        if constexpr (AR::SCALED) { hv = ldexpf(hv, kh); dv = ldexpf(dv, kg); }
-                        hv += bv[i];
+                        const float hv = fmaf(H[r], ch, bv[i]), dv = dH[r] * cg;          // (ch = cg = 1 without scaling)
                         gs[4 * g + i] = hv > 0.f ? dv : 0.f;
                         hs[4 * g + i] = fmaxf(hv, 0.f);
                         bs1v[r] += gs[4 * g + i];
