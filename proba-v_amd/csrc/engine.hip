@@ -266,13 +266,14 @@ static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const floa
     const bool h3 = e->impl >= 4 && wf.h3 && am.x && am.w;
     const float* wsplit = h3 ? wf.h3 : wf.x6;
     const int arith = h3 ? 2 : 1;
-    const bool x6s = e->impl >= 3 && wsplit && !no_strip && mfma_conv_strip_supported(g);
+    const bool pring = h3 && x6_strip_wants_tap_fragments(g, 2);                  // the H3 piece-ring strip kernel serves this geometry
+    const bool x6s = e->impl >= 3 && wsplit && !no_strip && (mfma_conv_strip_supported(g) || pring);
     const bool x6r = e->impl >= 3 && wsplit && !x6s && x6_conv_rowtile_supported(g);
     const bool x6 = x6s || x6r;
     ProfScope ps(e, pw ? (bwd ? CLS_PW_BWD_DATA : CLS_PW_FWD) : (bwd ? (x6 ? CLS_CONV3_BWD_DATA_X6 : CLS_CONV3_BWD_DATA) : (x6 ? CLS_CONV3_FWD_X6 : CLS_CONV3_FWD)), geom_macs(g), s);
     if (x6s) {
         reported = true;
-        const float* wq = (h3 && g.Cin == 25 && wf.h3t && x6_strip_wants_tap_fragments(g, 2)) ? wf.h3t : wsplit;
+        const float* wq = (pring && g.Cin == 25 && wf.h3t) ? wf.h3t : wsplit;
         return x6_conv_strip_forward(g, x, gate, wq, bias, skip, y, arith, am, s);
     }
     if (x6r) { reported = true; return x6_conv_rowtile_forward(g, x, gate, wsplit, bias, skip, y, arith, am, s); }
@@ -783,8 +784,9 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
     if (impl < 0 || impl > 4) { set_error("probav_conv3d_forward: impl must be 0..4", hipSuccess); return PROBAV_EINVAL; }
     if (impl >= 1) {
-        const bool x6row = impl >= 3 && !mfma_conv_strip_supported(g) && x6_conv_rowtile_supported(g);
-        const bool okk = x6row || (impl >= 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g));
+        const bool pstrip = impl == 4 && x6_strip_wants_tap_fragments(g, 2);
+        const bool x6row = impl >= 3 && !mfma_conv_strip_supported(g) && !pstrip && x6_conv_rowtile_supported(g);
+        const bool okk = x6row || pstrip || (impl >= 2 ? mfma_conv_strip_supported(g) : mfma_conv_supported(g));
         if (!okk) { set_error("probav_conv3d_forward: geometry not supported by this MFMA kernel", hipSuccess); return PROBAV_EINVAL; }
         int rc = op_scratch();
         if (rc) return rc;
@@ -794,7 +796,7 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
             if (rc) return rc;
             am.x = g_op_amax; am.w = g_op_amax + 1; am.y = g_op_amax + 4;
         }
-        rc = op_pack(g, w, (hipStream_t)stream, impl >= 3 ? impl - 2 : 0, !x6row && impl == 4 && x6_strip_wants_tap_fragments(g, 2));
+        rc = op_pack(g, w, (hipStream_t)stream, impl >= 3 ? impl - 2 : 0, pstrip);
         if (rc) return rc;
         if (x6row) return x6_conv_rowtile_forward(g, x, gate, g_op_frag, bias, skip, y, impl - 2, am, (hipStream_t)stream);
         if (impl >= 3) return x6_conv_strip_forward(g, x, gate, g_op_frag, bias, skip, y, impl - 2, am, (hipStream_t)stream);

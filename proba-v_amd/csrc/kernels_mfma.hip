@@ -754,9 +754,10 @@ int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate
 // ---------------------------------------------------------------------------------------------------
 struct StripArgs {
     ConvGeom g;
-    int Wp, Tp;                 // staged width / depth (Wo + 2, To + 2)
+    int Wp, Tp;                 // staged width / depth (Wo + 2, To + 2; piece-ring kernel: Wt + 2)
     int SR, nstrips;            // output rows per strip, strips per patch
     unsigned mTo, mNvr, mTi, mSrcCol;
+    int nsplit, Wt;             // piece-ring kernel: output rows cut into nsplit column ranges of Wt columns when four full rows do not fit the LDS
 };
 
 
@@ -1299,19 +1300,31 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     const int tsel = wave & 3, grp = wave >> 2;
     const int rowbytes = a.Wp * a.Tp * REC;
     float* part = reinterpret_cast<float*>(plds + SLOTS * rowbytes);          // [4 tiles][16 regs][64 lanes]
-    const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
+    // workgroup = (patch n, strip of output rows, column range sp): output columns ws0 .. ws0 + Wt - 1 (pstrip_plan(): Wo % nsplit == 0)
+    const int per = a.nstrips * a.nsplit;
+    const int n = blockIdx.x / per, srem = blockIdx.x - n * per;
+    const int strip = srem / a.nsplit, sp = srem - strip * a.nsplit;
+    const int ws0 = sp * a.Wt;
     const int hb = strip * a.SR;
     const int SRr = g.Ho - hb < a.SR ? g.Ho - hb : a.SR;
-    const int nvr = g.Wo * g.To;
+    const int nvr = a.Wt * g.To;                                             // voxels per output row of this column range (>= 128)
     const int NV = SRr * nvr, NTL = (NV + 31) >> 5, nrounds = (NTL + 3) >> 2;
-    const long out_base = ((long)n * g.Ho + hb) * nvr;
+    const long out_base = ((long)n * g.Ho + hb) * g.Wo * g.To;
     float* ybase = y + out_base * g.Cout;
     const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
     const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+    // offset of strip voxel vi (this lane's channel) from ybase / sbase: rows are contiguous only when the range is the whole row
+    auto elem_off = [&](int vi) -> int {
+        if (a.nsplit == 1) return vi * g.Cout + col;
+        const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+        const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+        return ((hrel * g.Wo + ws0 + w) * g.To + t) * g.Cout + col;
+    };
 
-    // staging: item i of a row = (input voxel i >> 2, channel chunk i & 3); RVP items per thread
-    const int items = g.Wi * g.Ti * 4;
-    constexpr int RVP = 2;                                                   // strip_plan(): Wi * Ti * 4 <= 512 * RVP
+    // staging: item i of a row = (local voxel i >> 2 = (local column lw, depth t), channel chunk i & 3); local column lw <-> input column
+    // ws0 + lw - pw (zero outside the patch), lw < Wt + 2; RVP items per thread
+    const int items = (a.Wt + 2) * g.Ti * 4;
+    constexpr int RVP = 2;                                                   // pstrip_plan(): (Wt + 2) * Ti * 4 <= 512 * RVP
     auto stage_load = [&](int q, float (&v)[RVP][8]) {
         const int ih = hb - g.ph + q;
         const bool rok = ih >= 0 && ih < g.Hi;
@@ -1321,9 +1334,12 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
 #pragma unroll
         for (int k = 0; k < RVP; ++k) {
             const int i = tid + 512 * k;
-            const bool live = rok && i < items;
             const int ic = i < items ? i : 0;
-            const int vox = ic >> 2, cc = ic & 3;
+            const int lvox = ic >> 2, cc = ic & 3;
+            const int lw = fdiv(lvox, g.Ti, a.mTi), t = lvox - lw * g.Ti;
+            const int iw = ws0 + lw - g.pw;
+            const bool live = rok && i < items && iw >= 0 && iw < g.Wi;
+            const int vox = (live ? iw : 0) * g.Ti + t;                      // input voxel of the row (clamped when dead)
             const float* src = xrow + vox * CIN + 8 * cc;
             const float* gsr = GATE ? grow + vox * CIN + 8 * cc : nullptr;
             if constexpr (CIN % 8 == 0) {
@@ -1341,7 +1357,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 // 25 channels: chunks 0..2 = channels 0..23 of the voxel; chunk 3 of the record at PADDED depth t' (the item's `vox`
                 // is then (w, t')) gathers channel 24 of padded depths t', t'+1, t'+2 = input depths t'-1, t', t'+1 (pt = 1): the
                 // tenth K chunk of a (dh, dw) group, so that a group is 5 k-blocks instead of 6
-                const int w = fdiv(vox, g.Ti, a.mTi), t = vox - w * g.Ti;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int tj = t - 1 + j;                                 // (cc == 3 only)
@@ -1360,9 +1375,9 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
         for (int k = 0; k < RVP; ++k) {
             const int i = tid + 512 * k;
             if (i < items) {
-                const int vox = i >> 2, cc = i & 3;
-                const int w = fdiv(vox, g.Ti, a.mTi), t = vox - w * g.Ti;
-                const int vd = (w + g.pw) * a.Tp + t + ((CIN == 25 && cc == 3) ? 0 : g.pt);   // (the gathered chunk is indexed by padded depth)
+                const int lvox = i >> 2, cc = i & 3;
+                const int lw = fdiv(lvox, g.Ti, a.mTi), t = lvox - lw * g.Ti;
+                const int vd = lw * a.Tp + t + ((CIN == 25 && cc == 3) ? 0 : g.pt);   // (the gathered chunk is indexed by padded depth)
                 Frag f[NP];
                 cut8<AR>(v[k], sa, f);
                 unsigned char* rec = slot + vd * REC;
@@ -1394,7 +1409,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int vi = tl * 32 + rowmap(i, half);
-            const int o = (tl < NTL && vi < NV && col < g.Cout) ? vi * g.Cout + col : 0;
+            const int o = (tl < NTL && vi < NV && col < g.Cout) ? elem_off(vi) : 0;
             skn[i] = sbase[o];
         }
     };
@@ -1491,7 +1506,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int vi = tile * 32 + rowmap(i, half);
-                oo[i] = (vi < NV && col < g.Cout) ? vi * g.Cout + col : -1;
+                oo[i] = (vi < NV && col < g.Cout) ? elem_off(vi) : -1;
                 float v = ldexpf(acc[i] + pv[i], eun) + bv;
                 if (g.relu) v = fmaxf(v, 0.f);
                 ov[i] = v + sk[i];
@@ -1517,23 +1532,29 @@ static bool pstrip_plan(const ConvGeom& g, StripPlan& p)
     p.ok = false;
     if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.Cout > 32 || (g.Cin != 25 && g.Cin != 32)) return false;
     if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return false;
-    const int nvr = g.Wo * g.To;
-    if (nvr < 128 || g.Ho < 3 || g.Wi * g.Ti * 4 > 512 * 2) return false;
     if (g.Cin == 25 && (g.pt != 1 || g.To != g.Ti)) return false;            // (the gathered channel-24 chunk is written for depth pad 1)
-    const int Wp = g.Wo + 2, Tp = g.To + 2;
-    const size_t lds = (size_t)4 * Wp * Tp * 128 + (size_t)4 * 16 * 64 * sizeof(float);
-    if (lds > 163840) return false;
-    int nstrips = (256 + g.N - 1) / g.N;
+    if (g.Ho < 3) return false;
+    const int Tp = g.To + 2;
+    // column ranges per row: as few as make four staged rows fit the LDS (T = 13: two), each row of a range still >= 128 voxels
+    int nsplit = 0, Wt = 0;
+    size_t lds = 0;
+    for (int ns = 1; ns <= 4; ++ns) {
+        if (g.Wo % ns) continue;
+        const int wt = g.Wo / ns;
+        const size_t need = (size_t)4 * (wt + 2) * Tp * 128 + (size_t)4 * 16 * 64 * sizeof(float);
+        if (need <= 163840 && wt * g.To >= 128 && (wt + 2) * g.Ti * 4 <= 512 * 2) { nsplit = ns; Wt = wt; lds = need; break; }
+    }
+    if (!nsplit) return false;
+    int nstrips = (256 + g.N * nsplit - 1) / (g.N * nsplit);
     if (nstrips < 1) nstrips = 1;
     if (nstrips > g.Ho / 4) nstrips = g.Ho / 4 > 0 ? g.Ho / 4 : 1;
     const int SR = (g.Ho + nstrips - 1) / nstrips;
     nstrips = (g.Ho + SR - 1) / SR;
-    p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = lds; p.grid = g.N * nstrips;
-    p.a.g = g; p.a.Wp = Wp; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips;
-    p.a.mTo = magic(g.To); p.a.mNvr = magic(nvr); p.a.mTi = magic(g.Ti); p.a.mSrcCol = 0;
+    p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = lds; p.grid = g.N * nstrips * nsplit;
+    p.a.g = g; p.a.Wp = Wt + 2; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips; p.a.nsplit = nsplit; p.a.Wt = Wt;
+    p.a.mTo = magic(g.To); p.a.mNvr = magic(Wt * g.To); p.a.mTi = magic(g.Ti); p.a.mSrcCol = 0;
     return true;
 }
-
 
 static StripPlan strip_plan(const ConvGeom& g)
 {
@@ -1560,7 +1581,7 @@ static StripPlan strip_plan(const ConvGeom& g)
     const int SR = (g.Ho + nstrips - 1) / nstrips;
     nstrips = (g.Ho + SR - 1) / SR;
     p.ok = true; p.CC = CC; p.KS = (CC + 1) / 2; p.lds_bytes = (lds + 15) & ~(size_t)15; p.grid = g.N * nstrips;
-    p.a.g = g; p.a.Wp = Wp; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips;
+    p.a.g = g; p.a.Wp = Wp; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips; p.a.nsplit = 1; p.a.Wt = g.Wo;
     p.a.mTo = magic(g.To); p.a.mNvr = magic(nvr); p.a.mTi = magic(g.Ti); p.a.mSrcCol = magic(g.Ti * CC);
     return p;
 }
@@ -1571,7 +1592,7 @@ bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
 bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith)
 {
     StripPlan pp;
-    return arith == 2 && strip_plan(g).ok && pstrip_plan(g, pp);
+    return arith == 2 && pstrip_plan(g, pp);
 }
 
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,

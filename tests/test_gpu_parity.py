@@ -72,6 +72,7 @@ CONV_CASES = [
     ("bwd-data of normConv gated (two channel passes)", 2, (22, 22, 9), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 1, 0),
     ("bwd-data of convReducer_1: full 32->32 gated, 24x24x9 out", 2, (22, 22, 7), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
     ("T=13 normConv same 25->32", 1, (22, 22, 13), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("bwd-data of the T=13 normConv: 32->25 gated (two column ranges in the piece-ring strip kernel)", 2, (22, 22, 13), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 1, 0),
 ]
 
 
