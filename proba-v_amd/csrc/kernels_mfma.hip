@@ -1323,7 +1323,9 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
 
     // staging: item i of a row = (local voxel i >> 2 = (local column lw, depth t), channel chunk i & 3); local column lw <-> input column
     // ws0 + lw - pw (zero outside the patch), lw < Wt + 2; RVP items per thread
-    const int items = (a.Wt + 2) * g.Ti * 4;
+    // (a whole-row range stages the patch columns only: its pad columns stay zero from the initial clear)
+    const int lw0 = a.nsplit == 1 ? g.pw : 0, Wl = a.nsplit == 1 ? g.Wi : a.Wt + 2;
+    const int items = Wl * g.Ti * 4;
     constexpr int RVP = 2;                                                   // pstrip_plan(): (Wt + 2) * Ti * 4 <= 512 * RVP
     auto stage_load = [&](int q, float (&v)[RVP][8]) {
         const int ih = hb - g.ph + q;
@@ -1336,7 +1338,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
             const int i = tid + 512 * k;
             const int ic = i < items ? i : 0;
             const int lvox = ic >> 2, cc = ic & 3;
-            const int lw = fdiv(lvox, g.Ti, a.mTi), t = lvox - lw * g.Ti;
+            const int lwr = fdiv(lvox, g.Ti, a.mTi), t = lvox - lwr * g.Ti, lw = lw0 + lwr;
             const int iw = ws0 + lw - g.pw;
             const bool live = rok && i < items && iw >= 0 && iw < g.Wi;
             const int vox = (live ? iw : 0) * g.Ti + t;                      // input voxel of the row (clamped when dead)
@@ -1376,7 +1378,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
             const int i = tid + 512 * k;
             if (i < items) {
                 const int lvox = i >> 2, cc = i & 3;
-                const int lw = fdiv(lvox, g.Ti, a.mTi), t = lvox - lw * g.Ti;
+                const int lwr = fdiv(lvox, g.Ti, a.mTi), t = lvox - lwr * g.Ti, lw = lw0 + lwr;
                 const int vd = lw * a.Tp + t + ((CIN == 25 && cc == 3) ? 0 : g.pt);   // (the gathered chunk is indexed by padded depth)
                 Frag f[NP];
                 cut8<AR>(v[k], sa, f);
