@@ -26,7 +26,7 @@ def main():
     dec = torch.empty(nvox, D, device=dev)
     if what == "pw_fwd":
         outs = {}
-        for impl in (2, 3):
+        for impl in (2, 3, 4):
             for _ in range(reps):
                 L.check(L.lib().probav_pw_forward(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(dec), nvox, D, impl,
                                                   L.current_stream()))
@@ -46,14 +46,15 @@ def main():
         dx = torch.empty(nvox, 32, device=dev)
         dw1, db1, dw2, db2 = (torch.empty(s, device=dev) for s in ((32, 256), (256,), (256, D), (D,)))
         res = {}
-        for impl in (2, 3):
+        for impl in (2, 3, 4):
             for _ in range(reps):
                 L.check(L.lib().probav_pw_backward(L.ptr(x), L.ptr(ddec), L.ptr(dskip), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(dx), L.ptr(dw1),
                                                    L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, D, impl, L.current_stream()))
             torch.cuda.synchronize()
             res[impl] = [t.double().cpu().clone() for t in (dx, dw1, db1, dw2, db2)]
-        for a, b, name in zip(res[2], res[3], ("dx", "dw1", "db1", "dw2", "db2")):
-            print("%s: impl 3 vs impl 2 max diff / max = %.3g" % (name, float((a - b).abs().max() / a.abs().max())))
+        for a, b, c, name in zip(res[2], res[3], res[4], ("dx", "dw1", "db1", "dw2", "db2")):
+            print("%s: impl 3 vs impl 2 max diff / max = %.3g ; impl 4 vs impl 2 = %.3g" % (
+                name, float((a - b).abs().max() / a.abs().max()), float((a - c).abs().max() / a.abs().max())))
 
 
     if what == "wgrad":
@@ -63,7 +64,7 @@ def main():
         xx = torch.randn(N, H, W, T, Cin, generator=g).to(dev)
         dyy = torch.randn(N, H, W, T, Cout, generator=g).to(dev)
         outs = {}
-        for impl in (1, 3):
+        for impl in (1, 3, 4):
             nbytes = L.lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(gm), impl)
             scratch = torch.empty(nbytes // 4 + 1, device=dev)
             dw = torch.empty(3, 3, 3, Cin, Cout, device=dev)
@@ -73,7 +74,8 @@ def main():
                                                     impl, L.current_stream()))
             torch.cuda.synchronize()
             outs[impl] = dw.double().cpu()
-        print("wgrad impl 3 vs impl 1: max diff / max = %.3g" % float((outs[3] - outs[1]).abs().max() / outs[1].abs().max()))
+        print("wgrad impl 3 vs impl 1: max diff / max = %.3g ; impl 4 vs impl 1 = %.3g" % (
+            float((outs[3] - outs[1]).abs().max() / outs[1].abs().max()), float((outs[4] - outs[1]).abs().max() / outs[1].abs().max())))
 
 
 if __name__ == "__main__":

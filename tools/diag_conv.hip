@@ -24,10 +24,10 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < nfrag; ++i) hw[i] = (float)((i * 40503u) % 1000) / 5000.f - 0.1f;
     hipMemcpy(w, hw.data(), nfrag * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) mfma_conv_forward(g, x, nullptr, w, nullptr, nullptr, y, 0);
+    for (int it = 0; it < 3; ++it) mfma_conv_forward(g, x, nullptr, w, nullptr, nullptr, y, Amax(), 0);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int it = 0; it < 5; ++it) mfma_conv_forward(g, x, nullptr, w, nullptr, nullptr, y, 0);
+    for (int it = 0; it < 5; ++it) mfma_conv_forward(g, x, nullptr, w, nullptr, nullptr, y, Amax(), 0);
     hipEventRecord(e1, 0); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> st(8192 * 8);
