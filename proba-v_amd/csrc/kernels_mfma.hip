@@ -1417,7 +1417,12 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) skn[i] = 0.f;
-    if (grp == 0 && sbase) load_skip(tsel);
+    // Without a ReLU the skip tile is added by the SECOND wave of the pair, into the partial sum it hands over (at the accumulator's
+    // scale: exact): that wave has one tap group less and no epilogue, so the stall its filter waits take behind these HBM loads
+    // (vmcnt retires in order) costs the round less than on the writing wave.
+    const bool skip_via_part = sbase && !g.relu;                             // wave-uniform
+    const int skip_grp = skip_via_part ? 1 : 0;
+    if (grp == skip_grp && sbase) load_skip(tsel);
 
     const uint4* wf = wfrag + lane;                                         // PACK_H3_CONV (32 channels) / PACK_H3_CONVP (25): fragment ((group * NST + st) * NP + piece) * 64 + lane
     for (int r = 0; r < nrounds; ++r) {
@@ -1484,11 +1489,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 }
             }
             if (grp == 1) {
+                if (skip_via_part) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
+                    for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i] + ldexpf(sk[i], -eun);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
+                }
             }
         } else if (do_load) stage_load(hiq + 1, nv_);
-        if (grp == 0 && sbase && r + 1 < nrounds) load_skip(4 * (r + 1) + tsel);
+        if (grp == skip_grp && sbase && r + 1 < nrounds) load_skip(4 * (r + 1) + tsel);
         XS_ACC(2);
         __syncthreads();                                   // partials are in LDS; every wave is past its taps
         XS_ACC(4);
@@ -1511,7 +1521,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 oo[i] = (vi < NV && col < g.Cout) ? elem_off(vi) : -1;
                 float v = ldexpf(acc[i] + pv[i], eun) + bv;
                 if (g.relu) v = fmaxf(v, 0.f);
-                ov[i] = v + sk[i];
+                ov[i] = skip_via_part ? v : v + sk[i];
                 omax = fmaxf(omax, oo[i] >= 0 ? fabsf(ov[i]) : 0.f);
             }
             if (full) {

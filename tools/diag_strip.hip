@@ -11,8 +11,8 @@ int main()
         const int cout = cin == 25 ? 32 : 25;
         ConvGeom g{B, 22, 22, 9, cin, 22, 22, 9, cout, 3, 3, 3, 1, 1, 1, 0, 0, 0};
         const size_t nin = (size_t)B * 22 * 22 * 9 * cin, nout = (size_t)B * 22 * 22 * 9 * cout;
-        float *x, *y, *wf, *bias; unsigned* am;
-        hipMalloc(&x, nin * 4); hipMalloc(&y, nout * 4); hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMalloc(&bias, 32 * 4); hipMalloc(&am, 64);
+        float *x, *y, *wf, *bias, *skp; unsigned* am;
+        hipMalloc(&x, nin * 4); hipMalloc(&y, nout * 4); hipMalloc(&skp, nout * 4); hipMemset(skp, 0, nout * 4); hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMalloc(&bias, 32 * 4); hipMalloc(&am, 64);
         std::vector<float> h(nin);
         for (size_t i = 0; i < nin; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
         hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
@@ -22,9 +22,9 @@ int main()
         for (int arith = 1; arith <= 2; ++arith) {
             Amax m; m.x = am; m.w = am + 1; m.y = am + 2;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int it = 0; it < 3; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, nullptr, y, arith, m, 0);
+            for (int it = 0; it < 3; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, cin == 25 ? skp : nullptr, y, arith, m, 0);
             hipEventRecord(e0, 0);
-            for (int it = 0; it < 20; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, nullptr, y, arith, m, 0);
+            for (int it = 0; it < 20; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, cin == 25 ? skp : nullptr, y, arith, m, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("strip cin %d arith %d: %.1f us\n", cin, arith, ms * 1000 / 20);
