@@ -47,6 +47,7 @@ struct probav_engine {
     std::vector<long> pkW1, pkW2;            // per block: fused expand/decay forward fragments
     std::vector<long> pkW2B, pkW1C;          // per block: extra fragments of the fused backward
     bool pw_mfma = false;
+    bool fwd_amax = false;    // the last training forward filled the amax slots of the saved activations (H3 kernels, impl 4)
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -547,6 +548,7 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     const AmaxSlots A(e, p, W, R);
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.w(li); m.y = ay; } return m; };
     if (h3 && hipMemsetAsync(A.base, 0, (size_t)p.amax_bwd * sizeof(unsigned), s) != hipSuccess) { set_error("probav_forward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    if (training) e->fwd_amax = h3;
 
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
     if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
@@ -615,6 +617,10 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     int nback = 0;
     auto new_slot = [&]() -> unsigned* { return h3 ? A.back(nback++) : nullptr; };
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.w(li); m.y = ay; } return m; };
+    if (h3 && !e->fwd_amax) {
+        set_error("probav_backward: the H3 kernels (impl 4) need the amax slots of a forward pass run with the same kernel family", hipSuccess);
+        return PROBAV_EINVAL;
+    }
     if (h3 && hipMemsetAsync(A.back(0), 0, (size_t)(p.n_amax - p.amax_bwd) * sizeof(unsigned), s) != hipSuccess) { set_error("probav_backward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
     auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };

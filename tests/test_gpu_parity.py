@@ -552,3 +552,20 @@ def test_h3_kernels_do_not_care_about_operand_magnitudes(dev, ea, eb):
 
     np.testing.assert_array_equal(fwd(x * sa, w * sb), fwd(x, w) * (sa * sb))
     np.testing.assert_array_equal(wgrad(x * sa, dy * sb), wgrad(x, dy) * (sa * sb))
+
+
+def test_h3_backward_refuses_a_forward_of_another_family(dev):
+    """The H3 kernels scale their operands from amax slots the forward pass fills; a backward pass after a forward of another
+    kernel family would read stale slots, so the engine refuses it instead of computing with arbitrary scales."""
+    from probav_amd.loss import Losses
+    m = _model(dev, params=synth.synth_params(seed=5, perturb=True))
+    lo = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(2, seed=6))
+    m.set_impl(3)
+    loss = lo.shiftCompensatedL1Loss(hr, mask, m(x, training=True))
+    m.set_impl(4)
+    with pytest.raises((RuntimeError, ValueError), match="same kernel family"):
+        loss.backward()
+    m.flat.grad = None
+    lo.shiftCompensatedL1Loss(hr, mask, m(x, training=True)).backward()          # a forward of the same family: fine
+    assert torch.isfinite(m.flat.grad).all()
