@@ -77,7 +77,11 @@ int main()
             x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, D, ARITH, pam, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+#ifdef PROBAV_STAMP2
+        const char* nm[8] = {"t0", "(a),(b) + dX reduce of the previous tile", "gate + cut", "(c)", "Tb store, dH' transpose, (d)", "H' transpose, (e)", "-", "t_end"};
+#else
         const char* nm[8] = {"t0", "wait: tile staged", "compute", "stage store", "wait: partials", "dX reduce", "epilogue", "t_end"};
+#endif
         for (int wave = 0; wave < 8; wave += 3) {
             double acc[8] = {0}; double life = 0;
             for (int b = 0; b < 256; ++b) {
