@@ -241,7 +241,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             w2[kb][p].u = w2kf[((c * 2 + kb) * NP + p) * 64 + lane];
             w3[kb][p].u = w1cf[((c * 2 + kb) * NP + p) * 64 + lane];
         }
-    unsigned char* Ti = TiAll + wave * NP * PT_IMG;
+    // H3: two images per wave (dH' and H' pieces), so that both transposes are in LDS before (c) and the reads of (d) and (e) overlap;
+    // the three-piece X6 images only fit once (the second store then waits for the reads of (d))
+    constexpr int NTI = AR::SCALED ? 2 : 1;
+    unsigned char* Ti = TiAll + wave * NTI * NP * PT_IMG;
+    unsigned char* Th = Ti + (NTI - 1) * NP * PT_IMG;
     float omax = 0.f;
     f32x16 dW1, dW2t;
     float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
@@ -396,30 +400,47 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
                 cut8_scaled<AR>(hs, hf[kb]);
             }
             XS2(1);
+            // dH' (and, with two images, H') pieces go to this wave's transpose images before (c), whose MFMAs cover the LDS writes.  LDS
+            // operations of one wave execute in order; the empty asm statements only keep the COMPILER from moving reads above the
+            // writes they depend on.
+            store_pieces<NP>(Ti, col, half, gf);
+            if constexpr (NTI == 2) store_pieces<NP>(Th, col, half, hf);
+            asm volatile("" ::: "memory");
             dx = mac<AR>(w3[0], gf[0], dx); dx = mac<AR>(w3[1], gf[1], dx);           // (c)
             XS2(2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tb[col * 33 + rowmap(r, half)] = dx[r];
-            // (d): dH' pieces through this wave's transpose image.  LDS operations of one wave execute in order; the empty asm
-            // statements only keep the COMPILER from moving reads above the writes they depend on.
-            store_pieces<NP>(Ti, col, half, gf);
-            asm volatile("" ::: "memory");
-            Frag at[NP], bt[NP];
+            if constexpr (NTI == 2) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < 2; ++kb) {                               // (d) and (e) side by side: four transposed reads per piece, then both products
+                    Frag at[NP], bt[NP], ae[NP], be[NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) { tr_frag<PB_ROW>(Xb + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
-                dW1 = mac<AR>(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
-            }
-            XS2(3);
-            asm volatile("" ::: "memory");
-            store_pieces<NP>(Ti, col, half, hf);                            // (e): H' pieces, same image
-            asm volatile("" ::: "memory");
+                    for (int p = 0; p < NP; ++p) {
+                        tr_frag<PB_ROW>(Xb + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]);
+                        tr_frag<PB_ROW>(Db + p * PB_IMG, lane, kb, ae[p]); tr_frag<PT_ROW>(Th + p * PT_IMG, lane, kb, be[p]);
+                    }
+                    dW1 = mac<AR>(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
+                    dW2t = mac<AR>(ae, be, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
+                }
+                XS2(3);
+            } else {
+                Frag at[NP], bt[NP];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) { tr_frag<PB_ROW>(Db + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
-                dW2t = mac<AR>(at, bt, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
+                    for (int p = 0; p < NP; ++p) { tr_frag<PB_ROW>(Xb + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
+                    dW1 = mac<AR>(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
+                }
+                XS2(3);
+                asm volatile("" ::: "memory");
+                store_pieces<NP>(Ti, col, half, hf);                            // (e): H' pieces, same image
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) { tr_frag<PB_ROW>(Db + p * PB_IMG, lane, kb, at[p]); tr_frag<PT_ROW>(Ti + p * PT_IMG, lane, kb, bt[p]); }
+                    dW2t = mac<AR>(at, bt, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
+                }
             }
             asm volatile("" ::: "memory");
             XS2(4);
@@ -486,7 +507,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
-        const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * H3::NP * PT_IMG;
+        const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 2 * H3::NP * PT_IMG;   // (two transpose images per wave)
         hipLaunchKernelGGL(pw_bwd_x6_kernel<H3>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
                            (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D, am);
     } else {
