@@ -73,6 +73,9 @@ size_t probav_workspace_bytes(const probav_engine* e, int batch, int training);
  * (nclass >= 8: wn, small, conv3 fwd, conv3 bwd-data, conv3 wgrad, 1x1x1 fwd, 1x1x1 bwd-data,
  * 1x1x1 wgrad) and clears the log.                                                                  */
 int probav_engine_profile(probav_engine* e, int enable, int max_launches);
+/* restrict the bracketing to the kernel classes whose bit is set (default: all).  An event pair around EVERY launch costs ~6 % of a
+ * training step (the launches no longer overlap their ramps); bench.py brackets only the dominant class inside its timed region.  */
+int probav_engine_profile_classes(probav_engine* e, uint32_t mask);
 int probav_engine_profile_read(probav_engine* e, int nclass, double* ms, double* macs, int64_t* launches);
 
 /* replaces  model(x, training=...)      models/trainClass.py:127,139 ; test.py:117 ; testClass.py:26

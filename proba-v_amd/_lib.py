@@ -34,6 +34,7 @@ SIGNATURES = {
     "probav_engine_set_impl": (c_int, [c_void_p, c_int]),
     "probav_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "probav_engine_profile": (c_int, [c_void_p, c_int, c_int]),
+    "probav_engine_profile_classes": (c_int, [c_void_p, ctypes.c_uint32]),
     "probav_engine_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "probav_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "probav_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),

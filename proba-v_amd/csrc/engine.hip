@@ -50,6 +50,7 @@ struct probav_engine {
     bool fwd_amax = false;    // the last training forward filled the amax slots of the saved activations (H3 kernels, impl 4)
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
     bool prof_on = false;
+    unsigned prof_mask = ~0u;   // kernel classes whose launches are bracketed (bit = class index)
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_cls;
     std::vector<double> prof_macs;
@@ -64,7 +65,7 @@ struct ProfScope {
     probav_engine* e; hipStream_t s; bool live;
     ProfScope(const probav_engine* ce, int cls, double macs, hipStream_t st) : e(const_cast<probav_engine*>(ce)), s(st), live(false)
     {
-        if (!e->prof_on || e->prof_used + 2 > e->prof_ev.size()) return;
+        if (!e->prof_on || !((e->prof_mask >> cls) & 1u) || e->prof_used + 2 > e->prof_ev.size()) return;
         live = true;
         e->prof_cls.push_back(cls);
         e->prof_macs.push_back(macs);
@@ -465,6 +466,13 @@ int probav_engine_profile(probav_engine* e, int enable, int max_launches)
     }
     e->prof_on = enable != 0;
     e->prof_used = 0; e->prof_cls.clear(); e->prof_macs.clear();
+    return PROBAV_OK;
+}
+
+int probav_engine_profile_classes(probav_engine* e, uint32_t mask)
+{
+    if (!e) { set_error("probav_engine_profile_classes: null engine", hipSuccess); return PROBAV_EINVAL; }
+    e->prof_mask = mask;
     return PROBAV_OK;
 }
 
