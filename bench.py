@@ -2,7 +2,11 @@
 """bench.py -- LR-patches/sec, fwd+bwd, WDSR-B r12 t9, 16x16 patches (+6 px border), batch 128 per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 starts its own ranks: the parent process (which never touches the GPU and never imports torch) runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` as a CHILD,
+forwards its output (rank 0 prints the JSON line) and exits with its status.  Launched under torch.distributed.run already
+(RANK / WORLD_SIZE in the environment), the script is one rank of that job.
 
 One "step" = one pass of the hot path over one batch of synthetic patches already resident in HBM:
 model forward (weight-norm, head, 12 WDSR-B blocks, reducers, pixel shuffle), shift-compensated L1 loss
@@ -11,16 +15,19 @@ plus, for N > 1, the one gradient all-reduce that data parallelism adds (RCCL ov
 The optimizer update and the cPSNR metric are not part of "fwd+bwd"; `--full-step` times them too and
 reports the result under "full_step" without changing `value`.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: the engine brackets every kernel launch of
-the timed steps with HIP events on the launch stream and reports per-class time and algorithmic MACs;
-the dominant class is priced against the fp32 MFMA/VALU peak of MI355X (157.3 TFLOP/s).
-`cpu_baseline` times the CPU oracle (torch-CPU restatement of the TF path; the TF reference itself
-cannot run here) on the host cores at the reference's CPU-runnable config (batch 8).
+Rank 0 prints ONE JSON line.  `value` comes from the wall clock around exactly K steps (barrier + synchronize on both
+sides, max over ranks); `step_ms` (median, p10, p90) from HIP events recorded on the launch stream at every step boundary.
+`roofline` is measured live: the engine brackets the launches of the dominant kernel class with HIP events on the launch
+stream; `achieved` = SURVEY.md §8d's algorithmic MACs of that class / its time.
+`cpu_baseline` times the CPU oracle (torch-CPU restatement of the TF path; the TF reference itself cannot run here) on the
+host cores at the reference's CPU-runnable config (batch 8).  `other_configs` carries BASELINE.json's config 3 (T = 13)
+and config 4 (full-frame inference) from short extra runs.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,15 +38,76 @@ CLASSES = ["weight_norm", "small", "conv3x3x3_fwd", "conv3x3x3_bwd_data", "conv3
            "conv1x1x1_fwd", "conv1x1x1_bwd_data", "conv1x1x1_wgrad",
            "conv3x3x3_fwd_x6", "conv3x3x3_bwd_data_x6", "conv3x3x3_wgrad_x6", "conv1x1x1_fwd_x6", "conv1x1x1_bwd_data_x6"]
 PEAK_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
-PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PF)
+PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (~2.5 PF)
 SPLIT_PRODUCTS = {3: 6, 4: 3}      # 16-bit MFMA products issued per fp32 product: x6 kernels (bf16 pieces) / H3 kernels (scaled fp16 pieces)
-PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak
 ALGO_MB_PER_PATCH = 402.414        # layer-boundary byte model, fwd + bwd (un-fused)
 PLAN_MB_PER_PATCH = 81.0           # bytes the fused plan moves (256-channel tensor never reaches HBM)
-HBM_PROFILE = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command
 ALGO_GFLOP_PER_PATCH = 12.436      # SURVEY.md §8d / BASELINE.md §2: fwd + bwd, p16t9c85r12
+PW_BWD_ALGO_MAC, PW_BWD_ISSUED_MAC = 29184, 37376     # per voxel: §8d (bwd of expConv + decConv) / incl. the recompute of the hidden tile
+IMPL_NAMES = {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16", 4: "h3-split-fp16"}
+DTYPES = {3: "f32 (products as 6 bf16-piece MFMA products, f32 accumulate)", 4: "f32 (products as 3 scaled-fp16-piece MFMA products, f32 accumulate)"}
 
 
+def hbm_profile_path():
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=128, help="patches per GPU (BASELINE.json: 128)")
+    ap.add_argument("--frames", type=int, default=9, help="numImgLR: 9 (headline), 13 or 7")
+    ap.add_argument("--impl", type=int, default=4, help="4 = H3 kernels: fp32 products as three products of scaled fp16 piece pairs on the 16-bit MFMA pipe (default), "
+                    "3 = x6 kernels: six bf16-piece products, "
+                    "2 = native fp32 MFMA + strip convolution, 1 = fp32 MFMA row-tile kernels, 0 = generic direct kernels")
+    ap.add_argument("--no-fp32-mfma-leg", action="store_true", help="skip the short extra run on the native fp32-MFMA kernels (impl 2)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short T=13 training and full-frame inference legs")
+    ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collective check without a GPU: every rank all-reduces a "
+                    "gradient-sized buffer over --backend and rank 0 prints a JSON line (CPU test of the N > 1 path)")
+    return ap.parse_args(argv)
+
+
+# -----------------------------------------------------------------------------------------------------------------------------
+# parent: start one process per GPU.  Nothing here may touch the GPU (no torch import): the ranks are children, never an exec
+# -----------------------------------------------------------------------------------------------------------------------------
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["PROBAV_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    return rc
+
+
+# -----------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(seconds=20.0):
     """The oracle's torch-CPU restatement, fp32, all host cores, BASELINE.json config 1 (batch 8)."""
     import torch
@@ -73,33 +141,55 @@ def cpu_baseline(seconds=20.0):
             "sample": "oracle/wdsr_torch.py fp32, batch 8 (cfg p16t9c85r12 on CPU), fwd + L1 loss + bwd, %d steps in %.1f s" % (n, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="patches per GPU (BASELINE.json: 128)")
-    ap.add_argument("--frames", type=int, default=9, help="numImgLR: 9 (headline), 13 or 7")
-    ap.add_argument("--impl", type=int, default=4, help="4 = H3 kernels: fp32 products as three products of scaled fp16 piece pairs on the 16-bit MFMA pipe (default), "
-                    "3 = x6 kernels: six bf16-piece products, "
-                    "2 = native fp32 MFMA + strip convolution, 1 = fp32 MFMA row-tile kernels, 0 = generic direct kernels")
-    ap.add_argument("--no-fp32-mfma-leg", action="store_true", help="skip the short extra run on the native fp32-MFMA kernels (impl 2)")
-    ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    args = ap.parse_args()
+def percentiles(ms):
+    s = sorted(ms)
+    q = lambda f: s[min(len(s) - 1, max(0, int(round(f * (len(s) - 1)))))]
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(s[0], 4), "max": round(s[-1], 4), "n": len(s)}
+
+
+def dry_run(args, world, rank):
+    """The N > 1 plumbing without a GPU: rendezvous, the gradient-sized all-reduce of trainClass.allreduce_mean_, barrier, max-over-ranks."""
+    import torch
+    import torch.distributed as dist
+    from probav_amd.arch import layer_table
+    from probav_amd.trainClass import allreduce_mean_
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    _, total = layer_table()
+    g = torch.full((total,), float(rank + 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.fill_(float(rank + 1))
+        allreduce_mean_(g)
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ok = bool(torch.allclose(g, torch.full_like(g, (world + 1) / 2.0)))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1, "backend": args.backend,
+                          "steps": args.steps, "allreduce_floats": total, "allreduce_ok": ok, "ms_per_step": round(float(tmax) / max(1, args.steps) * 1e3, 4)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if args.backend != "nccl":
+        raise SystemExit("--backend %s: the measured path runs on HIP devices over RCCL (backend nccl); gloo is for --dry-run" % args.backend)
 
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-        args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -110,38 +200,65 @@ def main():
     if world > 1:
         dist.barrier()
 
-    from probav_amd import _lib, synth
+    from probav_amd import _lib, synth, testClass
     from probav_amd.loss import Losses
     from probav_amd.modelsTF import WDSRConv3D
     from probav_amd.trainClass import allreduce_mean_, make_optimizer
 
-    T, B = args.frames, args.batch
-    model = WDSRConv3D("bench", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, True)
-    model.load_variables(synth.synth_params(seed=1234, numImgLR=T))            # same random-init weights on every rank
-    model = model.to(dev)
-    model.set_impl(args.impl)
+    B = args.batch
     losses = Losses(targetShape=(48, 48, 1))
-    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(B, seed=1234 + rank, numImgLR=T))
-    opt = make_optimizer("nadam", model, 5e-4)
-    L, h = _lib.lib(), model._handle()
-
-    def step(full=False):
-        pred = model(x, training=True)
-        loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
-        model.flat.grad = None
-        loss.backward()
-        if world > 1:
-            allreduce_mean_(model.flat.grad)
-        if full:
-            opt.step()
-            losses.shiftCompensatedcPSNR(hr, mask, pred.detach())
-        return loss
+    L = _lib.lib()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def make(T):
+        model = WDSRConv3D("bench", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, True)
+        model.load_variables(synth.synth_params(seed=1234, numImgLR=T))            # same random-init weights on every rank
+        model = model.to(dev)
+        model.set_impl(args.impl)
+        data = tuple(torch.as_tensor(a).to(dev) for a in synth.synth_batch(B, seed=1234 + rank, numImgLR=T))
+        return model, data
+
+    def stepper(model, data, opt=None):
+        x, hr, mask = data
+
+        def step(full=False):
+            pred = model(x, training=True)
+            loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
+            model.flat.grad = None
+            loss.backward()
+            if world > 1:
+                allreduce_mean_(model.flat.grad)
+            if full:
+                opt.step()
+                losses.shiftCompensatedcPSNR(hr, mask, pred.detach())
+            return loss
+        return step
+
+    def timed(step, k, *a):
+        """Wall clock around exactly k steps, max over ranks; HIP events at every step boundary (torch's current stream IS the launch stream)."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        sync()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(k):
+            loss = step(*a)
+            evs[i + 1].record()
+        sync()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax), [evs[i].elapsed_time(evs[i + 1]) for i in range(k)], loss
+
+    T = args.frames
+    model, data = make(T)
+    opt = make_optimizer("nadam", model, 5e-4)
+    step = stepper(model, data, opt)
+    h = model._handle()
     for _ in range(args.warmup):
         step()
     sync()
@@ -156,9 +273,8 @@ def main():
 
     # HIP events around EVERY launch cost ~6 % of the step (launch ramps no longer overlap), so the timed region brackets only the
     # launches of the dominant kernel class; which class that is, and the per-class table, come from two untimed steps bracketed in full.
-    prof_all, dom = None, None
+    prof_all, dom, psteps = None, None, 2
     if use_events:
-        psteps = 2
         _lib.check(L.probav_engine_profile_classes(h, 0xFFFFFFFF), "probav_engine_profile_classes")
         _lib.check(L.probav_engine_profile(h, 1, 512 * psteps), "probav_engine_profile")
         for _ in range(psteps):
@@ -168,47 +284,64 @@ def main():
         dom = max((c for c in prof_all if prof_all[c]["macs"] > 0), key=lambda c: prof_all[c]["ms"])
         _lib.check(L.probav_engine_profile_classes(h, 1 << CLASSES.index(dom)), "probav_engine_profile_classes")
         _lib.check(L.probav_engine_profile(h, 1, 64 * args.steps), "probav_engine_profile")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt, step_ms, loss = timed(step, args.steps)
     prof = None
     if use_events:
         prof = read_profile()                                                  # the dominant class over the timed steps
         _lib.check(L.probav_engine_profile_classes(h, 0xFFFFFFFF), "probav_engine_profile_classes")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+
     full = None
     if args.full_step:
         for _ in range(2):
             step(True)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(True)
-        sync()
-        full = (time.perf_counter() - t1) / args.steps * 1e3
+        dtf, _, _ = timed(step, args.steps, True)
+        full = dtf / args.steps * 1e3
 
     fp32_leg = None
     if args.impl >= 3 and not args.no_fp32_mfma_leg:
         model.set_impl(2)
         for _ in range(2):
             step()
-        sync()
-        k2 = max(3, args.steps // 4)
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            step()
-        sync()
-        t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        fp32_leg = {"value": round(world * B * k2 / float(t2), 2), "unit": "patches/s", "ms_per_step": round(float(t2) / k2 * 1e3, 4), "steps": k2,
+        k2 = max(3, args.steps // 10)
+        t2, _, _ = timed(step, k2)
+        fp32_leg = {"value": round(world * B * k2 / t2, 2), "unit": "patches/s", "ms_per_step": round(t2 / k2 * 1e3, 4), "steps": k2,
                     "note": "same step on the native fp32-MFMA kernels (--impl 2), for reference"}
         model.set_impl(args.impl)
+
+    other = None
+    if world == 1 and T == 9 and not args.no_other_configs:
+        other = {}
+        # BASELINE.json config 3, realised as the reference's only longer-T network (T = 13, ConvReduceAndUpscalev3)
+        del step, opt
+        model._ws.clear()
+        m13, d13 = make(13)
+        s13 = stepper(m13, d13)
+        for _ in range(3):
+            s13()
+        k3 = max(5, args.steps // 5)
+        t3, ms3, _ = timed(s13, k3)
+        other["config3_t13_training"] = {"value": round(B * k3 / t3, 2), "unit": "patches/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "steps": k3, "step_ms": percentiles(ms3),
+                                         "workload": "numImgLR 13 (reducer v3), %d patches of [22,22,13,1], fwd + shift-L1 + bwd" % B}
+        m13._ws.clear()
+        del m13, d13, s13
+        # BASELINE.json config 4: 32 image sets of 9 registered 128x128 frames -> 64 patches each -> forward, clip, round, 8x8 stitch to 384x384
+        import numpy as np
+        rng = np.random.default_rng(7)
+        frames = torch.as_tensor(np.clip(rng.normal(synth.NIR_MEAN, synth.NIR_STD, (32, 9, 128, 128)), 0, 16383).astype(np.float32)).to(dev)
+        inf = {}
+        for name, mb, reps in (("batched_2048", 2048, 5), ("reference_micro_batch_16", 16, 2)):
+            run = lambda: testClass.resolve_images(model, testClass.unfold_frames(frames), micro_batch=mb)
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                img = run()
+            torch.cuda.synchronize()
+            d4 = (time.perf_counter() - t0) / reps
+            inf[name] = {"micro_batch": mb, "images_per_s": round(32 / d4, 2), "patches_per_s": round(32 * 64 / d4, 1), "ms_per_32_images": round(d4 * 1e3, 3)}
+        assert img.shape == (32, 384, 384)
+        other["config4_inference"] = {"workload": "32 image sets x 9 frames of 128x128 resident in HBM -> unfold to 2048 patches of [22,22,9,1] -> forward -> "
+                                                  "clip[0,2^16] + round-half-even -> stitch to 32 x [384,384] (test.py path)", **inf}
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -216,13 +349,16 @@ def main():
             "metric": "LR-patches/sec fwd+bwd (WDSR-B r12 t%d, 16x16, bs%d)" % (T, B),
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPES.get(args.impl, "f32"), "data": "synthetic",
+            "step_ms": dict(percentiles(step_ms), note="rank 0, HIP events on the launch stream at every step boundary of the timed steps"),
             "config": {"workload": "cfg p16t%dc85r12: %d patches/GPU of [22,22,%d,1] -> [48,48,1], 12 WDSR-B blocks, 32 filters; "
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
                                    (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "impl": {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16", 4: "h3-split-fp16"}[args.impl],
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "world_size": dist.get_world_size() if world > 1 else 1, "backend": "nccl (RCCL)" if world > 1 else None,
+                       "impl": IMPL_NAMES[args.impl],
                        "arithmetic": ("fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as three exact products of fp16 piece pairs "
-                                      "(a = a0 + a1 to 2^-24, per-tensor power-of-two scaling) on the fp16 MFMA pipe (H3 kernels, error of the order of "
+                                      "(a = a0 + a1 to 2^-24, power-of-two operand scaling) on the fp16 MFMA pipe (H3 kernels, error of the order of "
                                       "fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 4 else
                                       "fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as six exact bf16-piece products on the "
                                       "bf16 MFMA pipe (x6 kernels, error of the order of fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 3
@@ -232,26 +368,29 @@ def main():
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",
                                   "note": "derived from the reference's TensorBoard logs (BASELINE.md), not a published figure"},
         }
+        hbm_profile = hbm_profile_path()
         if T == 9:
             # the HBM view SURVEY.md §8d asks for next to the compute roofline: the un-fused layer-boundary byte model, the bytes the
             # fused plan declares, and (when profiles/ holds the PMC passes of this workload) the bytes rocprofv3 counted
-            gbps = lambda mb: value * mb / 1e3
-            hv = {"peak_GBps": PEAK_HBM_GBPS,
+            gbps = lambda mb: value / world * mb / 1e3
+            hv = {"peak_GBps": PEAK_HBM_GBPS, "per_gpu": True,
                   "layer_boundary_model": {"MB_per_patch": ALGO_MB_PER_PATCH, "GBps": round(gbps(ALGO_MB_PER_PATCH), 1),
                                            "frac": round(gbps(ALGO_MB_PER_PATCH) / PEAK_HBM_GBPS, 4)},
                   "fused_plan": {"MB_per_patch": PLAN_MB_PER_PATCH, "GBps": round(gbps(PLAN_MB_PER_PATCH), 1),
                                  "frac": round(gbps(PLAN_MB_PER_PATCH) / PEAK_HBM_GBPS, 4)}}
-            if os.path.exists(HBM_PROFILE) and B == 128 and args.impl == 4:
-                with open(HBM_PROFILE) as fh:
+            if hbm_profile and B == 128 and args.impl == 4:
+                with open(hbm_profile) as fh:
                     bps = json.load(fh)["bytes_per_step"]
-                hv["counted_by_rocprof"] = {"GB_per_step": round(bps / 1e9, 2), "GBps": round(bps / 1e9 / (dt / args.steps) / world, 1) if world == 1 else None,
-                                            "source": os.path.relpath(HBM_PROFILE, ROOT)}
+                hv["counted_by_rocprof"] = {"GB_per_step": round(bps / 1e9, 2), "GBps": round(bps / 1e9 / (dt / args.steps), 1),
+                                            "source": os.path.relpath(hbm_profile, ROOT)}
             out["hbm_view"] = hv
         if fp32_leg is not None:
             out["fp32_mfma_path"] = fp32_leg
         if full is not None:
             out["full_step"] = {"ms_per_step": round(full, 4), "patches_per_s": round(world * B / full * 1e3, 2),
                                 "includes": "fwd + L1 loss + bwd + Nadam update + cPSNR metric"}
+        if other:
+            out["other_configs"] = other
         if prof:
             per = {c: {"ms_per_step": round(v["ms"] / psteps, 4), "launches_per_step": v["launches"] / psteps,
                        "tflops": round(2 * v["macs"] / (v["ms"] * 1e-3) / 1e12, 3) if v["ms"] > 0 and v["macs"] > 0 else None}
@@ -266,27 +405,41 @@ def main():
                                "algorithmic_gflop_per_launch": round(2 * prof[dom]["macs"] / max(1, prof[dom]["launches"]) / 1e9, 3),
                                "note": "rank 0, HIP events on the launch stream around every launch of this class during the timed steps "
                                        "(the other classes are bracketed only in two untimed steps: kernel_classes); "
-                                       "achieved = algorithmic fp32 FLOP/s" + (
+                                       "achieved = SURVEY.md §8d's algorithmic fp32 FLOP of the class / its time" + (
                                            "; this class runs split-operand kernels, which issue %d 16-bit MFMA products per fp32 product, so its "
                                            "ceiling is the dense bf16/fp16 MFMA peak (%.0f TFLOP/s) / %d" % (nprod, PEAK_BF16_TFLOPS, nprod) if x6 else
                                            "; peak = dense fp32 MFMA")}
+            if dom.startswith("conv1x1x1_bwd_data"):
+                out["roofline"]["issued_incl_recompute_tflops"] = round(ach * PW_BWD_ISSUED_MAC / PW_BWD_ALGO_MAC, 3)
+                out["roofline"]["recompute_note"] = ("the fused pointwise backward also recomputes the 256-channel hidden tile (8 192 MAC/voxel on top of the "
+                                                     "29 184 algorithmic ones); the recompute is NOT counted in `achieved`")
             out["kernel_classes_note"] = "HIP events around every launch of %d untimed steps after the warm-up" % psteps
             out["kernel_classes"] = per
-            if os.path.exists(HBM_PROFILE) and T == 9 and B == 128 and args.impl == 4:
-                with open(HBM_PROFILE) as fh:
+            if hbm_profile and T == 9 and B == 128 and args.impl == 4:
+                with open(hbm_profile) as fh:
                     hp = json.load(fh)
                 if dom in hp.get("per_class", {}):
                     out["roofline"]["traffic"] = hp["per_class"][dom]["bytes_per_launch"]
                     out["roofline"]["traffic_note"] = ("HBM bytes per launch of %s from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                        "passes of this command; FETCH_SIZE doubled per the gfx950 note), not collected in this run"
-                                                       % (hp["per_class"][dom]["kernel"], os.path.relpath(HBM_PROFILE, ROOT)))
+                                                       % (hp["per_class"][dom]["kernel"], os.path.relpath(hbm_profile, ROOT)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        return launch_ranks(args, argv)                # parent: no GPU call, no torch import; the ranks are child processes
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

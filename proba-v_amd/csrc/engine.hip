@@ -696,7 +696,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
         if (e->impl >= 1 && e->pw_mfma) {
             // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
             const long nvox = (long)B * Hin * Hin * T;
-            ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (3.0 * F * E + 2.0 * E * D), s);
+            ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (2.0 * F * E + 2.0 * E * D), s);   // bwd-data + bwd-filter of expConv and decConv; the recompute of H (F*E more) is not algorithmic work
             unsigned* anew = new_slot();                     // amax slot of dX
             if (h3) {
                 PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.b1 = A.b(le); m.dt = agdec; m.y = anew;

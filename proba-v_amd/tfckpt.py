@@ -206,7 +206,28 @@ def load_reference_checkpoint(model, prefix):
         params.setdefault(L.name, {})[name] = read_tensor(prefix, index, key)
     model.load_variables(params)
     step_key = "step" + _SUFFIX
-    return int(read_tensor(prefix, index, step_key)) if step_key in index else None
+    return int(read_tensor(prefix, index, step_key).reshape(-1)[0]) if step_key in index else None
+
+
+def load_reference_optimizer(model, prefix):
+    """The Keras optimizer state a reference checkpoint carries next to the weights: the two slots
+    `<variable>/.OPTIMIZER_SLOT/optimizer/{m,v}` of each of the 132 trainables, `optimizer/iter` and Nadam's running product
+    `optimizer/momentum_cache`, plus the trainer's `psnr`.  Returns {"iter", "momentum_cache", "m", "v", "psnr"} with m / v as flat
+    float32 arrays in the engine's parameter order, or None if the bundle has no slots (weights-only export)."""
+    index = read_index(prefix)
+    layers = model.layers
+    total = layers[-1].b_off + layers[-1].cout
+    m, v = np.zeros(total, np.float32), np.zeros(total, np.float32)
+    for (k, name, key), L in zip(model_variable_keys(len(layers)), [L for L in layers for _ in range(3)]):
+        base = key[:-len(_SUFFIX)] + "/.OPTIMIZER_SLOT/optimizer/"
+        if base + "m" + _SUFFIX not in index:
+            return None
+        lo, hi = {"g": (L.g_off, L.v_off), "v": (L.v_off, L.b_off), "bias": (L.b_off, L.b_off + L.cout)}[name]
+        m[lo:hi] = read_tensor(prefix, index, base + "m" + _SUFFIX).reshape(-1)
+        v[lo:hi] = read_tensor(prefix, index, base + "v" + _SUFFIX).reshape(-1)
+    get = lambda key, default: (read_tensor(prefix, index, key + _SUFFIX).item() if key + _SUFFIX in index else default)
+    return {"iter": int(get("optimizer/iter", 0)), "momentum_cache": float(get("optimizer/momentum_cache", 1.0)),
+            "m": m, "v": v, "psnr": float(get("psnr", 1.0))}
 
 
 # ---- writer (single shard, one data block per ~4 KB, uncompressed) ---------------------------------------
@@ -277,12 +298,24 @@ def write_bundle(prefix, tensors):
         fh.write(bytes(out))
 
 
-def save_reference_checkpoint(model, prefix, step=0, psnr=1.0):
-    """Export a WDSRModel in the reference's object-graph key scheme (model variables, `step`, `psnr`)."""
+def save_reference_checkpoint(model, prefix, step=0, psnr=1.0, optimizer=None):
+    """Export a WDSRModel in the reference's object-graph key scheme (model variables, `step`, `psnr`).
+    optimizer: optional {"iter", "momentum_cache", "m", "v"} (flat m / v in the engine's parameter order) written as the Keras
+    Nadam slots and counters, so that the reference -- or `load_reference_optimizer` -- resumes with its moments."""
     tensors = {"step" + _SUFFIX: np.array(step, np.int32), "psnr" + _SUFFIX: np.array(psnr, np.float32)}
     tv = [t.detach().cpu().numpy() for t in model.trainable_variables]
+    lay3 = [L for L in model.layers for _ in range(3)]
     for i, (k, name, key) in enumerate(model_variable_keys(len(model.layers))):
         tensors[key] = tv[i]
         if name == "g":
             tensors["model/layer_with_weights-%d/initialized%s" % (k, _SUFFIX)] = np.array(True)
+        if optimizer is not None:
+            L = lay3[i]
+            lo, hi = {"g": (L.g_off, L.v_off), "v": (L.v_off, L.b_off), "bias": (L.b_off, L.b_off + L.cout)}[name]
+            base = key[:-len(_SUFFIX)] + "/.OPTIMIZER_SLOT/optimizer/"
+            for slot in ("m", "v"):
+                tensors[base + slot + _SUFFIX] = np.asarray(optimizer[slot], np.float32)[lo:hi].reshape(tv[i].shape)
+    if optimizer is not None:
+        tensors["optimizer/iter" + _SUFFIX] = np.array(int(optimizer["iter"]), np.int64)
+        tensors["optimizer/momentum_cache" + _SUFFIX] = np.array(optimizer["momentum_cache"], np.float32)
     write_bundle(prefix, tensors)

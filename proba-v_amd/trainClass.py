@@ -41,6 +41,10 @@ class Mean:
     def result(self):
         return float(self.total) / self.count if self.count else 0.0
 
+    def snapshot(self):
+        """(running sum as a device scalar or None, count): what `result()` would divide, without reading the device."""
+        return self.total, self.count
+
 
 def shuffle_repeat_batch(n, epochs, batchSize, bufferSize, rng, repeat=True):
     """Index stream with tf.data semantics: from_tensor_slices -> shuffle(bufferSize, reshuffle each
@@ -143,6 +147,69 @@ def allreduce_mean_(flat_grad):
         flat_grad.div_(dist.get_world_size())
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
+
+
+def allreduce_metrics_(loss, metric):
+    """the scalar reduce of the reference's multi-GPU trainer (debug/trainClassMultiGPU0.py:162-178:
+    `strategy.reduce(MEAN, ...)` of the per-replica loss and metric): ONE 2-float all-reduce per step.  Returns
+    (mean loss, mean metric) as 0-d tensors; without torch.distributed it only takes the local means."""
+    import torch.distributed as dist
+    pair = torch.stack([loss.detach().double().mean(), metric.detach().double().mean()])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(pair, op=dist.ReduceOp.SUM)
+        pair = pair / dist.get_world_size()
+    return pair[0], pair[1]
+
+
+class _LateScalars:
+    """Per-step log lines and summary scalars WITHOUT a host sync per step: the running sums of the two train metrics are copied to a
+    pinned host buffer on the compute stream (non-blocking) with an event behind them, and the line of step k is emitted once that
+    event has completed -- normally while step k+1 is being enqueued.  Same text, same values, same order as the reference's
+    per-step `logger.info` / `tf.summary.scalar` (models/trainClass.py:104-108); `flush()` drains what is pending."""
+
+    def __init__(self, emit, device, depth=2):
+        self.emit, self.depth, self.pending = emit, depth, []
+        self.cuda = torch.device(device).type == "cuda"
+
+    def push(self, means, meta):
+        sums = [m.snapshot() for m in means]
+        vals = torch.stack([(t if t is not None else torch.zeros((), dtype=torch.float64)).to(torch.float64) for t, _ in sums])
+        counts = [c for _, c in sums]
+        if self.cuda:
+            host = torch.empty(vals.shape, dtype=torch.float64, pin_memory=True)
+            host.copy_(vals, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = vals.clone(), None
+        self.pending.append((host, ev, counts, meta))
+        while self.pending and (len(self.pending) > self.depth or self.pending[0][1] is None or self.pending[0][1].query()):
+            self._pop()
+
+    def _pop(self):
+        host, ev, counts, meta = self.pending.pop(0)
+        if ev is not None:
+            ev.synchronize()
+        self.emit([float(h) / c if c else 0.0 for h, c in zip(host, counts)], meta)
+
+    def flush(self):
+        while self.pending:
+            self._pop()
+
+
+def load_nadam_state(optimizer, step, momentum_cache, m, v):
+    """Put Keras-Nadam state (iteration count, running momentum product, first / second moments as flat arrays in the engine's
+    parameter order) into a HipNadam or torch.optim.NAdam over the model's single flat parameter."""
+    (p,) = [q for g in optimizer.param_groups for q in g["params"]]
+    mt = torch.as_tensor(m, dtype=torch.float32).reshape(p.shape).to(p.device)
+    vt = torch.as_tensor(v, dtype=torch.float32).reshape(p.shape).to(p.device)
+    if isinstance(optimizer, HipNadam):
+        optimizer.state[p] = {"step": int(step), "momentum_cache": float(momentum_cache), "m": mt.clone(), "v": vt.clone()}
+    elif isinstance(optimizer, torch.optim.NAdam):
+        optimizer.state[p] = {"step": torch.tensor(float(step)), "mu_product": torch.tensor(float(momentum_cache)),
+                              "exp_avg": mt.clone(), "exp_avg_sq": vt.clone()}
+    else:
+        raise TypeError("the reference checkpoint carries Nadam slots; optimizer is %s" % type(optimizer).__name__)
 
 
 class HipNadam(torch.optim.Optimizer):
@@ -277,6 +344,11 @@ class ModelTrainer:
 
     # -- checkpointing -------------------------------------------------------------------------------
     def _index_path(self):
+        """Index of the .pt checkpoints this trainer writes.  NOT `checkpoint`: that name is TensorFlow's CheckpointState file, and a
+        directory written by the reference must stay readable by the reference after this trainer has saved into it."""
+        return os.path.join(self.ckptDir, "checkpoint.pt-index")
+
+    def _tf_state_path(self):
         return os.path.join(self.ckptDir, "checkpoint")
 
     def _read_index(self):
@@ -293,23 +365,33 @@ class ModelTrainer:
     def _tf_latest(self):
         """Prefix of the latest TensorFlow-format checkpoint if `ckptDir/checkpoint` is a TF CheckpointState text file
         (`model_checkpoint_path: "ckpt-124"`), i.e. a directory written by the reference itself."""
-        if not os.path.exists(self._index_path()):
+        if not os.path.exists(self._tf_state_path()):
             return None
-        with open(self._index_path()) as fh:
+        with open(self._tf_state_path()) as fh:
             first = fh.readline().strip()
         if not first.startswith("model_checkpoint_path:"):
             return None
         return os.path.join(self.ckptDir, first.split(":", 1)[1].strip().strip('"'))
 
     def restore(self):
-        tf_prefix = self._tf_latest()
+        path = self.latest_checkpoint                   # checkpoints of this trainer are newer than a TF bundle in the same directory
+        tf_prefix = self._tf_latest() if not (path and os.path.exists(path)) else None
         if tf_prefix is not None:                       # weights trained by the reference (tf.train.Checkpoint bundle)
-            from .tfckpt import load_reference_checkpoint
+            from .tfckpt import load_reference_checkpoint, load_reference_optimizer
             step = load_reference_checkpoint(self._model, tf_prefix)
             self.step = int(step or 0)
-            print(f"[ INFO ] Model restored from TensorFlow checkpoint {tf_prefix} at step {self.step}.")
+            slots = load_reference_optimizer(self._model, tf_prefix)
+            if slots is not None:
+                self.psnr = slots["psnr"]
+            if slots is not None and isinstance(self.optimizer, (HipNadam, torch.optim.NAdam)):
+                load_nadam_state(self.optimizer, slots["iter"], slots["momentum_cache"], slots["m"], slots["v"])
+                print(f"[ INFO ] Model and Nadam state (iteration {slots['iter']}) restored from TensorFlow checkpoint {tf_prefix} at step {self.step}.")
+            else:
+                if self.optimizer is not None:
+                    logger.warning("[ WARN ] %s: optimizer state NOT restored (%s); the optimizer restarts from zero moments",
+                                   tf_prefix, "the bundle has no optimizer slots" if slots is None else "optimizer is not Nadam")
+                print(f"[ INFO ] Model restored from TensorFlow checkpoint {tf_prefix} at step {self.step}.")
             return
-        path = self.latest_checkpoint
         if path and os.path.exists(path):
             state = torch.load(path, map_location="cpu")
             self._model.load_variables(state["model"])
@@ -333,7 +415,7 @@ class ModelTrainer:
         torch.save({"model": model_state, "optimizer": self.optimizer.state_dict() if self.optimizer else None,
                     "step": self.step, "psnr": self.psnr, "save_counter": self.save_counter},
                    os.path.join(self.ckptDir, name))
-        kept = ([] if self._tf_latest() else self._read_index()) + [name]     # a TF CheckpointState file is superseded
+        kept = self._read_index() + [name]
         for old in kept[:-self.max_to_keep]:
             try:
                 os.remove(os.path.join(self.ckptDir, old))
@@ -374,9 +456,14 @@ class ModelTrainer:
         logger.info("[ INFO ] Loading data set to buffer cache...")
         yHR, yMask = y[0], y[1]
         rank, world = self._rank(), self._world()
-        if world > 1 and self.multiGPU:                 # per-replica batch = cfg batch (debug/trainClassMultiGPU0.py:67-73)
-            X, yHR, yMask = X[rank::world], yHR[rank::world], yMask[rank::world]
-        rng = np.random.default_rng(seed + rank)
+        if world > 1 and self.multiGPU:
+            # per-replica batch = cfg batch (debug/trainClassMultiGPU0.py:67-73).  Every rank gets EXACTLY len(X) // world samples
+            # (the tail of an indivisible data set is dropped): equal shard lengths give every rank the same number of batches, so the
+            # per-step gradient all-reduce never waits for a rank that has already finished.
+            per = len(X) // world
+            X, yHR, yMask = X[rank::world][:per], yHR[rank::world][:per], yMask[rank::world][:per]
+        rng = np.random.default_rng(seed + rank)                 # training order: consumed by the prefetch thread only
+        vrng = np.random.default_rng(seed + 7919)                # validation order: its own stream, the same on every rank
         dataSetLength = len(X)
         totalSteps = int(dataSetLength / globalBatchSize)           # tf.cast(len/batch, int64) truncates (:75)
         if totalSteps < 1:
@@ -388,10 +475,18 @@ class ModelTrainer:
         mask_dtype = torch.as_tensor(np.asarray(yMask[:1])).dtype
         batches = BatchPrefetcher((X, yHR, yMask), (torch.float32, torch.float32, mask_dtype),
                                   shuffle_repeat_batch(dataSetLength, epochs, globalBatchSize, bufferSize, rng), self._device())
+
+        def emit(vals, meta):
+            ep, st, gs = meta
+            logger.info(f"[ EPOCH {ep}/{epochs} ] - [ STEP {st}/{int(totalSteps)} ] Loss: {vals[0]:.6f}, cPSNR: {vals[1]:.3f}")
+            self._scalar("Train PSNR", vals[1], gs)
+            self._scalar("Train loss", vals[0], gs)
+        late = _LateScalars(emit, self._device())
         for xb, hb, mb in batches:
             if (totalSteps - step) == 0:
                 epoch += 1
                 step = self.step % totalSteps
+                late.flush()
                 logger.info(f"[ ***************  NEW EPOCH  *************** ] Epoch number {epoch}")
                 for m in (self.trainLoss, self.trainPSNR, self.testLoss, self.testPSNR):
                     m.reset_states()
@@ -399,43 +494,49 @@ class ModelTrainer:
             globalStep += 1
             self.trainStep(xb, hb, mb)
             self.step += 1
-            logger.info(f"[ EPOCH {epoch}/{epochs} ] - [ STEP {step}/{int(totalSteps)} ] Loss: {self.trainLoss.result():.6f}, cPSNR: {self.trainPSNR.result():.3f}")
-            self._scalar("Train PSNR", self.trainPSNR.result(), globalStep)
-            self._scalar("Train loss", self.trainLoss.result(), globalStep)
+            late.push((self.trainLoss, self.trainPSNR), (epoch, step, globalStep))      # the reference's per-step line, one step late, no sync
 
             if step != 0 and (step % self.evalStep) == 0:
+                late.flush()
                 self.testLoss.reset_states()
                 self.testPSNR.reset_states()
-                for k, vidx in enumerate(shuffle_repeat_batch(len(valData[0]), 1, globalBatchSize, bufferSize, rng, repeat=False)):
+                for k, vidx in enumerate(shuffle_repeat_batch(len(valData[0]), 1, globalBatchSize, bufferSize, vrng, repeat=False)):
                     if k >= valSteps:                   # .take(valSteps) (utils/utils.py:37-39)
                         break
                     self.testStep(self._to_dev(valData[0][vidx], torch.float32), self._to_dev(valData[1][vidx], torch.float32),
                                   self._to_dev(valData[2][vidx]))
-                self._scalar("Test loss", self.testLoss.result(), globalStep)
-                self._scalar("Test PSNR", self.testPSNR.result(), globalStep)
-                logger.info(f"[ *************** VAL INFO *************** ] Validation Loss: {self.testLoss.result():.6f}, Validation PSNR: {self.testPSNR.result():.3f}")
+                testLoss, testPSNR = self.testLoss.result(), self.testPSNR.result()
+                self._scalar("Test loss", testLoss, globalStep)
+                self._scalar("Test PSNR", testPSNR, globalStep)
+                logger.info(f"[ *************** VAL INFO *************** ] Validation Loss: {testLoss:.6f}, Validation PSNR: {testPSNR:.3f}")
                 if self._log is not None:
                     self._log.flush()
-                if saveBestOnly and (self.testPSNR.result() <= self.psnr):
+                if saveBestOnly and (testPSNR <= self.psnr):
                     continue
                 logger.info("[ SAVE ] Saving checkpoint...")
-                self.psnr = self.testPSNR.result()
+                self.psnr = testPSNR
                 self.save()
+        late.flush()
         if self._log is not None:
             self._log.flush()
 
     # -- one step (models/trainClass.py:124-143) -----------------------------------------------------------
+    def _dp(self):
+        return self.multiGPU and self._world() > 1
+
     def trainStep(self, patchLR, patchHR, maskHR):
         predPatchHR = self._model(patchLR, training=True)
         loss = self.loss(patchHR, maskHR, predPatchHR)             # Loss(patchHR, maskHR, predPatchHR)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()                                            # tape.gradient(loss, trainable_variables)
-        if self.multiGPU:
+        if self._dp():
             for p in self._model.parameters():
                 if p.grad is not None:
-                    allreduce_mean_(p.grad)
+                    allreduce_mean_(p.grad)                        # C1: one flat-gradient all-reduce
         self.optimizer.step()                                      # optimizer.apply_gradients
         metric = self.metric(patchHR, maskHR, predPatchHR.detach())
+        if self._dp():                                             # C2: strategy.reduce(MEAN) of loss and metric over the replicas
+            loss, metric = allreduce_metrics_(loss, metric)
         self.trainLoss(loss)
         self.trainPSNR(metric)
 
@@ -444,5 +545,7 @@ class ModelTrainer:
             predPatchHR = self._model(patchLR, training=False)
             loss = self.loss(patchHR, maskHR, predPatchHR)
             metric = self.metric(patchHR, maskHR, predPatchHR)
+        if self._dp():
+            loss, metric = allreduce_metrics_(loss, metric)
         self.testLoss(loss)
         self.testPSNR(metric)

@@ -44,6 +44,24 @@ def _worker(rank, world, port, tmp):
         other = mine.clone()
         dist.broadcast(other, src=0)
         assert torch.equal(mine, other), "replicas diverged"
+        # 3. a data set that does not divide by the world size (17 samples -> 9 / 8 per rank used to give the ranks different
+        #    batch counts and hang the tail all-reduce): shards are cut to len // world, both ranks take the same number of steps
+        model3 = _stub()
+        tr3 = ModelTrainer(model3, _l1, _metric, make_optimizer("sgd", model3, 0.1), os.path.join(tmp, "ck3"), os.path.join(tmp, "lg3"), multiGPU=True, evalStep=2)
+        n3 = 17
+        X3 = np.zeros((n3, 22, 22, 9, 1), np.float32)
+        y3 = rng.normal(size=(n3, 48, 48, 1)).astype(np.float32)
+        m3 = np.ones((n3, 48, 48, 1), bool)
+        tr3.fitTrainData(X3, [y3, m3], 3, 3, [X3[:6], y3[:6], m3[:6]], valSteps=1, saveBestOnly=False)
+        assert tr3.step == 8                         # 8 samples per rank * 3 epochs / batch 3 = 8 batches (the last one partial)
+        steps = torch.tensor([float(tr3.step)])
+        dist.all_reduce(steps)
+        assert float(steps) == 16.0
+        # 4. C2: logged loss / metric are means over the replicas -> identical running means on both ranks
+        pair = torch.tensor([tr3.testLoss.result(), tr3.testPSNR.result(), tr3.trainLoss.result(), tr3.trainPSNR.result()], dtype=torch.float64)
+        other = pair.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(pair, other), "scalar metrics are not reduced over the replicas"
         if rank == 0:
             open(os.path.join(tmp, "ok"), "w").write("ok")
     finally:

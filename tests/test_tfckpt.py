@@ -85,3 +85,41 @@ def test_trainer_restores_from_a_reference_format_directory(tmp_path):
     b = WDSRConv3D("b", "NIR", 1.0, 2.0, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True, seed=22)
     tr = ModelTrainer(b, None, None, None, str(ck), str(tmp_path / "logs"))
     assert tr.step == 184532 and torch.equal(a.flat.detach(), b.flat.detach())
+
+
+def test_trainer_restores_nadam_slots_and_leaves_the_tf_state_file_alone(tmp_path):
+    """a reference bundle carries Nadam's m / v slots, `optimizer/iter` and `momentum_cache`; the trainer resumes with them
+    (instead of t = 0 and zero moments), and its own saves do not overwrite TensorFlow's `checkpoint` state file."""
+    from probav_amd.trainClass import ModelTrainer, make_optimizer
+    a = WDSRConv3D("a", "NIR", 1.0, 2.0, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True, seed=31)
+    rng = np.random.default_rng(3)
+    n = a.flat.numel()
+    opt_state = {"iter": 4321, "momentum_cache": 0.0123, "m": rng.normal(size=n).astype(np.float32) * 1e-3,
+                 "v": (rng.normal(size=n).astype(np.float32) * 1e-3) ** 2}
+    ck = tmp_path / "ck"
+    ck.mkdir()
+    tfckpt.save_reference_checkpoint(a, str(ck / "ckpt-9"), step=77, psnr=47.25, optimizer=opt_state)
+    tf_state = 'model_checkpoint_path: "ckpt-9"\nall_model_checkpoint_paths: "ckpt-9"\n'
+    (ck / "checkpoint").write_text(tf_state)
+    got = tfckpt.load_reference_optimizer(a, str(ck / "ckpt-9"))
+    assert got["iter"] == 4321 and abs(got["momentum_cache"] - 0.0123) < 1e-7 and got["psnr"] == 47.25
+    np.testing.assert_array_equal(got["m"], opt_state["m"])
+    np.testing.assert_array_equal(got["v"], opt_state["v"])
+    b = WDSRConv3D("b", "NIR", 1.0, 2.0, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True, seed=32)
+    opt = make_optimizer("nadam", b, 5e-4)                           # torch.optim.NAdam on CPU (HipNadam on a device: same loader)
+    tr = ModelTrainer(b, None, None, opt, str(ck), str(tmp_path / "logs"))
+    assert tr.step == 77 and tr.psnr == 47.25
+    st = opt.state[b.flat]
+    assert float(st["step"]) == 4321 and abs(float(st["mu_product"]) - 0.0123) < 1e-7
+    np.testing.assert_array_equal(st["exp_avg"].numpy(), opt_state["m"])
+    np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), opt_state["v"])
+    tr.save()
+    assert (ck / "checkpoint").read_text() == tf_state               # still the reference's own state file
+    assert (ck / "checkpoint.pt-index").read_text().split() == ["ckpt-1.pt"]
+    # a later restore prefers this trainer's newer .pt checkpoint over the TF bundle
+    c = WDSRConv3D("c", "NIR", 1.0, 2.0, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True, seed=33)
+    tr2 = ModelTrainer(c, None, None, make_optimizer("nadam", c, 5e-4), str(ck), str(tmp_path / "logs2"))
+    assert tr2.step == 77 and torch.equal(c.flat.detach(), b.flat.detach())
+    # weights-only bundle: no slots -> None
+    tfckpt.save_reference_checkpoint(a, str(tmp_path / "w-1"), step=1)
+    assert tfckpt.load_reference_optimizer(a, str(tmp_path / "w-1")) is None

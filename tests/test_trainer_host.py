@@ -64,11 +64,15 @@ def test_fit_counts_steps_evaluates_and_rotates_checkpoints(tmp_path):
     tr.fitTrainData(X, [y, msk], 4, 4, [X[:8], y[:8], msk[:8]], valSteps=1, saveBestOnly=False)
     assert tr.step == 16                                  # 16 samples / batch 4 * 4 epochs
     assert not torch.equal(before, model.flat.detach())
-    names = open(tmp_path / "ckpt" / "checkpoint").read().split()
+    names = open(tmp_path / "ckpt" / "checkpoint.pt-index").read().split()
     assert names == ["ckpt-%d.pt" % k for k in range(4, 9)]          # 8 saves, max_to_keep = 5
-    assert sorted(os.listdir(tmp_path / "ckpt")) == sorted(names + ["checkpoint"])
-    tags = [json.loads(l)["tag"] for l in open(tmp_path / "logs" / "events.jsonl")]
+    assert sorted(os.listdir(tmp_path / "ckpt")) == sorted(names + ["checkpoint.pt-index"])      # TF's `checkpoint` state file is never written
+    events = [json.loads(l) for l in open(tmp_path / "logs" / "events.jsonl")]
+    tags = [e["tag"] for e in events]
     assert tags.count("Train loss") == 16 and tags.count("Test PSNR") == 8
+    # the per-step scalars are emitted late (no host sync per step) but complete, in order, and before the evaluation that follows them
+    assert [e["step"] for e in events if e["tag"] == "Train loss"] == list(range(1, 17))
+    assert tags.index("Test loss") > [i for i, e in enumerate(events) if e["tag"] == "Train loss" and e["step"] == 2][0]
     # restore picks up step, psnr and the weights
     model2 = _stub()
     tr2 = ModelTrainer(model2, _l1, _metric, make_optimizer("adam", model2, 1e-3), str(tmp_path / "ckpt"), str(tmp_path / "logs2"))
@@ -78,7 +82,7 @@ def test_fit_counts_steps_evaluates_and_rotates_checkpoints(tmp_path):
     tr3.optimizer = make_optimizer("sgd", tr3.model, 0.0)
     tr3.psnr = 1e9
     tr3.fitTrainData(X, [y, msk], 8, 1, [X[:8], y[:8], msk[:8]], valSteps=1, saveBestOnly=True)
-    assert not os.path.exists(tmp_path / "c3" / "checkpoint")
+    assert not os.path.exists(tmp_path / "c3" / "checkpoint.pt-index")
 
 
 def test_batch_prefetcher_preserves_order_and_values():
