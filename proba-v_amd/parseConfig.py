@@ -77,6 +77,8 @@ def parseConfig(path):
         unknown += [k for k in body if k not in _KNOWN and k not in unknown]
     assert not unknown, "Unsupported fields {} in {}".format(unknown, path)
 
+    if not sections:
+        raise KeyError("type")                      # the reference deletes the merged dict's 'type' entry (:79): a file without sections fails there
     config = {}
     for _, body in sections:
         config.update(body)

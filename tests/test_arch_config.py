@@ -70,3 +70,39 @@ def test_cfg_typing_rules_and_whitelist(tmp_path):
     bad.write_text("[Directories]\nraw_data=x\n[Train]\nbatch_sizes=8\n")
     with pytest.raises(AssertionError, match="Unsupported fields"):
         parseConfig(str(bad))
+
+
+# ---- pinned by the reference itself: tests/golden/cfg_cases.json holds what /root/reference/utils/parseConfig.py returned (or raised) for
+# each cfg text when tests/golden/make_cfg_fixture.py ran it in the build container -- the one piece of the reference that imports here
+def _cfg_cases():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "cfg_cases.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.mark.parametrize("case", _cfg_cases(), ids=lambda c: c["name"])
+def test_parseConfig_matches_the_reference_parser(case, tmp_path):
+    import builtins
+    p = tmp_path / (case["name"] + ".cfg")
+    p.write_text(case["text"])
+    if "error" in case:
+        with pytest.raises(getattr(builtins, case["error"])):
+            parseConfig(str(p))
+        return
+    got = parseConfig(str(p))
+    assert got == case["result"]
+    for k, v in case["result"].items():                  # == lets True == 1 and 3 == 3.0 through: the types must agree too
+        assert type(got[k]) is type(v), (k, got[k], v)
+        if isinstance(v, list):
+            assert [type(a) for a in got[k]] == [type(a) for a in v], k
+
+
+def test_repo_cfgs_equal_the_reference_cfgs_outside_the_directory_paths():
+    """cfg/*.cfg of this repo parse to the same dict as the reference's shipped files, except for the site-local [Directories] paths."""
+    cases = {c["name"]: c for c in _cfg_cases()}
+    for name in ("p16t9c85r12", "p16t12c85r12"):
+        ours = parseConfig(os.path.join(ROOT, "cfg", name + ".cfg"))
+        ref = cases["shipped_" + name]["result"]
+        dirs = {"raw_data", "preprocessing_out", "model_out", "test_out", "train_out"}
+        assert set(ours) == set(ref)
+        assert {k: v for k, v in ours.items() if k not in dirs} == {k: v for k, v in ref.items() if k not in dirs}

@@ -135,3 +135,55 @@ def test_sobel_l1_mix_restatement_conventions():
     c = ot.shift_l1edge_loss(torch.tensor(hr2), torch.tensor(m2), torch.tensor(pred + 37.0))
     d = ot.shift_l1edge_loss(torch.tensor(hr2), torch.tensor(m2), torch.tensor(pred))
     assert abs(float(c) - float(d)) < 1e-9 * float(d)
+
+
+# ---- third implementations: library routines that were written by neither the reference's authors nor this repository's ------------
+def test_depth_to_space_equals_torch_pixel_shuffle():
+    """tf.nn.depth_to_space(x, 3) with ONE output channel (models/modelsTF.py:52,73) is torch's pixel_shuffle on the NCHW view."""
+    import torch.nn.functional as F
+    x = np.random.default_rng(2).normal(size=(3, 16, 16, 9))
+    want = F.pixel_shuffle(torch.tensor(x).permute(0, 3, 1, 2), 3).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_array_equal(on.depth_to_space(x, 3), want)
+    np.testing.assert_array_equal(ot.depth_to_space(torch.tensor(x), 3).numpy(), want)
+
+
+def test_weight_norm_equals_torch_parametrization_away_from_the_clamp():
+    """TFA WeightNormalization (g * v / ||v||, norm over all kernel axes but the output one) == torch's weight_norm
+    parametrization with dim = the output axis; the two differ only at ||v||^2 < 1e-12 (TFA's l2_normalize epsilon)."""
+    from torch.nn.utils.parametrizations import weight_norm
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(3, 3, 3, 25, 32))
+    g = rng.uniform(0.5, 2.0, size=32)
+    conv = torch.nn.Conv3d(25, 32, 3, bias=False).double()            # torch layout [Cout, Cin, kh, kw, kt]
+    conv = weight_norm(conv, name="weight", dim=0)
+    with torch.no_grad():
+        conv.parametrizations.weight.original1.copy_(torch.tensor(v).permute(4, 3, 0, 1, 2))
+        conv.parametrizations.weight.original0.copy_(torch.tensor(g).reshape(32, 1, 1, 1, 1))
+    want = conv.weight.detach().permute(2, 3, 4, 1, 0).numpy()
+    np.testing.assert_allclose(on.weight_norm(v, g), want, rtol=1e-13)
+    # and its gradient (dg, dv) against autograd through the parametrization
+    dw = rng.normal(size=v.shape)
+    (conv.weight * torch.tensor(dw).permute(4, 3, 0, 1, 2)).sum().backward()
+    vt = torch.tensor(v, requires_grad=True)
+    gt = torch.tensor(g, requires_grad=True)
+    (ot.weight_norm(vt, gt) * torch.tensor(dw)).sum().backward()
+    np.testing.assert_allclose(vt.grad.numpy(), conv.parametrizations.weight.original1.grad.permute(2, 3, 4, 1, 0).numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(gt.grad.numpy(), conv.parametrizations.weight.original0.grad.reshape(-1).numpy(), rtol=1e-10)
+
+
+def test_conv_conventions_equal_torch_conv3d():
+    """Keras Conv3D 'same' / 'valid', stride 1, cross-correlation, kernel [kh,kw,kt,Cin,Cout] on [N,H,W,T,C] ==
+    torch.nn.functional.conv3d on the permuted tensors; tf.pad(REFLECT) == torch 'reflect' padding."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=(2, 6, 6, 5, 4))
+    w = rng.normal(size=(3, 3, 3, 4, 7))
+    b = rng.normal(size=7)
+    for pad in (1, 0):
+        want = F.conv3d(torch.tensor(x).permute(0, 4, 1, 2, 3), torch.tensor(w).permute(4, 3, 0, 1, 2), torch.tensor(b), padding=pad).permute(0, 2, 3, 4, 1).numpy()
+        got = on.conv_valid(on.pad_zero_same(x, w) if pad else x, w) + b          # the numpy tap loops never call into torch
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    N, H, W, T, C = x.shape
+    xt = torch.tensor(x).permute(0, 3, 4, 1, 2).reshape(N, T * C, H, W)                       # 2-D reflect pad over (H, W)
+    want = F.pad(xt, (1, 1, 1, 1), mode="reflect").reshape(N, T, C, H + 2, W + 2).permute(0, 3, 4, 1, 2).numpy()
+    np.testing.assert_array_equal(on.reflect_pad_hw(x), want)
