@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PROBAV_ABI_VERSION 1
+#define PROBAV_ABI_VERSION 2
 
 /* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
  * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale=True)   (models/modelsTF.py:8-17) */
@@ -60,10 +60,11 @@ int probav_layer_info(const probav_engine* e, int i, char name[32], int64_t* g_o
 /* kernel family: 0 = generic direct (VALU) kernels everywhere, 1 = fp32-MFMA row-tile kernels, 2 = fp32 MFMA + strip convolution,
  * 3 = 2 with the x6 kernels where they exist: fp32 in / fp32 out / fp32 accumulate, every fp32 product evaluated as six exact
  * bf16-piece products on the bf16 MFMA pipe, 4 (default) = the same kernels with the H3 arithmetic: three exact products of fp16 piece
- * pairs, every operand tensor scaled by a power of two chosen from its largest magnitude (amax slots in the workspace, filled by the
- * producing kernels).  3 and 4 are held to the tolerances of 2 in tests/test_gpu_parity.py.  Results of one family are bitwise
- * reproducible run to run; different families differ by fp32 rounding; with 4 a sample's result also depends on its batch mates at
- * that level (the scales are batch-wide maxima).                                                                                    */
+ * pairs, every operand scaled by a power of two chosen from the largest magnitude of its scaling group -- one SAMPLE of an activation /
+ * gradient tensor, one output COLUMN of a filter matrix (amax slots in the workspace, filled by the producing kernels).  3 and 4 are
+ * held to the tolerances of 2 in tests/test_gpu_parity.py.  Results of one family are bitwise reproducible run to run; different
+ * families differ by fp32 rounding.  In every family the forward result of a sample is independent of its batch mates, bit for bit
+ * (models/modelsTF.py:15-43 has no cross-sample term).                                                                            */
 int probav_engine_set_impl(probav_engine* e, int impl);
 size_t probav_workspace_bytes(const probav_engine* e, int batch, int training);
 /* per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
@@ -143,14 +144,15 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
  * x [nvox,32], w1 [32,256], b1 [256], w2 [256,D], b2 [D] -> dec [nvox,D]; the 256-channel tensor never reaches HBM
  * impl 2 = fp32 MFMA, 3 = fp32 products as six bf16-piece products on the bf16 MFMA pipe ("x6", same accuracy class),
  * 4 = three products of scaled fp16 piece pairs ("H3", same accuracy class) */
+/* vox_per_sample: voxels of one patch (nvox must be a multiple; 0 = treat the call as one sample): the unit the H3 arithmetic scales by */
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
-                      int64_t nvox, int D, int impl, void* stream);
+                      int64_t nvox, int64_t vox_per_sample, int D, int impl, void* stream);
 /* its reverse pass: d_dec [nvox,D], d_skip [nvox,32] (gradient arriving over the residual connection)
  * -> dx = d_skip + dL/dx [nvox,32], dw1 [32,256], db1 [256], dw2 [256,D], db2 [D]                              */
 size_t probav_pw_backward_scratch_bytes(int D);
 int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1,
                        const float* w2, float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch,
-                       size_t scratch_bytes, int64_t nvox, int D, int impl, void* stream);
+                       size_t scratch_bytes, int64_t nvox, int64_t vox_per_sample, int D, int impl, void* stream);
 /* weight normalisation of every layer of the engine: params -> weff, weffT, inv_norm (ws-internal
  * layouts, exported for tests): sizes probav_weff_count() floats and probav_cout_total() floats      */
 int64_t probav_weff_count(const probav_engine* e);
@@ -158,6 +160,20 @@ int64_t probav_cout_total(const probav_engine* e);
 int probav_wn_forward(probav_engine* e, const float* params, float* weff, float* weffT, float* inv_norm, void* stream);
 int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm,
                        float* grads, void* stream);
+
+/* ---- introspection of a training forward pass (parity tests; tf.keras would expose these as layer outputs) -------------------- */
+/* where a saved activation lives inside the caller's workspace after probav_forward(training=1): offset and length in floats.
+ * kind: ACT = input of residual block `index` (index num_res_blocks = output of the last block; ACT 0 = relu(mainConv1), models/modelsTF.py:58),
+ * DEC = decConv_index output (:182-183), RED = relu(convReducer_{index+1}) (:159-160), RESID1 = relu(residConv1) (:47)                 */
+#define PROBAV_VIEW_ACT 0
+#define PROBAV_VIEW_DEC 1
+#define PROBAV_VIEW_RED 2
+#define PROBAV_VIEW_RESID1 3
+int probav_workspace_view(const probav_engine* e, int batch, int training, int kind, int index, int64_t* offset_floats, int64_t* count);
+/* the post-ReLU hidden tile relu(expConv_block(x)) [B*(P+s)^2*T][256] (models/modelsTF.py:179-180) exactly as the fused forward kernel
+ * of the current kernel family (3 or 4) evaluates it -- that tensor never reaches memory otherwise.  Call after probav_forward(training=1)
+ * with the same workspace; the ReLU gates of the reverse pass are the signs of these values.                                          */
+int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int batch, int block, float* hidden, void* stream);
 
 #ifdef __cplusplus
 }

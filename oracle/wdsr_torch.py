@@ -35,8 +35,18 @@ def _conv(x, w, b, same):
     return y.permute(0, 2, 3, 1)
 
 
-def wn_conv(x, p, padding, relu):
+def wn_conv(x, p, padding, relu, gate=None, report=None):
+    """gate (optional, ReLU layers only): a boolean tensor used INSTEAD of the layer's own sign test, y * gate -- the ReLU masks of
+    another evaluation of the same network (tests: the masks the HIP forward produced).  report (optional list) then receives
+    (#gates that differ from this evaluation's own, largest |pre-activation| among them, rms of the pre-activations)."""
     y = _conv(x, weight_norm(p["v"], p["g"]), p["bias"], padding == "same")
+    if relu and gate is not None:
+        g = torch.as_tensor(gate, dtype=torch.bool).reshape(y.shape)
+        if report is not None:
+            flip = g != (y > 0)
+            yd = y.detach()
+            report.append((int(flip.sum()), float(yd[flip].abs().max()) if bool(flip.any()) else 0.0, float(yd.pow(2).mean().sqrt())))
+        return y * g
     return torch.relu(y) if relu else y
 
 
@@ -48,23 +58,33 @@ def depth_to_space(x, s):
     return x.reshape(N, H, W, s, s, co).permute(0, 1, 3, 2, 4, 5).reshape(N, H * s, W * s, co)
 
 
-def wdsr_forward(x, params, mean, std, numResBlocks=12, numImgLR=9, scale=3):
-    """WDSRConv3D.build graph (models/modelsTF.py:15-43)."""
+def wdsr_forward(x, params, mean, std, numResBlocks=12, numImgLR=9, scale=3, gates=None, gate_report=None):
+    """WDSRConv3D.build graph (models/modelsTF.py:15-43).
+    gates (optional): {layer name: bool array} -- ReLU masks taken from another evaluation (see wn_conv); gate_report: dict
+    receiving, per gated layer, (#differing gates, max |pre-activation| among them, rms pre-activation)."""
+    def G(name):
+        return None if gates is None else gates.get(name)
+
+    def R(name):
+        if gate_report is None or gates is None or name not in gates:
+            return None
+        return gate_report.setdefault(name, [])
     meanLR = x.mean(dim=3)                                     # :23
     xn = (x - mean) / std                                      # :26
     mn = (meanLR - mean) / std                                 # :27
-    h = wn_conv(xn, params["mainConv1"], "same", True)         # :58
+    h = wn_conv(xn, params["mainConv1"], "same", True, G("mainConv1"), R("mainConv1"))         # :58
     for i in range(numResBlocks):                              # :177-189
-        e = wn_conv(h, params["expConv_%d" % i], "same", True)
+        e = wn_conv(h, params["expConv_%d" % i], "same", True, G("expConv_%d" % i), R("expConv_%d" % i))
         d = wn_conv(e, params["decConv_%d" % i], "same", False)
         h = wn_conv(d, params["normConv_%d" % i], "same", False) + h
     for i, (_, pad, pad_t) in enumerate(reducer_plan(numImgLR)):   # :152-164, :76-121
         if pad or pad_t:                                       # tf.pad(mode='reflect') on H, W (and T)
             h = F.pad(h.permute(0, 4, 1, 2, 3), (pad_t, pad_t, pad, pad, pad, pad), mode="reflect").permute(0, 2, 3, 4, 1)
-        h = wn_conv(h, params["convReducer_%d" % (i + 1)], "valid", True)
+        name = "convReducer_%d" % (i + 1)
+        h = wn_conv(h, params[name], "valid", True, G(name), R(name))
     h = wn_conv(h, params["upscaleConv1"], "valid", False)     # :162-163
     main = depth_to_space(h[:, :, :, 0, :], scale)             # :71-73
-    r = wn_conv(mn, params["residConv1"], "valid", True)       # :45-53
+    r = wn_conv(mn, params["residConv1"], "valid", True, G("residConv1"), R("residConv1"))       # :45-53
     r = wn_conv(r, params["residConv2"], "valid", False)
     r = wn_conv(r, params["residConv3"], "valid", False)
     return (main + depth_to_space(r, scale)) * std + mean      # :38, :41

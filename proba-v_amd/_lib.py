@@ -55,13 +55,15 @@ SIGNATURES = {
     "probav_conv3d_wgrad_scratch_bytes": (c_size_t, [POINTER(c_int32 * 17), c_int]),
     "probav_conv3d_wgrad": (c_int, [POINTER(c_int32 * 17), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_int, c_void_p]),
-    "probav_pw_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "probav_pw_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "probav_pw_backward_scratch_bytes": (c_size_t, [c_int]),
-    "probav_pw_backward": (c_int, [c_void_p] * 12 + [c_size_t, c_int64, c_int, c_int, c_void_p]),
+    "probav_pw_backward": (c_int, [c_void_p] * 12 + [c_size_t, c_int64, c_int64, c_int, c_int, c_void_p]),
     "probav_weff_count": (c_int64, [c_void_p]),
     "probav_cout_total": (c_int64, [c_void_p]),
     "probav_wn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_wn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "probav_workspace_view": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -79,7 +81,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if L.probav_abi_version() != 1:
+        if L.probav_abi_version() != 2:
             raise RuntimeError("libprobav_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -23,7 +23,7 @@ struct LayerRec {
 struct probav_engine {
     probav_net_cfg cfg;
     std::vector<LayerRec> layers;
-    int64_t nparams = 0, weff_count = 0, cout_total = 0;
+    int64_t nparams = 0, weff_count = 0, cout_total = 0, cin_total = 0;
     WnLayer* d_layers = nullptr;
     int impl = 4;             // 0 direct kernels, 1 MFMA row-tile kernels, 2 MFMA + strip convolution where it applies,
                               // 3 = 2 with the x6 kernels (fp32 products as six bf16-piece MFMA products) where they exist,
@@ -95,9 +95,11 @@ static int add_layer(probav_engine* e, const std::string& name, int kh, int kw, 
     r.wn.b_off = r.wn.v_off + r.wn.K * cout;
     r.wn.w_off = (int)e->weff_count;
     r.wn.n_off = (int)e->cout_total;
+    r.wn.r_off = (int)e->cin_total;
     e->nparams += 2 * cout + (int64_t)r.wn.K * cout;
     e->weff_count += (int64_t)r.wn.K * cout;
     e->cout_total += cout;
+    e->cin_total += cin;
     e->layers.push_back(r);
     return (int)e->layers.size() - 1;
 }
@@ -106,7 +108,7 @@ static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }      // 64 f
 
 struct Plan {
     size_t weff, weffT, invn, dweff, xn, mn;
-    size_t amax; int n_amax, amax_bwd;        // amax slots (one 32-bit word each, x6_device.h): region offset, count, first backward slot
+    size_t amax; int n_amax, amax_bwd, amax_fwd, B;   // amax slots (one 32-bit word each, x6_device.h): region offset, count, first slot of the backward / forward per-sample arrays
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
     size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
@@ -167,10 +169,13 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
     p.weff = take(e->weff_count); p.weffT = take(e->weff_count); p.invn = take(e->cout_total);
-    {   // slots: [weights | biases] per layer, act[0..R], dec[0..R-1], reducer outputs, then the backward pass's tensors in launch order
+    {   // slots: per layer [weights | biases] (whole tensor), per output channel, per input channel (wn_forward's layout); then ONE SLOT PER
+        // SAMPLE for act[0..R], dec[0..R-1], the reducer outputs, and for the backward pass's tensors in launch order
         const int L = (int)e->layers.size(), nred = (int)e->iRed.size();
-        p.amax_bwd = 2 * L + 2 * R + 1 + nred;
-        p.n_amax = p.amax_bwd + 2 * R + 2 * nred + 8;
+        p.B = B;
+        p.amax_fwd = 2 * L + (int)e->cout_total + (int)e->cin_total;
+        p.amax_bwd = p.amax_fwd + B * (2 * R + 1 + nred);
+        p.n_amax = p.amax_bwd + (training ? B * (2 * R + 2 * nred + 8) : 0);
         p.amax = take((size_t)p.n_amax);
     }
     p.dweff = take(training ? e->weff_count : 0);
@@ -244,14 +249,16 @@ struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; const floa
 
 // amax slot addresses inside the workspace (layout: make_plan)
 struct AmaxSlots {
-    unsigned* base; int L, R, bwd;
-    AmaxSlots(const probav_engine* e, const Plan& p, float* W, int R_) : base(reinterpret_cast<unsigned*>(W + p.amax)), L((int)e->layers.size()), R(R_), bwd(p.amax_bwd) {}
-    unsigned* w(int li) const { return base + li; }
-    unsigned* b(int li) const { return base + L + li; }
-    unsigned* act(int i) const { return base + 2 * L + i; }
-    unsigned* dec(int i) const { return base + 2 * L + R + 1 + i; }
-    unsigned* red(int k) const { return base + 2 * L + 2 * R + 1 + k; }
-    unsigned* back(int j) const { return base + bwd + j; }     // j-th tensor produced by the backward pass
+    const probav_engine* e; unsigned* base; int L, R, B, fwd, bwd;
+    AmaxSlots(const probav_engine* e_, const Plan& p, float* W, int R_) : e(e_), base(reinterpret_cast<unsigned*>(W + p.amax)), L((int)e_->layers.size()), R(R_), B(p.B), fwd(p.amax_fwd), bwd(p.amax_bwd) {}
+    unsigned* w(int li) const { return base + li; }                                   // whole weight tensor of layer li
+    unsigned* b(int li) const { return base + L + li; }                               // its bias
+    unsigned* wcol(int li) const { return base + 2 * L + e->layers[li].wn.n_off; }     // per output channel (Cout slots): columns of the forward matrices
+    unsigned* wrow(int li) const { return base + 2 * L + (int)e->cout_total + e->layers[li].wn.r_off; }   // per input channel (Cin slots): columns of the backward-data matrices
+    unsigned* act(int i) const { return base + fwd + B * i; }                         // per-sample arrays (B slots each)
+    unsigned* dec(int i) const { return base + fwd + B * (R + 1 + i); }
+    unsigned* red(int k) const { return base + fwd + B * (2 * R + 1 + k); }
+    unsigned* back(int j) const { return base + bwd + B * j; }                        // j-th tensor produced by the backward pass
 };
 
 static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
@@ -283,16 +290,16 @@ static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const floa
     if (e->impl >= 1 && wfrag && mfma_conv_supported(g)) { reported = true; return mfma_conv_forward(g, x, gate, wfrag, bias, skip, y, am, s); }
     return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s);
 }
-// am.x / am.w: amax slots of x and of the layer's weights (H3 kernels); am.y: slot that must hold the output's amax afterwards
+// am.x / am.w: amax slots of x (one per sample) and of the layer's filter columns (H3 kernels); am.y: per-sample slots that must hold the output's amax afterwards
 static int conv_fwd(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
                     const Frags& wf, const float* bias, const float* skip, float* y, const Amax& am, hipStream_t s)
 {
     bool reported = false;
     int rc = conv_fwd_launch(e, g, x, gate, w, wf, bias, skip, y, am, reported, s);
-    if (rc == PROBAV_OK && am.y && !reported) rc = amax_tensor(y, (size_t)g.N * g.Ho * g.Wo * g.To * g.Cout, am.y, s);
+    if (rc == PROBAV_OK && am.y && !reported) rc = amax_tensor(y, (size_t)g.Ho * g.Wo * g.To * g.Cout, g.N, am.y, s);
     return rc;
 }
-// am.x / am.w: amax slots of x and of dy (H3 backward-filter kernel)
+// am.x / am.w: per-sample amax slots of x and of dy (H3 backward-filter kernel)
 static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x, const float* dy, const float* gate,
                       float* dw, float* db, float* partial, const Amax& am, hipStream_t s)
 {
@@ -386,7 +393,9 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
                 (dir ? e->pkBwd6 : e->pkFwd6)[li] = X.dst_off;
                 e->wpack_count += X.count;
                 e->jobs.push_back(X);
-                X.type += 10; X.dst_off = e->wpack_count; X.amax_slot = (int)li;      // PACK_H3_*
+                X.type += 10; X.dst_off = e->wpack_count;                              // PACK_H3_*: cut per output column of the packed matrix
+                X.amax_percol = 1; X.ncol = cout;                                      // columns of weff = output channels, of weffT = input channels
+                X.amax_slot = 2 * (int)e->layers.size() + (dir ? (int)e->cout_total + r.wn.r_off : r.wn.n_off);
                 X.count = cin == 25 ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS;
                 (dir ? e->pkBwdH : e->pkFwdH)[li] = X.dst_off;
                 e->wpack_count += X.count;
@@ -429,14 +438,16 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
             e->pkW1Cx6.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
             X.count = H3_PW_FRAG_WORDS;
             X.type = PACK_H3_PW_W1; X.src_off = e->layers[e->iExp[i]].wn.w_off; X.dst_off = e->wpack_count;
-            X.Cin = F; X.Cout = E; X.amax_slot = e->iExp[i];
+            const int L2 = 2 * (int)e->layers.size();
+            X.Cin = F; X.Cout = E; X.amax_slot = e->iExp[i]; X.amax_percol = 0; X.ncol = 0;         // (a): one scale for the tensor
             e->pkW1h.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
-            X.type = PACK_H3_PW_W1C; X.dst_off = e->wpack_count;
+            X.type = PACK_H3_PW_W1C; X.dst_off = e->wpack_count;                                        // (c): cut per cin row = per dX column
+            X.amax_percol = 1; X.ncol = F; X.amax_slot = L2 + (int)e->cout_total + e->layers[e->iExp[i]].wn.r_off;
             e->pkW1Ch.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
             X.type = PACK_H3_PW_W2; X.src_off = e->layers[e->iDec[i]].wn.w_off; X.dst_off = e->wpack_count;
-            X.Cin = E; X.Cout = D; X.amax_slot = e->iDec[i];
+            X.Cin = E; X.Cout = D; X.amax_percol = 1; X.ncol = D; X.amax_slot = L2 + e->layers[e->iDec[i]].wn.n_off;   // forward: cut per output column d
             e->pkW2h.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
-            X.type = PACK_H3_PW_W2K; X.dst_off = e->wpack_count;
+            X.type = PACK_H3_PW_W2K; X.dst_off = e->wpack_count; X.amax_percol = 0; X.ncol = 0; X.amax_slot = e->iDec[i];       // (b): one scale for the tensor
             e->pkW2Kh.push_back(X.dst_off); e->wpack_count += X.count; e->jobs.push_back(X);
         }
     }
@@ -554,11 +565,11 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     // amax slots (H3 arithmetic, impl 4): every tensor an H3 kernel reads has its largest magnitude in a slot by then
     const bool h3 = e->impl >= 4;
     const AmaxSlots A(e, p, W, R);
-    auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.w(li); m.y = ay; } return m; };
+    auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wcol(li); m.y = ay; } return m; };
     if (h3 && hipMemsetAsync(A.base, 0, (size_t)p.amax_bwd * sizeof(unsigned), s) != hipSuccess) { set_error("probav_forward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
     if (training) e->fwd_amax = h3;
 
-    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
+    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
     if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
     CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
@@ -568,12 +579,12 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
             const long nvox = (long)B * Hin * Hin * T;
             ProfScope ps(e, e->impl >= 3 ? CLS_PW_FWD_X6 : CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
             if (h3) {
-                PwAmax m; m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.b1 = A.b(e->iExp[i]); m.y = A.dec(i);
+                PwAmax m; m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.w2c = A.wcol(e->iDec[i]); m.b1 = A.b(e->iExp[i]); m.y = A.dec(i);
                 CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1h[i], W + p.wpack + e->pkW2h[i], bias(e->iExp[i]), bias(e->iDec[i]),
-                                 W + p.dec[i], nvox, D, 2, m, s));
+                                 W + p.dec[i], nvox, nvox / B, D, 2, m, s));
             } else if (e->impl >= 3) {
                 CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
-                                 W + p.dec[i], nvox, D, 1, PwAmax(), s));
+                                 W + p.dec[i], nvox, nvox / B, D, 1, PwAmax(), s));
             } else
                 CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                    W + p.dec[i], nvox, D, s));
@@ -624,7 +635,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     const AmaxSlots A(e, p, W, R);
     int nback = 0;
     auto new_slot = [&]() -> unsigned* { return h3 ? A.back(nback++) : nullptr; };
-    auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.w(li); m.y = ay; } return m; };
+    auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wrow(li); m.y = ay; } return m; };   // backward-data: the matrix' columns are the layer's INPUT channels
     if (h3 && !e->fwd_amax) {
         set_error("probav_backward: the H3 kernels (impl 4) need the amax slots of a forward pass run with the same kernel family", hipSuccess);
         return PROBAV_EINVAL;
@@ -672,7 +683,7 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
             if (rs.p == 1 && !rs.refl_t) CK(reflect_fold(oth, cur, B, hi, hi, ti * F, acur, s));
             else {
                 CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
-                if (h3) CK(amax_tensor(cur, (size_t)B * hi * hi * ti * F, acur, s));
+                if (h3) CK(amax_tensor(cur, (size_t)hi * hi * ti * F, B, acur, s));
             }
         } else {
             float* tmp = cur; cur = oth; oth = tmp;
@@ -699,12 +710,12 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
             ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (2.0 * F * E + 2.0 * E * D), s);   // bwd-data + bwd-filter of expConv and decConv; the recompute of H (F*E more) is not algorithmic work
             unsigned* anew = new_slot();                     // amax slot of dX
             if (h3) {
-                PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.b1 = A.b(le); m.dt = agdec; m.y = anew;
+                PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.w1r = A.wrow(le); m.b1 = A.b(le); m.dt = agdec; m.y = anew;
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1h[i], W + p.wpack + e->pkW2Kh[i], W + p.wpack + e->pkW1Ch[i],
-                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, 2, m, s));
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, nvox / B, D, 2, m, s));
             } else if (e->impl >= 3)
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2Kx6[i], W + p.wpack + e->pkW1Cx6[i],
-                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, 1, PwAmax(), s));
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, nvox / B, D, 1, PwAmax(), s));
             else
                 CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
                                     params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
@@ -731,6 +742,47 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     return PROBAV_OK;
 }
 
+// ---- introspection (parity tests) -----------------------------------------------------------------
+int probav_workspace_view(const probav_engine* e, int batch, int training, int kind, int index, int64_t* offset_floats, int64_t* count)
+{
+    if (!e || batch < 1 || !offset_floats || !count) { set_error("probav_workspace_view: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    const Plan p = make_plan(e, batch, training);
+    const probav_net_cfg& c = e->cfg;
+    const int64_t V = (int64_t)batch * e->Hin * e->Hin * c.num_img_lr;
+    const int R = c.num_res_blocks, nred = (int)e->iRed.size(), s2 = c.scale * c.scale;
+    switch (kind) {
+    case PROBAV_VIEW_ACT: if (index < 0 || index > R) break; *offset_floats = (int64_t)p.act[index]; *count = V * c.num_filters; return PROBAV_OK;
+    case PROBAV_VIEW_DEC: if (index < 0 || index >= R) break; *offset_floats = (int64_t)p.dec[index]; *count = V * c.dec_channels; return PROBAV_OK;
+    case PROBAV_VIEW_RED: if (index < 0 || index >= nred) break;
+        *offset_floats = (int64_t)p.red[index]; *count = (int64_t)batch * p.redH[index] * p.redH[index] * p.redT[index] * c.num_filters; return PROBAV_OK;
+    case PROBAV_VIEW_RESID1: if (index != 0) break; *offset_floats = (int64_t)p.r1; *count = (int64_t)batch * (e->Hin - 2) * (e->Hin - 2) * s2; return PROBAV_OK;
+    default: break;
+    }
+    set_error("probav_workspace_view: no such tensor", hipSuccess);
+    return PROBAV_EINVAL;
+}
+
+int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int B, int block, float* hidden, void* stream)
+{
+    if (!e || !params || !ws || !hidden || B < 1 || block < 0 || block >= e->cfg.num_res_blocks) { set_error("probav_debug_hidden: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    if (e->impl < 3 || !e->pw_mfma) { set_error("probav_debug_hidden: only the split-operand kernel families (impl 3, 4) expose their hidden tile", hipSuccess); return PROBAV_EINVAL; }
+    const Plan p = make_plan(e, B, 1);
+    if (ws_bytes < p.total * sizeof(float)) { set_error("probav_debug_hidden: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
+    float* W = (float*)ws;
+    const probav_net_cfg& c = e->cfg;
+    const int D = c.dec_channels, R = c.num_res_blocks, i = block;
+    const long nvox = (long)B * e->Hin * e->Hin * c.num_img_lr;
+    const AmaxSlots A(e, p, W, R);
+    // the forward launch of block i again, into a scratch output (gDec is dead between passes), with the hidden tile written out;
+    // no amax report (the slots of the saved tensors stay as the forward pass left them)
+    PwAmax m;
+    const bool h3 = e->impl >= 4;
+    if (h3) { m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.w2c = A.wcol(e->iDec[i]); m.b1 = A.b(e->iExp[i]); }
+    return x6_pw_forward(W + p.act[i], W + p.wpack + (h3 ? e->pkW1h[i] : e->pkW1x6[i]), W + p.wpack + (h3 ? e->pkW2h[i] : e->pkW2x6[i]),
+                         params + e->layers[e->iExp[i]].wn.b_off, params + e->layers[e->iDec[i]].wn.b_off, W + p.gDec, nvox, nvox / B, D, h3 ? 2 : 1, m,
+                         (hipStream_t)stream, hidden);
+}
+
 // ---- single operators ---------------------------------------------------------------------------
 static ConvGeom geom_from(const int32_t a[17])
 {
@@ -752,22 +804,37 @@ static bool geom_ok(const ConvGeom& g)
 // weights into MFMA fragments needs a device buffer, allocated on first use -- the engine path never does this.
 static float* g_op_frag = nullptr;
 static PackJob* g_op_job = nullptr;
-static unsigned* g_op_amax = nullptr;    // [0] activations, [1] weights (second weights: [2]), [4..] outputs / other operands
+static unsigned* g_op_amax = nullptr;    // amax slots of a single-operator call with H3 arithmetic (the engine gets them from the producing kernels)
+static size_t g_op_amax_cap = 0;
 static int op_scratch()
 {
     if (g_op_frag) return PROBAV_OK;
     hipError_t err = hipMalloc((void**)&g_op_frag, (size_t)4 << 20);
     if (err == hipSuccess) err = hipMalloc((void**)&g_op_job, 4 * sizeof(PackJob));
-    if (err == hipSuccess) err = hipMalloc((void**)&g_op_amax, 16 * sizeof(unsigned));
     if (err != hipSuccess) { set_error("single-operator scratch allocation", err); return PROBAV_EHIP; }
     return PROBAV_OK;
 }
-// amax of the operands of a single-operator call with H3 arithmetic (the engine gets them from the producing kernels)
-static int op_amax(const float* x, size_t nx, const float* w, size_t nw, hipStream_t s)
+// `count` zeroed slots in g_op_amax
+static int op_amax_reserve(size_t count, hipStream_t s)
 {
-    if (hipMemsetAsync(g_op_amax, 0, 16 * sizeof(unsigned), s) != hipSuccess) { set_error("single-operator amax reset", hipGetLastError()); return PROBAV_EHIP; }
-    int rc = amax_tensor(x, nx, g_op_amax + 0, s);
-    if (rc == PROBAV_OK && w) rc = amax_tensor(w, nw, g_op_amax + 1, s);
+    if (count > g_op_amax_cap) {
+        hipError_t err = hipStreamSynchronize(s);
+        if (err == hipSuccess && g_op_amax) err = hipFree(g_op_amax);
+        g_op_amax = nullptr; g_op_amax_cap = 0;
+        if (err == hipSuccess) err = hipMalloc((void**)&g_op_amax, (count + 1024) * sizeof(unsigned));
+        if (err != hipSuccess) { set_error("single-operator amax allocation", err); return PROBAV_EHIP; }
+        g_op_amax_cap = count + 1024;
+    }
+    if (hipMemsetAsync(g_op_amax, 0, count * sizeof(unsigned), s) != hipSuccess) { set_error("single-operator amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    return PROBAV_OK;
+}
+// convolution operands: slots [0, N) = x per sample, [N, 2N) = output / dY per sample, [2N, 2N + cols) = filter per output column
+static int op_amax_conv(const ConvGeom& g, const float* x, const float* w, const float* dy, hipStream_t s)
+{
+    int rc = op_amax_reserve((size_t)2 * g.N + 256, s);
+    if (!rc) rc = amax_tensor(x, (size_t)g.Hi * g.Wi * g.Ti * g.Cin, g.N, g_op_amax, s);
+    if (!rc && dy) rc = amax_tensor(dy, (size_t)g.Ho * g.Wo * g.To * g.Cout, g.N, g_op_amax + g.N, s);
+    if (!rc && w) rc = amax_columns(w, (long)g.kh * g.kw * g.kt * g.Cin, g.Cout, g_op_amax + 2 * g.N, s);
     return rc;
 }
 static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split = 0, bool per_tap = false)   // split: 0 fp32 fragments, 1 X6, 2 H3
@@ -781,7 +848,7 @@ static int op_pack(const ConvGeom& g, const float* w, hipStream_t s, int split =
     if (split) {
         const bool kc = g.Cin == 25 && !per_tap;                            // K-concatenated form (per_tap: the H3 piece-ring strip kernel)
         J.type = kc ? PACK_X6_CONVK : PACK_X6_CONV; J.count = kc ? X6_CONVK_FRAG_WORDS : X6_CONV_FRAG_WORDS; J.Cin = g.Cin; J.Cout = g.Cout; J.taps = 27;
-        if (split == 2) { J.type += 10; J.count = kc ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS; J.amax_slot = 1; }
+        if (split == 2) { J.type += 10; J.count = kc ? H3_CONVK_FRAG_WORDS : H3_CONV_FRAG_WORDS; J.amax_percol = 1; J.ncol = g.Cout; J.amax_slot = 2 * g.N; }
         if (split == 2 && g.Cin == 25 && per_tap) { J.type = PACK_H3_CONVP; J.count = H3_CONVK_FRAG_WORDS; }
     } else mfma_conv_pack_job(J, g.Cin, g.Cout);
     hipError_t err = hipStreamSynchronize(s);
@@ -806,9 +873,10 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
         if (rc) return rc;
         Amax am;
         if (impl == 4) {
-            rc = op_amax(x, (size_t)g.N * g.Hi * g.Wi * g.Ti * g.Cin, w, (size_t)g.kh * g.kw * g.kt * g.Cin * g.Cout, (hipStream_t)stream);
+            if (g.Cout > 256) { set_error("probav_conv3d_forward: Cout > 256", hipSuccess); return PROBAV_EINVAL; }
+            rc = op_amax_conv(g, x, w, nullptr, (hipStream_t)stream);
             if (rc) return rc;
-            am.x = g_op_amax; am.w = g_op_amax + 1; am.y = g_op_amax + 4;
+            am.x = g_op_amax; am.w = g_op_amax + 2 * g.N; am.y = g_op_amax + g.N;
         }
         rc = op_pack(g, w, (hipStream_t)stream, impl >= 3 ? impl - 2 : 0, pstrip);
         if (rc) return rc;
@@ -841,9 +909,9 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
         Amax am;
         if (impl == 4) {
             int rc = op_scratch();
-            if (!rc) rc = op_amax(x, (size_t)g.N * g.Hi * g.Wi * g.Ti * g.Cin, dy, (size_t)g.N * g.Ho * g.Wo * g.To * g.Cout, (hipStream_t)stream);
+            if (!rc) rc = op_amax_conv(g, x, nullptr, dy, (hipStream_t)stream);
             if (rc) return rc;
-            am.x = g_op_amax; am.w = g_op_amax + 1;
+            am.x = g_op_amax; am.w = g_op_amax + g.N;
         }
         return x6_conv_wgrad(g, x, dy, gate, dw, db, (float*)scratch, impl == 4 ? 2 : 1, am, (hipStream_t)stream);
     }
@@ -877,9 +945,9 @@ static int op_pack_pw(const float* w1, const float* w2, int D, hipStream_t s, co
     return mfma_pack(d_jobs4, 4, w1, w2, g_op_frag, nullptr, s);
 }
 
-// h3: PACK_H3_* fragments; the weights' amax must already be in g_op_amax[1] (w1) and [2] (w2)
+// h3: PACK_H3_* fragments; the weights' amax must already be in the slots op_amax_pw lays out (wbase = index of the first weight slot)
 static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s, const float** f1, const float** f2,
-                         const float** f2k = nullptr, const float** f1c = nullptr, bool h3 = false)
+                         const float** f2k = nullptr, const float** f1c = nullptr, bool h3 = false, int wbase = 0)
 {
     static float* frag = nullptr;
     static PackJob* d_jobs = nullptr;
@@ -893,7 +961,13 @@ static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s,
     J[3].type = PACK_X6_PW_W1C; J[3].src_is_T = 0; J[3].dst_off = 3 * X6_PW_FRAG_WORDS; J[3].count = X6_PW_FRAG_WORDS; J[3].Cin = 32; J[3].Cout = 256;
     J[0].type = PACK_X6_PW_W1; J[0].src_is_T = 0; J[0].dst_off = 0; J[0].count = X6_PW_FRAG_WORDS; J[0].Cin = 32; J[0].Cout = 256;
     J[1].type = PACK_X6_PW_W2; J[1].src_is_T = 1; J[1].dst_off = X6_PW_FRAG_WORDS; J[1].count = X6_PW_FRAG_WORDS; J[1].Cin = 256; J[1].Cout = D;
-    if (h3) for (int k = 0; k < 4; ++k) { J[k].type += 10; J[k].count = H3_PW_FRAG_WORDS; J[k].amax_slot = J[k].src_is_T ? 2 : 1; }
+    if (h3) {
+        for (int k = 0; k < 4; ++k) { J[k].type += 10; J[k].count = H3_PW_FRAG_WORDS; }
+        J[0].amax_slot = wbase + 0;                                              // W1 as the operand of (a): one scale
+        J[2].amax_slot = wbase + 1;                                              // W2 as the operand of (b): one scale
+        J[1].amax_percol = 1; J[1].ncol = D; J[1].amax_slot = wbase + 8;         // W2 forward: per output column d
+        J[3].amax_percol = 1; J[3].ncol = 32; J[3].amax_slot = wbase + 40;       // W1 as the operand of (c): per cin row
+    }
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipMemcpy(d_jobs, J, sizeof(J), hipMemcpyHostToDevice);
     if (err != hipSuccess) { set_error("probav_pw (x6): job upload", err); return PROBAV_EHIP; }
@@ -902,41 +976,43 @@ static int op_pack_pw_x6(const float* w1, const float* w2, int D, hipStream_t s,
     if (f1c) *f1c = frag + 3 * X6_PW_FRAG_WORDS;
     return mfma_pack(d_jobs, 4, w1, w2, frag, g_op_amax, s);
 }
-// amax of the operands of a single-operator call of the fused pointwise pair: [0] x, [1] w1, [2] w2, [3] b1, [5] d_dec
-static int op_amax_pw(const float* x, const float* w1, const float* w2, const float* b1, const float* d_dec, long nvox, int D, hipStream_t s)
+// amax of the operands of a single-operator call of the fused pointwise pair, ns samples: [0, ns) x, [ns, 2ns) d_dec, [2ns, 3ns) output;
+// wbase = 3 ns: +0 w1, +1 w2, +2 b1 (whole tensors), +8 .. w2 per output column, +40 .. w1 per input row
+static int op_amax_pw(const float* x, const float* w1, const float* w2, const float* b1, const float* d_dec, long nvox, long vps, int D, hipStream_t s, PwAmax& m)
 {
     int rc = op_scratch();
     if (rc) return rc;
-    if (hipMemsetAsync(g_op_amax, 0, 16 * sizeof(unsigned), s) != hipSuccess) { set_error("single-operator amax reset", hipGetLastError()); return PROBAV_EHIP; }
-    rc = amax_tensor(x, (size_t)nvox * 32, g_op_amax + 0, s);
-    if (!rc) rc = amax_tensor(w1, 32 * 256, g_op_amax + 1, s);
-    if (!rc) rc = amax_tensor(w2, (size_t)256 * D, g_op_amax + 2, s);
-    if (!rc) rc = amax_tensor(b1, 256, g_op_amax + 3, s);
-    if (!rc && d_dec) rc = amax_tensor(d_dec, (size_t)nvox * D, g_op_amax + 5, s);
+    const int ns = (int)(nvox / vps), wb = 3 * ns;
+    rc = op_amax_reserve((size_t)wb + 80, s);
+    if (!rc) rc = amax_tensor(x, (size_t)vps * 32, ns, g_op_amax, s);
+    if (!rc && d_dec) rc = amax_tensor(d_dec, (size_t)vps * D, ns, g_op_amax + ns, s);
+    if (!rc) rc = amax_tensor(w1, 32 * 256, 1, g_op_amax + wb + 0, s);
+    if (!rc) rc = amax_tensor(w2, (size_t)256 * D, 1, g_op_amax + wb + 1, s);
+    if (!rc) rc = amax_tensor(b1, 256, 1, g_op_amax + wb + 2, s);
+    if (!rc) rc = amax_columns(w2, 256, D, g_op_amax + wb + 8, s);
+    if (!rc) rc = amax_tensor(w1, 256, 32, g_op_amax + wb + 40, s);              // rows of W1 [32][256]
+    m.x = g_op_amax; m.dt = g_op_amax + ns; m.y = g_op_amax + 2 * ns;
+    m.w1 = g_op_amax + wb; m.w2 = g_op_amax + wb + 1; m.b1 = g_op_amax + wb + 2; m.w2c = g_op_amax + wb + 8; m.w1r = g_op_amax + wb + 40;
     return rc;
-}
-static PwAmax op_pw_slots()
-{
-    PwAmax m; m.x = g_op_amax; m.w1 = g_op_amax + 1; m.w2 = g_op_amax + 2; m.b1 = g_op_amax + 3; m.dt = g_op_amax + 5; m.y = g_op_amax + 4;
-    return m;
 }
 
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
-                      int64_t nvox, int D, int impl, void* stream)
+                      int64_t nvox, int64_t vox_per_sample, int D, int impl, void* stream)
 {
     if (!x || !w1 || !b1 || !w2 || !b2 || !dec || nvox < 1 || impl < 2 || impl > 4) { set_error("probav_pw_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_forward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
+    long vps = vox_per_sample > 0 ? (long)vox_per_sample : (long)nvox;
+    if (nvox % vps) { set_error("probav_pw_forward: nvox is not a multiple of vox_per_sample", hipSuccess); return PROBAV_EINVAL; }
     if (impl >= 3) {
         const float *g1, *g2;
         PwAmax am;
         if (impl == 4) {
-            int rc = op_amax_pw(x, w1, w2, b1, nullptr, (long)nvox, D, (hipStream_t)stream);
+            int rc = op_amax_pw(x, w1, w2, b1, nullptr, (long)nvox, vps, D, (hipStream_t)stream, am);
             if (rc) return rc;
-            am = op_pw_slots();
         }
-        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &g1, &g2, nullptr, nullptr, impl == 4);
+        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &g1, &g2, nullptr, nullptr, impl == 4, 3 * (int)(nvox / vps));
         if (rc) return rc;
-        return x6_pw_forward(x, g1, g2, b1, b2, dec, (long)nvox, D, impl - 2, am, (hipStream_t)stream);
+        return x6_pw_forward(x, g1, g2, b1, b2, dec, (long)nvox, vps, D, impl - 2, am, (hipStream_t)stream);
     }
     const float *f1, *f2, *f2b, *f1c;
     int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
@@ -948,24 +1024,25 @@ size_t probav_pw_backward_scratch_bytes(int D) { return mfma_pw_backward_slab_fl
 
 int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1, const float* w2,
                        float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
-                       int64_t nvox, int D, int impl, void* stream)
+                       int64_t nvox, int64_t vox_per_sample, int D, int impl, void* stream)
 {
     if (!x || !d_dec || !d_skip || !w1 || !b1 || !w2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch || nvox < 1 || impl < 2 || impl > 4) {
         set_error("probav_pw_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL;
     }
     if (!mfma_pw_supported(32, 256, D)) { set_error("probav_pw_backward: needs F=32, E=256, D<=26", hipSuccess); return PROBAV_EINVAL; }
     if (scratch_bytes < probav_pw_backward_scratch_bytes(D)) { set_error("probav_pw_backward: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+    long vps = vox_per_sample > 0 ? (long)vox_per_sample : (long)nvox;
+    if (nvox % vps) { set_error("probav_pw_backward: nvox is not a multiple of vox_per_sample", hipSuccess); return PROBAV_EINVAL; }
     const float *f1, *f2, *f2b, *f1c;
     if (impl >= 3) {
         PwAmax am;
         if (impl == 4) {
-            int rc = op_amax_pw(x, w1, w2, b1, d_dec, (long)nvox, D, (hipStream_t)stream);
+            int rc = op_amax_pw(x, w1, w2, b1, d_dec, (long)nvox, vps, D, (hipStream_t)stream, am);
             if (rc) return rc;
-            am = op_pw_slots();
         }
-        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c, impl == 4);
+        int rc = op_pack_pw_x6(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c, impl == 4, 3 * (int)(nvox / vps));
         if (rc) return rc;
-        return x6_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, D, impl - 2, am, (hipStream_t)stream);
+        return x6_pw_backward(x, d_dec, d_skip, f1, f2b, f1c, b1, dx, dw1, dw2, db1, db2, (float*)scratch, (long)nvox, vps, D, impl - 2, am, (hipStream_t)stream);
     }
     int rc = op_pack_pw(w1, w2, D, (hipStream_t)stream, &f1, &f2, &f2b, &f1c);
     if (rc) return rc;
@@ -975,7 +1052,7 @@ int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, 
 int probav_wn_forward(probav_engine* e, const float* params, float* weff, float* weffT, float* inv_norm, void* stream)
 {
     if (!e || !params || !weff || !weffT || !inv_norm) { set_error("probav_wn_forward: null argument", hipSuccess); return PROBAV_EINVAL; }
-    return wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, weff, weffT, inv_norm, nullptr, (hipStream_t)stream);
+    return wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, weff, weffT, inv_norm, nullptr, (hipStream_t)stream);
 }
 int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm, float* grads, void* stream)
 {

@@ -24,10 +24,12 @@ struct PackJob {
     int type, src_is_T;
     long src_off, dst_off, count;     // offsets in floats; count = floats written (multiple of 256)
     int Cin, Cout, CC, KS, taps;
-    int amax_slot;                    // PACK_H3_*: index of the source tensor's amax in the array handed to mfma_pack
+    int amax_slot;                    // PACK_H3_*: index of the source tensor's amax in the array handed to mfma_pack ...
+    int amax_percol, ncol;            // ... or, when amax_percol, of the FIRST of ncol per-column slots: the lane that packs output column / row `col`
+                                      //     of the matrix (conv: cout of the packed matrix; PW_W2: out d; PW_W1C: cin f) scales by slot amax_slot + col
 };
 
-// amax: per-tensor largest magnitudes (float bit patterns) of the weights, read by the PACK_H3_* jobs (may be null without such jobs)
+// amax: largest magnitudes (float bit patterns) of the weights, per tensor and per column (wn_forward's layout), read by the PACK_H3_* jobs (may be null without such jobs)
 int mfma_pack(const PackJob* d_jobs, int njobs, const float* weff, const float* weffT, float* wpack, const unsigned* amax, hipStream_t s);
 
 bool mfma_conv_supported(const ConvGeom& g);

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
     float* dst = wpack + J.dst_off;
     const bool h3 = J.type >= PACK_H3_PW_W1;
     const int type = h3 ? J.type - 10 : J.type;
-    const float wscale = h3 ? pow2i(h3_exp(amax[J.amax_slot])) : 1.f;
+    // H3 scale: the power of two of the matrix' output column / row `col` this lane packs (amax_percol: slot amax_slot + col) or of the
+    // whole tensor (slot amax_slot); kernels that read the fragments undo exactly this exponent (h3_exp_w of the same slot)
+    const float wscale_t = (h3 && !J.amax_percol) ? pow2i(h3_exp_w(amax[J.amax_slot])) : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < J.count; i += (long)gridDim.x * 256) {
         const int u = (int)(i & 3), lane = (int)((i >> 2) & 63), half = lane >> 5, col = lane & 31;
         long q = i >> 8;                                   // float4 index (per lane)
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
             }
             if (h3) {
                 unsigned pc[2];
+                const float wscale = J.amax_percol ? (col < J.ncol ? pow2i(h3_exp_w(amax[J.amax_slot + col])) : 1.f) : wscale_t;
                 cut_pair<H3>(v2[0], v2[1], wscale, pc);
                 reinterpret_cast<unsigned*>(dst)[i] = pc[piece];
             } else {
@@ -533,11 +536,12 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     constexpr int KS4 = (KS + 3) / 4;
     float sa = 1.f; int eun = 0; float omax = 0.f;
-    if constexpr (AM == 2) { const int ea = h3_exp(*am.x), ew = h3_exp(*am.w); sa = pow2i(ea); eun = -(ea + ew); }
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int n = wg / a.ntile_rows, h0 = (wg - n * a.ntile_rows) * a.R;
+    // H3 scales: this patch's activations (slot n) and, per lane, the filter column the lane accumulates
+    if constexpr (AM == 2) { const int ea = h3_exp(am.x[n]), ew = h3_exp_w(am.w[col < g.Cout ? col : 0]); sa = pow2i(ea); eun = -(ea + ew); }
     const int Rr = g.Ho - h0 < a.R ? g.Ho - h0 : a.R;
     const int nv = Rr * g.Wo * g.To, ntiles = (nv + 31) >> 5;
     const int nchunk = g.Cin / CC;
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(TileArgs a, const fl
             }
         }
     }
-    if (am.y) amax_commit(omax, am.y);
+    if (am.y) amax_commit(omax, am.y + n);
     STAMP(7);
 }
 
@@ -1031,7 +1035,10 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
     constexpr bool X6 = AM != 0;
     using AR = std::conditional_t<AM == 2, H3, probav::X6>;
     float sa = 1.f; int eun = 0; float omax = 0.f;
-    if constexpr (AM == 2) { const int ea = h3_exp(*am.x), ew = h3_exp(*am.w); sa = pow2i(ea); eun = -(ea + ew); }
+    if constexpr (AM == 2) {   // H3 scales: this patch's activations and, per lane, the filter column the lane accumulates
+        const int ea = h3_exp(am.x[blockIdx.x / a.nstrips]), ew = h3_exp_w(am.w[(threadIdx.x & 31) < a.g.Cout ? (threadIdx.x & 31) : 0]);
+        sa = pow2i(ea); eun = -(ea + ew);
+    }
     constexpr int CP = (CC & 1) ? CC : CC + 1;
     constexpr int KS4 = (KS + 3) / 4;
     constexpr int V = (CC % 4 == 0) ? 4 : 1;        // floats per load when staging
@@ -1265,7 +1272,7 @@ __global__ __launch_bounds__(512, 2) void conv3_strip_kernel(StripArgs a, const 
             XS_ACC(5);
         }
     }
-    if (am.y) amax_commit(omax, am.y);
+    if (am.y) amax_commit(omax, am.y + n);
     XS_OUT;
 }
 
@@ -1291,11 +1298,12 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     using AR = H3;
     constexpr int NP = 2, SLOTS = 4, REC = 128, PF = 3;
     const ConvGeom& g = a.g;
-    const int ea = h3_exp(*am.x), ew = h3_exp(*am.w);
-    const float sa = pow2i(ea);
-    const int eun = -(ea + ew);
     float omax = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    // H3 scales: this patch's activations (one slot per sample) and, per lane, the filter column the lane accumulates
+    const int ea = h3_exp(am.x[blockIdx.x / (a.nstrips * a.nsplit)]), ew = h3_exp_w(am.w[col < g.Cout ? col : 0]);
+    const float sa = pow2i(ea);
+    const int eun = -(ea + ew);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tsel = wave & 3, grp = wave >> 2;
     const int rowbytes = a.Wp * a.Tp * REC;
@@ -1534,7 +1542,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
         }
         XS_ACC(5);
     }
-    if (am.y) amax_commit(omax, am.y);
+    if (am.y) amax_commit(omax, am.y + n);
     XS_OUT;
 }
 

@@ -77,29 +77,57 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
         weffT[L.w_off + ((long)(L.taps - 1 - tap) * L.Cout + co) * L.Cin + ci] = q;
         wmax = fmaxf(wmax, fabsf(q));
     }
-    if (amax) {     // largest |effective weight| and |bias| of the layer: operand scales of the H3 kernels (slots li and nl + li)
+    if (amax) {     // largest |effective weight| and |bias| of the layer (slots li and nl + li) and of this output column: operand scales of the H3 kernels
 #pragma unroll
         for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-        if (lane == 0) { atomicMax(amax + li, __float_as_uint(wmax)); atomicMax(amax + nl + li, __float_as_uint(fabsf(params[L.b_off + co]))); }
+        if (lane == 0) {
+            atomicMax(amax + li, __float_as_uint(wmax)); atomicMax(amax + nl + li, __float_as_uint(fabsf(params[L.b_off + co])));
+            amax[2 * nl + L.n_off + co] = __float_as_uint(wmax);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ slot)
+// largest |effective weight| per INPUT channel (the output columns of the backward-data matrices weffT, and the rows of W1 the fused
+// pointwise backward scales its dX by): one wave per (layer, input channel), after wn_forward_kernel on the same stream
+__global__ __launch_bounds__(64) void wn_rowmax_kernel(const WnLayer* __restrict__ layers, int nl, const float* __restrict__ weff,
+                                                      unsigned* __restrict__ arow)
 {
+    int i = 0;
+    while (i + 1 < nl && (int)blockIdx.x >= layers[i + 1].r_off) ++i;
+    const WnLayer L = layers[i];
+    const int ci = blockIdx.x - L.r_off, lane = threadIdx.x;
     float m = 0.f;
-    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {                  // four independent loads in flight
-        const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(x)[i + stride];
-        const float4 c = reinterpret_cast<const float4*>(x)[i + 2 * stride], d = reinterpret_cast<const float4*>(x)[i + 3 * stride];
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+    for (int e = lane; e < L.taps * L.Cout; e += 64) {
+        const int tap = e / L.Cout, co = e - tap * L.Cout;
+        m = fmaxf(m, fabsf(weff[L.w_off + ((long)tap * L.Cin + ci) * L.Cout + co]));
     }
-    for (; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) arow[blockIdx.x] = __float_as_uint(m);
+}
+
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ xall, size_t n, unsigned* __restrict__ slots)
+{
+    const float* x = xall + (size_t)blockIdx.y * n;                 // sample blockIdx.y: n values (n % 4 == 0 or the base stays 16-byte aligned only for sample 0: see the scalar path)
+    unsigned* slot = slots + blockIdx.y;
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if ((n & 3) == 0) {
+        const size_t n4 = n >> 2;
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {                  // four independent loads in flight
+            const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(x)[i + stride];
+            const float4 c = reinterpret_cast<const float4*>(x)[i + 2 * stride], d = reinterpret_cast<const float4*>(x)[i + 3 * stride];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+        }
+        for (; i < n4; i += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     __shared__ float wm[4];
@@ -110,13 +138,37 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
         if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, __float_as_uint(m));
     }
 }
-int amax_tensor(const float* x, size_t n, unsigned* slot, hipStream_t s)
+int amax_tensor(const float* x, size_t per_sample, int N, unsigned* slots, hipStream_t s)
 {
-    size_t blocks = (n / 4 + 255) / 256;
+    if (N < 1) return PROBAV_OK;
+    size_t blocks = (per_sample / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, slot);
+    const size_t cap = N >= 2048 ? 1 : 2048 / (size_t)N;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, s, x, per_sample, slots);
     return check_launch("amax");
+}
+
+// largest |w[r][c]| over the rows r of a row-major [rows][cols] matrix -> slots[c] (plain store; cols <= 256): the per-column filter
+// scales of the H3 kernels for the single-operator entry points (the engine gets them from wn_forward)
+__global__ __launch_bounds__(256) void amax_columns_kernel(const float* __restrict__ w, long rows, int cols, unsigned* __restrict__ slots)
+{
+    __shared__ float part[256];
+    const int per = 256 / cols, c = threadIdx.x % cols, r0 = threadIdx.x / cols;      // `per` row streams per column
+    float m = 0.f;
+    if (r0 < per) for (long r = r0; r < rows; r += per) m = fmaxf(m, fabsf(w[r * cols + c]));
+    part[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        for (int k = 1; k < per; ++k) m = fmaxf(m, part[k * cols + threadIdx.x]);
+        slots[threadIdx.x] = __float_as_uint(m);
+    }
+}
+int amax_columns(const float* w, long rows, int cols, unsigned* slots, hipStream_t s)
+{
+    if (cols < 1 || cols > 256) { set_error("amax_columns: 1 <= cols <= 256", hipSuccess); return PROBAV_EINVAL; }
+    hipLaunchKernelGGL(amax_columns_kernel, dim3(1), dim3(256), 0, s, w, rows, cols, slots);
+    return check_launch("amax_columns");
 }
 
 // d loss/d g = sum(dw * v) / ||v|| ;  d loss/d v = g/||v|| * (dw - v * sum(dw * v) / ||v||^2)
@@ -143,11 +195,14 @@ __global__ __launch_bounds__(64) void wn_backward_kernel(const WnLayer* __restri
     }
 }
 
-int wn_forward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,
+int wn_forward(const WnLayer* d_layers, int nlayers, int cout_total, int cin_total, const float* params,
                float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s)
 {
     hipLaunchKernelGGL(wn_forward_kernel, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm, amax);
-    return check_launch("wn_forward");
+    int rc = check_launch("wn_forward");
+    if (rc || !amax) return rc;
+    hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total);
+    return check_launch("wn_rowmax");
 }
 int wn_backward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,
                 const float* dweff, const float* inv_norm, float* grads, hipStream_t s)
@@ -219,14 +274,14 @@ int tail_backward(const float* dy, float* dtail, int N, int P, int sc, float std
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx,
                                                           int N, int H, int W, int TC, unsigned* __restrict__ amax)
 {
-    const long total = (long)N * H * W * TC;
+    const int n = blockIdx.y;                                       // one sample per grid row: its largest |dx| goes to amax[n]
+    const long per = (long)H * W * TC;
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
         const int e = (int)(i % TC);
         long r = i / TC;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H);
-        const int n = (int)(r / H);
+        const int w = (int)(r % W);
+        const int h = (int)(r / W);
         int hs[2], ws[2], nh = 1, nw = 1;
         hs[0] = h + 1; ws[0] = w + 1;
         if (h == 1) hs[nh++] = 0;
@@ -237,10 +292,10 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         for (int a = 0; a < nh; ++a)
             for (int b = 0; b < nw; ++b)
                 s += dpad[(((long)n * (H + 2) + hs[a]) * (W + 2) + ws[b]) * TC + e];
-        dx[i] = s;
+        dx[(long)n * per + i] = s;
         m = fmaxf(m, fabsf(s));
     }
-    if (amax) {                                 // largest |dx| (H3 operand scale of the next layer's kernels): one guarded atomic per workgroup
+    if (amax) {                                 // largest |dx| of the sample (H3 operand scale of the next layer's kernels): one guarded atomic per workgroup
 #pragma unroll
         for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         __shared__ float wm[4];
@@ -248,17 +303,18 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         __syncthreads();
         if (threadIdx.x == 0) {
             m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-            if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(m));
+            if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax + n)) atomicMax(amax + n, __float_as_uint(m));
         }
     }
 }
 int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax, hipStream_t s)
 {
     if (H < 4 || W < 4) { set_error("reflect_fold: H, W must be >= 4", hipSuccess); return PROBAV_EINVAL; }
-    const long n = (long)N * H * W * TC;
-    long blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dpad, dx, N, H, W, TC, amax);
+    const long per = (long)H * W * TC;
+    long blocks = (per + 255) / 256;
+    const long cap = N >= 4096 ? 1 : 4096 / N;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, s, dpad, dx, N, H, W, TC, amax);
     return check_launch("reflect_fold");
 }
 

@@ -5,26 +5,29 @@
 
 namespace probav {
 
-// amax slots of the fused pointwise pair (H3 arithmetic, x6_device.h): x = the 32-channel input (forward) ; w1, w2, b1 = expConv
-// weights, decConv weights, expConv bias; dt = the incoming gradient (backward); y = slot receiving the output's amax (optional)
+// amax slots of the fused pointwise pair (H3 arithmetic, x6_device.h): x = the 32-channel input, ONE SLOT PER SAMPLE; dt = the incoming
+// gradient (backward), one slot per sample; w1, w2, b1 = expConv weights, decConv weights, expConv bias, one slot per TENSOR;
+// w2c = decConv weights per output column d (forward: PACK_H3_PW_W2 is cut per column); w1r = expConv weights per input row f (backward:
+// PACK_H3_PW_W1C is cut per row); y = slots receiving the output's amax per sample (optional)
 struct PwAmax { const unsigned* x = nullptr; const unsigned* w1 = nullptr; const unsigned* w2 = nullptr; const unsigned* b1 = nullptr;
-                const unsigned* dt = nullptr; unsigned* y = nullptr; };
+                const unsigned* dt = nullptr; const unsigned* w2c = nullptr; const unsigned* w1r = nullptr; unsigned* y = nullptr; };
 
-// arith 1: X6 (PACK_X6_PW_* fragments), 2: H3 (PACK_H3_PW_* fragments, am filled in)
+// arith 1: X6 (PACK_X6_PW_* fragments), 2: H3 (PACK_H3_PW_* fragments, am filled in).  vps = voxels per sample (nvox % vps == 0; 0 = one
+// sample): tiles never straddle samples.  hdump (optional, tests): receives the post-ReLU hidden tile [nvox][256]
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
-                  long nvox, int D, int arith, const PwAmax& am, hipStream_t s);
+                  long nvox, long vps, int D, int arith, const PwAmax& am, hipStream_t s, float* hdump = nullptr);
 
 // reverse pass of the fused pair; w1f = PACK_X6_PW_W1, w2kf = PACK_X6_PW_W2K, w1cf = PACK_X6_PW_W1C fragments;
 // slabs: mfma_pw_backward_slab_floats(D) floats
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
-                   const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, int D,
+                   const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
                    int arith, const PwAmax& am, hipStream_t s);
 
 // backward-filter of a 3x3x3 convolution with Cin = 25 or 32 and Cout = 32 (normConv, reducers; pads 0/1, reflect, ReLU gate);
 // partial: x6_wgrad_partial_floats(g) floats
 bool x6_wgrad_supported(const ConvGeom& g);
 size_t x6_wgrad_partial_floats(const ConvGeom& g);
-// arith 1: X6; 2: H3 with am.x = amax slot of x, am.w = amax slot of dY
+// arith 1: X6; 2: H3 with am.x = per-sample amax slots of x, am.w = per-sample amax slots of dY (g.N of each)
 int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial,
                   int arith, const Amax& am, hipStream_t s);
 

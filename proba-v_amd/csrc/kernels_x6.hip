@@ -30,11 +30,15 @@ namespace probav {
 template <class AR> struct PwfShape { static constexpr int WAVES = 12, WGS = 1; };
 template <> struct PwfShape<H3> { static constexpr int WAVES = 8, WGS = 2; };
 
-template <class AR>
+// Tiles never straddle two samples (vps voxels per sample are cut into ceil(vps / 32) tiles, the last one partial), and a wave owns a
+// CONTIGUOUS run of tiles: the H3 scales of X and of the hidden tile are per-sample scalars that change once or twice per wave, and a
+// sample's largest output magnitude is committed when the run leaves the sample.  DUMP (tests only): the post-ReLU hidden tile is
+// also written to hdump [nvox][256] (at the hidden tile's own power-of-two scale: only signs and relative sizes mean anything).
+template <class AR, bool DUMP>
 __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void pw_fwd_x6_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag,
                                                                      const uint4* __restrict__ w2frag, const float* __restrict__ b1,
                                                                      const float* __restrict__ b2, float* __restrict__ dec,
-                                                                     long nvox, int D, PwAmax am)
+                                                                     long nvox, int vps, int D, PwAmax am, float* __restrict__ hdump)
 {
     constexpr int NP = AR::NP, PWF_WAVES = PwfShape<AR>::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -42,30 +46,39 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
     uint4* sW2 = sW1 + 8 * 2 * NP * 64;                          // same
     float* sB1 = reinterpret_cast<float*>(sW2 + 8 * 2 * NP * 64);    // 256
     float* sB2 = sB1 + 256;                                      // 32
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    // H3 scales.  The hidden tensor exists only in registers, so its scale comes from a bound: |h| <= 32 amax(x) amax(w1) + amax(b1).
-    float sx = 1.f; int k1 = 0, k2 = 0; float sbias = 1.f, c1 = 1.f;
-    if constexpr (AR::SCALED) {
-        const unsigned ax = *am.x, aw1 = *am.w1;
-        const int ex = h3_exp(ax), ew1 = h3_exp(aw1), ew2 = h3_exp(*am.w2);
-        const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(*am.b1));
-        sx = pow2i(ex); sbias = pow2i(eh);
-        k1 = eh - ex - ew1;                                      // accumulator of the first product -> hidden at its own scale
-        c1 = pow2i(k1 < -126 ? -126 : k1);                       // (k1 <= -17 always: the bound is at least 32 amax(x) amax(w1); as a float factor it fuses with the bias add)
-        k2 = -(ew2 + eh);                                        // accumulator of the second product -> true values
-    }
+    int* sE2 = reinterpret_cast<int*>(sB2 + 32);                 // 32: H3 exponent of decConv's output column d (its weights are cut per column)
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * PWF_WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
-    if (tid < 256) sB1[tid] = b1[tid] * sbias;
-    if (tid < 32) sB2[tid] = tid < D ? b2[tid] : 0.f;
+    if (tid < 256) sB1[tid] = b1[tid];
+    if (tid < 32) { sB2[tid] = tid < D ? b2[tid] : 0.f; sE2[tid] = (AR::SCALED && tid < D) ? h3_exp_w(am.w2c[tid]) : 0; }
     __syncthreads();
+    // H3 scales.  The hidden tensor exists only in registers, so its scale comes from a bound: |h| <= 32 amax(x) amax(w1) + amax(b1), per sample.
+    float sx = 1.f, sbias = 1.f, c1 = 1.f; int eh = 0;
+    unsigned aw1 = 0u, ab1 = 0u; int ew1 = 0;
+    if constexpr (AR::SCALED) { aw1 = *am.w1; ab1 = *am.b1; ew1 = h3_exp_w(aw1); }
+    auto sample_scales = [&](int n) {
+        if constexpr (AR::SCALED) {
+            const unsigned ax = am.x[n];
+            const int ex = h3_exp(ax);
+            eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1));
+            sx = pow2i(ex); sbias = pow2i(eh);
+            const int k1 = -(ex + ew1);                              // accumulator of the first product -> true hidden values (bias added there, then 2^eh)
+            c1 = pow2i(k1 < -126 ? -126 : k1);
+        }
+    };
 
+    const int tps = (vps + 31) >> 5;                                 // tiles per sample
+    const long ntiles = (nvox / vps) * tps;
+    const long gw = (long)blockIdx.x * PWF_WAVES + wave, nw = (long)gridDim.x * PWF_WAVES;
+    const long tb = ntiles * gw / nw, te = ntiles * (gw + 1) / nw;   // this wave's run of tiles
+    int n = (int)(tb / tps), j = (int)(tb - (long)n * tps);
     float omax = 0.f;
-    const long ntiles = (nvox + 31) >> 5;
-    const long wstride = (long)gridDim.x * PWF_WAVES;
-    for (long tile = (long)blockIdx.x * PWF_WAVES + wave; tile < ntiles; tile += wstride) {
-        long v = tile * 32 + col;
-        const bool vok = v < nvox;
-        if (!vok) v = nvox - 1;
+    if (tb < te) sample_scales(n);
+    for (long tile = tb; tile < te; ++tile) {
+        const int vl = 32 * j + col;                                 // voxel inside the sample
+        const bool vok = vl < vps;
+        const long v = (long)n * vps + (vok ? vl : vps - 1);
         // B operand of the first product: X^T, k = cin 16kb + 8h + j
         Frag xb[2][NP];
 #pragma unroll
@@ -101,10 +114,16 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
                     const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        hs[4 * g + i] = fmaxf(fmaf(H[8 * kb + 4 * g + i], c1, bv[i]), 0.f);      // (c1 = 1 without scaling)
+                        hs[4 * g + i] = fmaxf(fmaf(H[8 * kb + 4 * g + i], c1, bv[i]), 0.f);      // true hidden values (c1 = 1 without scaling)
                     }
                 }
-                cut8_scaled<AR>(hs, hb[kb]);
+                cut8<AR>(hs, sbias, hb[kb]);                         // pieces of h 2^eh
+                if constexpr (DUMP) {
+                    if (vok) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hdump[v * 256 + 32 * c + rowmap(8 * kb + i, h)] = hs[i];
+                    }
+                }
             }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -120,33 +139,46 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
             for (int r = 0; r < 16; ++r) {
                 const int ch = rowmap(r, h);
                 float t = T[r];
-                if constexpr (AR::SCALED) t = ldexpf(t, k2);
+                if constexpr (AR::SCALED) t = ldexpf(t, -(sE2[ch] + eh));   // accumulator of the second product -> true values
                 t += sB2[ch];
                 if (ch < D) { o[ch] = t; omax = fmaxf(omax, fabsf(t)); }
             }
         }
+        if (++j == tps) {                                            // the run leaves sample n
+            if (am.y) amax_commit(omax, am.y + n);
+            omax = 0.f; j = 0; ++n;
+            if (tile + 1 < te) sample_scales(n);
+        }
     }
-    if (am.y) amax_commit(omax, am.y);
+    if (am.y && j != 0 && tb < te) amax_commit(omax, am.y + n);
 }
 
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
-                  long nvox, int D, int arith, const PwAmax& am, hipStream_t s)
+                  long nvox, long vps, int D, int arith, const PwAmax& am, hipStream_t s, float* hdump)
 {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
+    if (vps <= 0 || vps > nvox) vps = nvox;                          // one "sample"
+    if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_forward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
-        if (!am.x || !am.w1 || !am.w2 || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
-        const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32) * sizeof(float);
-        hipLaunchKernelGGL(pw_fwd_x6_kernel<H3>, dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
-                           b1, b2, dec, nvox, D, am);
+        if (!am.x || !am.w1 || !am.w2c || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+        const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32) * sizeof(float);
+        if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+                                      b1, b2, dec, nvox, (int)vps, D, am, hdump);
+        else hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, false>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+                                b1, b2, dec, nvox, (int)vps, D, am, hdump);
     } else {
-        const size_t lds = (size_t)2 * 8 * 2 * X6::NP * 64 * 16 + (256 + 32) * sizeof(float);
-        hipLaunchKernelGGL(pw_fwd_x6_kernel<X6>, dim3(256 * PwfShape<X6>::WGS), dim3(64 * PwfShape<X6>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
-                           b1, b2, dec, nvox, D, am);
+        const size_t lds = (size_t)2 * 8 * 2 * X6::NP * 64 * 16 + (256 + 32 + 32) * sizeof(float);
+        if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<X6, true>), dim3(256 * PwfShape<X6>::WGS), dim3(64 * PwfShape<X6>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+                                      b1, b2, dec, nvox, (int)vps, D, am, hdump);
+        else hipLaunchKernelGGL((pw_fwd_x6_kernel<X6, false>), dim3(256 * PwfShape<X6>::WGS), dim3(64 * PwfShape<X6>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+                                b1, b2, dec, nvox, (int)vps, D, am, hdump);
     }
     return check_launch("pw_fwd_x6");
 }
@@ -197,11 +229,16 @@ __device__ __forceinline__ void store_pieces(unsigned char* img, int col, int h,
     }
 }
 
+// Tiles never straddle two samples (ceil(vps / 32) tiles per sample, the last one partial) and a workgroup owns a CONTIGUOUS run of
+// tiles.  H3 scales are per sample: X and dT are cut with their own sample's power of two, (a)-(c) never mix samples, and the
+// accumulators of (d) / (e) -- which contract over voxels, i.e. over samples too -- are carried from one sample's scales to the next
+// when the run leaves a sample (an exact multiplication by a power of two; beyond 2^+-40 they are banked in the workgroup's slab at
+// true scale instead), so that one accumulation only ever holds one pair of scales.
 template <class AR>
 __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
     const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
-    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int D, PwAmax am)
+    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int vps, int D, PwAmax am)
 {
     constexpr int NP = AR::NP;
     constexpr int PB_TILE = NP * PB_IMG;                          // one staged tile: NP piece images
@@ -211,25 +248,26 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     float* TbAll = reinterpret_cast<float*>(DA + 2 * PB_TILE);   // [2 tile parities][8 waves][32][33] dX partials
     float* sB1 = TbAll + 16 * PB_TB;                              // 256 expand biases
     unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 256);       // [8 waves][NP pieces][32 voxels][72 B] transpose images
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // H3 scales.  Tensors that exist only in registers are scaled from bounds: |H| <= 32 amax(x) amax(w1) + amax(b1) (as in the
-    // forward kernel) and |dH| <= D amax(dT) amax(w2).
-    float sx = 1.f, sd = 1.f, sbias = 1.f, ch = 1.f, cg = 1.f;
-    int kh = 0, kg = 0, kdx = 0, kdw1 = 0, kdw2 = 0, kdb1 = 0;
-    if constexpr (AR::SCALED) {
-        const unsigned ax = *am.x, aw1 = *am.w1, aw2 = *am.w2, ad = *am.dt;
-        const int ex = h3_exp(ax), ew1 = h3_exp(aw1), ew2 = h3_exp(aw2), ed = h3_exp(ad);
-        const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(*am.b1));
-        const int eg = h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2));
-        sx = pow2i(ex); sd = pow2i(ed); sbias = pow2i(eh);
-        kh = eh - ex - ew1;           // accumulator (a) -> hidden values at their own scale
-        kg = eg - ew2 - ed;           // accumulator (b) -> hidden gradients at their own scale
-        ch = pow2i(kh < -126 ? -126 : kh);                          // (kh, kg <= -17 always, see the bounds: float factors that fuse with the bias add)
-        cg = pow2i(kg < -126 ? -126 : kg);
-        kdx = -(ew1 + eg);            // (c) partials -> true values
-        kdw1 = -(ex + eg); kdw2 = -(ed + eh); kdb1 = -eg;
-    }
-    if (tid < 256) sB1[tid] = b1[tid] * sbias;
+    // forward kernel) and |dH| <= D amax(dT) amax(w2), per sample.  W1 as the operand of (c) is cut per cin row (its dX column).
+    // A sample's scales are four exponents (scalar registers): ex, ed of X and dT, eh, eg of the hidden tile and its gradient.
+    struct Sc { int ex, ed, eh, eg; };
+    Sc cur = {0, 0, 0, 0}, nxt = cur;
+    unsigned aw1 = 0u, aw2 = 0u, ab1 = 0u; int ew1 = 0, ew2 = 0, ew1c = 0;
+    if constexpr (AR::SCALED) { aw1 = *am.w1; aw2 = *am.w2; ab1 = *am.b1; ew1 = h3_exp_w(aw1); ew2 = h3_exp_w(aw2); ew1c = h3_exp_w(am.w1r[col]); }
+    auto sample_scales = [&](int n) -> Sc {
+        Sc q = {0, 0, 0, 0};
+        if constexpr (AR::SCALED) {
+            const unsigned ax = am.x[n], ad = am.dt[n];
+            q.ex = h3_exp(ax); q.ed = h3_exp(ad);
+            q.eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1));
+            q.eg = h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2));
+        }
+        return q;
+    };
+    if (tid < 256) sB1[tid] = b1[tid];
     const int c = wave;                                           // this wave's hidden chunk
 
     Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
@@ -252,10 +290,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
 
-
     for (int i = tid; i < 2 * PB_TILE / 16; i += 512) reinterpret_cast<uint4*>(DA)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    const long ntiles = (nvox + 31) >> 5;
+    const int tps = (vps + 31) >> 5;                              // tiles per sample
+    const int ntiles = (int)(nvox / vps) * tps;
+    const int tbeg = (int)((long)ntiles * blockIdx.x / gridDim.x), tend = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);   // this workgroup's run of tiles
     // Staging belongs to the first-dispatched half of the workgroup (waves 0..3); the dX reduction is shared by both halves.  With the
     // staging spread over all eight waves the second half (which loses the per-SIMD issue arbitration) was the pole wave of every tile
     // while the first half waited ~20 % of a tile at the barrier; with staging AND reduction on the first half the roles flipped.
@@ -266,60 +305,103 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int f = tid + 256 * k; dvk[k] = f / D; dok[k] = f - dvk[k] * D; }
     float bs2[4] = {0.f, 0.f, 0.f, 0.f};
-    auto stage_load = [&](long tile, float4& xv, float (&d)[4]) {
+    // (raw loads only, clamped and unconditional: the elements beyond a partial tile are zeroed when the tile is stored -- a select right
+    // behind a load makes the compiler wait for every load separately)
+    auto stage_load = [&](int sn, int sj, float4& xv, float (&d)[4]) {
         if (!stager) return;
-        const long v0 = tile * 32;
-        const int nrem = (int)(nvox - v0 < 32 ? nvox - v0 : 32);
+        const long v0 = (long)sn * vps + 32 * sj;
+        const int nrem = vps - 32 * sj < 32 ? vps - 32 * sj : 32;
         const int vv = tid >> 3;
-        const float4 t = reinterpret_cast<const float4*>(x + (v0 + (vv < nrem ? vv : 0)) * 32)[tid & 7];
-        xv = vv < nrem ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv = reinterpret_cast<const float4*>(x + (v0 + (vv < nrem ? vv : 0)) * 32)[tid & 7];
         const float* dt0 = dT + v0 * D;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int f = tid + 256 * k;
-            const bool live = f < nrem * D;
-            const float a = dt0[live ? f : 0];
-            d[k] = live ? a : 0.f;
+            d[k] = dt0[f < nrem * D ? f : 0];
         }
     };
-    auto stage_store = [&](int buf, const float4& xv, const float (&d)[4]) {
+    auto stage_store = [&](int buf, int sj, const float4& xv, const float (&d)[4], float sx, float sd) {
         if (!stager) return;
+        const int nrem = vps - 32 * sj < 32 ? vps - 32 * sj : 32;
         {
+            const bool xl = (tid >> 3) < nrem;
             unsigned a[NP], b[NP];
-            cut_pair<AR>(xv.x, xv.y, sx, a);
-            cut_pair<AR>(xv.z, xv.w, sx, b);
+            cut_pair<AR>(xl ? xv.x : 0.f, xl ? xv.y : 0.f, sx, a);
+            cut_pair<AR>(xl ? xv.z : 0.f, xl ? xv.w : 0.f, sx, b);
             unsigned char* dst = XA + buf * PB_TILE + (tid >> 3) * PB_ROW + (tid & 7) * 8;
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(dst + p * PB_IMG) = make_uint2(a[p], b[p]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            const float dv = tid + 256 * k < nrem * D ? d[k] : 0.f;
             if (tid + 256 * k < 32 * D) {
                 unsigned short q[NP];
-                cut_one<AR>(d[k], sd, q);
+                cut_one<AR>(dv, sd, q);
                 unsigned char* dst = DA + buf * PB_TILE + dvk[k] * PB_ROW + dok[k] * 2;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<unsigned short*>(dst + p * PB_IMG) = q[p];
             }
-            bs2[k] += d[k];
+            bs2[k] += dv;
         }
     };
+    // one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]; the accumulators of (d), (e) and the db1 sums are added to it
+    // (at true scale) whenever the run leaves a sample, and at the end; the first flush stores
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    float* sl = slabs + (long)blockIdx.x * slab_floats;
+    bool flushed = false;                                             // wave-uniform
+    auto flush = [&](const Sc& q) {
+        asm volatile("" ::: "memory");                                // a rare path: nothing of it may be speculated into the tile loop
+        float a1[16], a2[16], a3[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a1[r] = dW1[r]; a2[r] = dW2t[r];
+            if constexpr (AR::SCALED) { a1[r] = ldexpf(a1[r], -(q.ex + q.eg)); a2[r] = ldexpf(a2[r], -(q.ed + q.eh)); }
+            float v = bs1v[r];                                        // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+            if constexpr (AR::SCALED) v = ldexpf(v, -q.eg);
+            a3[r] = v;
+            dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f;
+        }
+        if (flushed) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = rowmap(r, half);
+                a1[r] += sl[(long)rw * 256 + 32 * c + col];
+                if (rw < D) a2[r] += sl[8192 + (long)(32 * c + col) * D + rw];
+                if (col == 0) a3[r] += sl[8192 + 256 * (long)D + 32 * c + rw];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = rowmap(r, half);
+            sl[(long)rw * 256 + 32 * c + col] = a1[r];                                        // [cin][hidden]
+            if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = a2[r];                     // [hidden][out]
+            if (col == 0) sl[8192 + 256 * (long)D + 32 * c + rw] = a3[r];
+        }
+        flushed = true;
+    };
 
-    long tile = blockIdx.x;
+    int tile = tbeg;
+    int n = tbeg / tps, j = tbeg - n * tps;                           // (sample, tile inside it) of `tile`
     int buf = 0;
     XS_DECL;
 #ifdef PROBAV_STAMP2
     unsigned long long xs2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xs2t = 0;
 #endif
     __syncthreads();                                   // DA pads are zero
-    {
+    if (tile < tend) {
+        cur = sample_scales(n);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d[4] = {0.f, 0.f, 0.f, 0.f};
-        if (tile < ntiles) { stage_load(tile, xv, d); stage_store(0, xv, d); }
+        stage_load(n, j, xv, d);
+        stage_store(0, j, xv, d, pow2i(cur.ex), pow2i(cur.ed));
     }
     // dX of a tile = dOut + the eight chunk partials.  The partials of tile t are reduced during iteration t+1 (after the one barrier
     // per tile), from the buffer of t's parity, while iteration t+1 fills the other one.  Waves w and w+4 reduce voxels 8(w&3) .. 8(w&3)+7.
     const int rk0 = wave < 4 ? 0 : 2;                                 // waves w and w+4 share the 8 voxels 8(w&3)..: two of the four lane slices each
-    long pv0 = -1; float pdo[4] = {0.f, 0.f, 0.f, 0.f};               // previous tile: first voxel, its dOut values
+    long pv0 = -1; int pnrem = 0, pn = -1, pkdx = 0;                  // previous tile: first voxel, live voxels, sample, exponent of its dX partials
+    float pdo[4] = {0.f, 0.f, 0.f, 0.f};                              // ... and its dOut values
     auto reduce_prev = [&](int pb) {
         if (pv0 < 0) return;
 #pragma unroll
@@ -329,30 +411,40 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             if constexpr (AR::SCALED) {
                 sacc = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sacc += TbAll[(pb * 8 + j) * PB_TB + rv * 33 + col];
-                sacc = ldexpf(sacc, kdx) + pdo[k];
+                for (int jj = 0; jj < 8; ++jj) sacc += TbAll[(pb * 8 + jj) * PB_TB + rv * 33 + col];
+                sacc = ldexpf(sacc, pkdx) + pdo[k];
             } else {
                 sacc = pdo[k];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sacc += TbAll[(pb * 8 + j) * PB_TB + rv * 33 + col];
+                for (int jj = 0; jj < 8; ++jj) sacc += TbAll[(pb * 8 + jj) * PB_TB + rv * 33 + col];
             }
-            if (pv0 + rv < nvox) { dX[(pv0 + rv) * 32 + col] = sacc; omax = fmaxf(omax, fabsf(sacc)); }
+            if (rv < pnrem) { dX[(pv0 + rv) * 32 + col] = sacc; omax = fmaxf(omax, fabsf(sacc)); }
         }
     };
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < tend; ++tile, buf ^= 1) {
         XS_ACC(5);
         __syncthreads();                               // tile `tile` is staged in buffer `buf`; the previous tile's partials are complete
         XS_ACC(1);
         float* Tb = TbAll + (buf * 8 + wave) * PB_TB;
-        const long tnext = tile + gridDim.x;
+        // the next tile of the run: (nn, nj); its sample's scales are needed for the staging at the end of this iteration
+        int nn = n, nj = j + 1;
+        if (nj == tps) { nj = 0; ++nn; }
+        const bool has_next = tile + 1 < tend;
+        const bool leaves = nn != n;                                   // this is the run's last tile of sample n (wave-uniform)
         float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};
-        if (tnext < ntiles) stage_load(tnext, nxv, nd);                 // in flight during this tile's MFMAs
-        const long v0 = tile * 32;
+        stage_load(has_next ? nn : n, has_next ? nj : j, nxv, nd);     // in flight during this tile's MFMAs (after the last tile: a harmless re-read)
+        float ch = 1.f, cg = 1.f, sbias = 1.f;                         // accumulators (a), (b) -> hidden values / hidden gradients at their own scales
+        if constexpr (AR::SCALED) {
+            const int kh = cur.eh - cur.ex - ew1, kg = cur.eg - ew2 - cur.ed;   // (<= -17 always, see the bounds)
+            ch = pow2i(kh < -126 ? -126 : kh); cg = pow2i(kg < -126 ? -126 : kg); sbias = pow2i(cur.eh);
+        }
+        const long v0 = (long)n * vps + 32 * j;
+        const int nrem = vps - 32 * j < 32 ? vps - 32 * j : 32;
         float cdo[4] = {0.f, 0.f, 0.f, 0.f};                           // dOut of this tile's voxels, consumed by the next iteration's reduction
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
-            cdo[k] = dOut[(v0 + rv < nvox ? v0 + rv : v0) * 32 + col];
+            cdo[k] = dOut[(v0 + (rv < nrem ? rv : 0)) * 32 + col];
         }
         const unsigned char* Xb = XA + buf * PB_TILE;
         const unsigned char* Db = DA + buf * PB_TILE;
@@ -377,6 +469,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             dH = mac<AR>(w2[0], df[0], dH); dH = mac<AR>(w2[1], df[1], dH);           // (b)
             __builtin_amdgcn_sched_barrier(0);
             reduce_prev(buf ^ 1);                          // LDS reads, adds and two stores in the shadow of the 24 MFMAs just issued
+            if (pn >= 0 && pn != n) {                      // the previous tile was the last one of its sample: its dX is complete now
+                if (am.y) amax_commit(omax, am.y + pn);
+                omax = 0.f;
+            }
             __builtin_amdgcn_sched_barrier(0);
             XS2(0);
             Frag gf[2][NP], hf[2][NP];
@@ -390,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 8 * kb + 4 * g + i;
-                        const float hv = fmaf(H[r], ch, bv[i]), dv = dH[r] * cg;          // (ch = cg = 1 without scaling)
+                        const float hv = fmaf(H[r], ch, bv[i] * sbias), dv = dH[r] * cg;      // (ch = cg = sbias = 1 without scaling)
                         gs[4 * g + i] = hv > 0.f ? dv : 0.f;
                         hs[4 * g + i] = fmaxf(hv, 0.f);
                         bs1v[r] += gs[4 * g + i];
@@ -446,35 +542,35 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             XS2(4);
         }
         XS_ACC(2);
-        if (tnext < ntiles) stage_store(buf ^ 1, nxv, nd);
+        if constexpr (AR::SCALED) {
+            nxt = cur;
+            if (leaves && has_next) {
+                // (d), (e) of the next tile run at another sample's scales.  The running sums move to the new scales by an exact multiplication
+                // with a power of two (fp32 keeps 2^+-40 around sums of ~2^45 without leaving its range); a jump beyond that -- a dead sample
+                // next to a bright one -- banks the sums in the slab instead and starts over.
+                nxt = sample_scales(nn);
+                const int d1 = (nxt.ex + nxt.eg) - (cur.ex + cur.eg), d2 = (nxt.ed + nxt.eh) - (cur.ed + cur.eh), d3 = nxt.eg - cur.eg;
+                const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
+                if (big > 40) flush(cur);
+                else if (big != 0) {
+                    const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
+                }
+            }
+        }
+        if (has_next) stage_store(buf ^ 1, nj, nxv, nd, pow2i(nxt.ex), pow2i(nxt.ed));
         XS_ACC(3);
-        pv0 = v0;
+        pv0 = v0; pnrem = nrem; pn = n;
+        if constexpr (AR::SCALED) pkdx = -(ew1c + cur.eg);              // (c) partials -> true values: W1's row `col` and this sample's dH scale
 #pragma unroll
         for (int k = 0; k < 4; ++k) pdo[k] = cdo[k];
+        cur = nxt; n = nn; j = nj;
     }
     __syncthreads();
     reduce_prev(buf ^ 1);
-    if (am.y) amax_commit(omax, am.y);
-    // one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]
-    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
-    float* sl = slabs + (long)blockIdx.x * slab_floats;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rw = rowmap(r, half);
-        float a1 = dW1[r], a2 = dW2t[r];
-        if constexpr (AR::SCALED) { a1 = ldexpf(a1, kdw1); a2 = ldexpf(a2, kdw2); }
-        sl[(long)rw * 256 + 32 * c + col] = a1;                                        // [cin][hidden]
-        if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = a2;                     // [hidden][out]
-    }
-    // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = bs1v[r];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-        if constexpr (AR::SCALED) v = ldexpf(v, kdb1);
-        if (col == 0) sl[8192 + 256 * (long)D + 32 * c + rowmap(r, half)] = v;
-    }
+    if (am.y && pn >= 0) amax_commit(omax, am.y + pn);
+    flush(cur);                                            // the sums of the run's last sample(s), at that sample's scales (all exponents 0 without scaling)
     // db2[out] = sum of the staged dT values: thread t always staged out (t % D) and ((t + 512) % D); fixed-order sum
     __syncthreads();
     float* R = TbAll;                                                 // R[f] = column sum of staged element f (f < 1024)
@@ -485,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     __syncthreads();
     if (tid < D) {
         float t = 0.f;
-        for (int j = tid; j < 1024; j += D) t += R[j];
+        for (int jj = tid; jj < 1024; jj += D) t += R[jj];
         sl[8192 + 256 * (long)D + 256 + tid] = t;
     }
     XS_ACC(6);
@@ -496,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 }
 
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
-                   const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, int D,
+                   const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
                    int arith, const PwAmax& am, hipStream_t s)
 {
     static bool once = false;
@@ -505,15 +601,17 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
+    if (vps <= 0 || vps > nvox) vps = nvox;
+    if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_backward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
-        if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+        if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
         const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 2 * H3::NP * PT_IMG;   // (two transpose images per wave)
         hipLaunchKernelGGL(pw_bwd_x6_kernel<H3>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
-                           (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D, am);
+                           (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);
     } else {
         const size_t lds = (size_t)4 * X6::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * X6::NP * PT_IMG;
         hipLaunchKernelGGL(pw_bwd_x6_kernel<X6>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
-                           (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, D, am);
+                           (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);
     }
     int rc = check_launch("pw_bwd_x6");
     if (rc) return rc;
@@ -554,7 +652,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     constexpr int VS = NPC * CB;                   // bytes per voxel
     constexpr int NP = (CIN + 1) / 2;              // channel pairs staged per voxel
     float sx = 1.f, sd = 1.f; int kun = 0;         // H3: scales of x (am.x) and dY (am.w), exponent that undoes both
-    if constexpr (AR::SCALED) { const int ex = h3_exp(*am.x), ed = h3_exp(*am.w); sx = pow2i(ex); sd = pow2i(ed); kun = -(ex + ed); }
+    // (the contraction runs over the voxels of ALL samples, so both operands take ONE scale: that of their largest sample)
+    if constexpr (AR::SCALED) { const int ex = h3_exp(amax_over_samples(am.x, a.N)), ed = h3_exp(amax_over_samples(am.w, a.N)); sx = pow2i(ex); sd = pow2i(ed); kun = -(ex + ed); }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const int li = lane & 15, gcol = (lane >> 4) & 1;
@@ -836,7 +935,7 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
                   int arith, const Amax& am, hipStream_t s)
 {
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
-    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_wgrad: H3 arithmetic needs the amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
+    if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
     WgArgs a;
     a.nsplit = x6_wgrad_split(g, arith); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;
     a.N = g.N; a.H = g.Ho; a.W = g.Wo; a.T = g.To; a.Cout = g.Cout; a.Hi = g.Hi; a.Wi = g.Wi; a.Ti = g.Ti;

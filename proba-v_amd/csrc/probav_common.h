@@ -28,12 +28,16 @@ struct ConvGeom {
 
 namespace probav {
 
-// amax slots of one launch (H3 arithmetic, x6_device.h): the bit pattern of the largest |value| of a tensor (a non-negative
-// float), kept in device memory.  x / w: slots of the activation operand and of the filter, read by an H3 kernel to choose its
-// power-of-two operand scales; y: slot that receives (atomicMax) the largest output magnitude, written by any kernel when set.
+// amax slots of one launch (H3 arithmetic, x6_device.h): bit patterns of largest magnitudes (non-negative floats), kept in device memory.
+//   x : the activation operand, ONE SLOT PER SAMPLE (x[n] = largest |value| of patch n)
+//   w : forward / backward-data kernels: the filter, ONE SLOT PER OUTPUT COLUMN of the packed matrix (w[col]);
+//       backward-filter kernel: the incoming gradient dY, one slot per sample like x
+//   y : receives (atomicMax) the largest output magnitude of every sample (y[n]); written by any kernel when set
 struct Amax { const unsigned* x = nullptr; const unsigned* w = nullptr; unsigned* y = nullptr; };
-// largest |x[i]| -> *slot (atomicMax; the slot must have been zeroed), for tensors whose producer does not report it
-int amax_tensor(const float* x, size_t n, unsigned* slot, hipStream_t s);
+// largest |x[n][i]|, i < per_sample, -> slots[n] for n < N (atomicMax; the slots must have been zeroed), for tensors whose producer does not report it
+int amax_tensor(const float* x, size_t per_sample, int N, unsigned* slots, hipStream_t s);
+// largest |w[r][c]| over the rows of a row-major [rows][cols] matrix -> slots[c] (cols <= 256; plain store)
+int amax_columns(const float* w, long rows, int cols, unsigned* slots, hipStream_t s);
 
 void set_error(const char* what, hipError_t e);
 int check_launch(const char* what);
@@ -58,16 +62,19 @@ struct WnLayer {            // one weight-normalised layer inside the flat param
     int n_off;                  // offset into inv_norm (floats) == running sum of Cout
     int K;                      // taps * Cin
     int Cin, Cout, taps;
+    int r_off;                  // offset into the per-input-channel amax array == running sum of Cin
 };
-// amax (optional): 2 * nlayers zeroed slots; receives the largest |effective weight| (slot l) and |bias| (slot nlayers + l) per layer
-int wn_forward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
+// amax (optional): zeroed slots [2 nlayers + cout_total + cin_total]; receives per layer l the largest |effective weight| (slot l) and
+// |bias| (slot nlayers + l), per output channel the largest |weight| of its column (slot 2 nlayers + n_off + co) and per input
+// channel that of its rows (slot 2 nlayers + cout_total + r_off + ci)
+int wn_forward(const WnLayer* d_layers, int nlayers, int max_cout_total, int cin_total, const float* params,
                float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s);
 int wn_backward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
                 const float* dweff, const float* inv_norm, float* grads, hipStream_t s);
 int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, float mean, float stdv, hipStream_t s);
 int tail_forward(const float* up, const float* r3, float* y, int N, int P, int scale, float mean, float stdv, hipStream_t s);
 int tail_backward(const float* dy, float* dtail, int N, int P, int scale, float stdv, hipStream_t s);
-int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax /* optional: receives max |dx| */, hipStream_t s);
+int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax /* optional: N slots, receive max |dx| per sample */, hipStream_t s);
 // general form: gradient of tf.pad(x, [ph, pw, pt] 'reflect') folded back onto x [N,H,W,T,C]; pads <= 2
 int reflect_fold3(const float* dpad, float* dx, int N, int H, int W, int T, int C, int ph, int pw, int pt, hipStream_t s);
 int clip_round(const float* in, float* out, size_t n, float lo, float hi, hipStream_t s);

@@ -4,9 +4,12 @@
 //   X6  three bf16 truncation pieces per value, the six largest piece products (v_mfma_f32_32x32x16_bf16).  No scaling.
 //   H3  two fp16 round-to-nearest pieces per value (a = a0 + a1 to 2^-24 |a|: the sign of a1 is the 23rd bit), three piece
 //       products a1 b0 + a0 b1 + a0 b0 (v_mfma_f32_32x32x16_f16; dropped a1 b1 <= 2^-24 |ab|) -- half the MFMAs of X6.  fp16 has
-//       5 exponent bits, so every operand TENSOR is multiplied by a power of two that puts its largest magnitude (or a bound
-//       on it) into [2^14, 2^15); the product is scaled back once, in the epilogue.  Elements down to 2^-17 of the tensor
-//       maximum keep full relative precision, smaller ones an absolute error of 2^-40 of the maximum.
+//       5 exponent bits, so every operand is multiplied by a power of two that puts the largest magnitude of its SCALING GROUP (or
+//       a bound on it) into [2^14, 2^15); the product is scaled back once, in the epilogue.  A scale may vary along an operand's
+//       free index but not along the contracted one, so the groups are: one SAMPLE (patch) of an activation / gradient tensor
+//       (samples never meet in a forward or backward-data contraction: a patch's result does not depend on its batch mates, bit
+//       for bit) and one OUTPUT COLUMN of a filter matrix.  Elements down to 2^-17 of their group's maximum keep full relative
+//       precision, smaller ones an absolute error of 2^-40 of that maximum.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -47,13 +50,28 @@ __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r
 
 // ---- H3 scaling: amax slots hold the bit pattern of a non-negative float (atomicMax on the bits orders them) ----
 // exponent e with amax * 2^e in [2^14, 2^15); 0 for an all-zero tensor; clamped so that 2^e stays a normal float
-__device__ __forceinline__ int h3_exp(unsigned amax_bits)
+// Upper clamps: a group whose maximum is below 2^-46 (activations, gradients) / 2^-16 (filters) is scaled as if it had that maximum and
+// gives up one bit per binade below it.  They bound the sum of two operand exponents by 90, so that a value of ordinary magnitude
+// brought to an accumulator's scale (the skip tile of the strip kernels) cannot overflow whatever the operands hold.
+constexpr int H3_EMAX_ACT = 60, H3_EMAX_W = 30;
+__device__ __forceinline__ int h3_exp_raw(unsigned amax_bits, int emax)
 {
     const int E = (int)((amax_bits >> 23) & 0xffu);
     const int e = E == 0 ? 0 : 141 - E;
-    return e > 126 ? 126 : e;
+    return e > emax ? emax : e;
 }
+__device__ __forceinline__ int h3_exp(unsigned amax_bits) { return h3_exp_raw(amax_bits, H3_EMAX_ACT); }      // activations, gradients, bounds on register-resident tiles
+__device__ __forceinline__ int h3_exp_w(unsigned amax_bits) { return h3_exp_raw(amax_bits, H3_EMAX_W); }      // filters
 __device__ __forceinline__ int h3_exp(float bound) { return h3_exp(__float_as_uint(bound)); }
+// largest slot of a per-sample array (wave-wide; every lane returns it): the scale of a tensor that is contracted over its samples
+__device__ __forceinline__ unsigned amax_over_samples(const unsigned* slots, int n)
+{
+    unsigned m = 0u;
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) { const unsigned v = slots[i]; m = v > m ? v : m; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)m, o, 64); m = v > m ? v : m; }
+    return m;
+}
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }      // -126 <= e <= 127
 // the largest |value| a wave has produced -> its tensor's slot (one atomic per wave)
 __device__ __forceinline__ void amax_commit(float m, unsigned* slot)

@@ -3,12 +3,13 @@
 Argument order is the reference's: ``(patchHR, maskHR, predPatchHR)`` (models/loss.py:37,55,73).  One fused
 HIP launch evaluates all (2*cropBorder+1)^2 candidate registrations of every sample and returns the
 per-sample minima of the L1 and L2 terms, the cPSNR maximum and the arg-min shifts; the backward
-launch differentiates the arg-min shift including the brightness-bias term.  The
+launch differentiates the arg-min shift including the brightness-bias term.  Both are
+torch custom ops (`torch.ops.probav.shift_loss` with its registered autograd formula, `probav.shift_metrics`).  The
 reference unrolls the same work into ~600 TensorFlow ops per step (models/loss.py:79-81).
 """
 import torch
 
-from . import _lib
+from . import _lib, ops             # noqa: F401  (ops registers torch.ops.probav.*)
 
 
 def _prep(patchHR, maskHR, predPatchHR):
@@ -25,35 +26,8 @@ def _prep(patchHR, maskHR, predPatchHR):
 
 
 def _launch_forward(hr, m, pred, border, bit_depth):
-    B, S = pred.shape[0], pred.shape[1]
-    dev = pred.device
-    f = torch.empty((3, B), dtype=torch.float32, device=dev)          # l1 | l2 | cpsnr
-    arg = torch.empty((2, B), dtype=torch.int32, device=dev)
-    means = torch.empty(2, dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().probav_shift_loss_forward(
-        _lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), B, S, border, bit_depth, _lib.ptr(f[0]), _lib.ptr(f[1]),
-        _lib.ptr(f[2]), _lib.ptr(arg[0]), _lib.ptr(arg[1]), _lib.ptr(means[0:1]), _lib.ptr(means[1:2]),
-        _lib.current_stream()), "probav_shift_loss_forward")
-    return f, arg, means
-
-
-class _ShiftLoss(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, pred, hr, m, border, bit_depth, which):
-        f, arg, means = _launch_forward(hr, m, pred, border, bit_depth)
-        ctx.save_for_backward(pred, hr, m, arg[which - 1].contiguous())
-        ctx.border, ctx.which = border, which
-        return means[which - 1].clone()
-
-    @staticmethod
-    def backward(ctx, g):
-        pred, hr, m, arg = ctx.saved_tensors
-        g = g.contiguous().float().reshape(1)
-        dpred = torch.empty_like(pred)
-        _lib.check(_lib.lib().probav_shift_loss_backward(
-            _lib.ptr(hr), _lib.ptr(m), _lib.ptr(pred), _lib.ptr(arg), pred.shape[0], pred.shape[1], ctx.border,
-            ctx.which, _lib.ptr(g), _lib.ptr(dpred), _lib.current_stream()), "probav_shift_loss_backward")
-        return dpred, None, None, None, None, None
+    """One launch for all shifts: torch.ops.probav.shift_metrics -> (f [3,B] = l1 | l2 | cpsnr, arg [2,B], means [2])."""
+    return torch.ops.probav.shift_metrics(hr, m, pred, border, bit_depth)
 
 
 class _ShiftL1Edge(torch.autograd.Function):
@@ -135,13 +109,13 @@ class Losses:
         """models/loss.py:73-84 -> scalar: mean over the batch of the minimum masked, bias-corrected L1."""
         hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
         self._check(pred)
-        return _ShiftLoss.apply(pred, hr, m, self.cropBorder, self.bitDepth, 1)
+        return torch.ops.probav.shift_loss(pred, hr, m, self.cropBorder, self.bitDepth, 1)[0]
 
     def shiftCompensatedL2Loss(self, patchHR, maskHR, predPatchHR):
         """models/loss.py:55-71."""
         hr, m, pred = _prep(patchHR, maskHR, predPatchHR)
         self._check(pred)
-        return _ShiftLoss.apply(pred, hr, m, self.cropBorder, self.bitDepth, 2)
+        return torch.ops.probav.shift_loss(pred, hr, m, self.cropBorder, self.bitDepth, 2)[0]
 
     def shiftCompensatedcPSNR(self, patchHR, maskHR, predPatchHR):
         """models/loss.py:37-53 -> [B]: maximum cPSNR over the shifts (no gradient, as in trainStep)."""

@@ -5,53 +5,17 @@ decayRate, numImgLR, patchSizeLR, isGrayScale)`` keeps the reference's names, ar
 (models/modelsTF.py:8-17) and returns a callable model: ``model(x, training=False)`` maps
 float32 ``[N, P+maxShift, P+maxShift, T, 1]`` to ``[N, scale*P, scale*P, 1]`` and exposes
 ``trainable_variables`` in the reference checkpoint's order.  All arithmetic happens in
-libprobav_hip.so (csrc/); torch only owns the device memory, the stream and the autograd edge
-(one custom Function whose backward is the engine's reverse pass).
+libprobav_hip.so (csrc/); torch only owns the device memory, the stream and the autograd edge: the model is ONE
+torch custom op, `torch.ops.probav.wdsr_forward`, whose registered autograd formula is `torch.ops.probav.wdsr_backward`
+(the engine's reverse pass) -- probav_amd/ops.py.
 """
 import ctypes
 from ctypes import c_char, c_int32, c_int64, c_void_p, byref
 
 import torch
 
-from . import _lib
+from . import _lib, ops                                 # noqa: F401  (ops registers torch.ops.probav.*)
 from .arch import layer_table
-
-
-class _WDSRFunction(torch.autograd.Function):
-    """y = model(x); backward = d loss / d (flat parameter buffer).  x gets no gradient (the reference
-    never differentiates w.r.t. the input patches)."""
-
-    @staticmethod
-    def forward(ctx, flat, x, model, training):
-        B = x.shape[0]
-        S = model.scale * model.patchSizeLR
-        y = torch.empty((B, S, S, 1), dtype=torch.float32, device=x.device)
-        ws = model._workspace(B, training)
-        L = _lib.lib()
-        _lib.check(L.probav_forward(model._handle(), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws),
-                                    ws.numel() * 4, B, 1 if training else 0, _lib.current_stream()), "probav_forward")
-        model._ws_gen += 1
-        ctx.model, ctx.B, ctx.gen, ctx.training = model, B, model._ws_gen, training
-        ctx.save_for_backward(flat)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        model = ctx.model
-        if not ctx.training:
-            raise RuntimeError("backward through model(x, training=False): call the model with training=True "
-                               "to keep the activations the reverse pass needs")
-        if ctx.gen != model._ws_gen:
-            raise RuntimeError("the engine workspace was overwritten by a later forward pass before this "
-                               "backward ran (one forward/backward pair at a time per model)")
-        (flat,) = ctx.saved_tensors
-        dy = dy.contiguous().float()
-        grads = torch.empty_like(flat)
-        ws = model._workspace(ctx.B, True)
-        L = _lib.lib()
-        _lib.check(L.probav_backward(model._handle(), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws),
-                                     ws.numel() * 4, ctx.B, _lib.current_stream()), "probav_backward")
-        return grads, None, None, None
 
 
 class WDSRModel(torch.nn.Module):
@@ -84,7 +48,6 @@ class WDSRModel(torch.nn.Module):
         self.flat = torch.nn.Parameter(flat)
         self._engine = None
         self._ws = {}
-        self._ws_gen = 0
 
     # -- reference-facing surface ------------------------------------------------------------------
     @property
@@ -132,7 +95,9 @@ class WDSRModel(torch.nn.Module):
             raise RuntimeError("model parameters are on %s but the input is on %s" % (self.flat.device, x.device))
         x = x.contiguous().float()
         need_grad = bool(training) and torch.is_grad_enabled() and self.flat.requires_grad
-        return _WDSRFunction.apply(self.flat, x, self, need_grad)
+        y, ws = torch.ops.probav.wdsr_forward(self.flat, x, int(self._handle().value), self.scale * self.patchSizeLR, need_grad)
+        self._ws = {(int(x.shape[0]), need_grad, self.flat.device): ws}     # the last call's workspace (saved activations): introspection, tests
+        return y
 
     # -- engine plumbing ---------------------------------------------------------------------------
     def _handle(self):
@@ -161,20 +126,18 @@ class WDSRModel(torch.nn.Module):
         return out
 
     def set_impl(self, impl):
-        """0 = generic direct kernels, 1 = MFMA row-tile kernels, 2 = MFMA + strip convolution (default),
-        3 = 2 with the x6 kernels (fp32 products as six bf16-piece products on the bf16 MFMA pipe)."""
+        """0 = generic direct kernels, 1 = fp32-MFMA row-tile kernels, 2 = fp32 MFMA + strip convolution,
+        3 = 2 with the x6 kernels (fp32 products as six bf16-piece products on the bf16 MFMA pipe),
+        4 (default) = the same kernels with the H3 arithmetic (three products of fp16 piece pairs, operands scaled by a power
+        of two per sample / per filter column).  Every family computes a sample independently of its batch mates, bit for bit."""
         _lib.check(_lib.lib().probav_engine_set_impl(self._handle(), int(impl)), "probav_engine_set_impl")
 
     def _workspace(self, batch, training):
-        key = (int(batch), bool(training), self.flat.device)
-        ws = self._ws.get(key)
+        """The workspace the LAST forward call of this (batch, training) shape produced (every call gets its own: an output of
+        torch.ops.probav.wdsr_forward, held by the autograd graph until its backward has run)."""
+        ws = self._ws.get((int(batch), bool(training), self.flat.device))
         if ws is None:
-            nbytes = _lib.lib().probav_workspace_bytes(self._handle(), int(batch), 1 if training else 0)
-            if nbytes == 0:
-                raise RuntimeError("probav_workspace_bytes returned 0")
-            self._ws.clear()                       # one live workspace (sized for 288 GB HBM, but no need to hoard)
-            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.flat.device)
-            self._ws[key] = ws
+            raise RuntimeError("no forward pass of batch %d (training=%s) has run on this model" % (batch, training))
         return ws
 
     def __del__(self):

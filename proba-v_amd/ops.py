@@ -1,0 +1,187 @@
+"""torch custom ops (`torch.ops.probav.*`) over the C ABI of libprobav_hip.so -- the north-star boundary: the hot path is
+"hand-written HIP kernels exposed as torch custom ops"; PyTorch owns device memory, the stream and the autograd graph, nothing else.
+
+Registered with `torch.library.custom_op` (schema, dispatcher entry, fake-tensor rule, autograd formula), so they are visible to the
+dispatcher, `torch.compile` / AOT-autograd and `torch.library.opcheck` (tests/test_gpu_ops.py):
+
+  probav::wdsr_forward(flat, x, engine, out_size, training) -> (y, ws)      model(x, training=...)      models/trainClass.py:127,139
+  probav::wdsr_backward(flat, dy, ws, engine) -> dflat                      tape.gradient(loss, vars)   models/trainClass.py:131
+  probav::shift_loss(pred, hr, mask, border, bit_depth, which) -> (loss, arg, per_sample)
+                                                                            Losses.shiftCompensatedL1Loss / L2Loss   models/loss.py:55-84
+  probav::shift_loss_backward(hr, mask, pred, arg, upstream, border, which) -> dpred
+  probav::shift_metrics(hr, mask, pred, border, bit_depth) -> (f[3,B], arg[2,B], means[2])     one launch: L1, L2, cPSNR of every sample
+  probav::nadam_step(theta, grad, m, v, lr, b1, b2, eps, c_g, c_m, c_v) -> ()                 optimizer.apply_gradients   trainClass.py:132
+  probav::clip_round(x, lo, hi) -> y                                        tf.clip_by_value + tf.round   test.py:118-119
+
+`engine` is the probav_engine* of include/probav_hip.h as an integer (the ops are stateless; the handle owns only the layer table),
+`ws` the workspace of one forward call: an OUTPUT of wdsr_forward (it carries the activations to the reverse pass, like the residuals of
+any differentiable op; torch's caching allocator recycles the block from step to step), an input of wdsr_backward.  Every op raises on CPU tensors:
+there is no fallback implementation.
+"""
+from ctypes import c_void_p
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+def _dev(t, name):
+    return _lib.require_device(t, name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the network
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _ws_floats(engine, batch, training):
+    nbytes = _lib.lib().probav_workspace_bytes(c_void_p(engine), int(batch), 1 if training else 0)
+    if nbytes == 0:
+        raise RuntimeError("probav_workspace_bytes returned 0")
+    return (nbytes + 3) // 4
+
+
+@torch.library.custom_op("probav::wdsr_forward", mutates_args=(), device_types="cuda")
+def wdsr_forward(flat: Tensor, x: Tensor, engine: int, out_size: int, training: bool) -> tuple[Tensor, Tensor]:
+    """-> (y [B, out_size, out_size, 1], ws): ws is the engine workspace of this call -- with training=True it holds the activations the
+    reverse pass needs (the op is functional: the saved state is an OUTPUT, like the residuals of any differentiable op)."""
+    _dev(x, "model input")
+    B = x.shape[0]
+    y = torch.empty((B, out_size, out_size, 1), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_ws_floats(engine, B, training), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().probav_forward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4, B,
+                                         1 if training else 0, _lib.current_stream()), "probav_forward")
+    return y, ws
+
+
+@wdsr_forward.register_fake
+def _(flat, x, engine, out_size, training):
+    B = x.shape[0]
+    return (x.new_empty((B, out_size, out_size, 1), dtype=torch.float32), x.new_empty((_ws_floats(engine, int(B), training),), dtype=torch.float32))
+
+
+@torch.library.custom_op("probav::wdsr_backward", mutates_args=("ws",), device_types="cuda")
+def wdsr_backward(flat: Tensor, dy: Tensor, ws: Tensor, engine: int) -> Tensor:
+    """d loss / d flat from d loss / d y; `ws` = the workspace the matching forward returned (its gradient buffers are scratch: mutated)."""
+    _dev(dy, "output gradient")
+    grads = torch.empty_like(flat)
+    _lib.check(_lib.lib().probav_backward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
+                                          dy.shape[0], _lib.current_stream()), "probav_backward")
+    return grads
+
+
+@wdsr_backward.register_fake
+def _(flat, dy, ws, engine):
+    return torch.empty_like(flat)
+
+
+def _wdsr_setup(ctx, inputs, output):
+    flat, x, engine, out_size, training = inputs
+    ctx.save_for_backward(flat)
+    ctx.ws, ctx.engine, ctx.training = output[1], engine, training
+
+
+def _wdsr_bwd(ctx, dy, dws):
+    if not ctx.training:
+        raise RuntimeError("backward through model(x, training=False): call the model with training=True "
+                           "to keep the activations the reverse pass needs")
+    (flat,) = ctx.saved_tensors
+    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ctx.ws, ctx.engine)
+    return g, None, None, None, None
+
+
+wdsr_forward.register_autograd(_wdsr_bwd, setup_context=_wdsr_setup)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# shift-compensated loss / metric
+# ---------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op("probav::shift_metrics", mutates_args=(), device_types="cuda")
+def shift_metrics(hr: Tensor, mask: Tensor, pred: Tensor, border: int, bit_depth: int) -> tuple[Tensor, Tensor, Tensor]:
+    _dev(pred, "predPatchHR")
+    B, S = pred.shape[0], pred.shape[1]
+    dev = pred.device
+    f = torch.empty((3, B), dtype=torch.float32, device=dev)          # l1 | l2 | cpsnr
+    arg = torch.empty((2, B), dtype=torch.int32, device=dev)
+    means = torch.empty(2, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().probav_shift_loss_forward(
+        _lib.ptr(hr), _lib.ptr(mask), _lib.ptr(pred), B, S, border, bit_depth, _lib.ptr(f[0]), _lib.ptr(f[1]),
+        _lib.ptr(f[2]), _lib.ptr(arg[0]), _lib.ptr(arg[1]), _lib.ptr(means[0:1]), _lib.ptr(means[1:2]),
+        _lib.current_stream()), "probav_shift_loss_forward")
+    return f, arg, means
+
+
+@shift_metrics.register_fake
+def _(hr, mask, pred, border, bit_depth):
+    B = pred.shape[0]
+    return (pred.new_empty((3, B), dtype=torch.float32), pred.new_empty((2, B), dtype=torch.int32), pred.new_empty((2,), dtype=torch.float32))
+
+
+@torch.library.custom_op("probav::shift_loss_backward", mutates_args=(), device_types="cuda")
+def shift_loss_backward(hr: Tensor, mask: Tensor, pred: Tensor, arg: Tensor, upstream: Tensor, border: int, which: int) -> Tensor:
+    _dev(pred, "predPatchHR")
+    dpred = torch.empty_like(pred)
+    _lib.check(_lib.lib().probav_shift_loss_backward(
+        _lib.ptr(hr), _lib.ptr(mask), _lib.ptr(pred), _lib.ptr(arg), pred.shape[0], pred.shape[1], border,
+        which, _lib.ptr(upstream), _lib.ptr(dpred), _lib.current_stream()), "probav_shift_loss_backward")
+    return dpred
+
+
+@shift_loss_backward.register_fake
+def _(hr, mask, pred, arg, upstream, border, which):
+    return torch.empty_like(pred)
+
+
+@torch.library.custom_op("probav::shift_loss", mutates_args=(), device_types="cuda")
+def shift_loss(pred: Tensor, hr: Tensor, mask: Tensor, border: int, bit_depth: int, which: int) -> tuple[Tensor, Tensor, Tensor]:
+    """which = 1: L1 (models/loss.py:73-84), 2: L2 (:55-71) -> (batch-mean loss [scalar], arg-min shift per sample [B], per-sample minima [B])."""
+    f, arg, means = torch.ops.probav.shift_metrics(hr, mask, pred, border, bit_depth)
+    return means[which - 1].clone(), arg[which - 1].clone(), f[which - 1].clone()
+
+
+@shift_loss.register_fake
+def _(pred, hr, mask, border, bit_depth, which):
+    B = pred.shape[0]
+    return (pred.new_empty((), dtype=torch.float32), pred.new_empty((B,), dtype=torch.int32), pred.new_empty((B,), dtype=torch.float32))
+
+
+def _shift_setup(ctx, inputs, output):
+    pred, hr, mask, border, bit_depth, which = inputs
+    ctx.save_for_backward(pred, hr, mask, output[1])
+    ctx.border, ctx.which = border, which
+
+
+def _shift_bwd(ctx, g_loss, g_arg, g_per):
+    pred, hr, mask, arg = ctx.saved_tensors
+    dpred = torch.ops.probav.shift_loss_backward(hr, mask, pred, arg, g_loss.contiguous().float().reshape(1), ctx.border, ctx.which)
+    return dpred, None, None, None, None, None
+
+
+shift_loss.register_autograd(_shift_bwd, setup_context=_shift_setup)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# optimizer update, inference epilogue
+# ---------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op("probav::nadam_step", mutates_args=("theta", "m", "v"), device_types="cuda")
+def nadam_step(theta: Tensor, grad: Tensor, m: Tensor, v: Tensor, lr: float, beta_1: float, beta_2: float, eps: float,
+               c_g: float, c_m: float, c_v: float) -> None:
+    _dev(theta, "parameter")
+    _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(theta), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), theta.numel(), lr, beta_1, beta_2, eps,
+                                            c_g, c_m, c_v, _lib.current_stream()), "probav_nadam_step")
+
+
+@nadam_step.register_fake
+def _(theta, grad, m, v, lr, beta_1, beta_2, eps, c_g, c_m, c_v):
+    return None
+
+
+@torch.library.custom_op("probav::clip_round", mutates_args=(), device_types="cuda")
+def clip_round(x: Tensor, lo: float, hi: float) -> Tensor:
+    _dev(x, "clip_round input")
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().probav_clip_round(_lib.ptr(x), _lib.ptr(out), x.numel(), lo, hi, _lib.current_stream()), "probav_clip_round")
+    return out
+
+
+@clip_round.register_fake
+def _(x, lo, hi):
+    return torch.empty_like(x)

@@ -9,7 +9,7 @@ only the stitched uint16-range image returns to the host.
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops            # noqa: F401  (ops registers torch.ops.probav.*)
 
 
 def _device_of(model):
@@ -23,9 +23,7 @@ def resolve_device(model, lr_batch):
     x = x.to(device=dev, dtype=torch.float32)
     with torch.no_grad():
         sr = model(x, training=False)
-        out = torch.empty_like(sr)
-        _lib.check(_lib.lib().probav_clip_round(_lib.ptr(sr), _lib.ptr(out), sr.numel(), 0.0, float(2 ** 16),
-                                                _lib.current_stream()), "probav_clip_round")
+        out = torch.ops.probav.clip_round(sr, 0.0, float(2 ** 16))
     return out
 
 
@@ -41,6 +39,21 @@ def resolveByBatch(model, lr_batch, batch_size=16):
     if rem:
         cache.append(resolve(model, lr_batch[batch_size * n: batch_size * n + rem]))
     return np.concatenate(cache)
+
+
+def resolveBySampleAveraging(model, lr_batch, rng=None):
+    """test.py:137-146: the mean over 20 predictions, each on a cumulative random permutation of the LR frames (axis 3); every
+    prediction is clipped and rounded (it goes through `resolve`) before the mean.  `rng`: numpy Generator (the reference draws
+    from the global numpy state).  Returns a device tensor [b, 3P, 3P, 1]."""
+    rng = np.random.default_rng() if rng is None else rng
+    x = torch.as_tensor(np.ascontiguousarray(lr_batch) if isinstance(lr_batch, np.ndarray) else lr_batch).to(_device_of(model))
+    acc = None
+    for _ in range(20):
+        idx = torch.as_tensor(rng.permutation(x.shape[3])).to(x.device)
+        x = x.index_select(3, idx)                            # the permutations compound, as in the reference
+        sr = resolve_device(model, x.contiguous())
+        acc = sr.double() if acc is None else acc + sr.double()
+    return (acc / 20.0).float()
 
 
 def reconstruct_from_patches(images):
@@ -117,7 +130,9 @@ def stitch_device(sr, sets):
 
 def resolve_images(model, patches, micro_batch=2048):
     """All image sets at once: patches [sets, n*n, P+s, P+s, T, 1] -> uint16-range images [sets, 3nP, 3nP] (device tensor).
-    Samples are independent, so any micro-batch gives bit-identical pixels to the reference's batches of 16."""
+    Samples are independent in every kernel family (models/modelsTF.py:15-43 has no cross-sample term; the H3 kernels scale their
+    operands per sample), so any micro-batch gives bit-identical pixels to the reference's batches of 16
+    (tests/test_gpu_h3_range.py::test_forward_is_bitwise_independent_of_the_batch)."""
     dev = _device_of(model)
     p = torch.as_tensor(patches)
     sets = p.shape[0]
@@ -126,3 +141,11 @@ def resolve_images(model, patches, micro_batch=2048):
     for i in range(0, flat.shape[0], micro_batch):
         outs.append(resolve_device(model, flat[i:i + micro_batch].to(dev)))
     return stitch_device(torch.cat(outs), sets)
+
+
+def evaluate_device(model, X_test_patches, micro_batch=2048):
+    """test.py:103-111 through the device pipeline: every image set in micro-batches of `micro_batch` patches (16 = the reference's
+    resolveByBatch), clip / round and the 8 x 8 stitch on the device, ONE copy back.  Returns a list of [384, 384, 1] float64 arrays,
+    element for element what `evaluate` returns."""
+    imgs = resolve_images(model, X_test_patches, micro_batch=micro_batch).cpu().numpy().astype(np.float64)
+    return [im[:, :, None] for im in imgs]

@@ -223,7 +223,7 @@ class HipNadam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        from . import _lib
+        from . import _lib, ops                          # noqa: F401  (ops registers torch.ops.probav.nadam_step)
         for group in self.param_groups:
             b1, b2 = group["beta_1"], group["beta_2"]
             for p in group["params"]:
@@ -244,9 +244,7 @@ class HipNadam(torch.optim.Optimizer):
                 c_m = mu_t1 / (1.0 - pi_t * mu_t1)
                 c_v = 1.0 / (1.0 - b2 ** t)
                 g = p.grad.contiguous()
-                _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]), p.numel(),
-                                                        group["lr"], b1, b2, group["epsilon"], c_g, c_m, c_v,
-                                                        _lib.current_stream()), "probav_nadam_step")
+                torch.ops.probav.nadam_step(p, g, st["m"], st["v"], group["lr"], b1, b2, group["epsilon"], c_g, c_m, c_v)
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -259,7 +257,7 @@ class HipAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        from . import _lib
+        from . import _lib, ops                          # noqa: F401  (ops registers torch.ops.probav.nadam_step)
         for group in self.param_groups:
             b1, b2 = group["beta_1"], group["beta_2"]
             for p in group["params"]:
@@ -273,9 +271,7 @@ class HipAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 t = st["step"]
                 c_m = (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
-                _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(p), _lib.ptr(p.grad.contiguous()), _lib.ptr(st["m"]), _lib.ptr(st["v"]), p.numel(),
-                                                        group["lr"], b1, b2, group["epsilon"], 0.0, c_m, 1.0,
-                                                        _lib.current_stream()), "probav_nadam_step")
+                torch.ops.probav.nadam_step(p, p.grad.contiguous(), st["m"], st["v"], group["lr"], b1, b2, group["epsilon"], 0.0, c_m, 1.0)
 
 
 class HipSGD(torch.optim.Optimizer):
@@ -286,7 +282,7 @@ class HipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        from . import _lib
+        from . import _lib, ops                          # noqa: F401  (ops registers torch.ops.probav.nadam_step)
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -295,9 +291,7 @@ class HipSGD(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
-                _lib.check(_lib.lib().probav_nadam_step(_lib.ptr(p), _lib.ptr(p.grad.contiguous()), _lib.ptr(st["m"]), _lib.ptr(st["v"]), p.numel(),
-                                                        group["lr"], 0.0, 0.0, 1.0, 1.0, 0.0, 0.0,
-                                                        _lib.current_stream()), "probav_nadam_step")
+                torch.ops.probav.nadam_step(p, p.grad.contiguous(), st["m"], st["v"], group["lr"], 0.0, 0.0, 1.0, 1.0, 0.0, 0.0)
 
 
 def make_optimizer(name, model, learning_rate):

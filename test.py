@@ -2,8 +2,8 @@
 """Inference CLI with the reference's flags and flow (test.py:25-100): --cfg --band --totest.
 
 Loads <preprocessing_out>/resolverDir/<TEST|TRAIN>patchesLR_<band>.npy ([sets, 64, T, 1, 22, 22]), restores the latest
-checkpoint, resolves every image set patch-wise on the MI355X engine (micro-batches of 16, clip to [0, 2**16], round
-half to even), stitches 8 x 8 patches into 384 x 384 and writes uint16 PNGs named imgsetNNNN.png, skipping the ids in
+checkpoint, resolves every image set patch-wise on the MI355X engine (all sets in micro-batches of --micro-batch patches; forward, clip to
+[0, 2**16], round half to even and the 8 x 8 stitch into 384 x 384 stay on the device) and writes uint16 PNGs named imgsetNNNN.png, skipping the ids in
 removedTrainSets<band>.txt exactly as the reference does.
 """
 import argparse
@@ -16,7 +16,7 @@ import torch
 from probav_amd.modelsTF import WDSRConv3D
 from probav_amd.parseConfig import parseConfig
 from probav_amd.pngio import imsave_uint16
-from probav_amd.testClass import evaluate
+from probav_amd.testClass import evaluate, evaluate_device
 from probav_amd.trainClass import ModelTrainer
 
 logging.basicConfig(format="%(asctime)s - %(message)s", level=logging.INFO)
@@ -31,6 +31,10 @@ def parser():
     p.add_argument("--cfg", default="cfg/FINAL.cfg", type=str)
     p.add_argument("--band", type=str, default="RED")
     p.add_argument("--totest", type=str, default="TEST")
+    p.add_argument("--micro-batch", type=int, default=2048, help="patches per forward launch; 16 = the reference's resolveByBatch (test.py:125). "
+                   "Samples are independent, so the images do not depend on it")
+    p.add_argument("--reference-loop", action="store_true", help="the reference's own host loop: per image set, micro-batches of 16, one "
+                   "device-to-host copy per micro-batch (4x slower; same pixels)")
     return p.parse_args()
 
 
@@ -49,7 +53,7 @@ def main(config, opt):
     ckptDir = os.path.join(config["model_out"], "ckpt_%s" % basename, opt.band)
     ModelTrainer(model, None, None, None, ckptDir, os.path.join(config["model_out"], "logs_%s" % basename, opt.band))   # restores the latest checkpoint
     logger.info("[ INFO ] Generating predictions...")
-    y_preds = evaluate(model, patchLR)
+    y_preds = evaluate(model, patchLR) if opt.reference_loop else evaluate_device(model, patchLR, micro_batch=opt.micro_batch)
 
     band = opt.band.upper()
     toOmit = []

@@ -52,6 +52,18 @@ def make(T, seed_w, seed_x, batch=2):
                 out["grad/%s/%s" % (name, key)] = a
     out["grad_norms"] = np.array(norms)
     np.savez_compressed(os.path.join(HERE, "wdsr_t%d_b%d.npz" % (T, batch)), **out)
+    if T == 9:
+        # ALL 132 gradient tensors of the headline network, element-wise (a norm cannot see a wrong direction): the fp64
+        # gradient rounded to fp32, flat in the engine's parameter order ([g | v | bias] per layer, probav_amd.arch.layer_table)
+        from probav_amd.arch import layer_table
+        layers, total = layer_table(numImgLR=T)
+        gflat = np.zeros(total, np.float64)
+        for L in layers:
+            g = grads[L.name]
+            gflat[L.g_off:L.v_off] = g["g"].numpy()
+            gflat[L.v_off:L.b_off] = g["v"].numpy().reshape(-1)
+            gflat[L.b_off:L.b_off + L.cout] = g["bias"].numpy()
+        np.savez_compressed(os.path.join(HERE, "wdsr_t%d_b%d_grads.npz" % (T, batch)), grad_flat=gflat.astype(np.float32))
     print("T=%d: loss %.6f  cpsnr %s  |pred| max %.1f" % (T, float(loss), out["cpsnr"], np.abs(out["pred"]).max()))
 
 

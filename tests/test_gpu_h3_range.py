@@ -1,0 +1,276 @@
+"""H3 arithmetic (impl 4, the default kernel family) under INTRA-TENSOR dynamic range (lead item).
+
+H3 evaluates an fp32 product as three products of fp16 piece pairs and therefore scales its operands by powers of two.  A
+scale may vary along an operand's free index, never along the contracted one; the kernels scale per SAMPLE (activations and
+gradients: a patch never meets another patch in a forward / backward-data contraction) and per OUTPUT COLUMN (filters).  These
+tests put the dynamic range where a per-tensor scale would lose it and judge every output slice -- one sample, one output
+channel -- against ITS OWN maximum, holding impl 4 to the bound the native fp32-MFMA kernels (impl 2) meet on the same inputs:
+
+  * a near-zero sample (2^-30) next to a full-scale one, and a 2^20 outlier voxel inside one sample;
+  * filter columns with log-uniform gains over 2^-30 .. 1;
+  * channel gains on the CONTRACTED index (input channels): the small channels' contributions are small in every output, so the
+    per-slice error stays at fp32 level although those inputs are represented coarsely;
+  * the one documented limit: in the backward-FILTER products the contraction runs over voxels, the slices are (cin, cout) pairs,
+    and the operands are scaled per tensor -- a channel 2^-30 below its tensor mates gets a coarse gradient slice (graceful: the
+    error stays below 2^-38 of the product of the tensor maxima, test_wgrad_limit_is_graceful).
+
+The forward result of a sample does not depend on its batch mates, bit for bit (the reference's model(x) has no cross-sample
+term, models/modelsTF.py:15-43): test_forward_is_bitwise_independent_of_the_batch."""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wdsr_numpy as on
+from probav_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _L():
+    from probav_amd import _lib as L
+    return L
+
+
+def _geom(N, Hi, Wi, Ti, Cin, Ho, Wo, To, Cout, k, pad, reflect=0, relu=0):
+    return (ctypes.c_int32 * 17)(N, Hi, Wi, Ti, Cin, Ho, Wo, To, Cout, k[0], k[1], k[2], pad[0], pad[1], pad[2], reflect, relu)
+
+
+def _t(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
+
+
+def _gains(rng, n, lo=-30):
+    g = 2.0 ** rng.uniform(lo, 0, size=n)
+    g[rng.integers(n)] = 1.0
+    g[rng.integers(n)] = 2.0 ** lo
+    return g.astype(np.float32)
+
+
+def _slice_err(got, ref, axes):
+    """max over slices of  max|got - ref| / max|ref|  with the maxima taken over `axes` (the axes INSIDE a slice)."""
+    num = np.abs(got.astype(np.float64) - ref).max(axis=axes)
+    den = np.abs(ref).max(axis=axes)
+    return float((num / np.maximum(den, 1e-300)).max())
+
+
+def _conv(dev, impl, g, x, w, bias=None, skip=None, gate=None):
+    L = _L()
+    N, ho, Cout = g[0], (g[5], g[6], g[7]), g[8]
+    y = torch.full((N,) + ho + (Cout,), float("nan"), device=dev)
+    args = [_t(a, dev) if a is not None else None for a in (x, gate, w, bias, skip)]
+    L.check(L.lib().probav_conv3d_forward(ctypes.byref(g), *[L.ptr(a) for a in args], L.ptr(y), impl, L.current_stream()), "probav_conv3d_forward")
+    return y.cpu().numpy()
+
+
+def _oracle_conv(x, w, bias, skip, pad):
+    xp = np.pad(np.asarray(x, np.float64), [(0, 0), (pad[0],) * 2, (pad[1],) * 2, (pad[2],) * 2, (0, 0)])
+    y = on.conv_valid(xp, w)
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64)
+    if skip is not None:
+        y = y + np.asarray(skip, np.float64)
+    return y
+
+
+# normConv forward (pstrip<25>), its backward-data (pstrip<32>), a reducer (row-tile kernel)
+CASES = [("normConv same 25->32 + skip", 4, (22, 22, 9), 25, 32, (1, 1, 1), True),
+         ("bwd-data of normConv: same 32->25", 4, (22, 22, 9), 32, 25, (1, 1, 1), False),
+         ("convReducer valid 32->32", 4, (22, 22, 7), 32, 32, (0, 0, 0), False)]
+BAR = 2e-6          # per-slice bound the native fp32-MFMA kernels meet on every case below (asserted for impl 2 as well)
+
+
+@pytest.mark.parametrize("impl", [2, 4])
+@pytest.mark.parametrize("scenario", ["dead_sample", "outlier_voxel", "filter_column_gains", "input_channel_gains", "everything"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_forward_slices_under_dynamic_range(dev, case, scenario, impl):
+    name, N, hwt, Cin, Cout, pad, use_skip = case
+    rng = np.random.default_rng(zlib.crc32((name + scenario).encode()))
+    ho = tuple(hwt[i] + 2 * pad[i] - 2 for i in range(3))
+    x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, Cin, Cout)) / np.sqrt(27 * Cin)).astype(np.float32)
+    skip = None
+    if scenario in ("dead_sample", "everything"):
+        x[1] *= np.float32(2.0 ** -30)                            # a near-zero patch between full-scale ones
+        x[2] *= np.float32(2.0 ** 11)
+    if scenario in ("outlier_voxel", "everything"):
+        x[0, 7, 9, 2, :] *= np.float32(2.0 ** 20)                 # one hot voxel: everything else of that sample sits 2^-20 below the maximum
+    if scenario in ("filter_column_gains", "everything"):
+        w *= _gains(rng, Cout)                                    # output channels 2^-30 .. 1
+    if scenario in ("input_channel_gains", "everything"):
+        x *= _gains(rng, Cin, -24)                                # CONTRACTED channels 2^-24 .. 1
+    if use_skip:                                                   # a skip tile of the output's own magnitude, per sample and channel
+        ref0 = _oracle_conv(x, w, None, None, pad)
+        skip = (rng.normal(size=ref0.shape) * np.abs(ref0).max(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
+    g = _geom(N, hwt[0], hwt[1], hwt[2], Cin, ho[0], ho[1], ho[2], Cout, (3, 3, 3), pad)
+    try:
+        y = _conv(dev, impl, g, x, w, None, skip)
+    except ValueError:
+        pytest.skip("geometry not covered by this kernel family's strip kernel")
+    ref = _oracle_conv(x, w, None, skip, pad)
+    e_slice = _slice_err(y, ref, (1, 2, 3))                       # slice = (sample, output channel)
+    print("impl %d %s / %s: worst (sample, channel) slice error %.3g" % (impl, name, scenario, e_slice))
+    assert e_slice < BAR, (name, scenario, impl, e_slice)
+
+
+@pytest.mark.parametrize("impl", [2, 4])
+@pytest.mark.parametrize("scenario", ["dead_sample", "outlier_voxel", "w2_column_gains", "input_channel_gains"])
+def test_fused_pointwise_slices_under_dynamic_range(dev, scenario, impl):
+    L = _L()
+    D, vps, ns = 25, 22 * 22 * 3, 3
+    nvox = vps * ns
+    rng = np.random.default_rng(zlib.crc32(scenario.encode()))
+    x = rng.normal(size=(ns, vps, 32)).astype(np.float32)
+    w1 = (rng.normal(size=(32, 256)) / np.sqrt(32)).astype(np.float32)
+    b1 = rng.normal(scale=0.3, size=256).astype(np.float32)
+    w2 = (rng.normal(size=(256, D)) / 16).astype(np.float32)
+    b2 = np.zeros(D, np.float32)
+    ddec = rng.normal(size=(ns, vps, D)).astype(np.float32)
+    dskip = np.zeros((ns, vps, 32), np.float32)
+    if scenario == "dead_sample":
+        x[1] *= np.float32(2.0 ** -30); b1[:] = 0                 # (with a bias the hidden units of a dead sample ARE the bias: nothing to resolve)
+        ddec[2] *= np.float32(2.0 ** -30)
+    if scenario == "outlier_voxel":
+        x[0, 100] *= np.float32(2.0 ** 20); ddec[1, 7] *= np.float32(2.0 ** 20)
+    if scenario == "w2_column_gains":
+        w2 *= _gains(rng, D)
+    if scenario == "input_channel_gains":
+        x *= _gains(rng, 32, -24)
+    X, W1, W2 = x.reshape(nvox, 32).astype(np.float64), w1.astype(np.float64), w2.astype(np.float64)
+    Hpre = X @ W1 + b1
+    Hh = np.maximum(Hpre, 0)
+    ref = (Hh @ W2 + b2).reshape(ns, vps, D)
+    xd, w1d, b1d, w2d, b2d, ddd, dsd = (_t(a, dev) for a in (x, w1, b1, w2, b2, ddec, dskip))
+    dec = torch.full((nvox, D), float("nan"), device=dev)
+    L.check(L.lib().probav_pw_forward(L.ptr(xd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(dec), nvox, vps, D, impl, L.current_stream()))
+    e_fwd = _slice_err(dec.cpu().numpy().reshape(ns, vps, D), ref, (1,))
+    nbytes = L.lib().probav_pw_backward_scratch_bytes(D)
+    scratch = torch.empty(nbytes // 4 + 1, device=dev)
+    dH = (ddec.reshape(nvox, D).astype(np.float64) @ W2.T) * (Hpre > 0)
+    rdx = (dH @ W1.T).reshape(ns, vps, 32)
+    dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
+    dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
+    L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
+                                       L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, vps, D, impl, L.current_stream()))
+    e_dx = _slice_err(dx.cpu().numpy().reshape(ns, vps, 32), rdx, (1,))
+    # the weight gradients sum over the samples: whole-tensor metric (a dead sample contributes nothing, by construction)
+    e_dw1 = np.abs(dw1.cpu().double().numpy() - X.T @ dH).max() / np.abs(X.T @ dH).max()
+    e_dw2 = np.abs(dw2.cpu().double().numpy() - Hh.T @ ddec.reshape(nvox, D)).max() / np.abs(Hh.T @ ddec.reshape(nvox, D)).max()
+    print("impl %d pointwise / %s: forward slice %.3g, dX slice %.3g, dW1 %.3g, dW2 %.3g" % (impl, scenario, e_fwd, e_dx, e_dw1, e_dw2))
+    assert e_fwd < 5e-6 and e_dx < 5e-6 and e_dw1 < 5e-6 and e_dw2 < 5e-6, (scenario, impl, e_fwd, e_dx, e_dw1, e_dw2)
+
+
+def _wgrad(dev, impl, g, x, dy):
+    L = _L()
+    nbytes = L.lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(g), impl)
+    scratch = torch.empty(nbytes // 4 + 1, device=dev)
+    dw, db = torch.empty((3, 3, 3, g[4], g[8]), device=dev), torch.empty((g[8],), device=dev)
+    xd, dd = _t(x, dev), _t(dy, dev)
+    L.check(L.lib().probav_conv3d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dd), None, L.ptr(dw), L.ptr(db), L.ptr(scratch), nbytes, impl, L.current_stream()))
+    return dw.cpu().double().numpy()
+
+
+def _oracle_wgrad(x, dy, pad):
+    xp = np.pad(x.astype(np.float64), [(0, 0), (pad,) * 2, (pad,) * 2, (pad,) * 2, (0, 0)])
+    N, H, W, T, _ = dy.shape
+    out = np.zeros((3, 3, 3, x.shape[-1], dy.shape[-1]))
+    d = dy.astype(np.float64)
+    for a in range(3):
+        for b in range(3):
+            for c in range(3):
+                out[a, b, c] = np.einsum("nhwti,nhwto->io", xp[:, a:a + H, b:b + W, c:c + T, :], d)
+    return out
+
+
+@pytest.mark.parametrize("impl", [1, 4])
+@pytest.mark.parametrize("scenario", ["dead_sample", "outlier_voxel"])
+def test_wgrad_under_sample_and_voxel_range(dev, scenario, impl):
+    """Backward-filter: a dead sample and a hot voxel do not cost the filter gradient anything (judged per (cin, cout) slice = per element)."""
+    rng = np.random.default_rng(zlib.crc32(("wg" + scenario).encode()))
+    N, hwt, Cin, Cout = 3, (22, 22, 9), 25, 32
+    x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
+    dy = rng.normal(size=(N,) + hwt + (Cout,)).astype(np.float32)
+    if scenario == "dead_sample":
+        x[1] *= np.float32(2.0 ** -30); dy[1] *= np.float32(2.0 ** -30)
+    else:
+        x[0, 5, 5, 4] *= np.float32(2.0 ** 20)
+    g = _geom(N, 22, 22, 9, Cin, 22, 22, 9, Cout, (3, 3, 3), (1, 1, 1))
+    ref = _oracle_wgrad(x, dy, 1)
+    got = _wgrad(dev, impl, g, x, dy)
+    e = _slice_err(got, ref, (0, 1, 2))                           # slice = (cin, cout): the 27 taps of one filter plane
+    print("impl %d wgrad / %s: worst (cin, cout) slice error %.3g" % (impl, scenario, e))
+    assert e < 1e-5, (scenario, impl, e)
+
+
+def test_wgrad_limit_is_graceful(dev):
+    """The documented limit of H3: the backward-filter product contracts over voxels (over ALL samples), so its operands are scaled per
+    TENSOR; an input channel far below its tensor mates is represented coarsely and ITS gradient slices lose relative accuracy -- gradually:
+    channels down to 2^-10 of the tensor maximum keep fp32-level slices (values down to 2^-17 of the maximum have both fp16 pieces normal),
+    the smallest channel here (2^-24) still has 1e-2; the whole-tensor metric does not see any of it, and the x6 family (impl 3, no
+    scaling) resolves every slice."""
+    rng = np.random.default_rng(7)
+    N, hwt, Cin, Cout = 2, (22, 22, 9), 25, 32
+    x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
+    dy = rng.normal(size=(N,) + hwt + (Cout,)).astype(np.float32)
+    gains = _gains(rng, Cin, -24)
+    x *= gains
+    g = _geom(N, 22, 22, 9, Cin, 22, 22, 9, Cout, (3, 3, 3), (1, 1, 1))
+    ref = _oracle_wgrad(x, dy, 1)
+    got4, got3 = _wgrad(dev, 4, g, x, dy), _wgrad(dev, 3, g, x, dy)
+    assert np.abs(got4 - ref).max() < 2e-6 * np.abs(ref).max()                      # the whole-tensor metric does not see it at all
+    per3 = np.abs(got3 - ref).max(axis=(0, 1, 2, 4)) / np.abs(ref).max(axis=(0, 1, 2, 4))          # slice = input channel
+    per4 = np.abs(got4 - ref).max(axis=(0, 1, 2, 4)) / np.abs(ref).max(axis=(0, 1, 2, 4))
+    for c in np.argsort(gains):
+        print("input channel gain 2^%6.2f: slice error x6 %.2e  H3 %.2e" % (np.log2(gains[c]), per3[c], per4[c]))
+    assert per3.max() < 1e-5
+    assert per4[gains >= 2.0 ** -10].max() < 1e-5 and per4.max() < 1e-2
+
+
+def _model(dev, params, T=9):
+    from probav_amd.modelsTF import WDSRConv3D
+    m = WDSRConv3D("t", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, True, seed=0)
+    m.load_variables(params)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("impl", [4, 3, 2])
+def test_forward_is_bitwise_independent_of_the_batch(dev, impl):
+    """model(x) of the reference has no cross-sample term (models/modelsTF.py:15-43): a patch's prediction must not depend on what
+    else is in the batch or on the micro-batch size -- bit for bit, for the default H3 family too (per-sample operand scales)."""
+    m = _model(dev, synth.synth_params(seed=41, perturb=True))
+    m.set_impl(impl)
+    x = synth.synth_batch(48, seed=42)[0]
+    x[5] *= np.float32(1e-3)                                      # a dim patch and a saturated one among ordinary ones
+    x[6] = np.clip(x[6] * 3.0, 0, 65535)
+    xd = torch.as_tensor(x).to(dev)
+    with torch.no_grad():
+        full = m(xd, training=False).clone()
+        for lo, hi in ((0, 16), (16, 32), (5, 7), (6, 7), (40, 48)):
+            part = m(xd[lo:hi].contiguous(), training=False)
+            assert torch.equal(part, full[lo:hi]), (impl, lo, hi)
+        perm = torch.randperm(48, generator=torch.Generator().manual_seed(0)).to(dev)
+        shuffled = m(xd[perm].contiguous(), training=False)
+        assert torch.equal(shuffled, full[perm]), impl
+    # the training forward (saves activations) gives the same bits as the inference forward
+    assert torch.equal(m(xd[:16].contiguous(), training=True).detach(), full[:16])
+
+
+def test_end_to_end_with_a_dead_and_a_bright_patch(dev):
+    """Whole network, default family: a patch at 2^-8 of the usual radiometry and one at 4x next to ordinary ones -- every sample's
+    prediction within 1e-5 of the fp64 oracle relative to ITS OWN range (north_star: 1e-3)."""
+    from oracle import wdsr_torch as ot
+    params = synth.synth_params(seed=51, perturb=True)
+    m = _model(dev, params)
+    x = synth.synth_batch(4, seed=52)[0]
+    x[1] = (x[1] - synth.NIR_MEAN) * np.float32(2.0 ** -8) + np.float32(synth.NIR_MEAN)      # a nearly flat patch (tiny normalised values)
+    x[2] = np.clip(x[2] * 4.0, 0, 65535)
+    with torch.no_grad():
+        y = m(torch.as_tensor(x).to(dev), training=False).cpu().double().numpy()
+    ref = ot.wdsr_forward(torch.tensor(x, dtype=torch.float64), ot.to_torch_params(params, requires_grad=False), synth.NIR_MEAN, synth.NIR_STD).numpy()
+    for n in range(4):
+        dev_n = np.abs(ref[n] - synth.NIR_MEAN).max()             # the sample's own signal range around the band mean
+        e = np.abs(y[n] - ref[n]).max() / max(dev_n, 1.0)
+        print("sample %d: |y - ref| max / own range = %.3g" % (n, e))
+        assert e < 1e-5, (n, e)

@@ -335,6 +335,17 @@ def test_end_to_end_against_golden(dev, T, impl):
     grads = [g.cpu().double().numpy() for g in m.variable_gradients()]
     names = m.variable_names
     assert len(grads) == z["grad_norms"].shape[0]
+    if T == 9:
+        # ALL 132 gradient tensors element-wise against the committed fp64 gradient (tests/golden/wdsr_t9_b2_grads.npz): a norm cannot
+        # see a wrong direction.  Metric here: relative L2 per tensor (ReLU gates at ~0 flip between an fp32 and an fp64 evaluation;
+        # test_gradients_match_oracle_with_the_devices_relu_masks removes exactly that effect and then holds 1e-3 in the max norm).
+        gref = np.load(os.path.join(GOLD, "wdsr_t9_b2_grads.npz"))["grad_flat"].astype(np.float64)
+        gdev = m.flat.grad.detach().cpu().double().numpy()
+        for L_ in m.layers:
+            for key, lo, hi in (("g", L_.g_off, L_.v_off), ("v", L_.v_off, L_.b_off), ("bias", L_.b_off, L_.b_off + L_.cout)):
+                tol = 2e-2 if key == "g" else 5e-3
+                err = np.sqrt(((gdev[lo:hi] - gref[lo:hi]) ** 2).sum()) / (np.sqrt((gref[lo:hi] ** 2).sum()) + 1e-30)
+                assert err < tol, (L_.name, key, err)
     for k, (n, g) in enumerate(zip(names, grads)):
         ref_norm, ref_max = z["grad_norms"][k]
         # Metric: relative L2 error per tensor.  Element-wise maxima are not meaningful for these gradients: one
@@ -371,7 +382,7 @@ def test_fused_pointwise_forward_backward(dev, nvox):
     ref = Hh @ W2 + b2
     for impl in (2, 3, 4):                    # native fp32 MFMA, the six-product bf16 split and the three-product fp16 split: one tolerance
         dec = torch.full((nvox, D), float("nan"), device=dev)
-        L.check(L.lib().probav_pw_forward(L.ptr(xd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(dec), nvox, D, impl,
+        L.check(L.lib().probav_pw_forward(L.ptr(xd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(dec), nvox, 0, D, impl,
                                           L.current_stream()))
         err = np.abs(dec.cpu().double().numpy() - ref).max() / np.abs(ref).max()
         print("pw_forward impl %d nvox %d: max err / max |ref| = %.3g" % (impl, nvox, err))
@@ -384,7 +395,7 @@ def test_fused_pointwise_forward_backward(dev, nvox):
         dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
         dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
         L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
-                                           L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, D, impl, L.current_stream()))
+                                           L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, 0, D, impl, L.current_stream()))
         for name, got in (("dx", dx), ("dw1", dw1), ("db1", db1), ("dw2", dw2), ("db2", db2)):
             r = refs[name]
             err = np.abs(got.cpu().double().numpy() - r).max() / np.abs(r).max()
@@ -504,22 +515,31 @@ def test_trainer_and_inference_on_device(dev, tmp_path):
     np.testing.assert_array_equal(pt[1, 8 * 3 + 5, :, :, 4, 0].cpu().numpy(), padded[1, 4, 48:70, 80:102])      # patch (3,5): rows 48.., cols 80..
     big = testClass.resolve_images(m, pt, micro_batch=128)
     ref_imgs = testClass.evaluate(m, pt.cpu().numpy(), batch_size=16)
-    # The default (H3) kernels choose each tensor's power-of-two operand scale from the largest magnitude IN THE BATCH, so a patch's
-    # result depends on its batch mates at the level of fp32 rounding: after clip + round a handful of pixels may land on the other
-    # side of a .5.  The x6 and fp32 kernels have no such coupling: micro-batching is bitwise invisible there.
-    d = np.abs(big.cpu().numpy() - np.stack(ref_imgs)[..., 0])
-    assert d.max() <= 1.0 and (d > 0).mean() < 1e-4, (d.max(), (d > 0).mean())
+    # Samples are independent in every kernel family (the H3 kernels scale their operands per SAMPLE, not per batch): the reference's
+    # micro-batches of 16 and one batch of 128 give the same pixels, bit for bit.
+    np.testing.assert_array_equal(big.cpu().numpy(), np.stack(ref_imgs)[..., 0])
     m.set_impl(3)
     big3 = testClass.resolve_images(m, pt, micro_batch=128)
     ref3 = testClass.evaluate(m, pt.cpu().numpy(), batch_size=16)
     np.testing.assert_array_equal(big3.cpu().numpy(), np.stack(ref3)[..., 0])
     assert np.abs(big3.cpu().numpy() - big.cpu().numpy()).max() <= 1.0
     m.set_impl(4)
-    # a second forward before backward is refused instead of silently using clobbered activations
+    # every forward call owns its workspace (an output of torch.ops.probav.wdsr_forward): a second forward before the first one's
+    # backward clobbers nothing, and both reverse passes give the same gradient
     p1 = m(xs, training=True)
-    _ = m(xs, training=True)
-    with pytest.raises(RuntimeError, match="overwritten"):
-        p1.sum().backward()
+    p2 = m(xs[:4].contiguous(), training=True)
+    m.flat.grad = None
+    p1.sum().backward()
+    g1 = m.flat.grad.clone()
+    m.flat.grad = None
+    m(xs, training=True).sum().backward()
+    assert torch.equal(g1, m.flat.grad)
+    m.flat.grad = None
+    p2.sum().backward()
+    assert torch.isfinite(m.flat.grad).all()
+    with torch.no_grad():
+        y = m(xs, training=True)                              # no graph: inference workspace, nothing to differentiate
+    assert not y.requires_grad
 
 
 @pytest.mark.parametrize("ea,eb", [(-37, 21), (30, -5), (0, 0)])
@@ -569,3 +589,128 @@ def test_h3_backward_refuses_a_forward_of_another_family(dev):
     m.flat.grad = None
     lo.shiftCompensatedL1Loss(hr, mask, m(x, training=True)).backward()          # a forward of the same family: fine
     assert torch.isfinite(m.flat.grad).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Gradient parity with the ReLU masks of the device.  The gradient of this network is discontinuous in its ~27 million
+# ReLU gates per patch pair; an fp32 and an fp64 evaluation decide a few gates whose pre-activation is ~0 differently, and each such gate
+# moves single filter-gradient entries by ~1/sqrt(#voxels).  Taking the masks from the HIP forward removes exactly that effect: what is
+# left is the arithmetic of the kernels, and it is held to SURVEY.md section 8c's bar, 1e-3 of the per-tensor max norm, element-wise.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _device_gates(m, flat_used, B, T=9):
+    """{layer: bool array}: the ReLU decisions of the last training forward of `m`, read from the saved activations (a post-ReLU value is
+    > 0 exactly where the gate is open) and, for the 256-channel hidden tiles that never reach memory, recomputed by the forward
+    kernel itself (probav_debug_hidden)."""
+    L = _lib()
+    h, ws = m._handle(), m._workspace(B, True)
+    hin = 22
+
+    def view(kind, idx):
+        off, cnt = ctypes.c_int64(), ctypes.c_int64()
+        L.check(L.lib().probav_workspace_view(h, B, 1, kind, idx, ctypes.byref(off), ctypes.byref(cnt)), "probav_workspace_view")
+        return ws[off.value: off.value + cnt.value]
+    gates = {"mainConv1": (view(0, 0) > 0).cpu().numpy(), "residConv1": (view(3, 0) > 0).cpu().numpy()}
+    nvox = B * hin * hin * T
+    hid = torch.empty(nvox * 256, device=ws.device)
+    for i in range(12):
+        L.check(L.lib().probav_debug_hidden(h, L.ptr(flat_used), L.ptr(ws), ws.numel() * 4, B, i, L.ptr(hid), L.current_stream()), "probav_debug_hidden")
+        gates["expConv_%d" % i] = (hid > 0).cpu().numpy()
+    k = 0
+    while True:
+        try:
+            gates["convReducer_%d" % (k + 1)] = (view(2, k) > 0).cpu().numpy()
+        except ValueError:
+            break
+        k += 1
+    return gates
+
+
+@pytest.mark.parametrize("impl", [4, 3])
+def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl):
+    from probav_amd.loss import Losses
+    z = np.load(os.path.join(GOLD, "wdsr_t9_b2.npz"))
+    params = synth.synth_params(seed=101, perturb=True)
+    m = _model(dev, 9, params)
+    m.set_impl(impl)
+    lo = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(z[k]).to(dev) for k in ("x", "hr", "mask"))
+    pred = m(x, training=True)
+    loss = lo.shiftCompensatedL1Loss(hr, mask, pred)
+    loss.backward()
+    gates = _device_gates(m, m.flat.detach(), 2)
+    report = {}
+    pt = ot.to_torch_params(params)
+    pred_o, loss_o, grads_o = ot.train_step_grads(torch.tensor(z["x"], dtype=torch.float64), torch.tensor(z["hr"]), torch.tensor(z["mask"]),
+                                                  pt, synth.NIR_MEAN, synth.NIR_STD, gates=gates, gate_report=report)
+    nflip = sum(r[0][0] for r in report.values())
+    ngate = sum(int(np.prod(g.shape)) for g in gates.values())
+    worst_margin = max((r[0][1] / max(r[0][2], 1e-30)) for r in report.values())
+    print("impl %d: %d of %d ReLU gates differ between the device and the fp64 evaluation; largest |pre-activation| among them = %.3g of the layer's rms"
+          % (impl, nflip, ngate, worst_margin))
+    assert worst_margin < 1e-4, "a gate that differs is NOT a ~0 pre-activation: the forward itself is off"
+    assert abs(float(loss) - float(loss_o)) < 1e-5 * float(loss_o)
+    gdev = m.flat.grad.detach().cpu().double().numpy()
+    worst = (0.0, None)
+    for L_ in m.layers:
+        go = grads_o[L_.name]
+        for key, lo_, hi_ in (("g", L_.g_off, L_.v_off), ("v", L_.v_off, L_.b_off), ("bias", L_.b_off, L_.b_off + L_.cout)):
+            ref = go[key].numpy().reshape(-1)
+            e = np.abs(gdev[lo_:hi_] - ref).max() / (np.abs(ref).max() + 1e-30)
+            if e > worst[0]:
+                worst = (e, L_.name + "/" + key)
+            assert e < 1e-3, (L_.name, key, e)
+    print("impl %d: worst per-tensor max-norm gradient error with the device's gates: %.3g (%s)" % (impl, worst[0], worst[1]))
+
+
+def test_train_steps_match_oracle(dev, tmp_path):
+    """models/trainClass.py:124-135 as a whole -- forward, loss, tape.gradient, apply_gradients, metric, running means -- for three
+    consecutive steps on B = 2, teacher-forced: at every step the fp64 oracle is evaluated at the parameters the device holds, with the
+    device's ReLU masks, and
+      (1) the loss and the cPSNR agree (1e-5), (2) all 132 gradient tensors agree element-wise (1e-3 max norm),
+      (3) oracle-Nadam applied to the device's gradient reproduces the device's next parameters (flat-buffer offsets, zero_grad, optimizer
+          state across steps: 2e-6 of the largest parameter),
+      (4) after the FIRST step the free-running oracle trajectory is also matched: all but a handful of the 535 267 parameters within 1e-5.
+    Free-running parity of later steps is not a meaningful bar for ANY fp32 implementation: Nadam's first updates are ~lr * sign(g), so the
+    ~1e-3 of the gradient entries that sit within fp32 noise of zero move by up to 2 lr = 1e-3 (measured with the oracle itself, fp32 vs
+    fp64 on CPU: 6 % of the parameters differ by more than 1e-5 after two steps, 52 % after three)."""
+    from oracle.nadam_numpy import Nadam
+    from probav_amd.loss import Losses
+    from probav_amd.trainClass import ModelTrainer, make_optimizer
+    params0 = synth.synth_params(seed=7, perturb=True)
+    m = _model(dev, 9, params0)
+    lo = Losses(targetShape=(48, 48, 1))
+    opt = make_optimizer("nadam", m, 5e-4)
+    tr = ModelTrainer(m, lo.shiftCompensatedL1Loss, lo.shiftCompensatedcPSNR, opt, str(tmp_path / "ck"), str(tmp_path / "lg"), multiGPU=False)
+    x, hr, mask = synth.synth_batch(2, seed=8)
+    xs, hs, ms = torch.as_tensor(x).to(dev), torch.as_tensor(hr).to(dev), torch.as_tensor(mask).to(dev)
+    ref_opt = Nadam(lr=5e-4)
+    free_opt = Nadam(lr=5e-4)
+    for step in range(3):
+        theta_k = m.flat.detach().clone()
+        tk = theta_k.cpu().double().numpy()
+        tr.trainLoss.reset_states(); tr.trainPSNR.reset_states()
+        tr.trainStep(xs, hs, ms)
+        g_dev = m.flat.grad.detach().cpu().double().numpy()
+        theta_next = m.flat.detach().cpu().double().numpy()
+        gates = _device_gates(m, theta_k, 2)
+        pt = ot.to_torch_params(synth.unflatten_params(theta_k.cpu().numpy()))
+        pred_o, loss_o, grads_o = ot.train_step_grads(torch.tensor(x, dtype=torch.float64), torch.tensor(hr), torch.tensor(mask), pt,
+                                                      synth.NIR_MEAN, synth.NIR_STD, gates=gates)
+        assert abs(tr.trainLoss.result() - float(loss_o)) < 1e-5 * float(loss_o), step                       # (1)
+        psnr_o = float(ot.shift_cpsnr(torch.tensor(hr), torch.tensor(mask), pred_o).mean())
+        assert abs(tr.trainPSNR.result() - psnr_o) < 1e-5 * abs(psnr_o), step
+        g_o = np.zeros_like(g_dev)
+        for L_ in m.layers:                                                                                   # (2)
+            for key, a, b in (("g", L_.g_off, L_.v_off), ("v", L_.v_off, L_.b_off), ("bias", L_.b_off, L_.b_off + L_.cout)):
+                ref = grads_o[L_.name][key].numpy().reshape(-1)
+                g_o[a:b] = ref
+                e = np.abs(g_dev[a:b] - ref).max() / (np.abs(ref).max() + 1e-30)
+                assert e < 1e-3, (step, L_.name, key, e)
+        want = ref_opt.step(tk, g_dev)                                                                        # (3)
+        assert np.abs(theta_next - want).max() < 2e-6 * np.abs(want).max(), (step, np.abs(theta_next - want).max())
+        if step == 0:                                                                                         # (4)
+            free = free_opt.step(tk, g_o)
+            d = np.abs(theta_next - free)
+            print("after one free-running step: max |dtheta| %.3g, fraction beyond 1e-5: %.3g" % (d.max(), (d > 1e-5).mean()))
+            assert (d > 1e-5).mean() < 1e-4 and d.max() <= 2.2 * 5e-4
+    assert tr.optimizer.state[m.flat]["step"] == 3

@@ -28,7 +28,7 @@ def main():
         outs = {}
         for impl in (2, 3, 4):
             for _ in range(reps):
-                L.check(L.lib().probav_pw_forward(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(dec), nvox, D, impl,
+                L.check(L.lib().probav_pw_forward(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(dec), nvox, 0, D, impl,
                                                   L.current_stream()))
             torch.cuda.synchronize()
             outs[impl] = dec.double().cpu()
@@ -49,7 +49,7 @@ def main():
         for impl in (2, 3, 4):
             for _ in range(reps):
                 L.check(L.lib().probav_pw_backward(L.ptr(x), L.ptr(ddec), L.ptr(dskip), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(dx), L.ptr(dw1),
-                                                   L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, D, impl, L.current_stream()))
+                                                   L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, 0, D, impl, L.current_stream()))
             torch.cuda.synchronize()
             res[impl] = [t.double().cpu().clone() for t in (dx, dw1, db1, dw2, db2)]
         for a, b, c, name in zip(res[2], res[3], res[4], ("dx", "dw1", "db1", "dw2", "db2")):

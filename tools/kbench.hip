@@ -1,0 +1,84 @@
+// Diagnostic (not part of the product): times the hot H3 kernels in isolation on random data at the benchmark's shapes (batch 128, T = 9).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I proba-v_amd/csrc tools/kbench.hip -o tools/kbench.bin && tools/kbench.bin [iters]
+// -DKB_OLD builds against the round-1 signatures (per-tensor amax slots), for A/B runs of two source trees.
+#include "../proba-v_amd/csrc/kernels_small.hip"
+#include "../proba-v_amd/csrc/kernels_mfma.hip"
+#include "../proba-v_amd/csrc/kernels_x6.hip"
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+using namespace probav;
+
+static int g_pass = 0;
+template <class F> static float timeit(const char* name, int iters, double gflop, F f)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) f();
+    hipDeviceSynchronize();
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) f();
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    const float us = ms * 1e3f / iters;
+    if (g_pass) printf("%-44s %8.1f us   %7.1f TFLOP/s (algorithmic fp32)\n", name, us, gflop / us * 1e3);
+    if (hipGetLastError() != hipSuccess) printf("   !! HIP error\n");
+    return us;
+}
+
+int main(int argc, char** argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    const int B = 128, D = 25;
+    const long V = 22 * 22 * 9, nvox = (long)B * V;
+    std::vector<float> h((size_t)nvox * 32);
+    unsigned long long s = 88172645463325252ull;
+    for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((s >> 11) & 0xffffff) / 16777216.f - 0.5f; }
+    float *x32, *y32, *z32, *x25, *y25;
+    hipMalloc(&x32, nvox * 32 * 4); hipMalloc(&y32, nvox * 32 * 4); hipMalloc(&z32, nvox * 32 * 4); hipMalloc(&x25, nvox * 25 * 4); hipMalloc(&y25, nvox * 25 * 4);
+    hipMemcpy(x32, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice); hipMemcpy(y32, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(z32, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(x25, h.data(), nvox * 25 * 4, hipMemcpyHostToDevice); hipMemcpy(y25, h.data(), nvox * 25 * 4, hipMemcpyHostToDevice);
+    // amax slots: every slot = 1.0f (the data is in [-0.5, 0.5]; weights are random pieces)
+    unsigned* am_; hipMalloc(&am_, 8192 * 4);
+    { std::vector<unsigned> one(8192, 0x3f800000u); hipMemcpy(am_, one.data(), 8192 * 4, hipMemcpyHostToDevice); }
+    float *w, *b1, *b2, *dW1, *dW2, *db1, *db2, *slabs, *wf, *bias, *dw, *db, *part;
+    hipMalloc(&w, 4 * X6_PW_FRAG_WORDS * 4); hipMalloc(&b1, 256 * 4); hipMalloc(&b2, 32 * 4);
+    hipMemset(w, 0x3c, 4 * X6_PW_FRAG_WORDS * 4); hipMemset(b1, 0, 256 * 4); hipMemset(b2, 0, 32 * 4);
+    hipMalloc(&dW1, 8192 * 4); hipMalloc(&dW2, 256 * D * 4); hipMalloc(&db1, 256 * 4); hipMalloc(&db2, D * 4);
+    hipMalloc(&slabs, mfma_pw_backward_slab_floats(D) * 4);
+    hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMemset(wf, 0x3c, X6_CONV_FRAG_WORDS * 4);
+    hipMalloc(&bias, 32 * 4); hipMemset(bias, 0, 32 * 4);
+    hipMalloc(&dw, 27 * 32 * 32 * 4); hipMalloc(&db, 32 * 4);
+    ConvGeom gf{B, 22, 22, 9, 25, 22, 22, 9, 32, 3, 3, 3, 1, 1, 1, 0, 0, 0};      // normConv forward
+    ConvGeom gb{B, 22, 22, 9, 32, 22, 22, 9, 25, 3, 3, 3, 1, 1, 1, 0, 0, 0};      // its backward-data
+    hipMalloc(&part, x6_wgrad_partial_floats(gf) * 4);
+    Amax am; am.x = am_; am.w = am_ + 2048; am.y = am_ + 4096;
+    PwAmax pam; pam.x = am_; pam.w1 = am_ + 2048; pam.w2 = am_ + 2049; pam.b1 = am_ + 2050; pam.dt = am_ + 1024; pam.y = am_ + 4096;
+#ifndef KB_OLD
+    pam.w2c = am_ + 2100; pam.w1r = am_ + 2200;
+#endif
+    const double gv = (double)nvox * 2e-9;
+    for (g_pass = 0; g_pass < 3; ++g_pass) {          // pass 0 warms the clocks up and is not printed
+    if (g_pass) printf("-- pass %d\n", g_pass);
+#ifdef KB_OLD
+    timeit("pw_fwd  (expConv+ReLU+decConv)", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, D, 2, pam, 0); });
+    timeit("pw_bwd  (fused reverse)", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, D, 2, pam, 0); });
+#else
+    timeit("pw_fwd  (expConv+ReLU+decConv)", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, V, D, 2, pam, 0); });
+    timeit("pw_bwd  (fused reverse)", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, V, D, 2, pam, 0); });
+    { PwAmax q = pam; q.y = nullptr;
+      timeit("pw_bwd  no amax report", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, V, D, 2, q, 0); });
+      timeit("pw_fwd  no amax report", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, V, D, 2, q, 0); }); }
+    { const long V2 = 4352, nv2 = B * V2;
+      timeit("pw_bwd  vps = 4352 (full tiles only)", iters, (double)nv2 * 2e-9 * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nv2, V2, D, 2, pam, 0); });
+      timeit("pw_bwd  vps = 2*4356", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, 2 * V, D, 2, pam, 0); }); }
+    timeit("pw_fwd  one sample (vps = nvox)", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, nvox, D, 2, pam, 0); });
+    timeit("pw_bwd  one sample (vps = nvox)", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, nvox, D, 2, pam, 0); });
+#endif
+    timeit("pstrip<25> normConv forward + skip", iters, gv * 21600, [&] { x6_conv_strip_forward(gf, x25, nullptr, wf, bias, y32, z32, 2, am, 0); });
+    timeit("pstrip<32> normConv backward-data", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });
+    timeit("wgrad<25> normConv backward-filter", iters, gv * 21600, [&] { x6_conv_wgrad(gf, x25, y32, nullptr, dw, db, part, 2, am, 0); });
+    }
+    return 0;
+}
