@@ -271,9 +271,12 @@ def run_rank(args):
         _lib.check(L.probav_engine_profile(h, 0, 0))
         return {c: {"ms": ms[i], "macs": macs[i], "launches": int(cnt[i])} for i, c in enumerate(CLASSES)}
 
-    # HIP events around EVERY launch cost ~6 % of the step (launch ramps no longer overlap), so the timed region brackets only the
-    # launches of the dominant kernel class; which class that is, and the per-class table, come from two untimed steps bracketed in full.
-    prof_all, dom, psteps = None, None, 2
+    # THE timed region: exactly K steps, nothing else on the stream but the K + 1 step-boundary events.
+    dt, step_ms, loss = timed(step, args.steps)
+    # Roofline leg, right behind it: the same steps with the engine's HIP events around kernel launches.  Events around EVERY launch cost
+    # ~6 % of the step (launch ramps no longer overlap), so two steps bracketed in full give the per-class table and name the dominant
+    # class, and a second timed run of steps brackets only that class's launches (its average launch time is the roofline's `achieved`).
+    prof_all, prof, dom, psteps, rsteps = None, None, None, 2, max(5, min(args.steps, 30))
     if use_events:
         _lib.check(L.probav_engine_profile_classes(h, 0xFFFFFFFF), "probav_engine_profile_classes")
         _lib.check(L.probav_engine_profile(h, 1, 512 * psteps), "probav_engine_profile")
@@ -283,11 +286,9 @@ def run_rank(args):
         prof_all = read_profile()
         dom = max((c for c in prof_all if prof_all[c]["macs"] > 0), key=lambda c: prof_all[c]["ms"])
         _lib.check(L.probav_engine_profile_classes(h, 1 << CLASSES.index(dom)), "probav_engine_profile_classes")
-        _lib.check(L.probav_engine_profile(h, 1, 64 * args.steps), "probav_engine_profile")
-    dt, step_ms, loss = timed(step, args.steps)
-    prof = None
-    if use_events:
-        prof = read_profile()                                                  # the dominant class over the timed steps
+        _lib.check(L.probav_engine_profile(h, 1, 64 * rsteps), "probav_engine_profile")
+        dtr, _, _ = timed(step, rsteps)
+        prof = read_profile()                                                  # the dominant class over rsteps timed steps
         _lib.check(L.probav_engine_profile_classes(h, 0xFFFFFFFF), "probav_engine_profile_classes")
 
     full = None
@@ -403,8 +404,10 @@ def run_rank(args):
                                "frac": round(ach / peak, 4), "traffic": None,
                                "avg_launch_ms": round(prof[dom]["ms"] / max(1, prof[dom]["launches"]), 4),
                                "algorithmic_gflop_per_launch": round(2 * prof[dom]["macs"] / max(1, prof[dom]["launches"]) / 1e9, 3),
-                               "note": "rank 0, HIP events on the launch stream around every launch of this class during the timed steps "
-                                       "(the other classes are bracketed only in two untimed steps: kernel_classes); "
+                               "timed_steps": rsteps, "ms_per_step_while_bracketed": round(dtr / rsteps * 1e3, 4),
+                               "note": "rank 0, HIP events on the launch stream around every launch of this class during a second timed run of steps "
+                                       "right behind the headline one (which carries no kernel events; the other classes are bracketed in two "
+                                       "further steps: kernel_classes); "
                                        "achieved = SURVEY.md §8d's algorithmic fp32 FLOP of the class / its time" + (
                                            "; this class runs split-operand kernels, which issue %d 16-bit MFMA products per fp32 product, so its "
                                            "ceiling is the dense bf16/fp16 MFMA peak (%.0f TFLOP/s) / %d" % (nprod, PEAK_BF16_TFLOPS, nprod) if x6 else

@@ -32,6 +32,20 @@ def _dev(t, name):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # the network
 # ---------------------------------------------------------------------------------------------------------------------------------
+_WS_POOLS = {}
+
+
+def _ws_pool(device):
+    """A private, never-split allocator pool for the engine workspaces (torch.cuda.MemPool): a multi-GB block that returns to the general
+    pool gets carved up by the next megabyte-sized request, and the following step then pays a hipMalloc of the full size (~80 ms,
+    device-synchronous).  In its own pool a freed workspace block can only be taken by the next workspace."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _WS_POOLS.get(key)
+    if pool is None:
+        pool = _WS_POOLS[key] = torch.cuda.MemPool(no_split=True)
+    return pool
+
+
 def _ws_floats(engine, batch, training):
     nbytes = _lib.lib().probav_workspace_bytes(c_void_p(engine), int(batch), 1 if training else 0)
     if nbytes == 0:
@@ -46,7 +60,8 @@ def wdsr_forward(flat: Tensor, x: Tensor, engine: int, out_size: int, training: 
     _dev(x, "model input")
     B = x.shape[0]
     y = torch.empty((B, out_size, out_size, 1), dtype=torch.float32, device=x.device)
-    ws = torch.empty(_ws_floats(engine, B, training), dtype=torch.float32, device=x.device)
+    with torch.cuda.use_mem_pool(_ws_pool(x.device), device=x.device):
+        ws = torch.empty(_ws_floats(engine, B, training), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().probav_forward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4, B,
                                          1 if training else 0, _lib.current_stream()), "probav_forward")
     return y, ws
@@ -75,16 +90,22 @@ def _(flat, dy, ws, engine):
 
 def _wdsr_setup(ctx, inputs, output):
     flat, x, engine, out_size, training = inputs
-    ctx.save_for_backward(flat)
-    ctx.ws, ctx.engine, ctx.training = output[1], engine, training
+    # the workspace is an OUTPUT of this node: it must go through save_for_backward (a plain attribute would close the reference cycle
+    # node -> ctx -> ws -> grad_fn -> node and every step's 3 GB would stay alive until the cycle collector runs, if ever)
+    ctx.save_for_backward(flat, output[1])
+    ctx.engine, ctx.training = engine, training
+    ctx.mark_non_differentiable(output[1])
+    ctx.set_materialize_grads(False)           # ... and it never carries a gradient: do not let autograd zero-fill 3 GB for it
 
 
 def _wdsr_bwd(ctx, dy, dws):
+    if dy is None:
+        return None, None, None, None, None
     if not ctx.training:
         raise RuntimeError("backward through model(x, training=False): call the model with training=True "
                            "to keep the activations the reverse pass needs")
-    (flat,) = ctx.saved_tensors
-    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ctx.ws, ctx.engine)
+    flat, ws = ctx.saved_tensors
+    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ws, ctx.engine)
     return g, None, None, None, None
 
 
@@ -147,9 +168,12 @@ def _shift_setup(ctx, inputs, output):
     pred, hr, mask, border, bit_depth, which = inputs
     ctx.save_for_backward(pred, hr, mask, output[1])
     ctx.border, ctx.which = border, which
+    ctx.set_materialize_grads(False)
 
 
 def _shift_bwd(ctx, g_loss, g_arg, g_per):
+    if g_loss is None:                         # (only the batch-mean loss is differentiable; the per-sample minima are a by-product)
+        return None, None, None, None, None, None
     pred, hr, mask, arg = ctx.saved_tensors
     dpred = torch.ops.probav.shift_loss_backward(hr, mask, pred, arg, g_loss.contiguous().float().reshape(1), ctx.border, ctx.which)
     return dpred, None, None, None, None, None

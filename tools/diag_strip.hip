@@ -12,15 +12,14 @@ int main()
         ConvGeom g{B, 22, 22, 9, cin, 22, 22, 9, cout, 3, 3, 3, 1, 1, 1, 0, 0, 0};
         const size_t nin = (size_t)B * 22 * 22 * 9 * cin, nout = (size_t)B * 22 * 22 * 9 * cout;
         float *x, *y, *wf, *bias, *skp; unsigned* am;
-        hipMalloc(&x, nin * 4); hipMalloc(&y, nout * 4); hipMalloc(&skp, nout * 4); hipMemset(skp, 0, nout * 4); hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMalloc(&bias, 32 * 4); hipMalloc(&am, 64);
+        hipMalloc(&x, nin * 4); hipMalloc(&y, nout * 4); hipMalloc(&skp, nout * 4); hipMemset(skp, 0, nout * 4); hipMalloc(&wf, X6_CONV_FRAG_WORDS * 4); hipMalloc(&bias, 32 * 4); hipMalloc(&am, 4096 * 4);
         std::vector<float> h(nin);
         for (size_t i = 0; i < nin; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
         hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
         hipMemset(wf, 0x3c, X6_CONV_FRAG_WORDS * 4); hipMemset(bias, 0, 32 * 4);
-        const unsigned one = 0x3f800000u; unsigned hv[4] = {one, one, 0, 0};
-        hipMemcpy(am, hv, 16, hipMemcpyHostToDevice);
+        { std::vector<unsigned> hv(4096, 0x3f800000u); hipMemcpy(am, hv.data(), 4096 * 4, hipMemcpyHostToDevice); }     // per-sample / per-column slots: all 1.0
         for (int arith = 1; arith <= 2; ++arith) {
-            Amax m; m.x = am; m.w = am + 1; m.y = am + 2;
+            Amax m; m.x = am; m.w = am + 1024; m.y = am + 2048;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             for (int it = 0; it < 3; ++it) x6_conv_strip_forward(g, x, nullptr, wf, bias, cin == 25 ? skp : nullptr, y, arith, m, 0);
             hipEventRecord(e0, 0);

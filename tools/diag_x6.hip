@@ -12,10 +12,10 @@ int main()
 {
     const int B = 128, cin = 25, cout = 32;
     ConvGeom g{B, 22, 22, 9, cin, 22, 22, 9, cout, 3, 3, 3, 1, 1, 1, 0, 0, 0};
-    unsigned* am_; hipMalloc(&am_, 64);
-    { const unsigned one = 0x3f800000u; unsigned hv[8] = {one, one, one, one, one, one, 0, 0}; hipMemcpy(am_, hv, 32, hipMemcpyHostToDevice); }
-    Amax am; am.x = am_; am.w = am_ + 1; am.y = am_ + 6;
-    PwAmax pam; pam.x = am_; pam.w1 = am_ + 1; pam.w2 = am_ + 2; pam.b1 = am_ + 3; pam.dt = am_ + 4; pam.y = am_ + 7;
+    unsigned* am_; hipMalloc(&am_, 8192 * 4);
+    { std::vector<unsigned> hv(8192, 0x3f800000u); hipMemcpy(am_, hv.data(), 8192 * 4, hipMemcpyHostToDevice); }      // per-sample / per-column slots: all 1.0
+    Amax am; am.x = am_; am.w = am_ + 2048; am.y = am_ + 4096;
+    PwAmax pam; pam.x = am_; pam.w1 = am_ + 2048; pam.w2 = am_ + 2049; pam.b1 = am_ + 2050; pam.dt = am_ + 1024; pam.w2c = am_ + 2100; pam.w1r = am_ + 2200; pam.y = am_ + 4096;
     const int ARITH = 2;
     const size_t nin = (size_t)B * 22 * 22 * 9 * cin, nout = (size_t)B * 22 * 22 * 9 * cout;
     float *x, *dy, *dw, *db, *part;
@@ -74,7 +74,7 @@ int main()
         hipMemcpy(dO, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
         hipMemset(w, 0x3c, 3 * X6_PW_FRAG_WORDS * 4); hipMemset(b1, 0, 256 * 4);
         for (int it = 0; it < 3; ++it)
-            x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, D, ARITH, pam, 0);
+            x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, 22 * 22 * 9, D, ARITH, pam, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
 #ifdef PROBAV_STAMP2
