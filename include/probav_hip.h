@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PROBAV_ABI_VERSION 2
+#define PROBAV_ABI_VERSION 3
 
 /* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
  * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale=True)   (models/modelsTF.py:8-17) */
@@ -89,6 +89,22 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
  * (training=1) on the same ws / batch.                                                              */
 int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws,
                     size_t ws_bytes, int batch, void* stream);
+
+/* ---- optimizer update fused with the weight normalisation of the next step ---------------------------------
+ * replaces  optimizer.apply_gradients(...)  +  the WeightNormalization kernel recomputation of the NEXT model call
+ *           (models/trainClass.py:132 ; models/modelsTF.py:191-197 ; Keras Nadam / Adam / SGD of train.py:77-83 by coefficients, as probav_nadam_step)
+ * One launch updates all parameters in place (params, m, v: probav_param_count floats) and writes the effective weights of the UPDATED
+ * parameters (both layouts, inverse norms, amax slots); a second one packs the MFMA operand fragments.  Everything lands in the
+ * caller-owned weight cache (probav_weight_cache_bytes).  probav_forward_wc / probav_backward_wc are probav_forward / probav_backward
+ * reading that cache instead of recomputing it: three launches leave every training step.  The cache is valid exactly as long as
+ * `params` is not modified by anyone else.                                                                                          */
+size_t probav_weight_cache_bytes(const probav_engine* e);
+int probav_optimizer_step_fused(probav_engine* e, float* params, const float* grads, float* m, float* v, float lr, float beta1,
+                                float beta2, float eps, float c_g, float c_m, float c_v, void* wcache, size_t wcache_bytes, void* stream);
+int probav_forward_wc(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes, int batch,
+                      int training, const void* wcache, size_t wcache_bytes, void* stream);
+int probav_backward_wc(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes, int batch,
+                       const void* wcache, size_t wcache_bytes, void* stream);
 
 /* ---- loss / metric ------------------------------------------------------------------------------ */
 /* replaces Losses.shiftCompensatedL1Loss / L2Loss / cPSNR               models/loss.py:37-84
@@ -173,7 +189,8 @@ int probav_workspace_view(const probav_engine* e, int batch, int training, int k
 /* the post-ReLU hidden tile relu(expConv_block(x)) [B*(P+s)^2*T][256] (models/modelsTF.py:179-180) exactly as the fused forward kernel
  * of the current kernel family (3 or 4) evaluates it -- that tensor never reaches memory otherwise.  Call after probav_forward(training=1)
  * with the same workspace; the ReLU gates of the reverse pass are the signs of these values.                                          */
-int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int batch, int block, float* hidden, void* stream);
+int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int batch, int block, float* hidden,
+                        const void* wcache /* the weight cache the forward pass ran from, or NULL */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,12 @@ SIGNATURES = {
     "probav_wn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_wn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_workspace_view": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
-    "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "probav_weight_cache_bytes": (c_size_t, [c_void_p]),
+    "probav_optimizer_step_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
+                                            c_void_p, c_size_t, c_void_p]),
+    "probav_forward_wc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "probav_backward_wc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None
@@ -81,7 +86,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if L.probav_abi_version() != 2:
+        if L.probav_abi_version() != 3:
             raise RuntimeError("libprobav_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -244,17 +244,34 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     return p;
 }
 
+// Weight cache (optional, caller-owned): everything a forward / backward pass derives from the parameters alone -- effective weights in
+// both layouts, inverse norms, the weights' amax slots, the packed MFMA operand fragments.  probav_optimizer_step_fused fills it for the
+// parameters it has just updated; the *_wc entry points then skip the weight-norm and packing launches.
+struct WcPlan { size_t weff, weffT, invn, amax, wpack, total; int n_wamax; };
+static WcPlan make_wc_plan(const probav_engine* e)
+{
+    WcPlan c; size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
+    c.weff = take(e->weff_count); c.weffT = take(e->weff_count); c.invn = take(e->cout_total);
+    c.n_wamax = 2 * (int)e->layers.size() + (int)e->cout_total + (int)e->cin_total;
+    c.amax = take((size_t)c.n_wamax); c.wpack = take(e->wpack_count);
+    c.total = off;
+    return c;
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; const float* h3 = nullptr; const float* h3t = nullptr; };   // h3t: per-tap H3 fragments of a 25-channel layer
 
 // amax slot addresses inside the workspace (layout: make_plan)
 struct AmaxSlots {
-    const probav_engine* e; unsigned* base; int L, R, B, fwd, bwd;
-    AmaxSlots(const probav_engine* e_, const Plan& p, float* W, int R_) : e(e_), base(reinterpret_cast<unsigned*>(W + p.amax)), L((int)e_->layers.size()), R(R_), B(p.B), fwd(p.amax_fwd), bwd(p.amax_bwd) {}
-    unsigned* w(int li) const { return base + li; }                                   // whole weight tensor of layer li
-    unsigned* b(int li) const { return base + L + li; }                               // its bias
-    unsigned* wcol(int li) const { return base + 2 * L + e->layers[li].wn.n_off; }     // per output channel (Cout slots): columns of the forward matrices
-    unsigned* wrow(int li) const { return base + 2 * L + (int)e->cout_total + e->layers[li].wn.r_off; }   // per input channel (Cin slots): columns of the backward-data matrices
+    const probav_engine* e; unsigned* base; unsigned* wbase; int L, R, B, fwd, bwd;
+    // wslots: where the weights' slots live -- the head of the workspace's amax region, or the weight cache's
+    AmaxSlots(const probav_engine* e_, const Plan& p, float* W, int R_, unsigned* wslots = nullptr)
+        : e(e_), base(reinterpret_cast<unsigned*>(W + p.amax)), wbase(wslots ? wslots : reinterpret_cast<unsigned*>(W + p.amax)), L((int)e_->layers.size()), R(R_), B(p.B), fwd(p.amax_fwd), bwd(p.amax_bwd) {}
+    unsigned* w(int li) const { return wbase + li; }                                   // whole weight tensor of layer li
+    unsigned* b(int li) const { return wbase + L + li; }                               // its bias
+    unsigned* wcol(int li) const { return wbase + 2 * L + e->layers[li].wn.n_off; }     // per output channel (Cout slots): columns of the forward matrices
+    unsigned* wrow(int li) const { return wbase + 2 * L + (int)e->cout_total + e->layers[li].wn.r_off; }   // per input channel (Cin slots): columns of the backward-data matrices
     unsigned* act(int i) const { return base + fwd + B * i; }                         // per-sample arrays (B slots each)
     unsigned* dec(int i) const { return base + fwd + B * (R + 1 + i); }
     unsigned* red(int k) const { return base + fwd + B * (2 * R + 1 + k); }
@@ -541,36 +558,42 @@ size_t probav_workspace_bytes(const probav_engine* e, int batch, int training)
     return make_plan(e, batch, training).total * sizeof(float);
 }
 
-int probav_forward(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes,
-                   int B, int training, void* stream)
+static int forward_impl(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes,
+                        int B, int training, const float* WC, void* stream)
 {
     if (!e || !params || !x || !y || !ws || B < 1) { set_error("probav_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const Plan p = make_plan(e, B, training);
     if (ws_bytes < p.total * sizeof(float)) { set_error("probav_forward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
     float* W = (float*)ws;
+    const WcPlan wc = make_wc_plan(e);
+    // where the parameter-derived tensors live: inside the workspace (recomputed by this call) or in the caller's weight cache
+    const float* Wweff = WC ? WC + wc.weff : W + p.weff;
+    const float* Wpack = WC ? WC + wc.wpack : W + p.wpack;
     const probav_net_cfg& c = e->cfg;
     const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
-    auto weff = [&](int li) { return W + p.weff + e->layers[li].wn.w_off; };
+    auto weff = [&](int li) { return Wweff + e->layers[li].wn.w_off; };
     auto bias = [&](int li) { return params + e->layers[li].wn.b_off; };
     auto frag = [&](int li) -> Frags {
         Frags f;
-        if (e->pkFwd[li] >= 0) f.f32 = W + p.wpack + e->pkFwd[li];
-        if (e->pkFwd6[li] >= 0) f.x6 = W + p.wpack + e->pkFwd6[li];
-        if (e->pkFwdH[li] >= 0) f.h3 = W + p.wpack + e->pkFwdH[li];
-        if (e->pkFwdHt[li] >= 0) f.h3t = W + p.wpack + e->pkFwdHt[li];
+        if (e->pkFwd[li] >= 0) f.f32 = Wpack + e->pkFwd[li];
+        if (e->pkFwd6[li] >= 0) f.x6 = Wpack + e->pkFwd6[li];
+        if (e->pkFwdH[li] >= 0) f.h3 = Wpack + e->pkFwdH[li];
+        if (e->pkFwdHt[li] >= 0) f.h3t = Wpack + e->pkFwdHt[li];
         return f;
     };
     // amax slots (H3 arithmetic, impl 4): every tensor an H3 kernel reads has its largest magnitude in a slot by then
     const bool h3 = e->impl >= 4;
-    const AmaxSlots A(e, p, W, R);
+    const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wcol(li); m.y = ay; } return m; };
     if (h3 && hipMemsetAsync(A.base, 0, (size_t)p.amax_bwd * sizeof(unsigned), s) != hipSuccess) { set_error("probav_forward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
     if (training) e->fwd_amax = h3;
 
-    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
-    if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
+    if (!WC) {
+        { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
+        if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
+    }
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
     CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
     for (int i = 0; i < R; ++i) {
@@ -580,13 +603,13 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
             ProfScope ps(e, e->impl >= 3 ? CLS_PW_FWD_X6 : CLS_PW_FWD, (double)nvox * ((double)F * E + (double)E * D), s);
             if (h3) {
                 PwAmax m; m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.w2c = A.wcol(e->iDec[i]); m.b1 = A.b(e->iExp[i]); m.y = A.dec(i);
-                CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1h[i], W + p.wpack + e->pkW2h[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                CK(x6_pw_forward(W + p.act[i], Wpack + e->pkW1h[i], Wpack + e->pkW2h[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                  W + p.dec[i], nvox, nvox / B, D, 2, m, s));
             } else if (e->impl >= 3) {
-                CK(x6_pw_forward(W + p.act[i], W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                CK(x6_pw_forward(W + p.act[i], Wpack + e->pkW1x6[i], Wpack + e->pkW2x6[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                  W + p.dec[i], nvox, nvox / B, D, 1, PwAmax(), s));
             } else
-                CK(mfma_pw_forward(W + p.act[i], W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
+                CK(mfma_pw_forward(W + p.act[i], Wpack + e->pkW1[i], Wpack + e->pkW2[i], bias(e->iExp[i]), bias(e->iDec[i]),
                                    W + p.dec[i], nvox, D, s));
         } else {
             CK(conv_fwd(e, make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), W + p.act[i], nullptr, weff(e->iExp[i]), frag(e->iExp[i]), bias(e->iExp[i]), nullptr, W + p.H, Amax(), s));
@@ -610,29 +633,46 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
     return PROBAV_OK;
 }
 
-int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes,
-                    int B, void* stream)
+int probav_forward(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes,
+                   int B, int training, void* stream)
+{
+    return forward_impl(e, params, x, y, ws, ws_bytes, B, training, nullptr, stream);
+}
+int probav_forward_wc(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes,
+                      int B, int training, const void* wcache, size_t wcache_bytes, void* stream)
+{
+    if (!e || !wcache || wcache_bytes < make_wc_plan(e).total * sizeof(float)) { set_error("probav_forward_wc: weight cache missing / too small", hipSuccess); return PROBAV_EINVAL; }
+    return forward_impl(e, params, x, y, ws, ws_bytes, B, training, (const float*)wcache, stream);
+}
+
+static int backward_impl(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes,
+                         int B, const float* WC, void* stream)
 {
     if (!e || !params || !dy || !grads || !ws || B < 1) { set_error("probav_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const Plan p = make_plan(e, B, 1);
     if (ws_bytes < p.total * sizeof(float)) { set_error("probav_backward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
     float* W = (float*)ws;
+    const WcPlan wc = make_wc_plan(e);
+    const float* Wweff = WC ? WC + wc.weff : W + p.weff;
+    const float* WweffT = WC ? WC + wc.weffT : W + p.weffT;
+    const float* Winvn = WC ? WC + wc.invn : W + p.invn;
+    const float* Wpack = WC ? WC + wc.wpack : W + p.wpack;
     const probav_net_cfg& c = e->cfg;
     const int F = c.num_filters, E = F * c.exp_rate, D = c.dec_channels, T = c.num_img_lr, R = c.num_res_blocks;
     const int Hin = e->Hin, P = c.patch_size_lr, s2 = c.scale * c.scale;
-    auto weffT = [&](int li) { return W + p.weffT + e->layers[li].wn.w_off; };
+    auto weffT = [&](int li) { return WweffT + e->layers[li].wn.w_off; };
     auto fragT = [&](int li) -> Frags {
         Frags f;
-        if (e->pkBwd[li] >= 0) f.f32 = W + p.wpack + e->pkBwd[li];
-        if (e->pkBwd6[li] >= 0) f.x6 = W + p.wpack + e->pkBwd6[li];
-        if (e->pkBwdH[li] >= 0) f.h3 = W + p.wpack + e->pkBwdH[li];
-        if (e->pkBwdHt[li] >= 0) f.h3t = W + p.wpack + e->pkBwdHt[li];
+        if (e->pkBwd[li] >= 0) f.f32 = Wpack + e->pkBwd[li];
+        if (e->pkBwd6[li] >= 0) f.x6 = Wpack + e->pkBwd6[li];
+        if (e->pkBwdH[li] >= 0) f.h3 = Wpack + e->pkBwdH[li];
+        if (e->pkBwdHt[li] >= 0) f.h3t = Wpack + e->pkBwdHt[li];
         return f;
     };
     // amax slots of the gradient tensors, in launch order (the forward pass left those of the weights and activations)
     const bool h3 = e->impl >= 4;
-    const AmaxSlots A(e, p, W, R);
+    const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
     int nback = 0;
     auto new_slot = [&]() -> unsigned* { return h3 ? A.back(nback++) : nullptr; };
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wrow(li); m.y = ay; } return m; };   // backward-data: the matrix' columns are the layer's INPUT channels
@@ -711,20 +751,20 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
             unsigned* anew = new_slot();                     // amax slot of dX
             if (h3) {
                 PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.w1r = A.wrow(le); m.b1 = A.b(le); m.dt = agdec; m.y = anew;
-                CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1h[i], W + p.wpack + e->pkW2Kh[i], W + p.wpack + e->pkW1Ch[i],
+                CK(x6_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1h[i], Wpack + e->pkW2Kh[i], Wpack + e->pkW1Ch[i],
                                   params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, nvox / B, D, 2, m, s));
             } else if (e->impl >= 3)
-                CK(x6_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1x6[i], W + p.wpack + e->pkW2Kx6[i], W + p.wpack + e->pkW1Cx6[i],
+                CK(x6_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1x6[i], Wpack + e->pkW2Kx6[i], Wpack + e->pkW1Cx6[i],
                                   params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, nvox / B, D, 1, PwAmax(), s));
             else
-                CK(mfma_pw_backward(W + p.act[i], gDec, cur, W + p.wpack + e->pkW1[i], W + p.wpack + e->pkW2B[i], W + p.wpack + e->pkW1C[i],
+                CK(mfma_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1[i], Wpack + e->pkW2B[i], Wpack + e->pkW1C[i],
                                     params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
             float* tmp2 = cur; cur = oth; oth = tmp2;
             acur = anew;
             continue;
         }
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
-        CK(conv_fwd(e, ge, W + p.act[i], nullptr, W + p.weff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, Amax(), s));
+        CK(conv_fwd(e, ge, W + p.act[i], nullptr, Wweff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, Amax(), s));
         // decConv_i
         CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, Amax(), s));
@@ -738,9 +778,42 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
     // mainConv1 (input-facing: no backward-data)
     CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
                   dweff(e->iMain), dbias(e->iMain), part, Amax(), s));
-    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.dweff, W + p.invn, grads, s)); }
+    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.dweff, Winvn, grads, s)); }
     return PROBAV_OK;
 }
+
+int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes, int B, void* stream)
+{
+    return backward_impl(e, params, dy, grads, ws, ws_bytes, B, nullptr, stream);
+}
+int probav_backward_wc(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes, int B,
+                       const void* wcache, size_t wcache_bytes, void* stream)
+{
+    if (!e || !wcache || wcache_bytes < make_wc_plan(e).total * sizeof(float)) { set_error("probav_backward_wc: weight cache missing / too small", hipSuccess); return PROBAV_EINVAL; }
+    return backward_impl(e, params, dy, grads, ws, ws_bytes, B, (const float*)wcache, stream);
+}
+
+size_t probav_weight_cache_bytes(const probav_engine* e) { return e ? make_wc_plan(e).total * sizeof(float) : 0; }
+
+int probav_optimizer_step_fused(probav_engine* e, float* params, const float* grads, float* m, float* v, float lr, float beta1, float beta2,
+                                float eps, float c_g, float c_m, float c_v, void* wcache, size_t wcache_bytes, void* stream)
+{
+    if (!e || !params || !grads || !m || !v || !wcache) { set_error("probav_optimizer_step_fused: null argument", hipSuccess); return PROBAV_EINVAL; }
+    const WcPlan wc = make_wc_plan(e);
+    if (wcache_bytes < wc.total * sizeof(float)) { set_error("probav_optimizer_step_fused: weight cache too small", hipSuccess); return PROBAV_ENOSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    float* C = (float*)wcache;
+    unsigned* wam = reinterpret_cast<unsigned*>(C + wc.amax);
+    if (hipMemsetAsync(wam, 0, (size_t)wc.n_wamax * sizeof(unsigned), s) != hipSuccess) { set_error("probav_optimizer_step_fused: amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    // one launch: the update of all 132 tensors + the weight normalisation of the updated parameters (+ the per-row maxima and the operand
+    // packing of the next pass behind it): the next probav_forward_wc starts at the head kernel
+    { ProfScope ps(e, CLS_WN, 0.0, s);
+      CK(optimizer_wn_step(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, grads, m, v, lr, beta1, beta2, eps, c_g, c_m, c_v,
+                           C + wc.weff, C + wc.weffT, C + wc.invn, wam, s)); }
+    if (!e->jobs.empty()) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), C + wc.weff, C + wc.weffT, C + wc.wpack, wam, s)); }
+    return PROBAV_OK;
+}
+
 
 // ---- introspection (parity tests) -----------------------------------------------------------------
 int probav_workspace_view(const probav_engine* e, int batch, int training, int kind, int index, int64_t* offset_floats, int64_t* count)
@@ -762,7 +835,7 @@ int probav_workspace_view(const probav_engine* e, int batch, int training, int k
     return PROBAV_EINVAL;
 }
 
-int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int B, int block, float* hidden, void* stream)
+int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int B, int block, float* hidden, const void* wcache, void* stream)
 {
     if (!e || !params || !ws || !hidden || B < 1 || block < 0 || block >= e->cfg.num_res_blocks) { set_error("probav_debug_hidden: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     if (e->impl < 3 || !e->pw_mfma) { set_error("probav_debug_hidden: only the split-operand kernel families (impl 3, 4) expose their hidden tile", hipSuccess); return PROBAV_EINVAL; }
@@ -772,13 +845,16 @@ int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t 
     const probav_net_cfg& c = e->cfg;
     const int D = c.dec_channels, R = c.num_res_blocks, i = block;
     const long nvox = (long)B * e->Hin * e->Hin * c.num_img_lr;
-    const AmaxSlots A(e, p, W, R);
+    const WcPlan wc = make_wc_plan(e);
+    const float* WC = (const float*)wcache;                           // the forward pass ran from the weight cache: its fragments and weight slots live there
+    const float* Wpack = WC ? WC + wc.wpack : W + p.wpack;
+    const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
     // the forward launch of block i again, into a scratch output (gDec is dead between passes), with the hidden tile written out;
     // no amax report (the slots of the saved tensors stay as the forward pass left them)
     PwAmax m;
     const bool h3 = e->impl >= 4;
     if (h3) { m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.w2c = A.wcol(e->iDec[i]); m.b1 = A.b(e->iExp[i]); }
-    return x6_pw_forward(W + p.act[i], W + p.wpack + (h3 ? e->pkW1h[i] : e->pkW1x6[i]), W + p.wpack + (h3 ? e->pkW2h[i] : e->pkW2x6[i]),
+    return x6_pw_forward(W + p.act[i], Wpack + (h3 ? e->pkW1h[i] : e->pkW1x6[i]), Wpack + (h3 ? e->pkW2h[i] : e->pkW2x6[i]),
                          params + e->layers[e->iExp[i]].wn.b_off, params + e->layers[e->iDec[i]].wn.b_off, W + p.gDec, nvox, nvox / B, D, h3 ? 2 : 1, m,
                          (hipStream_t)stream, hidden);
 }

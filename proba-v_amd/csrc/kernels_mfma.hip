@@ -1322,11 +1322,11 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
     const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
     // offset of strip voxel vi (this lane's channel) from ybase / sbase: rows are contiguous only when the range is the whole row
-    auto elem_off = [&](int vi) -> int {
-        if (a.nsplit == 1) return vi * g.Cout + col;
+    auto elem_off_ch = [&](int vi, int ch) -> int {
+        if (a.nsplit == 1) return vi * g.Cout + ch;
         const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
         const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
-        return ((hrel * g.Wo + ws0 + w) * g.To + t) * g.Cout + col;
+        return ((hrel * g.Wo + ws0 + w) * g.To + t) * g.Cout + ch;
     };
 
     // staging: item i of a row = (local voxel i >> 2 = (local column lw, depth t), channel chunk i & 3); local column lw <-> input column
@@ -1414,24 +1414,13 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     XS_DECL;
     XS_ACC(1);
 
-    float skn[16];
-    auto load_skip = [&](int tl) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int vi = tl * 32 + rowmap(i, half);
-            const int o = (tl < NTL && vi < NV && col < g.Cout) ? elem_off(vi) : 0;
-            skn[i] = sbase[o];
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 16; ++i) skn[i] = 0.f;
-    // Without a ReLU the skip tile is added by the SECOND wave of the pair, into the partial sum it hands over (at the accumulator's
-    // scale: exact): that wave has one tap group less and no epilogue, so the stall its filter waits take behind these HBM loads
-    // (vmcnt retires in order) costs the round less than on the writing wave.
-    const bool skip_via_part = sbase && !g.relu;                             // wave-uniform
-    const int skip_grp = skip_via_part ? 1 : 0;
-    if (grp == skip_grp && sbase) load_skip(tsel);
-
+    // Epilogue layout: after the two halves of a tile have met, the writing wave turns the tile around inside its 4 KB slot of the
+    // exchange buffer ([voxel][32 channels]) and every lane ends up with FOUR CONSECUTIVE CHANNELS of four voxels: lane l <-> voxel rows
+    // (l >> 3) + 8 jj, channels 4 (l & 7) .. + 3.  Skip tile and output then move as 16-byte accesses (4 instead of 16 per lane and
+    // tile; dword stores are bound by store issue, ~7 B/clk/CU), and the skip loads are issued AFTER the tap loop, so that they no
+    // longer sit in front of the filter fragments in the in-order vmcnt queue.
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int eq = lane & 7, er = lane >> 3;                                // epilogue coordinates: channel quad, voxel row (mod 8)
     const uint4* wf = wfrag + lane;                                         // PACK_H3_CONV (32 channels) / PACK_H3_CONVP (25): fragment ((group * NST + st) * NP + piece) * 64 + lane
     for (int r = 0; r < nrounds; ++r) {
         const int vlast_next = (r + 2) * 128 - 1 < NV - 1 ? (r + 2) * 128 - 1 : NV - 1;
@@ -1442,9 +1431,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        float sk[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sk[i] = skn[i];
         if (tile < NTL) {
             int vi = tile * 32 + col;
             vi = vi < NV ? vi : NV - 1;
@@ -1497,47 +1483,82 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 }
             }
             if (grp == 1) {
-                if (skip_via_part) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i] + ldexpf(sk[i], -eun);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
-                }
+                for (int i = 0; i < 16; ++i) part[(tsel * 16 + i) * 64 + lane] = acc[i];
             }
         } else if (do_load) stage_load(hiq + 1, nv_);
-        if (grp == skip_grp && sbase && r + 1 < nrounds) load_skip(4 * (r + 1) + tsel);
+        // The two waves of a pair SHARE the epilogue of their tile: the first one writes voxel rows er + 0, er + 8, the second one rows
+        // er + 16, er + 24.  Each loads its half of the skip tile now (16-byte rows, consumed after the second barrier).
+        f32x4u skq[2];
+        int eoff[2];                                                         // element offset of (row er + 8 (2 grp + jj), channel 4 eq) from ybase / sbase, -1 = dead row
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int vi = tile * 32 + er + 8 * (2 * grp + jj);
+            eoff[jj] = (tile < NTL && vi < NV) ? elem_off_ch(vi, 4 * eq) : -1;
+            skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
+        }
+        if (sbase && tile < NTL) {
+            if (g.Cout == 32) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) skq[jj] = *reinterpret_cast<const f32x4u*>(sbase + (eoff[jj] < 0 ? 0 : eoff[jj]));
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || 4 * eq + c >= g.Cout) ? 0 : eoff[jj] + c];
+            }
+        }
         XS_ACC(2);
         __syncthreads();                                   // partials are in LDS; every wave is past its taps
         XS_ACC(4);
-        float pv[16];
-        if (grp == 0 && tile < NTL) {
+        // Between the two barriers the first wave of a pair turns the tile around inside the tile's own 4 KB slot of the exchange buffer (only
+        // this wave touches the slot in this interval: the partner wrote it before the first barrier) and takes its two rows; the partner
+        // reads ITS two rows after the second barrier, before it can write the slot again (program order): no access is left to chance.
+        float* slot = part + tsel * 16 * 64;
+        float4 tq[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pv[i] = part[(tsel * 16 + i) * 64 + lane];
+        for (int jj = 0; jj < 2; ++jj) tq[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp == 0 && tile < NTL) {
+            float fv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) fv[i] = part[(tsel * 16 + i) * 64 + lane];                // the partner's partial sums
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     // (all of them read before the slot is rewritten)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = ldexpf(acc[i] + fv[i], eun) + bv;                   // final values in the accumulator layout: the filter column's exponent and the bias are per lane here
+                if (g.relu) v = fmaxf(v, 0.f);
+                slot[rowmap(i, half) * 32 + col] = v;                         // [voxel][channel]
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (a wave's LDS operations execute in order: the wait orders the compiler)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) tq[jj] = *reinterpret_cast<const float4*>(slot + (er + 8 * jj) * 32 + 4 * eq);
         }
         if (do_load) { stage_store(hiq + 1, nv_); ++hiq; }  // replaces the oldest row, which no tile of the next round reads
         XS_ACC(3);
-        __syncthreads();                                   // partial buffer may be rewritten, the new row is visible
+        __syncthreads();                                   // the turned tiles and the new row are visible
         XS_ACC(4);
-        if (grp == 0 && tile < NTL) {
-            const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
-            int oo[16];
-            float ov[16];
+        if (tile < NTL) {
+            if (grp == 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int vi = tile * 32 + rowmap(i, half);
-                oo[i] = (vi < NV && col < g.Cout) ? elem_off(vi) : -1;
-                float v = ldexpf(acc[i] + pv[i], eun) + bv;
-                if (g.relu) v = fmaxf(v, 0.f);
-                ov[i] = skip_via_part ? v : v + sk[i];
-                omax = fmaxf(omax, oo[i] >= 0 ? fabsf(ov[i]) : 0.f);
+                for (int jj = 0; jj < 2; ++jj) tq[jj] = *reinterpret_cast<const float4*>(slot + (er + 8 * (2 + jj)) * 32 + 4 * eq);
             }
-            if (full) {
+            const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;            // wave-uniform
 #pragma unroll
-                for (int i = 0; i < 16; ++i) ybase[oo[i]] = ov[i];
-            } else {
+            for (int jj = 0; jj < 2; ++jj) {
+                const float4 t = tq[jj];
+                f32x4u o = {t.x + skq[jj][0], t.y + skq[jj][1], t.z + skq[jj][2], t.w + skq[jj][3]};
+                if (full) {
+                    *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                } else if (eoff[jj] >= 0) {
+                    if (4 * eq + 4 <= g.Cout) {
+                        *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) if (oo[i] >= 0) ybase[oo[i]] = ov[i];
+                        for (int c = 0; c < 4; ++c) if (4 * eq + c < g.Cout) { ybase[eoff[jj] + c] = o[c]; omax = fmaxf(omax, fabsf(o[c])); }
+                    }
+                }
             }
         }
         XS_ACC(5);

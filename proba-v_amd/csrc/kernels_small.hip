@@ -53,21 +53,54 @@ __device__ __forceinline__ int find_layer(const WnLayer* L, int nl, int chan, in
     return i;
 }
 
+// Optimizer coefficients of the fused update (the rule of nadam_kernel below; Keras Nadam / Adam / SGD by coefficients)
+struct OptCoef { float lr, b1, b2, eps, c_g, c_m, c_v; };
+__device__ __forceinline__ float opt_update(float theta, float g, float& m, float& v, const OptCoef& c)
+{
+    m = c.b1 * m + (1.f - c.b1) * g;
+    v = c.b2 * v + (1.f - c.b2) * g * g;
+    return theta - c.lr * (c.c_g * g + c.c_m * m) / (sqrtf(v * c.c_v) + c.eps);
+}
+
+// UPDATE: the optimizer step of this column's parameters (g[co], bias[co], v[:, co]) runs first, in the same wave, and the
+// reparameterisation that follows is that of the UPDATED parameters: the next forward pass finds its effective weights ready
+// (reference: optimizer.apply_gradients, then WeightNormalization's kernel recomputed at the next call --
+// models/trainClass.py:132, models/modelsTF.py:191-197).  The arithmetic of every element is the one of nadam_kernel.
+template <bool UPDATE>
 __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restrict__ layers, int nl,
-                                                       const float* __restrict__ params, float* __restrict__ weff,
+                                                       float* __restrict__ params, float* __restrict__ weff,
                                                        float* __restrict__ weffT, float* __restrict__ inv_norm,
-                                                       unsigned* __restrict__ amax)
+                                                       unsigned* __restrict__ amax, const float* __restrict__ grad,
+                                                       float* __restrict__ om, float* __restrict__ ov, OptCoef oc)
 {
     int co;
     const int li = find_layer(layers, nl, blockIdx.x, co);
     const WnLayer L = layers[li];
-    const float* v = params + L.v_off;
+    float* v = params + L.v_off;
     const int lane = threadIdx.x;
+    float gain = params[L.g_off + co], bias_abs = fabsf(params[L.b_off + co]);
+    if constexpr (UPDATE) {
+        {   // the gain g[co] and the bias[co]: every lane computes both (the values are needed below), lanes 0 and 1 store them
+            const int ig = L.g_off + co, ib = L.b_off + co;
+            float mg = om[ig], vg = ov[ig], mb = om[ib], vb = ov[ib];
+            gain = opt_update(gain, grad[ig], mg, vg, oc);
+            const float bnew = opt_update(params[ib], grad[ib], mb, vb, oc);
+            bias_abs = fabsf(bnew);
+            if (lane == 0) { params[ig] = gain; om[ig] = mg; ov[ig] = vg; }
+            if (lane == 1) { params[ib] = bnew; om[ib] = mb; ov[ib] = vb; }
+        }
+        for (int k = lane; k < L.K; k += 64) {                      // the filter column; each lane re-reads only what it wrote itself
+            const int i = L.v_off + k * L.Cout + co;
+            float mi = om[i], vi = ov[i];
+            params[i] = opt_update(params[i], grad[i], mi, vi, oc);
+            om[i] = mi; ov[i] = vi;
+        }
+    }
     float ss = 0.f;
     for (int k = lane; k < L.K; k += 64) { const float q = v[(long)k * L.Cout + co]; ss = fmaf(q, q, ss); }
     ss = wave_sum(ss);
     const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));            // tf.nn.l2_normalize epsilon
-    const float scale = params[L.g_off + co] * inv;
+    const float scale = gain * inv;
     if (lane == 0) inv_norm[L.n_off + co] = inv;
     float wmax = 0.f;
     for (int k = lane; k < L.K; k += 64) {
@@ -81,7 +114,7 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
 #pragma unroll
         for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
         if (lane == 0) {
-            atomicMax(amax + li, __float_as_uint(wmax)); atomicMax(amax + nl + li, __float_as_uint(fabsf(params[L.b_off + co])));
+            atomicMax(amax + li, __float_as_uint(wmax)); atomicMax(amax + nl + li, __float_as_uint(bias_abs));
             amax[2 * nl + L.n_off + co] = __float_as_uint(wmax);
         }
     }
@@ -198,8 +231,20 @@ __global__ __launch_bounds__(64) void wn_backward_kernel(const WnLayer* __restri
 int wn_forward(const WnLayer* d_layers, int nlayers, int cout_total, int cin_total, const float* params,
                float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s)
 {
-    hipLaunchKernelGGL(wn_forward_kernel, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm, amax);
+    hipLaunchKernelGGL(wn_forward_kernel<false>, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, const_cast<float*>(params), weff, weffT, inv_norm, amax,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, OptCoef());
     int rc = check_launch("wn_forward");
+    if (rc || !amax) return rc;
+    hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total);
+    return check_launch("wn_rowmax");
+}
+int optimizer_wn_step(const WnLayer* d_layers, int nlayers, int cout_total, int cin_total, float* params, const float* grad, float* m, float* v,
+                      float lr, float b1, float b2, float eps, float c_g, float c_m, float c_v,
+                      float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s)
+{
+    OptCoef oc = {lr, b1, b2, eps, c_g, c_m, c_v};
+    hipLaunchKernelGGL(wn_forward_kernel<true>, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm, amax, grad, m, v, oc);
+    int rc = check_launch("optimizer_wn_step");
     if (rc || !amax) return rc;
     hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total);
     return check_launch("wn_rowmax");

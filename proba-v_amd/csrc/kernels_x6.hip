@@ -16,6 +16,7 @@
 // k-slots of k-block 0, registers 8..15 those of k-block 1, and the A operand is packed with the same permutation.
 #include "kernels_x6.h"
 #include "x6_device.h"
+#include <type_traits>
 
 namespace probav {
 
@@ -134,14 +135,28 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
             }
         }
         if (vok) {
+            // registers 4g .. 4g+3 are the four CONSECUTIVE output channels 8g + 4h + (0..3) of this lane's voxel: one 16-byte store each
+            // (the rows of dec are D floats long, so the stores are only 4-byte aligned: the hardware splits them where it must)
             float* o = dec + v * D;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = rowmap(r, h);
-                float t = T[r];
-                if constexpr (AR::SCALED) t = ldexpf(t, -(sE2[ch] + eh));   // accumulator of the second product -> true values
-                t += sB2[ch];
-                if (ch < D) { o[ch] = t; omax = fmaxf(omax, fabsf(t)); }
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 8 * g + 4 * h;
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    t[i] = T[4 * g + i];
+                    if constexpr (AR::SCALED) t[i] = ldexpf(t[i], -(sE2[c0 + i] + eh));   // accumulator of the second product -> true values
+                    t[i] += sB2[c0 + i];
+                }
+                if (c0 + 4 <= D) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    f32x4u q = {t[0], t[1], t[2], t[3]};
+                    *reinterpret_cast<f32x4u*>(o + c0) = q;
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (c0 + i < D) { o[c0 + i] = t[i]; omax = fmaxf(omax, fabsf(t[i])); }
+                }
             }
         }
         if (++j == tps) {                                            // the run leaves sample n
@@ -267,7 +282,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         }
         return q;
     };
-    if (tid < 256) sB1[tid] = b1[tid];
     const int c = wave;                                           // this wave's hidden chunk
 
     Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
@@ -295,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     const int tps = (vps + 31) >> 5;                              // tiles per sample
     const int ntiles = (int)(nvox / vps) * tps;
     const int tbeg = (int)((long)ntiles * blockIdx.x / gridDim.x), tend = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);   // this workgroup's run of tiles
+    // (a contiguous run also measures 5 % faster than the round-1 order tile = block + k * grid)
     // Staging belongs to the first-dispatched half of the workgroup (waves 0..3); the dX reduction is shared by both halves.  With the
     // staging spread over all eight waves the second half (which loses the per-SIMD issue arbitration) was the pole wave of every tile
     // while the first half waited ~20 % of a tile at the barrier; with staging AND reduction on the first half the roles flipped.
@@ -391,8 +406,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     unsigned long long xs2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xs2t = 0;
 #endif
     __syncthreads();                                   // DA pads are zero
+    if (tile < tend) cur = sample_scales(n);
+    if (tid < 256) sB1[tid] = b1[tid] * pow2i(cur.eh);            // the expand biases at the hidden tile's scale of the run's first sample (rewritten when the run enters another sample)
     if (tile < tend) {
-        cur = sample_scales(n);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f); float d[4] = {0.f, 0.f, 0.f, 0.f};
         stage_load(n, j, xv, d);
         stage_store(0, j, xv, d, pow2i(cur.ex), pow2i(cur.ed));
@@ -421,22 +437,33 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             if (rv < pnrem) { dX[(pv0 + rv) * 32 + col] = sacc; omax = fmaxf(omax, fabsf(sacc)); }
         }
     };
-    for (; tile < tend; ++tile, buf ^= 1) {
+    float omax_done = 0.f; int n_done = -1;             // a finished sample's largest |dX| (per lane) waiting to be committed
+    auto commit_done = [&]() {
+        if (n_done >= 0 && am.y) amax_commit(omax_done, am.y + n_done);
+        n_done = -1;
+    };
+    // One tile.  Two instances: the INTERIOR one (the next tile exists and belongs to the same sample: no scale change, no bookkeeping) is
+    // the hot loop; the BOUNDARY one (last tile of a sample inside the run, or of the run) carries everything that happens once per sample.
+    auto do_tile = [&](auto boundary_tag) {
+        constexpr bool BND = decltype(boundary_tag)::value;
         XS_ACC(5);
         __syncthreads();                               // tile `tile` is staged in buffer `buf`; the previous tile's partials are complete
         XS_ACC(1);
         float* Tb = TbAll + (buf * 8 + wave) * PB_TB;
         // the next tile of the run: (nn, nj); its sample's scales are needed for the staging at the end of this iteration
         int nn = n, nj = j + 1;
-        if (nj == tps) { nj = 0; ++nn; }
-        const bool has_next = tile + 1 < tend;
-        const bool leaves = nn != n;                                   // this is the run's last tile of sample n (wave-uniform)
+        bool has_next = true, leaves = false;
+        if constexpr (BND) {
+            if (nj == tps) { nj = 0; ++nn; }
+            has_next = tile + 1 < tend;
+            leaves = nn != n;                                          // this is the run's last tile of sample n (wave-uniform)
+        }
         float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};
         stage_load(has_next ? nn : n, has_next ? nj : j, nxv, nd);     // in flight during this tile's MFMAs (after the last tile: a harmless re-read)
-        float ch = 1.f, cg = 1.f, sbias = 1.f;                         // accumulators (a), (b) -> hidden values / hidden gradients at their own scales
+        float ch = 1.f, cg = 1.f;                                      // accumulators (a), (b) -> hidden values / hidden gradients at their own scales
         if constexpr (AR::SCALED) {
             const int kh = cur.eh - cur.ex - ew1, kg = cur.eg - ew2 - cur.ed;   // (<= -17 always, see the bounds)
-            ch = pow2i(kh < -126 ? -126 : kh); cg = pow2i(kg < -126 ? -126 : kg); sbias = pow2i(cur.eh);
+            ch = pow2i(kh < -126 ? -126 : kh); cg = pow2i(kg < -126 ? -126 : kg);
         }
         const long v0 = (long)n * vps + 32 * j;
         const int nrem = vps - 32 * j < 32 ? vps - 32 * j : 32;
@@ -469,9 +496,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             dH = mac<AR>(w2[0], df[0], dH); dH = mac<AR>(w2[1], df[1], dH);           // (b)
             __builtin_amdgcn_sched_barrier(0);
             reduce_prev(buf ^ 1);                          // LDS reads, adds and two stores in the shadow of the 24 MFMAs just issued
-            if (pn >= 0 && pn != n) {                      // the previous tile was the last one of its sample: its dX is complete now
-                if (am.y) amax_commit(omax, am.y + pn);
-                omax = 0.f;
+            if (pn >= 0 && pn != n) {                      // the previous tile was the last one of its sample: its dX is complete now; the
+                omax_done = omax; n_done = pn; omax = 0.f; // wave-wide maximum and the atomic wait for the next boundary tile (rare code stays out of this loop)
             }
             __builtin_amdgcn_sched_barrier(0);
             XS2(0);
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 8 * kb + 4 * g + i;
-                        const float hv = fmaf(H[r], ch, bv[i] * sbias), dv = dH[r] * cg;      // (ch = cg = sbias = 1 without scaling)
+                        const float hv = fmaf(H[r], ch, bv[i]), dv = dH[r] * cg;              // (sB1 holds b1 2^eh of the current sample; ch = cg = 1 without scaling)
                         gs[4 * g + i] = hv > 0.f ? dv : 0.f;
                         hs[4 * g + i] = fmaxf(hv, 0.f);
                         bs1v[r] += gs[4 * g + i];
@@ -542,8 +568,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             XS2(4);
         }
         XS_ACC(2);
-        if constexpr (AR::SCALED) {
-            nxt = cur;
+        nxt = cur;
+        if constexpr (AR::SCALED && BND) {
+            commit_done();
             if (leaves && has_next) {
                 // (d), (e) of the next tile run at another sample's scales.  The running sums move to the new scales by an exact multiplication
                 // with a power of two (fp32 keeps 2^+-40 around sums of ~2^45 without leaving its range); a jump beyond that -- a dead sample
@@ -557,6 +584,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
                 }
+                if (nxt.eh != cur.eh) {                    // the biases at the next sample's hidden scale: every wave is past its last read of
+                    __syncthreads();                       // sB1 for this tile here, and the next tile's first barrier publishes the new values
+                    if (tid < 256) sB1[tid] = b1[tid] * pow2i(nxt.eh);
+                }
             }
         }
         if (has_next) stage_store(buf ^ 1, nj, nxv, nd, pow2i(nxt.ex), pow2i(nxt.ed));
@@ -566,9 +597,17 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) pdo[k] = cdo[k];
         cur = nxt; n = nn; j = nj;
+    };
+    while (tile < tend) {
+        int seg_last = (n + 1) * tps - 1;                              // last tile of sample n inside this run
+        if (seg_last > tend - 1) seg_last = tend - 1;
+        for (; tile < seg_last; ++tile, buf ^= 1) do_tile(std::false_type());
+        do_tile(std::true_type());
+        ++tile; buf ^= 1;
     }
     __syncthreads();
     reduce_prev(buf ^ 1);
+    commit_done();
     if (am.y && pn >= 0) amax_commit(omax, am.y + pn);
     flush(cur);                                            // the sums of the run's last sample(s), at that sample's scales (all exponents 0 without scaling)
     // db2[out] = sum of the staged dT values: thread t always staged out (t % D) and ((t + 512) % D); fixed-order sum

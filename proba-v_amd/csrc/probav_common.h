@@ -69,6 +69,12 @@ struct WnLayer {            // one weight-normalised layer inside the flat param
 // channel that of its rows (slot 2 nlayers + cout_total + r_off + ci)
 int wn_forward(const WnLayer* d_layers, int nlayers, int max_cout_total, int cin_total, const float* params,
                float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s);
+// the optimizer update of EVERY parameter (rule and coefficients of nadam_step) fused with the weight normalisation of the updated
+// parameters: one wave per (layer, output channel) updates its g, bias and filter column, then writes the column of weff / weffT /
+// inv_norm and the amax slots exactly as wn_forward does
+int optimizer_wn_step(const WnLayer* d_layers, int nlayers, int cout_total, int cin_total, float* params, const float* grad, float* m, float* v,
+                      float lr, float b1, float b2, float eps, float c_g, float c_m, float c_v,
+                      float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s);
 int wn_backward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
                 const float* dweff, const float* inv_norm, float* grads, hipStream_t s);
 int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, float mean, float stdv, hipStream_t s);

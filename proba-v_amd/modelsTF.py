@@ -48,6 +48,7 @@ class WDSRModel(torch.nn.Module):
         self.flat = torch.nn.Parameter(flat)
         self._engine = None
         self._ws = {}
+        self._wcache, self._wcache_version = None, None
 
     # -- reference-facing surface ------------------------------------------------------------------
     @property
@@ -95,7 +96,7 @@ class WDSRModel(torch.nn.Module):
             raise RuntimeError("model parameters are on %s but the input is on %s" % (self.flat.device, x.device))
         x = x.contiguous().float()
         need_grad = bool(training) and torch.is_grad_enabled() and self.flat.requires_grad
-        y, ws = torch.ops.probav.wdsr_forward(self.flat, x, int(self._handle().value), self.scale * self.patchSizeLR, need_grad)
+        y, ws = torch.ops.probav.wdsr_forward(self.flat, x, int(self._handle().value), self.scale * self.patchSizeLR, need_grad, self.weight_cache())
         self._ws = {(int(x.shape[0]), need_grad, self.flat.device): ws}     # the last call's workspace (saved activations): introspection, tests
         return y
 
@@ -131,6 +132,26 @@ class WDSRModel(torch.nn.Module):
         4 (default) = the same kernels with the H3 arithmetic (three products of fp16 piece pairs, operands scaled by a power
         of two per sample / per filter column).  Every family computes a sample independently of its batch mates, bit for bit."""
         _lib.check(_lib.lib().probav_engine_set_impl(self._handle(), int(impl)), "probav_engine_set_impl")
+
+    # -- weight cache (SURVEY.md section 8f-2) -----------------------------------------------------------------
+    def weight_cache_buffer(self):
+        """The device buffer the fused optimizer step writes the next step's effective weights / operand fragments into."""
+        if self._wcache is None or self._wcache.device != self.flat.device:
+            n = _lib.lib().probav_weight_cache_bytes(self._handle())
+            self._wcache = torch.empty((n + 3) // 4, dtype=torch.float32, device=self.flat.device)
+            self._wcache_version = None
+        return self._wcache
+
+    def mark_weight_cache(self):
+        """Called by the fused optimizer right after it has updated `flat` and filled the cache: valid until `flat` changes again."""
+        self._wcache_version = (self.flat._version, self.flat.data_ptr())
+
+    def weight_cache(self):
+        """The cache if it still matches the parameters (any in-place change of `flat` bumps its version counter), else None."""
+        if self._wcache is not None and self._wcache_version == (self.flat._version, self.flat.data_ptr()) \
+                and self._wcache.device == self.flat.device:
+            return self._wcache
+        return None
 
     def _workspace(self, batch, training):
         """The workspace the LAST forward call of this (batch, training) shape produced (every call gets its own: an output of

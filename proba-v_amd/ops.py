@@ -11,6 +11,8 @@ dispatcher, `torch.compile` / AOT-autograd and `torch.library.opcheck` (tests/te
   probav::shift_loss_backward(hr, mask, pred, arg, upstream, border, which) -> dpred
   probav::shift_metrics(hr, mask, pred, border, bit_depth) -> (f[3,B], arg[2,B], means[2])     one launch: L1, L2, cPSNR of every sample
   probav::nadam_step(theta, grad, m, v, lr, b1, b2, eps, c_g, c_m, c_v) -> ()                 optimizer.apply_gradients   trainClass.py:132
+  probav::optimizer_wn_step(theta, grad, m, v, wcache, engine, lr, ...) -> ()                 the same update fused with the weight normalisation
+                                                                            and operand packing of the NEXT step (wdsr_forward's optional `wcache`)
   probav::clip_round(x, lo, hi) -> y                                        tf.clip_by_value + tf.round   test.py:118-119
 
 `engine` is the probav_engine* of include/probav_hip.h as an integer (the ops are stateless; the handle owns only the layer table),
@@ -19,6 +21,7 @@ any differentiable op; torch's caching allocator recycles the block from step to
 there is no fallback implementation.
 """
 from ctypes import c_void_p
+from typing import Optional
 
 import torch
 from torch import Tensor
@@ -54,42 +57,56 @@ def _ws_floats(engine, batch, training):
 
 
 @torch.library.custom_op("probav::wdsr_forward", mutates_args=(), device_types="cuda")
-def wdsr_forward(flat: Tensor, x: Tensor, engine: int, out_size: int, training: bool) -> tuple[Tensor, Tensor]:
+def wdsr_forward(flat: Tensor, x: Tensor, engine: int, out_size: int, training: bool, wcache: Optional[Tensor] = None) -> tuple[Tensor, Tensor]:
     """-> (y [B, out_size, out_size, 1], ws): ws is the engine workspace of this call -- with training=True it holds the activations the
-    reverse pass needs (the op is functional: the saved state is an OUTPUT, like the residuals of any differentiable op)."""
+    reverse pass needs (the op is functional: the saved state is an OUTPUT, like the residuals of any differentiable op).
+    wcache (optional): the weight cache probav::optimizer_wn_step filled for exactly these parameters; the weight-norm and packing
+    launches are then skipped."""
     _dev(x, "model input")
     B = x.shape[0]
     y = torch.empty((B, out_size, out_size, 1), dtype=torch.float32, device=x.device)
     with torch.cuda.use_mem_pool(_ws_pool(x.device), device=x.device):
         ws = torch.empty(_ws_floats(engine, B, training), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().probav_forward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4, B,
-                                         1 if training else 0, _lib.current_stream()), "probav_forward")
+    L = _lib.lib()
+    if wcache is None:
+        _lib.check(L.probav_forward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4, B,
+                                    1 if training else 0, _lib.current_stream()), "probav_forward")
+    else:
+        _lib.check(L.probav_forward_wc(c_void_p(engine), _lib.ptr(flat), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4, B,
+                                       1 if training else 0, _lib.ptr(wcache), wcache.numel() * 4, _lib.current_stream()), "probav_forward_wc")
     return y, ws
 
 
 @wdsr_forward.register_fake
-def _(flat, x, engine, out_size, training):
+def _(flat, x, engine, out_size, training, wcache=None):
     B = x.shape[0]
     return (x.new_empty((B, out_size, out_size, 1), dtype=torch.float32), x.new_empty((_ws_floats(engine, int(B), training),), dtype=torch.float32))
 
 
 @torch.library.custom_op("probav::wdsr_backward", mutates_args=("ws",), device_types="cuda")
-def wdsr_backward(flat: Tensor, dy: Tensor, ws: Tensor, engine: int) -> Tensor:
-    """d loss / d flat from d loss / d y; `ws` = the workspace the matching forward returned (its gradient buffers are scratch: mutated)."""
+def wdsr_backward(flat: Tensor, dy: Tensor, ws: Tensor, engine: int, wcache: Optional[Tensor] = None) -> Tensor:
+    """d loss / d flat from d loss / d y; `ws` = the workspace the matching forward returned (its gradient buffers are scratch: mutated);
+    wcache = the weight cache that forward ran from, if any."""
     _dev(dy, "output gradient")
     grads = torch.empty_like(flat)
-    _lib.check(_lib.lib().probav_backward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
-                                          dy.shape[0], _lib.current_stream()), "probav_backward")
+    L = _lib.lib()
+    if wcache is None:
+        _lib.check(L.probav_backward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
+                                     dy.shape[0], _lib.current_stream()), "probav_backward")
+    else:
+        _lib.check(L.probav_backward_wc(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
+                                        dy.shape[0], _lib.ptr(wcache), wcache.numel() * 4, _lib.current_stream()), "probav_backward_wc")
     return grads
 
 
 @wdsr_backward.register_fake
-def _(flat, dy, ws, engine):
+def _(flat, dy, ws, engine, wcache=None):
     return torch.empty_like(flat)
 
 
 def _wdsr_setup(ctx, inputs, output):
-    flat, x, engine, out_size, training = inputs
+    flat, x, engine, out_size, training, wcache = inputs
+    ctx.wcache = wcache
     # the workspace is an OUTPUT of this node: it must go through save_for_backward (a plain attribute would close the reference cycle
     # node -> ctx -> ws -> grad_fn -> node and every step's 3 GB would stay alive until the cycle collector runs, if ever)
     ctx.save_for_backward(flat, output[1])
@@ -100,13 +117,13 @@ def _wdsr_setup(ctx, inputs, output):
 
 def _wdsr_bwd(ctx, dy, dws):
     if dy is None:
-        return None, None, None, None, None
+        return None, None, None, None, None, None
     if not ctx.training:
         raise RuntimeError("backward through model(x, training=False): call the model with training=True "
                            "to keep the activations the reverse pass needs")
     flat, ws = ctx.saved_tensors
-    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ws, ctx.engine)
-    return g, None, None, None, None
+    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ws, ctx.engine, ctx.wcache)
+    return g, None, None, None, None, None
 
 
 wdsr_forward.register_autograd(_wdsr_bwd, setup_context=_wdsr_setup)
@@ -195,6 +212,22 @@ def nadam_step(theta: Tensor, grad: Tensor, m: Tensor, v: Tensor, lr: float, bet
 
 @nadam_step.register_fake
 def _(theta, grad, m, v, lr, beta_1, beta_2, eps, c_g, c_m, c_v):
+    return None
+
+
+@torch.library.custom_op("probav::optimizer_wn_step", mutates_args=("theta", "m", "v", "wcache"), device_types="cuda")
+def optimizer_wn_step(theta: Tensor, grad: Tensor, m: Tensor, v: Tensor, wcache: Tensor, engine: int, lr: float, beta_1: float, beta_2: float,
+                      eps: float, c_g: float, c_m: float, c_v: float) -> None:
+    """nadam_step on the engine's flat parameter buffer, fused with the weight normalisation (and operand packing) of the UPDATED
+    parameters into `wcache` (probav_weight_cache_bytes): the next wdsr_forward(..., wcache) starts at its first convolution."""
+    _dev(theta, "parameter")
+    _lib.check(_lib.lib().probav_optimizer_step_fused(c_void_p(engine), _lib.ptr(theta), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), lr, beta_1, beta_2,
+                                                      eps, c_g, c_m, c_v, _lib.ptr(wcache), wcache.numel() * 4, _lib.current_stream()),
+               "probav_optimizer_step_fused")
+
+
+@optimizer_wn_step.register_fake
+def _(theta, grad, m, v, wcache, engine, lr, beta_1, beta_2, eps, c_g, c_m, c_v):
     return None
 
 

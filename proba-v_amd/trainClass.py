@@ -212,14 +212,26 @@ def load_nadam_state(optimizer, step, momentum_cache, m, v):
         raise TypeError("the reference checkpoint carries Nadam slots; optimizer is %s" % type(optimizer).__name__)
 
 
+def _fused_update(model, p, g, st, lr, b1, b2, eps, c_g, c_m, c_v):
+    """One optimizer update of the flat parameter `p`: with a WDSRModel behind it (make_optimizer passes it) the update is fused with the
+    weight normalisation and operand packing of the NEXT forward pass (torch.ops.probav.optimizer_wn_step, SURVEY.md section 8f-2);
+    otherwise the plain fused element-wise launch."""
+    if model is not None and p is model.flat:
+        torch.ops.probav.optimizer_wn_step(p, g, st["m"], st["v"], model.weight_cache_buffer(), int(model._handle().value), lr, b1, b2, eps, c_g, c_m, c_v)
+        model.mark_weight_cache()
+    else:
+        torch.ops.probav.nadam_step(p, g, st["m"], st["v"], lr, b1, b2, eps, c_g, c_m, c_v)
+
+
 class HipNadam(torch.optim.Optimizer):
     """Keras ``Nadam`` (optimizer_v2 defaults: beta_1 0.9, beta_2 0.999, epsilon 1e-7, schedule_decay 0.004)
     as ONE fused HIP launch per parameter tensor (the model has a single flat one).  The momentum schedule
     (mu_t, the running product Pi_t = `momentum_cache`) is tracked on the host in double, like Keras tracks it in
     variables; `state_dict()` carries step, momentum cache and the two slots, so checkpoints resume exactly."""
 
-    def __init__(self, params, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, schedule_decay=0.004):
+    def __init__(self, params, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, schedule_decay=0.004, model=None):
         super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon, schedule_decay=schedule_decay))
+        self.model = model
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -244,7 +256,7 @@ class HipNadam(torch.optim.Optimizer):
                 c_m = mu_t1 / (1.0 - pi_t * mu_t1)
                 c_v = 1.0 / (1.0 - b2 ** t)
                 g = p.grad.contiguous()
-                torch.ops.probav.nadam_step(p, g, st["m"], st["v"], group["lr"], b1, b2, group["epsilon"], c_g, c_m, c_v)
+                _fused_update(self.model, p, g, st, group["lr"], b1, b2, group["epsilon"], c_g, c_m, c_v)
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -252,8 +264,9 @@ class HipAdam(torch.optim.Optimizer):
     outside the bias correction.  Same fused launch as HipNadam (the kernel computes
     theta -= lr (c_g g + c_m m) / (sqrt(c_v v) + eps); here c_g = 0, c_m = sqrt(1 - b2^t) / (1 - b1^t), c_v = 1)."""
 
-    def __init__(self, params, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    def __init__(self, params, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, model=None):
         super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon))
+        self.model = model
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -271,14 +284,15 @@ class HipAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 t = st["step"]
                 c_m = (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
-                torch.ops.probav.nadam_step(p, p.grad.contiguous(), st["m"], st["v"], group["lr"], b1, b2, group["epsilon"], 0.0, c_m, 1.0)
+                _fused_update(self.model, p, p.grad.contiguous(), st, group["lr"], b1, b2, group["epsilon"], 0.0, c_m, 1.0)
 
 
 class HipSGD(torch.optim.Optimizer):
     """Keras ``SGD`` without momentum through the same fused launch (c_g = 1, c_m = 0, c_v = 0, eps = 1: theta -= lr g)."""
 
-    def __init__(self, params, lr=1e-2):
+    def __init__(self, params, lr=1e-2, model=None):
         super().__init__(params, dict(lr=lr))
+        self.model = model
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -291,7 +305,7 @@ class HipSGD(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
-                torch.ops.probav.nadam_step(p, p.grad.contiguous(), st["m"], st["v"], group["lr"], 0.0, 0.0, 1.0, 1.0, 0.0, 0.0)
+                _fused_update(self.model, p, p.grad.contiguous(), st, group["lr"], 0.0, 0.0, 1.0, 1.0, 0.0, 0.0)
 
 
 def make_optimizer(name, model, learning_rate):
@@ -302,14 +316,14 @@ def make_optimizer(name, model, learning_rate):
     on_gpu = bool(params) and params[0].is_cuda
     if name == "adam":
         if on_gpu:
-            return HipAdam(params, lr=learning_rate)
+            return HipAdam(params, lr=learning_rate, model=model if hasattr(model, "weight_cache_buffer") else None)
         return torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7)
     if name == "nadam":
         if params and params[0].is_cuda:
-            return HipNadam(params, lr=learning_rate)
+            return HipNadam(params, lr=learning_rate, model=model if hasattr(model, "weight_cache_buffer") else None)
         return torch.optim.NAdam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
     if on_gpu:
-        return HipSGD(params, lr=learning_rate)
+        return HipSGD(params, lr=learning_rate, model=model if hasattr(model, "weight_cache_buffer") else None)
     return torch.optim.SGD(params, lr=learning_rate)
 
 

@@ -21,9 +21,9 @@ def _model(dev, T=9):
 
 def test_ops_are_registered_with_schemas():
     import probav_amd.ops  # noqa: F401
-    want = {"wdsr_forward": "(Tensor flat, Tensor x, SymInt engine, SymInt out_size, bool training) -> (Tensor, Tensor)",
-            "wdsr_backward": "(Tensor flat, Tensor dy, Tensor(a2!) ws, SymInt engine) -> Tensor",
-            "nadam_step": None, "shift_loss": None, "shift_loss_backward": None, "shift_metrics": None, "clip_round": None}
+    want = {"wdsr_forward": "(Tensor flat, Tensor x, SymInt engine, SymInt out_size, bool training, Tensor? wcache=None) -> (Tensor, Tensor)",
+            "wdsr_backward": "(Tensor flat, Tensor dy, Tensor(a2!) ws, SymInt engine, Tensor? wcache=None) -> Tensor",
+            "nadam_step": None, "optimizer_wn_step": None, "shift_loss": None, "shift_loss_backward": None, "shift_metrics": None, "clip_round": None}
     for name, schema in want.items():
         op = getattr(torch.ops.probav, name).default
         if schema is not None:
@@ -97,3 +97,63 @@ def test_ops_trace_under_torch_compile_fullgraph(dev):
         pytest.skip("torch.compile unavailable on this box: %r" % (exc,))
     got.backward()
     assert float(got) == float(want) and torch.equal(flat.grad, gw)
+
+
+def test_fused_optimizer_weight_norm_step(dev):
+    """SURVEY.md section 8f-2: probav::optimizer_wn_step = Keras Nadam on all 132 tensors + the weight normalisation (and operand packing)
+    of the UPDATED parameters in the same call.  (1) the parameters equal the plain fused Nadam launch and the fp64 restatement,
+    (2) the cached effective weights equal oracle.weight_norm(updated v, updated g), (3) a forward/backward pass from the cache equals the
+    pass that recomputes everything, bit for bit, and stops being used as soon as the parameters change behind its back."""
+    from oracle import wdsr_numpy as on
+    from oracle.nadam_numpy import Nadam
+    from probav_amd import _lib as L
+    from probav_amd.loss import Losses
+    from probav_amd.trainClass import HipNadam, make_optimizer
+    m = _model(dev)
+    lo = Losses(targetShape=(48, 48, 1))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(2, seed=71))
+    opt = make_optimizer("nadam", m, 5e-4)
+    assert isinstance(opt, HipNadam) and opt.model is m
+    ref = Nadam(lr=5e-4)
+    theta = m.flat.detach().cpu().double().numpy()
+    plain = m.flat.detach().clone()
+    popt = HipNadam([torch.nn.Parameter(plain)], lr=5e-4)              # the same rule through the plain element-wise launch
+    for k in range(3):
+        m.flat.grad = None
+        assert (m.weight_cache() is not None) == (k > 0)
+        lo.shiftCompensatedL1Loss(hr, mask, m(x, training=True)).backward()
+        g = m.flat.grad.detach().clone()
+        opt.step()
+        popt.param_groups[0]["params"][0].grad = g
+        popt.step()
+        theta = ref.step(theta, g.cpu().double().numpy())
+        d = (m.flat.detach() - popt.param_groups[0]["params"][0].detach()).abs().max()                        # (1) same rule, two kernels: rounding only
+        assert float(d) < 1e-6 * float(m.flat.detach().abs().max()), float(d)
+        assert np.abs(m.flat.detach().cpu().double().numpy() - theta).max() < 2e-6 * np.abs(theta).max()
+    wc = m.weight_cache()
+    assert wc is not None
+    # (2) weff inside the cache (its first block, layers in order, [tap][ci][co]) against the oracle on the updated parameters
+    flat = m.flat.detach().cpu().numpy()
+    params = synth.unflatten_params(flat)
+    nw = L.lib().probav_weff_count(m._handle())
+    weff = wc[:nw].cpu().double().numpy()
+    off = 0
+    for Lh in m.layers:
+        w = on.weight_norm(params[Lh.name]["v"], params[Lh.name]["g"])
+        assert np.abs(weff[off:off + w.size].reshape(w.shape) - w).max() < 2e-6 * np.abs(w).max(), Lh.name
+        off += w.size
+    # (3) cached pass == recomputing pass, bit for bit
+    m.flat.grad = None
+    y_c = m(x, training=True)
+    lo.shiftCompensatedL1Loss(hr, mask, y_c).backward()
+    g_c = m.flat.grad.detach().clone()
+    m._wcache_version = None                                            # drop the cache: the same parameters, everything recomputed
+    m.flat.grad = None
+    y_r = m(x, training=True)
+    lo.shiftCompensatedL1Loss(hr, mask, y_r).backward()
+    assert torch.equal(y_c, y_r) and torch.equal(g_c, m.flat.grad)
+    opt.step()
+    assert m.weight_cache() is not None
+    with torch.no_grad():
+        m.flat.mul_(1.0)                                                # any in-place change of the parameters invalidates the cache
+    assert m.weight_cache() is None

@@ -603,6 +603,7 @@ def _device_gates(m, flat_used, B, T=9):
     kernel itself (probav_debug_hidden)."""
     L = _lib()
     h, ws = m._handle(), m._workspace(B, True)
+    wc = m.weight_cache()                    # the cache the forward pass ran from (None: it recomputed the weights into its workspace)
     hin = 22
 
     def view(kind, idx):
@@ -613,7 +614,7 @@ def _device_gates(m, flat_used, B, T=9):
     nvox = B * hin * hin * T
     hid = torch.empty(nvox * 256, device=ws.device)
     for i in range(12):
-        L.check(L.lib().probav_debug_hidden(h, L.ptr(flat_used), L.ptr(ws), ws.numel() * 4, B, i, L.ptr(hid), L.current_stream()), "probav_debug_hidden")
+        L.check(L.lib().probav_debug_hidden(h, L.ptr(flat_used), L.ptr(ws), ws.numel() * 4, B, i, L.ptr(hid), L.ptr(wc), L.current_stream()), "probav_debug_hidden")
         gates["expConv_%d" % i] = (hid > 0).cpu().numpy()
     k = 0
     while True:
@@ -685,6 +686,16 @@ def test_train_steps_match_oracle(dev, tmp_path):
     xs, hs, ms = torch.as_tensor(x).to(dev), torch.as_tensor(hr).to(dev), torch.as_tensor(mask).to(dev)
     ref_opt = Nadam(lr=5e-4)
     free_opt = Nadam(lr=5e-4)
+    # the ReLU masks of a step's forward pass must be read BEFORE the optimizer touches the parameters and refills the weight cache:
+    # they are captured from inside optimizer.step (the trainer itself stays untouched)
+    captured = {}
+    real_step = opt.step
+
+    def step_and_capture(*a, **k):
+        captured["gates"] = _device_gates(m, m.flat.detach(), 2)
+        captured["used_cache"] = m.weight_cache() is not None
+        return real_step(*a, **k)
+    opt.step = step_and_capture
     for step in range(3):
         theta_k = m.flat.detach().clone()
         tk = theta_k.cpu().double().numpy()
@@ -692,7 +703,8 @@ def test_train_steps_match_oracle(dev, tmp_path):
         tr.trainStep(xs, hs, ms)
         g_dev = m.flat.grad.detach().cpu().double().numpy()
         theta_next = m.flat.detach().cpu().double().numpy()
-        gates = _device_gates(m, theta_k, 2)
+        gates = captured["gates"]
+        assert captured["used_cache"] == (step > 0)          # from the second step on the forward pass starts from the fused optimizer's weight cache
         pt = ot.to_torch_params(synth.unflatten_params(theta_k.cpu().numpy()))
         pred_o, loss_o, grads_o = ot.train_step_grads(torch.tensor(x, dtype=torch.float64), torch.tensor(hr), torch.tensor(mask), pt,
                                                       synth.NIR_MEAN, synth.NIR_STD, gates=gates)
