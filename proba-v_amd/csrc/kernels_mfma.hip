@@ -23,6 +23,8 @@
 #include <type_traits>
 #include <cstdint>
 
+#include <mutex>
+
 namespace probav {
 
 // In-kernel phase stamps for tools/diag_conv.hip (a separate diagnostic build defines PROBAV_STAMP; the product
@@ -697,7 +699,7 @@ void mfma_conv_pack_job(PackJob& J, int Cin, int Cout)
 template <typename K>
 static void allow_big_lds(K kernel)
 {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
 }
 
 int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
@@ -706,8 +708,8 @@ int mfma_conv_forward(const ConvGeom& g, const float* x, const float* gate, cons
     const ConvPlan p = conv_plan(g, false);
     if (!p.ok) { set_error("mfma_conv_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
-    static bool once = false;
-    if (!once) { allow_big_lds(conv3_mfma_kernel<25, 13, 0>); allow_big_lds(conv3_mfma_kernel<16, 8, 0>); allow_big_lds(conv3_mfma_kernel<1, 1, 0>); once = true; }
+    static std::once_flag once;
+    std::call_once(once, [] { allow_big_lds(conv3_mfma_kernel<25, 13, 0>); allow_big_lds(conv3_mfma_kernel<16, 8, 0>); allow_big_lds(conv3_mfma_kernel<1, 1, 0>); });
     if (p.CC == 1) hipLaunchKernelGGL((conv3_mfma_kernel<1, 1, 0>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am);
     else if (p.CC == 25) hipLaunchKernelGGL((conv3_mfma_kernel<25, 13, 0>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am);
     else            hipLaunchKernelGGL((conv3_mfma_kernel<16, 8, 0>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am);
@@ -727,12 +729,10 @@ int x6_conv_rowtile_forward(const ConvGeom& g, const float* x, const float* gate
     if (!x6_conv_rowtile_supported(g)) { set_error("x6_conv_rowtile_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_rowtile_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
     const dim3 grid((unsigned)(g.N * p.a.ntile_rows)), block(256);
-    static bool once = false;
-    if (!once) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         allow_big_lds(conv3_mfma_kernel<16, 8, 1>); allow_big_lds(conv3_mfma_kernel<25, 13, 1>);
-        allow_big_lds(conv3_mfma_kernel<16, 8, 2>); allow_big_lds(conv3_mfma_kernel<25, 13, 2>);
-        once = true;
-    }
+        allow_big_lds(conv3_mfma_kernel<16, 8, 2>); allow_big_lds(conv3_mfma_kernel<25, 13, 2>); });
 #define PROBAV_RT(C, K, A) hipLaunchKernelGGL((conv3_mfma_kernel<C, K, A>), grid, block, p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag6, bias, skip, y, am)
     if (arith == 2) { if (p.CC == 25) PROBAV_RT(25, 13, 2); else PROBAV_RT(16, 8, 2); }
     else            { if (p.CC == 25) PROBAV_RT(25, 13, 1); else PROBAV_RT(16, 8, 1); }
@@ -1643,12 +1643,10 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
     if (arith == 2 && x6_strip_wants_tap_fragments(g, arith)) {               // H3: the piece-ring kernel (filters: PACK_H3_CONV)
         StripPlan pp;
         (void)pstrip_plan(g, pp);
-        static bool oncep = false;
-        if (!oncep) {
+        static std::once_flag oncep;
+        std::call_once(oncep, [] {
             allow_big_lds(conv3_pstrip_kernel<25, false>); allow_big_lds(conv3_pstrip_kernel<25, true>);
-            allow_big_lds(conv3_pstrip_kernel<32, false>); allow_big_lds(conv3_pstrip_kernel<32, true>);
-            oncep = true;
-        }
+            allow_big_lds(conv3_pstrip_kernel<32, false>); allow_big_lds(conv3_pstrip_kernel<32, true>); });
 #define PROBAV_PSTRIP(C, G) hipLaunchKernelGGL((conv3_pstrip_kernel<C, G>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
         if (g.Cin == 25) { if (gate) PROBAV_PSTRIP(25, true); else PROBAV_PSTRIP(25, false); }
         else             { if (gate) PROBAV_PSTRIP(32, true); else PROBAV_PSTRIP(32, false); }
@@ -1657,16 +1655,14 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
     }
     const StripPlan p = strip_plan(g);
     if (!p.ok) { set_error("mfma_conv_strip_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
-    static bool once = false;
-    if (!once) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 0>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 0>);
         allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 0>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 0>);
         allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 1>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 1>);
         allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 1>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 1>);
         allow_big_lds(conv3_strip_kernel<25, 13, false, 5, 2>); allow_big_lds(conv3_strip_kernel<25, 13, true, 5, 2>);
-        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 2>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 2>);
-        once = true;
-    }
+        allow_big_lds(conv3_strip_kernel<32, 16, false, 4, 2>); allow_big_lds(conv3_strip_kernel<32, 16, true, 4, 2>); });
 #define PROBAV_STRIP(C, K, G, S, X) hipLaunchKernelGGL((conv3_strip_kernel<C, K, G, S, X>), dim3(p.grid), dim3(512), p.lds_bytes, s, p.a, x, gate, (const float4*)wfrag, bias, skip, y, am)
 #define PROBAV_STRIP_A(X) do { \
         if (p.CC == 25) { if (gate) PROBAV_STRIP(25, 13, true, 5, X); else PROBAV_STRIP(25, 13, false, 5, X); } \
@@ -1862,14 +1858,12 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
     const int grid = wgrad_grid(p, g), total = g.N * p.a.ntile_rows;
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
-    static bool once = false;
+    static std::once_flag once;
 #define PROBAV_WGRAD(CI, GT) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<CI, GT>), dim3(grid), dim3(256), p.lds_bytes, s, p.a, total, x, dy, gate, partial, partial_b)
-    if (!once) {
+    std::call_once(once, [] {
         allow_big_lds(conv3_wgrad_mfma_kernel<25, false>); allow_big_lds(conv3_wgrad_mfma_kernel<25, true>);
         allow_big_lds(conv3_wgrad_mfma_kernel<32, false>); allow_big_lds(conv3_wgrad_mfma_kernel<32, true>);
-        allow_big_lds(conv3_wgrad_mfma_kernel<1, false>); allow_big_lds(conv3_wgrad_mfma_kernel<1, true>);
-        once = true;
-    }
+        allow_big_lds(conv3_wgrad_mfma_kernel<1, false>); allow_big_lds(conv3_wgrad_mfma_kernel<1, true>); });
     if (g.Cin == 1) { if (gate) PROBAV_WGRAD(1, true); else PROBAV_WGRAD(1, false); }
     else if (g.Cin == 25) { if (gate) PROBAV_WGRAD(25, true); else PROBAV_WGRAD(25, false); }
     else { if (gate) PROBAV_WGRAD(32, true); else PROBAV_WGRAD(32, false); }
@@ -2007,8 +2001,8 @@ bool mfma_pw_supported(int F, int E, int D) { return F == 32 && E == 256 && D >=
 int mfma_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                     long nvox, int D, hipStream_t s)
 {
-    static bool once = false;
-    if (!once) { allow_big_lds(pw_fwd_mfma_kernel); once = true; }
+    static std::once_flag once;
+    std::call_once(once, [] { allow_big_lds(pw_fwd_mfma_kernel); });
     const size_t lds = (size_t)(2 * 8 * 4 * 64 * 4 + 256 + 32) * sizeof(float);
     hipLaunchKernelGGL(pw_fwd_mfma_kernel, dim3(512), dim3(256), lds, s, x, (const float4*)w1frag, (const float4*)w2frag, b1, b2, dec, nvox, D);
     return check_launch("pw_fwd_mfma");
@@ -2251,8 +2245,8 @@ int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const f
                      const float* w1khch, const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2,
                      float* slabs, long nvox, int D, hipStream_t s)
 {
-    static bool once = false;
-    if (!once) { allow_big_lds(pw_bwd2_mfma_kernel); once = true; }
+    static std::once_flag once;
+    std::call_once(once, [] { allow_big_lds(pw_bwd2_mfma_kernel); });
     const size_t lds = (size_t)(2 * PW2_XT + 2 * PW2_DT + PW2_WAVES * 2 * PW2_TB) * sizeof(float);
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
     hipLaunchKernelGGL(pw_bwd2_mfma_kernel, dim3(PW_BWD_GRID), dim3(64 * PW2_WAVES), lds, s, x, dT, dOut, (const float4*)w1kcin,

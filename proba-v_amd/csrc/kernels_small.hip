@@ -6,6 +6,7 @@
 //   clip + round-half-even                              (test.py:117-119, models/testClass.py:27-28)
 //   shift-compensated L1 / L2 / cPSNR fwd + bwd         (models/loss.py:37-84, 140-187, 226-238)
 #include "probav_common.h"
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 
@@ -18,10 +19,18 @@ void set_error(const char* what, hipError_t e)
     else snprintf(g_err, sizeof(g_err), "%s", what);
 }
 const char* last_error() { return g_err; }
+static std::atomic<int> g_attr_err{(int)hipSuccess};                 // first failed hipFuncSetAttribute, sticky (process-wide: the attribute is)
+void note_attr_error(hipError_t e)
+{
+    int ok = (int)hipSuccess;
+    if (e != hipSuccess) g_attr_err.compare_exchange_strong(ok, (int)e);
+}
 int check_launch(const char* what)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(what, e); return PROBAV_EHIP; }
+    const int a = g_attr_err.load();
+    if (a != (int)hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for a kernel of this library", (hipError_t)a); return PROBAV_EHIP; }
     return PROBAV_OK;
 }
 

@@ -18,6 +18,8 @@
 #include "x6_device.h"
 #include <type_traits>
 
+#include <mutex>
+
 namespace probav {
 
 
@@ -171,14 +173,12 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                   long nvox, long vps, int D, int arith, const PwAmax& am, hipStream_t s, float* hdump)
 {
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     if (vps <= 0 || vps > nvox) vps = nvox;                          // one "sample"
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_forward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
@@ -634,12 +634,10 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
                    const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
                    int arith, const PwAmax& am, hipStream_t s)
 {
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     if (vps <= 0 || vps > nvox) vps = nvox;
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_backward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
@@ -990,14 +988,13 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
     size_t lds = (size_t)3 * a.Wp * a.Tp * vs + 16;
     const size_t xch = (size_t)4 * (7 * 16 + 1) * 64 * sizeof(float);                 // exchange area of the epilogue
     if (lds < xch) lds = xch;
-    static bool once = false;
-    if (!once) {
-#define PROBAV_WGA(C, G, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<C, G, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    static std::once_flag once;
+    std::call_once(once, [] {
+#define PROBAV_WGA(C, G, A) note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<C, G, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
         PROBAV_WGA(25, false, X6); PROBAV_WGA(25, true, X6); PROBAV_WGA(32, false, X6); PROBAV_WGA(32, true, X6);
         PROBAV_WGA(25, false, H3); PROBAV_WGA(25, true, H3); PROBAV_WGA(32, false, H3); PROBAV_WGA(32, true, H3);
 #undef PROBAV_WGA
-        once = true;
-    }
+    });
 #define PROBAV_WG6(C, G, A) hipLaunchKernelGGL((conv3_wgrad_x6_kernel<C, G, A>), dim3(grid), dim3(512), lds, s, a, x, dy, gate, partial, partial_b, am)
     if (arith == 2) {
         if (g.Cin == 25) { if (gate) PROBAV_WG6(25, true, H3); else PROBAV_WG6(25, false, H3); }

@@ -40,6 +40,10 @@ int amax_tensor(const float* x, size_t per_sample, int N, unsigned* slots, hipSt
 int amax_columns(const float* w, long rows, int cols, unsigned* slots, hipStream_t s);
 
 void set_error(const char* what, hipError_t e);
+// check_launch: hipGetLastError after a launch -> PROBAV_OK / PROBAV_EHIP.  It also reports (once set, sticky) a failed
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) of any kernel: note_attr_error() records it from inside the std::call_once
+// blocks that raise the LDS limits, so the failure surfaces as what it is instead of as an opaque launch error later.
+void note_attr_error(hipError_t e);
 int check_launch(const char* what);
 const char* last_error();
 

@@ -62,6 +62,13 @@ def _worker(rank, world, port, tmp):
         other = pair.clone()
         dist.broadcast(other, src=0)
         assert torch.equal(pair, other), "scalar metrics are not reduced over the replicas"
+        # 5. checkpoints under DP: only rank 0 writes (the replicas are identical), and what it wrote restores on any rank
+        dist.barrier()
+        names = open(os.path.join(tmp, "ck3", "checkpoint.pt-index")).read().split()
+        assert names and all(n.endswith(".pt") for n in names) and len(names) <= 5
+        model4 = _stub()
+        tr4 = ModelTrainer(model4, _l1, _metric, make_optimizer("sgd", model4, 0.1), os.path.join(tmp, "ck3"), os.path.join(tmp, "lg4_%d" % rank), multiGPU=True)
+        assert tr4.step > 0 and tr4.save_counter == int(names[-1][5:-3])
         if rank == 0:
             open(os.path.join(tmp, "ok"), "w").write("ok")
     finally:

@@ -507,6 +507,14 @@ def test_trainer_and_inference_on_device(dev, tmp_path):
     np.testing.assert_array_equal(img[48:96, 96:144], sr[8 + 2])          # row-major block order (test.py:149-160)
     imgs = testClass.evaluate(m, patches[None], batch_size=16)
     np.testing.assert_array_equal(imgs[0], img)
+    np.testing.assert_array_equal(testClass.evaluate_device(m, patches[None], micro_batch=16)[0], img)      # the device pipeline test.py uses
+    # test.py:137-146, resolveBySampleAveraging: mean of 20 clipped + rounded predictions over compounding frame permutations
+    avg = testClass.resolveBySampleAveraging(m, patches[:4], rng=np.random.default_rng(3)).cpu().numpy()
+    rng3, xp, acc = np.random.default_rng(3), patches[:4], 0.0
+    for _ in range(20):
+        xp = xp[:, :, :, rng3.permutation(9), :]
+        acc = acc + testClass.resolve(m, np.ascontiguousarray(xp)).astype(np.float64)
+    np.testing.assert_allclose(avg, (acc / 20.0).astype(np.float32), rtol=0, atol=1e-3)
     # device-side pipeline for whole images: unfold of the reflect-padded frame, any micro-batch, on-device stitch
     frames = np.clip(np.random.default_rng(2).normal(synth.NIR_MEAN, synth.NIR_STD, (2, 9, 128, 128)), 0, 16383).astype(np.float32)
     pt = testClass.unfold_frames(torch.as_tensor(frames).to(dev))
