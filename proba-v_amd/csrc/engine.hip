@@ -48,6 +48,7 @@ struct probav_engine {
     std::vector<long> pkW2B, pkW1C;          // per block: extra fragments of the fused backward
     bool pw_mfma = false;
     bool fwd_amax = false;    // the last training forward filled the amax slots of the saved activations (H3 kernels, impl 4)
+    bool fwd_unfused = false; // ... and laid its workspace out for the unfused pointwise pair (impl 0): the backward pass must agree
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
     bool prof_on = false;
     unsigned prof_mask = ~0u;   // kernel classes whose launches are bracketed (bit = class index)
@@ -195,7 +196,9 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     p.r1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
     p.r2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
     p.r3 = take((size_t)B * P * P * s2);
-    p.H = take(V * E);
+    // the 256-channel hidden tensor (1 KB per voxel) only exists in memory when the pointwise pair runs UNfused (generic kernels, impl 0)
+    const bool unfused = !(e->impl >= 1 && e->pw_mfma);
+    p.H = take(unfused ? V * E : 0);
     p.dH = p.gA = p.gB = p.gDec = p.dtail = p.dr2 = p.dr1 = p.partial = 0;
     if (training) {
         size_t gmax = (size_t)B * (Hin + 2) * (Hin + 2) * T * F;
@@ -212,7 +215,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         p.dtail = take((size_t)B * P * P * s2);
         p.dr2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
         p.dr1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
-        p.dH = take(V * E);
+        p.dH = take(unfused ? V * E : 0);
         // every layer's backward-filter geometry, exactly as probav_backward launches it
         std::vector<ConvGeom> gs;
         gs.push_back(make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1));
@@ -588,7 +591,7 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
     const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wcol(li); m.y = ay; } return m; };
     if (h3 && hipMemsetAsync(A.base, 0, (size_t)p.amax_bwd * sizeof(unsigned), s) != hipSuccess) { set_error("probav_forward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
-    if (training) e->fwd_amax = h3;
+    if (training) { e->fwd_amax = h3; e->fwd_unfused = !(e->impl >= 1 && e->pw_mfma); }
 
     if (!WC) {
         { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
@@ -676,6 +679,10 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     int nback = 0;
     auto new_slot = [&]() -> unsigned* { return h3 ? A.back(nback++) : nullptr; };
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wrow(li); m.y = ay; } return m; };   // backward-data: the matrix' columns are the layer's INPUT channels
+    if (e->fwd_unfused != !(e->impl >= 1 && e->pw_mfma)) {
+        set_error("probav_backward: the kernel family changed between forward and backward in a way that changes the workspace layout (impl 0 <-> >= 1)", hipSuccess);
+        return PROBAV_EINVAL;
+    }
     if (h3 && !e->fwd_amax) {
         set_error("probav_backward: the H3 kernels (impl 4) need the amax slots of a forward pass run with the same kernel family", hipSuccess);
         return PROBAV_EINVAL;
