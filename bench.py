@@ -330,16 +330,20 @@ def run_rank(args):
         rng = np.random.default_rng(7)
         frames = torch.as_tensor(np.clip(rng.normal(synth.NIR_MEAN, synth.NIR_STD, (32, 9, 128, 128)), 0, 16383).astype(np.float32)).to(dev)
         inf = {}
-        for name, mb, reps in (("batched_2048", 2048, 5), ("reference_micro_batch_16", 16, 2)):
+        for name, mb, reps in (("batched_2048", 2048, 6), ("reference_micro_batch_16", 16, 3)):
             run = lambda: testClass.resolve_images(model, testClass.unfold_frames(frames), micro_batch=mb)
-            run()
+            for _ in range(2):                      # the first pass sizes the workspace pool for this batch, the second finds it warm
+                run()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            each = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 img = run()
-            torch.cuda.synchronize()
-            d4 = (time.perf_counter() - t0) / reps
-            inf[name] = {"micro_batch": mb, "images_per_s": round(32 / d4, 2), "patches_per_s": round(32 * 64 / d4, 1), "ms_per_32_images": round(d4 * 1e3, 3)}
+                torch.cuda.synchronize()
+                each.append(time.perf_counter() - t0)
+            d4 = sum(each) / reps
+            inf[name] = {"micro_batch": mb, "images_per_s": round(32 / d4, 2), "patches_per_s": round(32 * 64 / d4, 1), "ms_per_32_images": round(d4 * 1e3, 3),
+                         "ms_each": [round(e * 1e3, 2) for e in each]}
         assert img.shape == (32, 384, 384)
         other["config4_inference"] = {"workload": "32 image sets x 9 frames of 128x128 resident in HBM -> unfold to 2048 patches of [22,22,9,1] -> forward -> "
                                                   "clip[0,2^16] + round-half-even -> stitch to 32 x [384,384] (test.py path)", **inf}
