@@ -762,6 +762,8 @@ struct StripArgs {
     int SR, nstrips;            // output rows per strip, strips per patch
     unsigned mTo, mNvr, mTi, mSrcCol;
     int nsplit, Wt;             // piece-ring kernel: output rows cut into nsplit column ranges of Wt columns when four full rows do not fit the LDS
+    int nslot;                  // alternating-halves kernel: ring depth
+    unsigned mNslot;
 };
 
 
@@ -1462,10 +1464,18 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 }
                 const int sw = (ra >> 7) & 7;                                // absolute record index & 7, as stored
                 const int cp = cc ^ sw;
+#ifdef PSX_NOA
+                af[0].u = make_uint4(ra, cp, ra, cp); af[1].u = make_uint4(cp, ra, cp, ra);
+#else
                 af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
                 af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
+#endif
                 const uint4* pw = wf + ((long)gg * NST + st) * NP * 64;
+#ifdef PSX_NOW
+                wq[0].u = make_uint4(gg, st, lane, 1); wq[1].u = make_uint4(st, gg, 2, lane);
+#else
                 wq[0].u = pw[0]; wq[1].u = pw[64];
+#endif
             };
 #pragma unroll
             for (int st = 0; st < PF; ++st) request(g0, st, A[st], W[st]);
@@ -1567,6 +1577,316 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
     XS_OUT;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Piece-ring strip convolution with ALTERNATING HALVES (H3 arithmetic).  conv3_pstrip_kernel runs its eight waves through the same
+// program: the two waves of a SIMD go through their taps together and through their epilogues together, so the matrix pipe idles
+// during every epilogue, staging and pipeline refill (stamps: taps 70 % of a wave's life, and the pipe is busy for 45 % of that).
+// Here the halves of the workgroup (waves 0-3 / 4-7: one wave of each on every SIMD) take turns: in segment s half (s & 1) runs
+// the taps of four tiles -- one WHOLE tile per wave, no split of the taps over a wave pair and therefore no exchange of partial sums --
+// while the other half finishes the tiles it computed in segment s - 1 (scale, bias, ReLU, turn-around through its own 4 KB of
+// LDS, skip, 16-byte stores) and stages the input rows of segment s + 1, its own next taps.  One barrier per segment; on every SIMD
+// a tap-loop wave always runs beside a wave doing memory and vector work.
+// Ring: `nslot` rows (pp_plan(): the rows of two consecutive segments never collide); records, swizzle, filter fragments and the
+// gathered channel-24 chunk are those of conv3_pstrip_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, bool GATE, int RVP>
+__global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
+                                                         const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                         const float* __restrict__ skip, float* __restrict__ y, Amax am)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    using AR = H3;
+    constexpr int NP = 2, REC = 128, PF = 3;
+    const ConvGeom& g = a.g;
+    float omax = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int gtid = tid & 255;                                              // thread of its half (staging index)
+    const int per = a.nstrips * a.nsplit;
+    const int n = blockIdx.x / per, srem = blockIdx.x - n * per;
+    const int ea = h3_exp(am.x[n]), ew = h3_exp_w(am.w[col < g.Cout ? col : 0]);
+    const float sa = pow2i(ea);
+    const int eun = -(ea + ew);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tsel = wave & 3, grp = wave >> 2;
+    const int rowbytes = a.Wp * a.Tp * REC, NS = a.nslot;
+    float* turn = reinterpret_cast<float*>(plds + NS * rowbytes) + tsel * 1024;      // [32 voxels][32 channels], shared by waves tsel and tsel + 4 (never in the same role)
+    const int strip = srem / a.nsplit, sp = srem - strip * a.nsplit;
+    const int ws0 = sp * a.Wt;
+    const int hb = strip * a.SR;
+    const int SRr = g.Ho - hb < a.SR ? g.Ho - hb : a.SR;
+    const int nvr = a.Wt * g.To;                                             // voxels per output row of this column range
+    const int NV = SRr * nvr, NTL = (NV + 31) >> 5, nseg = (NTL + 3) >> 2;
+    const long out_base = ((long)n * g.Ho + hb) * g.Wo * g.To;
+    float* ybase = y + out_base * g.Cout;
+    const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
+    const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+    auto elem_off_ch = [&](int vi, int ch) -> int {
+        if (a.nsplit == 1) return vi * g.Cout + ch;
+        const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+        const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+        return ((hrel * g.Wo + ws0 + w) * g.To + t) * g.Cout + ch;
+    };
+    // last ring row (relative to the strip's first input row) that segment sg reads
+    auto need = [&](int sg) -> int {
+        const int vlast = (sg + 1) * 128 - 1 < NV - 1 ? (sg + 1) * 128 - 1 : NV - 1;
+        return fdiv(vlast, nvr, a.mNvr) + 2;
+    };
+
+    // staging by ONE half (256 threads): item i of a row = (local voxel i >> 2, channel chunk i & 3), as in conv3_pstrip_kernel
+    const int lw0 = a.nsplit == 1 ? g.pw : 0, Wl = a.nsplit == 1 ? g.Wi : a.Wt + 2;
+    const int items = Wl * g.Ti * 4;                                         // pp_plan(): <= 256 * RVP
+    auto stage_load = [&](int q, float (&v)[RVP][8]) {
+        const int ih = hb - g.ph + q;
+        const bool rok = ih >= 0 && ih < g.Hi;
+        const long rbase = (((long)n * g.Hi + (rok ? ih : 0)) * g.Wi) * (long)g.Ti * CIN;
+        const float* xrow = x + rbase;
+        const float* grow = GATE ? gate + rbase : nullptr;
+#pragma unroll
+        for (int k = 0; k < RVP; ++k) {
+            const int i = gtid + 256 * k;
+            const int ic = i < items ? i : 0;
+            const int lvox = ic >> 2, cc = ic & 3;
+            const int lwr = fdiv(lvox, g.Ti, a.mTi), t = lvox - lwr * g.Ti, lw = lw0 + lwr;
+            const int iw = ws0 + lw - g.pw;
+            const bool live = rok && i < items && iw >= 0 && iw < g.Wi;
+            const int vox = (live ? iw : 0) * g.Ti + t;
+            const float* src = xrow + vox * CIN + 8 * cc;
+            const float* gsr = GATE ? grow + vox * CIN + 8 * cc : nullptr;
+            if constexpr (CIN % 8 == 0) {
+                const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
+                float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                if constexpr (GATE) {
+                    const float4 m0 = reinterpret_cast<const float4*>(gsr)[0], m1 = reinterpret_cast<const float4*>(gsr)[1];
+                    const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = m[j] > 0.f ? f[j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = live ? f[j] : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tj = t - 1 + j;                                 // (cc == 3 only: the gathered channel-24 chunk)
+                    const bool cok = cc < 3 || (j < 3 && tj >= 0 && tj < g.Ti);
+                    const int o = cc < 3 ? 8 * cc + j : (cok ? (j - 1) * CIN + 24 : 8 * cc);
+                    float f = (xrow + vox * CIN)[o];
+                    if constexpr (GATE) f = (grow + vox * CIN)[o] > 0.f ? f : 0.f;
+                    v[k][j] = (live && cok) ? f : 0.f;
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int q, const float (&v)[RVP][8]) {
+        unsigned char* slot = plds + (q - fdiv(q, NS, a.mNslot) * NS) * rowbytes;
+#pragma unroll
+        for (int k = 0; k < RVP; ++k) {
+            const int i = gtid + 256 * k;
+            if (i < items) {
+                const int lvox = i >> 2, cc = i & 3;
+                const int lwr = fdiv(lvox, g.Ti, a.mTi), t = lvox - lwr * g.Ti, lw = lw0 + lwr;
+                const int vd = lw * a.Tp + t + ((CIN == 25 && cc == 3) ? 0 : g.pt);
+                Frag f[NP];
+                cut8<AR>(v[k], sa, f);
+                unsigned char* rec = slot + vd * REC;
+                const int sw = (int)((rec - plds) >> 7) & 7;
+                *reinterpret_cast<uint4*>(rec + ((cc ^ sw) << 4)) = f[0].u;
+                *reinterpret_cast<uint4*>(rec + (((4 + cc) ^ sw) << 4)) = f[1].u;
+            }
+        }
+    };
+
+    {   // zero the ring (pads stay zero), then the rows of segment 0: the halves take alternate rows
+        uint4* z = reinterpret_cast<uint4*>(plds);
+        for (int i = tid; i < NS * rowbytes / 16; i += 512) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    int hiq = nseg > 0 ? need(0) : -1;
+#pragma unroll 1
+    for (int q = grp; q <= hiq; q += 2) {
+        float v[RVP][8];
+        stage_load(q, v);
+        stage_store(q, v);
+    }
+    __syncthreads();
+    XS_DECL;
+    XS_ACC(1);
+
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int eq = lane & 7, er = lane >> 3;                                // epilogue coordinates: channel quad, voxel row (mod 8)
+    const uint4* wf = wfrag + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 1
+    for (int sg = 0; sg <= nseg; ++sg) {
+        const int hi_next = sg + 1 < nseg ? need(sg + 1) : hiq;             // (uniform; both halves keep count)
+        if (grp == (sg & 1)) {
+            // ---- taps of one whole tile ----
+            const int tile = 4 * sg + tsel;
+            if (sg < nseg && tile < NTL) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                int vi = tile * 32 + col;
+                vi = vi < NV ? vi : NV - 1;
+                const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+                const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+                const int vox0 = w * a.Tp + t;
+                const int s0 = hrel - fdiv(hrel, NS, a.mNslot) * NS;
+                const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
+                const int sb0 = s0 * rowbytes, sb1 = s1 * rowbytes, sb2 = s2 * rowbytes;
+                auto rec_addr = [&](int gg, int dt) -> int {
+                    const int dh = gg / 3, dw = gg - 3 * dh;                 // wave-uniform
+                    const int sb = dh == 0 ? sb0 : (dh == 1 ? sb1 : sb2);
+                    return sb + (vox0 + dw * a.Tp + dt) * REC;
+                };
+                constexpr int NST = CIN == 25 ? 5 : 6;
+                Frag A[NST][NP], W[NST][NP];
+                auto request = [&](int gg, int st, Frag (&af)[NP], Frag (&wq)[NP]) {
+                    int ra, cc;
+                    if constexpr (CIN == 25) {
+                        const int c0 = 2 * st, c1 = 2 * st + 1;
+                        const int dt0 = c0 / 3, cc0 = c0 % 3, dt1 = c1 < 9 ? c1 / 3 : 0, cc1 = c1 < 9 ? c1 % 3 : 3;
+                        ra = rec_addr(gg, 0) + (half ? dt1 : dt0) * REC;
+                        cc = half ? cc1 : cc0;
+                    } else {
+                        const int dt = st >> 1, kb = st & 1;
+                        ra = rec_addr(gg, dt);
+                        cc = 2 * kb + half;
+                    }
+                    const int sw = (ra >> 7) & 7;
+                    const int cp = cc ^ sw;
+                    af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
+                    af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
+                    const uint4* pw = wf + ((long)gg * NST + st) * NP * 64;
+                    wq[0].u = pw[0]; wq[1].u = pw[64];
+                };
+#pragma unroll
+                for (int st = 0; st < PF; ++st) request(0, st, A[st], W[st]);
+#pragma unroll 1
+                for (int gg = 0; gg <= 8; ++gg) {
+                    const int gn = gg + 1 <= 8 ? gg + 1 : 8;
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) {
+                        if (st + PF < NST) request(gg, st + PF, A[st + PF], W[st + PF]);
+                        else request(gn, st + PF - NST, A[st + PF - NST], W[st + PF - NST]);   // (after the last group: a harmless re-read)
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc = mac<AR>(A[st], W[st], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            XS_ACC(2);
+        } else {
+            // ---- finish the tile of the previous segment; stage the rows of the next one ----
+            const int tile = 4 * (sg - 1) + tsel;
+            const bool fin = sg >= 1 && tile < NTL;                          // wave-uniform
+            const bool do_load = hi_next > hiq;
+            float nv_[RVP][8];
+            if (do_load) stage_load(hiq + 1, nv_);
+            if (fin) {
+                f32x4u skq[4];
+                int eoff[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int vi = tile * 32 + er + 8 * jj;
+                    eoff[jj] = vi < NV ? elem_off_ch(vi, 4 * eq) : -1;
+                    skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
+                }
+                if (sbase) {
+                    if (g.Cout == 32) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) skq[jj] = *reinterpret_cast<const f32x4u*>(sbase + (eoff[jj] < 0 ? 0 : eoff[jj]));
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || 4 * eq + c >= g.Cout) ? 0 : eoff[jj] + c];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = ldexpf(acc[i], eun) + bv;                       // the filter column's exponent and the bias are per lane in the accumulator layout
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    turn[rowmap(i, half) * 32 + col] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (a wave's LDS operations execute in order: the wait orders the compiler)
+                float4 tq[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) tq[jj] = *reinterpret_cast<const float4*>(turn + (er + 8 * jj) * 32 + 4 * eq);
+                const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 t = tq[jj];
+                    f32x4u o = {t.x + skq[jj][0], t.y + skq[jj][1], t.z + skq[jj][2], t.w + skq[jj][3]};
+                    if (full) {
+                        *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    } else if (eoff[jj] >= 0) {
+                        if (4 * eq + 4 <= g.Cout) {
+                            *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (4 * eq + c < g.Cout) { ybase[eoff[jj] + c] = o[c]; omax = fmaxf(omax, fabsf(o[c])); }
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the turn buffer is free again before the partner wave can reach its own epilogue (next barrier)
+            }
+            if (do_load) {
+                stage_store(hiq + 1, nv_);
+#pragma unroll 1
+                for (int q = hiq + 2; q <= hi_next; ++q) {                   // (a short row range can need two new rows for one segment)
+                    stage_load(q, nv_);
+                    stage_store(q, nv_);
+                }
+            }
+            XS_ACC(3);
+        }
+        hiq = hi_next;
+        __syncthreads();
+        XS_ACC(4);
+    }
+    if (am.y) amax_commit(omax, am.y + n);
+    XS_OUT;
+}
+
+// plan of the alternating-halves form: geometry of pstrip_plan(); a half (256 threads) stages a row; ring depth from the rows two consecutive segments touch
+static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
+{
+    p.ok = false;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.Cout > 32 || (g.Cin != 25 && g.Cin != 32)) return false;
+    if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return false;
+    if (g.Cin == 25 && (g.pt != 1 || g.To != g.Ti)) return false;
+    if (g.Ho < 3) return false;
+    const int Tp = g.To + 2;
+    for (int ns = 1; ns <= 4; ++ns) {
+        if (g.Wo % ns) continue;
+        const int wt = g.Wo / ns, nvr = wt * g.To;
+        const int items = (ns == 1 ? g.Wi : wt + 2) * g.Ti * 4;
+        if (items > 256 * 3 || nvr < 32) continue;
+        int nstrips = (256 + g.N * ns - 1) / (g.N * ns);
+        if (nstrips < 1) nstrips = 1;
+        if (nstrips > g.Ho / 4) nstrips = g.Ho / 4 > 0 ? g.Ho / 4 : 1;
+        const int SR = (g.Ho + nstrips - 1) / nstrips;
+        nstrips = (g.Ho + SR - 1) / SR;
+        // ring depth: while a segment's taps read rows hlo(s) .. need(s), the other half writes the rows up to need(s + 1)
+        const int NV = SR * nvr, nseg = ((NV + 31) / 32 + 3) / 4;
+        auto needf = [&](int sg) { const int vl = std::min(NV - 1, (sg + 1) * 128 - 1); return vl / nvr + 2; };
+        int nslot = needf(0) + 1;
+        for (int sg = 0; sg + 1 < nseg; ++sg) nslot = std::max(nslot, needf(sg + 1) - (sg * 128) / nvr + 1);
+        const size_t need = (size_t)nslot * (wt + 2) * Tp * 128 + (size_t)4 * 1024 * sizeof(float);
+        if (need > 163840) continue;
+        p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = need; p.grid = g.N * nstrips * ns;
+        p.a.g = g; p.a.Wp = wt + 2; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips; p.a.nsplit = ns; p.a.Wt = wt;
+        p.a.mTo = magic(g.To); p.a.mNvr = magic(nvr); p.a.mTi = magic(g.Ti); p.a.mSrcCol = 0;
+        p.a.nslot = nslot; p.a.mNslot = magic(nslot);
+        rvp = items <= 512 ? 2 : 3;
+        return true;
+    }
+    return false;
+}
+
 // plan of the piece-ring form: 3x3x3, zero pads, Cin 25 / 32, Cout <= 32, >= 128 voxels per output row
 static bool pstrip_plan(const ConvGeom& g, StripPlan& p)
 {
@@ -1642,6 +1962,23 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
     if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_strip_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2 && x6_strip_wants_tap_fragments(g, arith)) {               // H3: the piece-ring kernel (filters: PACK_H3_CONV)
         StripPlan pp;
+        int rvp = 2;
+        static const bool no_pp = getenv("PROBAV_NO_PP") != nullptr;          // diagnostic: the same-program form (conv3_pstrip_kernel) instead
+        if (!no_pp && pp_plan(g, pp, rvp)) {
+            static std::once_flag onceq;
+            std::call_once(onceq, [] {
+                allow_big_lds(conv3_pp_kernel<25, false, 2>); allow_big_lds(conv3_pp_kernel<25, true, 2>);
+                allow_big_lds(conv3_pp_kernel<32, false, 2>); allow_big_lds(conv3_pp_kernel<32, true, 2>);
+                allow_big_lds(conv3_pp_kernel<25, false, 3>); allow_big_lds(conv3_pp_kernel<25, true, 3>);
+                allow_big_lds(conv3_pp_kernel<32, false, 3>); allow_big_lds(conv3_pp_kernel<32, true, 3>); });
+#define PROBAV_PP(C, G, R) hipLaunchKernelGGL((conv3_pp_kernel<C, G, R>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
+#define PROBAV_PP_R(C, G) do { if (rvp == 2) PROBAV_PP(C, G, 2); else PROBAV_PP(C, G, 3); } while (0)
+            if (g.Cin == 25) { if (gate) PROBAV_PP_R(25, true); else PROBAV_PP_R(25, false); }
+            else             { if (gate) PROBAV_PP_R(32, true); else PROBAV_PP_R(32, false); }
+#undef PROBAV_PP_R
+#undef PROBAV_PP
+            return check_launch("conv3_pp");
+        }
         (void)pstrip_plan(g, pp);
         static std::once_flag oncep;
         std::call_once(oncep, [] {
