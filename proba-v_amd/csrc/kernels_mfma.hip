@@ -1713,7 +1713,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const int eq = lane & 7, er = lane >> 3;                                // epilogue coordinates: channel quad, voxel row (mod 8)
-    const uint4* wf = wfrag + lane;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1741,7 +1740,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 };
                 constexpr int NST = CIN == 25 ? 5 : 6;
                 Frag A[NST][NP], W[NST][NP];
-                auto request = [&](int gg, int st, Frag (&af)[NP], Frag (&wq)[NP]) {
+                auto request_A = [&](int gg, int st, Frag (&af)[NP]) {
                     int ra, cc;
                     if constexpr (CIN == 25) {
                         const int c0 = 2 * st, c1 = 2 * st + 1;
@@ -1755,32 +1754,73 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     }
                     const int sw = (ra >> 7) & 7;
                     const int cp = cc ^ sw;
+#ifdef PSX_A1
+                    if (st != 0) return;
+#endif
+#ifdef PSX_NOA
+                    af[0].u = make_uint4(ra, cp, ra, cp); af[1].u = make_uint4(cp, ra, cp, ra);
+#else
                     af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
                     af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
-                    const uint4* pw = wf + ((long)gg * NST + st) * NP * 64;
-                    wq[0].u = pw[0]; wq[1].u = pw[64];
+#endif
                 };
+                auto request_W = [&](int gg, int st, Frag (&wq)[NP]) {
+                    const uint4* pw = wfrag + ((long)gg * NST + st) * NP * 64;      // wave-uniform base + lane: scalar-base loads
+#ifdef PSX_W1
+                    if (st != 0) return;
+#endif
+#ifdef PSX_NOW
+                    wq[0].u = make_uint4(gg, st, lane, 1); wq[1].u = make_uint4(st, gg, 2, lane);
+#else
+                    wq[0].u = pw[lane]; wq[1].u = pw[64 + lane];
+#endif
+                };
+#ifdef PPX_PRIO
+                __builtin_amdgcn_s_setprio(PPX_PRIO);
+#endif
 #pragma unroll
-                for (int st = 0; st < PF; ++st) request(0, st, A[st], W[st]);
+                for (int st = 0; st < PF; ++st) { request_W(0, st, W[st]); request_A(0, st, A[st]); }
+                // One k-block = three MFMAs.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles and whatever else a wave issues in
+                // the gap is hidden only while it fits the other 24 (MI355X_MICROARCH.md, issue costs): the requests of a later k-block are
+                // therefore dealt out over the three gaps instead of standing in front of the first MFMA.
 #pragma unroll 1
                 for (int gg = 0; gg <= 8; ++gg) {
                     const int gn = gg + 1 <= 8 ? gg + 1 : 8;
 #pragma unroll
                     for (int st = 0; st < NST; ++st) {
-                        if (st + PF < NST) request(gg, st + PF, A[st + PF], W[st + PF]);
-                        else request(gn, st + PF - NST, A[st + PF - NST], W[st + PF - NST]);   // (after the last group: a harmless re-read)
+                        constexpr int dummy = 0; (void)dummy;
+                        const bool same = st + PF < NST;                      // (compile-time after unrolling)
+                        const int gq = same ? gg : gn, sq = same ? st + PF : st + PF - NST;   // (after the last group: a harmless re-read)
+                        acc = MFMA16H(A[st][1], W[st][0], acc);
                         __builtin_amdgcn_sched_barrier(0);
-                        acc = mac<AR>(A[st], W[st], acc);
+                        request_A(gq, sq, A[sq]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc = MFMA16H(A[st][0], W[st][1], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        request_W(gq, sq, W[sq]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc = MFMA16H(A[st][0], W[st][0], acc);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#ifdef PPX_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             XS_ACC(2);
         } else {
             // ---- finish the tile of the previous segment; stage the rows of the next one ----
             const int tile = 4 * (sg - 1) + tsel;
+#ifdef PPX_IDLE
+            const bool fin = false, do_load = false;
+            { float t_ = 0.f;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) t_ += acc[i];
+              if (t_ == 1234.5f) ybase[lane] = t_; }
+#else
             const bool fin = sg >= 1 && tile < NTL;                          // wave-uniform
             const bool do_load = hi_next > hiq;
+#endif
             float nv_[RVP][8];
             if (do_load) stage_load(hiq + 1, nv_);
             if (fin) {
