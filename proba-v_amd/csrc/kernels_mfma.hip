@@ -1369,14 +1369,17 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 // 25 channels: chunks 0..2 = channels 0..23 of the voxel; chunk 3 of the record at PADDED depth t' (the item's `vox`
                 // is then (w, t')) gathers channel 24 of padded depths t', t'+1, t'+2 = input depths t'-1, t', t'+1 (pt = 1): the
                 // tenth K chunk of a (dh, dw) group, so that a group is 5 k-blocks instead of 6
+                // (integer selects only: with short-circuit conditions hipcc splits the lanes into two branches, each with its own load and a full vmcnt(0))
+                const int is3 = cc == 3 ? 1 : 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int tj = t - 1 + j;                                 // (cc == 3 only)
-                    const bool cok = cc < 3 || (j < 3 && tj >= 0 && tj < g.Ti);
-                    const int o = cc < 3 ? 8 * cc + j : (cok ? (j - 1) * CIN + 24 : 8 * cc);    // relative to the voxel's channel 0 (clamped when dead)
+                    const int tj = t - 1 + j;                                 // (cc == 3 only: the gathered channel-24 chunk)
+                    const int cok3 = j < 3 ? ((tj >= 0 ? 1 : 0) & (tj < g.Ti ? 1 : 0)) : 0;
+                    const int o3 = cok3 ? (j - 1) * CIN + 24 : 24;            // (clamped to the voxel's own channel 24 when dead)
+                    const int o = is3 ? o3 : 8 * cc + j;
                     float f = (xrow + vox * CIN)[o];
                     if constexpr (GATE) f = (grow + vox * CIN)[o] > 0.f ? f : 0.f;
-                    v[k][j] = (live && cok) ? f : 0.f;
+                    v[k][j] = ((live ? 1 : 0) & ((1 - is3) | cok3)) ? f : 0.f;
                 }
             }
         }
@@ -1632,65 +1635,110 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         return fdiv(vlast, nvr, a.mNvr) + 2;
     };
 
-    // staging by ONE half (256 threads): item i of a row = (local voxel i >> 2, channel chunk i & 3), as in conv3_pstrip_kernel
+    // Staging by ONE half (256 threads).  A thread's items are the same for every row, so what does not depend on the row is worked out once:
+    // item i <-> (local voxel lv = i / NCH, channel chunk cc = i % NCH) with NCH = 4 chunks of 8 channels (32 channels) or 3 (25 channels:
+    // channels 0..23; the voxel's fourth chunk GATHERS channel 24 of padded depths t', t'+1, t'+2 and is one extra item per voxel, thread lv).
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int NCH = CIN == 25 ? 3 : 4;
     const int lw0 = a.nsplit == 1 ? g.pw : 0, Wl = a.nsplit == 1 ? g.Wi : a.Wt + 2;
-    const int items = Wl * g.Ti * 4;                                         // pp_plan(): <= 256 * RVP
-    auto stage_load = [&](int q, float (&v)[RVP][8]) {
+    const int nvs = Wl * g.Ti, items = nvs * NCH;                            // pp_plan(): items <= 256 * RVP, nvs <= 256
+    struct Staged { float v[RVP][8]; float g3[3]; };
+    int s_src[RVP], s_vd[RVP], s_cc[RVP], s_live[RVP];                      // source offset (floats) inside an input row, record, chunk, 1 = inside the patch's columns
+    int s3_src = 0, s3_vd = 0, s3_m = 0;                                    // gathered chunk: offset of (voxel, channel 24), record, validity bits of depths t-1, t, t+1 (bit 3: item exists)
+    {
+        auto locate = [&](int lv, int& lw, int& t, int& iwc, int& colok) {
+            const int lwr = fdiv(lv, g.Ti, a.mTi);
+            t = lv - lwr * g.Ti; lw = lw0 + lwr;
+            const int iw = ws0 + lw - g.pw;
+            colok = (iw >= 0 ? 1 : 0) & (iw < g.Wi ? 1 : 0);
+            iwc = iw < 0 ? 0 : (iw < g.Wi ? iw : g.Wi - 1);
+        };
+#pragma unroll
+        for (int k = 0; k < RVP; ++k) {
+            const int it = gtid + 256 * k;
+            const int ic = it < items ? it : 0;
+            const int lv = CIN == 25 ? (int)(((unsigned)ic * 43691u) >> 17) : ic >> 2;      // ic / 3 (ic < 2^16)
+            const int cc = ic - lv * NCH;
+            int lw, t, iwc, colok;
+            locate(lv, lw, t, iwc, colok);
+            s_src[k] = (iwc * g.Ti + t) * CIN + 8 * cc;
+            s_vd[k] = it < items ? lw * a.Tp + t + g.pt : -1;
+            s_cc[k] = cc;
+            s_live[k] = colok;
+        }
+        if constexpr (CIN == 25) {
+            const int lv = gtid < nvs ? gtid : 0;
+            int lw, t, iwc, colok;
+            locate(lv, lw, t, iwc, colok);
+            s3_src = (iwc * g.Ti + t) * CIN + 24;
+            s3_vd = lw * a.Tp + t;                                             // (indexed by PADDED depth t' = t: the chunk holds padded depths t', t'+1, t'+2 = input depths t-1, t, t+1)
+            s3_m = (colok && t - 1 >= 0 ? 1 : 0) | (colok ? 2 : 0) | (colok && t + 1 < g.Ti ? 4 : 0) | (gtid < nvs ? 8 : 0);
+        }
+    }
+    // stage_load only REQUESTS (clamped addresses, nothing consumed): what must be zero -- rows and columns outside the patch, the dead
+    // depths of the gathered chunk -- is zeroed in stage_store, so that the loads stay in flight across the barrier
+    auto stage_load = [&](int q, Staged& sv) {
         const int ih = hb - g.ph + q;
         const bool rok = ih >= 0 && ih < g.Hi;
         const long rbase = (((long)n * g.Hi + (rok ? ih : 0)) * g.Wi) * (long)g.Ti * CIN;
         const float* xrow = x + rbase;
-        const float* grow = GATE ? gate + rbase : nullptr;
 #pragma unroll
         for (int k = 0; k < RVP; ++k) {
-            const int i = gtid + 256 * k;
-            const int ic = i < items ? i : 0;
-            const int lvox = ic >> 2, cc = ic & 3;
-            const int lwr = fdiv(lvox, g.Ti, a.mTi), t = lvox - lwr * g.Ti, lw = lw0 + lwr;
-            const int iw = ws0 + lw - g.pw;
-            const bool live = rok && i < items && iw >= 0 && iw < g.Wi;
-            const int vox = (live ? iw : 0) * g.Ti + t;
-            const float* src = xrow + vox * CIN + 8 * cc;
-            const float* gsr = GATE ? grow + vox * CIN + 8 * cc : nullptr;
-            if constexpr (CIN % 8 == 0) {
-                const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
-                float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                if constexpr (GATE) {
-                    const float4 m0 = reinterpret_cast<const float4*>(gsr)[0], m1 = reinterpret_cast<const float4*>(gsr)[1];
-                    const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            const f32x4u t0 = *reinterpret_cast<const f32x4u*>(xrow + s_src[k]), t1 = *reinterpret_cast<const f32x4u*>(xrow + s_src[k] + 4);
+            float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            if constexpr (GATE) {
+                const float* grow = gate + rbase;
+                const f32x4u m0 = *reinterpret_cast<const f32x4u*>(grow + s_src[k]), m1 = *reinterpret_cast<const f32x4u*>(grow + s_src[k] + 4);
+                const float m[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = m[j] > 0.f ? f[j] : 0.f;
-                }
+                for (int j = 0; j < 8; ++j) f[j] = m[j] > 0.f ? f[j] : 0.f;
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[k][j] = live ? f[j] : 0.f;
-            } else {
+            for (int j = 0; j < 8; ++j) sv.v[k][j] = f[j];
+        }
+        if constexpr (CIN == 25) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int tj = t - 1 + j;                                 // (cc == 3 only: the gathered channel-24 chunk)
-                    const bool cok = cc < 3 || (j < 3 && tj >= 0 && tj < g.Ti);
-                    const int o = cc < 3 ? 8 * cc + j : (cok ? (j - 1) * CIN + 24 : 8 * cc);
-                    float f = (xrow + vox * CIN)[o];
-                    if constexpr (GATE) f = (grow + vox * CIN)[o] > 0.f ? f : 0.f;
-                    v[k][j] = (live && cok) ? f : 0.f;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const int o = s3_src + (((s3_m >> j) & 1) ? (j - 1) * CIN : 0);
+                float f = xrow[o];
+                if constexpr (GATE) f = (gate + rbase)[o] > 0.f ? f : 0.f;
+                sv.g3[j] = f;
             }
         }
     };
-    auto stage_store = [&](int q, const float (&v)[RVP][8]) {
-        unsigned char* slot = plds + (q - fdiv(q, NS, a.mNslot) * NS) * rowbytes;
+    auto stage_store = [&](int q, Staged& sv) {
+        const int sl = q - fdiv(q, NS, a.mNslot) * NS;
+        unsigned char* slot = plds + sl * rowbytes;
+        const int rec0 = sl * a.Wp * a.Tp;                                   // absolute record index of the slot's first record (the swizzle key)
+        const int ih = hb - g.ph + q;
+        const int rok = (ih >= 0 && ih < g.Hi) ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < RVP; ++k) {
-            const int i = gtid + 256 * k;
-            if (i < items) {
-                const int lvox = i >> 2, cc = i & 3;
-                const int lwr = fdiv(lvox, g.Ti, a.mTi), t = lvox - lwr * g.Ti, lw = lw0 + lwr;
-                const int vd = lw * a.Tp + t + ((CIN == 25 && cc == 3) ? 0 : g.pt);
+            if (s_vd[k] >= 0) {
+                const int live = rok & s_live[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sv.v[k][j] = live ? sv.v[k][j] : 0.f;
                 Frag f[NP];
-                cut8<AR>(v[k], sa, f);
-                unsigned char* rec = slot + vd * REC;
-                const int sw = (int)((rec - plds) >> 7) & 7;
-                *reinterpret_cast<uint4*>(rec + ((cc ^ sw) << 4)) = f[0].u;
-                *reinterpret_cast<uint4*>(rec + (((4 + cc) ^ sw) << 4)) = f[1].u;
+                cut8<AR>(sv.v[k], sa, f);
+                unsigned char* rec = slot + s_vd[k] * REC;
+                const int sw = (rec0 + s_vd[k]) & 7;
+                *reinterpret_cast<uint4*>(rec + ((s_cc[k] ^ sw) << 4)) = f[0].u;
+                *reinterpret_cast<uint4*>(rec + (((4 + s_cc[k]) ^ sw) << 4)) = f[1].u;
+            }
+        }
+        if constexpr (CIN == 25) {
+            if (s3_m & 8) {
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v8[j] = (rok & (s3_m >> j) & 1) ? sv.g3[j] : 0.f;
+                Frag f[NP];
+                cut8<AR>(v8, sa, f);
+                unsigned char* rec = slot + s3_vd * REC;
+                const int sw = (rec0 + s3_vd) & 7;
+                *reinterpret_cast<uint4*>(rec + ((3 ^ sw) << 4)) = f[0].u;
+                *reinterpret_cast<uint4*>(rec + ((7 ^ sw) << 4)) = f[1].u;
             }
         }
     };
@@ -1703,7 +1751,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     int hiq = nseg > 0 ? need(0) : -1;
 #pragma unroll 1
     for (int q = grp; q <= hiq; q += 2) {
-        float v[RVP][8];
+        Staged v;
         stage_load(q, v);
         stage_store(q, v);
     }
@@ -1711,11 +1759,53 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     XS_DECL;
     XS_ACC(1);
 
-    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const int eq = lane & 7, er = lane >> 3;                                // epilogue coordinates: channel quad, voxel row (mod 8)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int NST = CIN == 25 ? 5 : 6;                                   // k-blocks per (dh, dw) group
+    Frag A[NST][NP], W[NST][NP];
+    // what a half requests at the END of its taps, so that it has landed when its finishing segment begins: the skip tile of the
+    // tile just computed and the next input row (global loads only; the barrier between the segments waits for LDS traffic alone)
+    Staged nv_;
+    f32x4u skq[4];
+    int eoff[4];
+    bool have_nv = false;
+    auto load_skip = [&](int tile) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int vi = tile * 32 + er + 8 * jj;
+            eoff[jj] = vi < NV ? elem_off_ch(vi, 4 * eq) : -1;
+            skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
+        }
+        if (sbase) {
+            if (g.Cout == 32) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) skq[jj] = *reinterpret_cast<const f32x4u*>(sbase + (eoff[jj] < 0 ? 0 : eoff[jj]));
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || 4 * eq + c >= g.Cout) ? 0 : eoff[jj] + c];
+            }
+        }
+    };
+    auto request_W = [&](int gg, int st, Frag (&wq)[NP]) {
+        const uint4* pw = wfrag + ((long)gg * NST + st) * NP * 64;      // wave-uniform base + lane: scalar-base loads
+#ifdef PSX_W1
+        if (st != 0) return;
+#endif
+#ifdef PSX_NOW
+        wq[0].u = make_uint4(gg, st, lane, 1); wq[1].u = make_uint4(st, gg, 2, lane);
+#else
+        wq[0].u = pw[lane]; wq[1].u = pw[64 + lane];
+#endif
+    };
+    // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
+    if (grp == 0) {
+#pragma unroll
+        for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
+    }
 #pragma unroll 1
     for (int sg = 0; sg <= nseg; ++sg) {
         const int hi_next = sg + 1 < nseg ? need(sg + 1) : hiq;             // (uniform; both halves keep count)
@@ -1738,8 +1828,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     const int sb = dh == 0 ? sb0 : (dh == 1 ? sb1 : sb2);
                     return sb + (vox0 + dw * a.Tp + dt) * REC;
                 };
-                constexpr int NST = CIN == 25 ? 5 : 6;
-                Frag A[NST][NP], W[NST][NP];
                 auto request_A = [&](int gg, int st, Frag (&af)[NP]) {
                     int ra, cc;
                     if constexpr (CIN == 25) {
@@ -1764,49 +1852,51 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
 #endif
                 };
-                auto request_W = [&](int gg, int st, Frag (&wq)[NP]) {
-                    const uint4* pw = wfrag + ((long)gg * NST + st) * NP * 64;      // wave-uniform base + lane: scalar-base loads
-#ifdef PSX_W1
-                    if (st != 0) return;
-#endif
-#ifdef PSX_NOW
-                    wq[0].u = make_uint4(gg, st, lane, 1); wq[1].u = make_uint4(st, gg, 2, lane);
-#else
-                    wq[0].u = pw[lane]; wq[1].u = pw[64 + lane];
-#endif
-                };
 #ifdef PPX_PRIO
                 __builtin_amdgcn_s_setprio(PPX_PRIO);
 #endif
 #pragma unroll
-                for (int st = 0; st < PF; ++st) { request_W(0, st, W[st]); request_A(0, st, A[st]); }
+                for (int st = 0; st < PF; ++st) request_A(0, st, A[st]);
                 // One k-block = three MFMAs.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles and whatever else a wave issues in
                 // the gap is hidden only while it fits the other 24 (MI355X_MICROARCH.md, issue costs): the requests of a later k-block are
                 // therefore dealt out over the three gaps instead of standing in front of the first MFMA.
-#pragma unroll 1
-                for (int gg = 0; gg <= 8; ++gg) {
-                    const int gn = gg + 1 <= 8 ? gg + 1 : 8;
+                auto group = [&](int gg, auto last_tag) {
+                    constexpr bool LAST = decltype(last_tag)::value;         // the tile's last group requests nothing beyond itself: no load is left in flight at the barrier
 #pragma unroll
                     for (int st = 0; st < NST; ++st) {
-                        constexpr int dummy = 0; (void)dummy;
                         const bool same = st + PF < NST;                      // (compile-time after unrolling)
-                        const int gq = same ? gg : gn, sq = same ? st + PF : st + PF - NST;   // (after the last group: a harmless re-read)
+                        const int gq = same ? gg : gg + 1, sq = same ? st + PF : st + PF - NST;
                         acc = MFMA16H(A[st][1], W[st][0], acc);
                         __builtin_amdgcn_sched_barrier(0);
-                        request_A(gq, sq, A[sq]);
+                        if (same || !LAST) request_A(gq, sq, A[sq]);
                         __builtin_amdgcn_sched_barrier(0);
                         acc = MFMA16H(A[st][0], W[st][1], acc);
                         __builtin_amdgcn_sched_barrier(0);
-                        request_W(gq, sq, W[sq]);
+                        if (same || !LAST) request_W(gq, sq, W[sq]);
                         __builtin_amdgcn_sched_barrier(0);
                         acc = MFMA16H(A[st][0], W[st][0], acc);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
+                };
+#ifndef PPX_NOTAPS
+#pragma unroll 1
+                for (int gg = 0; gg < 8; ++gg) group(gg, std::false_type());
+                group(8, std::true_type());
+#endif
 #ifdef PPX_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
+#if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
+                load_skip(tile);
+#endif
             }
+#if !defined(PPX_IDLE) && !defined(PPX_NOSTAGE)
+            {   // the row this half stages in its finishing segment (the first one beyond what segment sg + 1 reads)
+                const int hi_n2 = sg + 2 < nseg ? need(sg + 2) : hi_next;
+                have_nv = hi_n2 > hi_next;
+                if (have_nv) stage_load(hi_next + 1, nv_);
+            }
+#endif
             XS_ACC(2);
         } else {
             // ---- finish the tile of the previous segment; stage the rows of the next one ----
@@ -1818,31 +1908,24 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
               for (int i = 0; i < 16; ++i) t_ += acc[i];
               if (t_ == 1234.5f) ybase[lane] = t_; }
 #else
+#ifdef PPX_NOEPI
+            const bool fin = false;
+            { float t_ = 0.f;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) t_ += acc[i];
+              if (t_ == 1234.5f) ybase[lane] = t_; }
+#else
             const bool fin = sg >= 1 && tile < NTL;                          // wave-uniform
+#endif
+#ifdef PPX_NOSTAGE
+            const bool do_load = false;
+#else
             const bool do_load = hi_next > hiq;
 #endif
-            float nv_[RVP][8];
-            if (do_load) stage_load(hiq + 1, nv_);
+#endif
+            if (do_load && !have_nv) stage_load(hiq + 1, nv_);               // (only the very first finishing segment: no taps came before it)
+            have_nv = false;
             if (fin) {
-                f32x4u skq[4];
-                int eoff[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int vi = tile * 32 + er + 8 * jj;
-                    eoff[jj] = vi < NV ? elem_off_ch(vi, 4 * eq) : -1;
-                    skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
-                }
-                if (sbase) {
-                    if (g.Cout == 32) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) skq[jj] = *reinterpret_cast<const f32x4u*>(sbase + (eoff[jj] < 0 ? 0 : eoff[jj]));
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || 4 * eq + c >= g.Cout) ? 0 : eoff[jj] + c];
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float v = ldexpf(acc[i], eun) + bv;                       // the filter column's exponent and the bias are per lane in the accumulator layout
@@ -1881,10 +1964,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     stage_store(q, nv_);
                 }
             }
+            if (sg + 1 < nseg) {
+#pragma unroll
+                for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
+            }
             XS_ACC(3);
         }
         hiq = hi_next;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: global loads requested for the next segment and the output stores stay in flight
         XS_ACC(4);
     }
     if (am.y) amax_commit(omax, am.y + n);
@@ -1903,8 +1990,8 @@ static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
     for (int ns = 1; ns <= 4; ++ns) {
         if (g.Wo % ns) continue;
         const int wt = g.Wo / ns, nvr = wt * g.To;
-        const int items = (ns == 1 ? g.Wi : wt + 2) * g.Ti * 4;
-        if (items > 256 * 3 || nvr < 32) continue;
+        const int nvs = (ns == 1 ? g.Wi : wt + 2) * g.Ti, items = nvs * (g.Cin == 25 ? 3 : 4);     // staged voxels / items per row (a half = 256 threads stages it)
+        if (items > 256 * 3 || nvs > 256 || nvr < 32) continue;
         int nstrips = (256 + g.N * ns - 1) / (g.N * ns);
         if (nstrips < 1) nstrips = 1;
         if (nstrips > g.Ho / 4) nstrips = g.Ho / 4 > 0 ? g.Ho / 4 : 1;
