@@ -30,6 +30,8 @@ struct probav_engine {
                               // 4 = 3 with the H3 arithmetic (three products of scaled fp16 piece pairs) where it exists
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed;
+    ReduceSide side = {};                           // side stream of the slab sums (probav_common.h), created on first use
+    bool side_tried = false;
     struct RedSpec { int k, p, pt, refl, refl_t; };   // one valid convReducer: kernel size, H/W pad, depth pad, mirrored H/W pad, mirrored depth pad
     std::vector<RedSpec> redSpec;
     int Hin = 0;
@@ -112,7 +114,8 @@ struct Plan {
     size_t amax; int n_amax, amax_bwd, amax_fwd, B;   // amax slots (one 32-bit word each, x6_device.h): region offset, count, first slot of the backward / forward per-sample arrays
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
-    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
+    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, pmax = 0, wpack, total;
+    int nparts = 1;
 };
 
 static ConvGeom make_geom(int N, int Hi, int Ti, int Cin, int Ho, int To, int Cout, int kh, int kw, int kt,
@@ -241,7 +244,11 @@ static Plan make_plan(const probav_engine* e, int B, int training)
             if (q > pmax) pmax = q;
         }
         if (e->pw_mfma && mfma_pw_backward_slab_floats(D) > pmax) pmax = mfma_pw_backward_slab_floats(D);
-        p.partial = take(pmax);
+        // one region per backward-filter launch (4 outside the blocks + reducers, 2 per block): the slabs of a launch are summed on the
+        // side stream while the main chain has moved on, so no two launches may share a region
+        p.pmax = (pmax + 63) & ~(size_t)63;
+        p.nparts = 5 + (int)e->iRed.size() + 3 * R;
+        p.partial = take(p.pmax * p.nparts);
     }
     p.total = off;
     return p;
@@ -291,6 +298,11 @@ static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const floa
     // the experimental 19-frame reducer: 5x5x5 kernels, pads of 2, mirrored depth pads (and their backward-data forms): generic kernels
     const bool exotic = g.reflect_t || g.ph > 2 || g.pw > 2 || g.pt > 2 || (!pw && g.kh != 3) || (g.reflect_hw && g.ph > 1);
     if (exotic) { ProfScope ps(e, bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD, geom_macs(g), s); return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s); }
+    if (e->impl >= 1 && !gate && !skip && bias && conv3d_cin1_forward_supported(g)) {
+        ProfScope ps(e, CLS_CONV3_FWD, geom_macs(g), s);
+        reported = true;
+        return conv3d_cin1_forward(g, x, w, bias, y, am.y, s);
+    }
     static const bool no_strip = getenv("PROBAV_NO_STRIP") != nullptr;            // diagnostic: route strip-eligible layers to the row-tile kernel
     const bool h3 = e->impl >= 4 && wf.h3 && am.x && am.w;
     const float* wsplit = h3 ? wf.h3 : wf.x6;
@@ -526,6 +538,12 @@ void probav_engine_destroy(probav_engine* e)
 {
     if (!e) return;
     for (auto ev : e->prof_ev) (void)hipEventDestroy(ev);
+    if (e->side.side) {
+        (void)hipStreamSynchronize(e->side.side);
+        for (auto ev : e->side.ev) (void)hipEventDestroy(ev);
+        (void)hipEventDestroy(e->side.joined);
+        (void)hipStreamDestroy(e->side.side);
+    }
     if (e->d_layers) (void)hipFree(e->d_layers);
     if (e->d_jobs) (void)hipFree(e->d_jobs);
     delete e;
@@ -648,6 +666,19 @@ int probav_forward_wc(probav_engine* e, const float* params, const float* x, flo
     return forward_impl(e, params, x, y, ws, ws_bytes, B, training, (const float*)wcache, stream);
 }
 
+static ReduceSide* engine_side(probav_engine* e)
+{
+    if (!e->side_tried) {
+        e->side_tried = true;
+        ReduceSide c = {};
+        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c.joined, hipEventDisableTiming) == hipSuccess;
+        if (ok) e->side = c; else (void)hipGetLastError();          // (without it the sums simply stay on the caller's stream)
+    }
+    return e->side.side ? &e->side : nullptr;
+}
+
 static int backward_impl(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes,
                          int B, const float* WC, void* stream)
 {
@@ -690,19 +721,23 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     if (h3 && hipMemsetAsync(A.back(0), 0, (size_t)(p.n_amax - p.amax_bwd) * sizeof(unsigned), s) != hipSuccess) { set_error("probav_backward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
     auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
-    float* part = W + p.partial;
+    int npart = 0;
+    auto next_part = [&]() -> float* { float* q = W + p.partial + (size_t)(npart < p.nparts ? npart : p.nparts - 1) * p.pmax; ++npart; return q; };
+    struct SideGuard { ReduceSide* c; explicit SideGuard(ReduceSide* c_) : c(c_) { if (c) { c->k = 0; reduce_side_activate(c); } } ~SideGuard() { if (c) reduce_side_activate(nullptr); } };
+    static const bool no_side = getenv("PROBAV_NO_SIDE_STREAM") != nullptr;   // diagnostic: slab sums on the caller's stream
+    SideGuard side_guard(no_side ? nullptr : engine_side(e));
 
     CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first
     {
         const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), part, Amax(), s));
+        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), next_part(), Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, Amax(), s));
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), part, Amax(), s));
+        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), next_part(), Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, Amax(), s));
         const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
-        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), part, Amax(), s));
+        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), next_part(), Amax(), s));
     }
     // upscale + reducers (models/modelsTF.py:152-164)
     const int nred = (int)e->iRed.size();
@@ -712,7 +747,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     {
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
-        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), part, Amax(), s));
+        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), next_part(), Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
     }
     for (int k = nred - 1; k >= 0; --k) {
@@ -722,7 +757,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
         const ConvGeom gr = red_geom(e, B, (size_t)k, hi, ti, F);
         { Amax m; if (h3) { m.x = k ? A.red(k - 1) : A.act(R); m.w = acur; }
-          CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), part, m, s)); }
+          CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), next_part(), m, s)); }
         unsigned* aoth = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, amx(acur, e->iRed[k], aoth), s));
         if (refl) {
@@ -748,7 +783,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
         // normConv_i: d loss/d w, then d loss/d dec_i
         { Amax m; if (h3) { m.x = A.dec(i); m.w = acur; }
-          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), part, m, s)); }
+          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), next_part(), m, s)); }
         unsigned* agdec = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, amx(acur, ln, agdec), s));
         if (e->impl >= 1 && e->pw_mfma) {
@@ -759,13 +794,13 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
             if (h3) {
                 PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.w1r = A.wrow(le); m.b1 = A.b(le); m.dt = agdec; m.y = anew;
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1h[i], Wpack + e->pkW2Kh[i], Wpack + e->pkW1Ch[i],
-                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, nvox / B, D, 2, m, s));
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), next_part(), nvox, nvox / B, D, 2, m, s));
             } else if (e->impl >= 3)
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1x6[i], Wpack + e->pkW2Kx6[i], Wpack + e->pkW1Cx6[i],
-                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, nvox / B, D, 1, PwAmax(), s));
+                                  params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), next_part(), nvox, nvox / B, D, 1, PwAmax(), s));
             else
                 CK(mfma_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1[i], Wpack + e->pkW2B[i], Wpack + e->pkW1C[i],
-                                    params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), part, nvox, D, s));
+                                    params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), next_part(), nvox, D, s));
             float* tmp2 = cur; cur = oth; oth = tmp2;
             acur = anew;
             continue;
@@ -773,10 +808,10 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
         CK(conv_fwd(e, ge, W + p.act[i], nullptr, Wweff + e->layers[le].wn.w_off, Frags(), params + e->layers[le].wn.b_off, nullptr, Hbuf, Amax(), s));
         // decConv_i
-        CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), part, Amax(), s));
+        CK(conv_wgrad(e, gd, Hbuf, gDec, nullptr, dweff(ld), dbias(ld), next_part(), Amax(), s));
         CK(conv_fwd(e, bwd_data_geom(gd), gDec, nullptr, weffT(ld), fragT(ld), nullptr, nullptr, dH, Amax(), s));
         // expConv_i: ReLU gate (H > 0) applied where dH is consumed; skip path adds d loss/d act[i+1]
-        CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), part, Amax(), s));
+        CK(conv_wgrad(e, ge, W + p.act[i], dH, Hbuf, dweff(le), dbias(le), next_part(), Amax(), s));
         unsigned* aoth = new_slot();
         CK(conv_fwd(e, bwd_data_geom(ge), dH, Hbuf, weffT(le), fragT(le), nullptr, cur, oth, amx(nullptr, le, aoth), s));
         float* tmp = cur; cur = oth; oth = tmp;
@@ -784,7 +819,8 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     }
     // mainConv1 (input-facing: no backward-data)
     CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
-                  dweff(e->iMain), dbias(e->iMain), part, Amax(), s));
+                  dweff(e->iMain), dbias(e->iMain), next_part(), Amax(), s));
+    CK(reduce_join(s));                                                       // every slab sum has landed in dweff / the bias gradients
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.dweff, Winvn, grads, s)); }
     return PROBAV_OK;
 }

@@ -11,6 +11,7 @@
 // wave-uniform, so the compiler fetches them through the scalar cache (s_load) and the FMAs take
 // them as SGPR operands -- filter reuse costs no vector memory traffic at all.
 #include "probav_common.h"
+#include "x6_device.h"
 
 namespace probav {
 
@@ -100,6 +101,78 @@ static int launch_fwd(const ConvGeom& g, const float* x, const float* gate, cons
     if (vec4) hipLaunchKernelGGL((conv_direct_fwd_kernel<COUT_T, 4>), grid, dim3(256), 0, s, g, x, gate, w, bias, skip, y);
     else      hipLaunchKernelGGL((conv_direct_fwd_kernel<COUT_T, 1>), grid, dim3(256), 0, s, g, x, gate, w, bias, skip, y);
     return check_launch("conv_direct_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mainConv1 (models/modelsTF.py:23-24): ONE input channel -> 32, 3x3x3, zero pads of 1, ReLU.  0.5 GMAC against 71 MB of output: bound
+// by the store stream, so no matrix unit: a thread keeps the 27 x 4 filter values of its four output channels in registers and walks
+// the voxels of an output row; eight lanes x 16 bytes = one voxel's 128-byte row.  Input rows h-1..h+1 sit zero-padded in LDS.
+// Also leaves the per-sample amax of its output (the next layer's H3 scale) instead of a separate pass over the 71 MB.
+// ---------------------------------------------------------------------------------------------------
+constexpr int C1_ROWS = 4;                  // consecutive (sample, row) pairs per workgroup
+__global__ __launch_bounds__(256) void conv3_cin1_fwd_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, unsigned* __restrict__ amax)
+{
+    extern __shared__ float c1_in[];                                          // [3][W + 2][T + 2]
+    const int tid = threadIdx.x, cg = tid & 7, vs = tid >> 3;
+    const int Wp = g.Wi + 2, Tp = g.Ti + 2, nin = 3 * Wp * Tp, nv = g.Wo * g.To;
+    float4 wt[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) wt[k] = *reinterpret_cast<const float4*>(w + k * 32 + 4 * cg);
+    const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned mT = 0xffffffffu / (unsigned)g.To + 1u, mTp = 0xffffffffu / (unsigned)Tp + 1u, mWT = 0xffffffffu / (unsigned)(Wp * Tp) + 1u;
+    const long nrows = (long)g.N * g.Ho;
+#pragma unroll 1
+    for (int r = 0; r < C1_ROWS; ++r) {
+        const long R = (long)blockIdx.x * C1_ROWS + r;
+        if (R >= nrows) break;
+        const int n = (int)(R / g.Ho), h = (int)(R - (long)n * g.Ho);
+        __syncthreads();                                                       // the previous row's readers are done
+        for (int i = tid; i < nin; i += 256) {
+            const int dh = (int)__umulhi((unsigned)i, mWT), rem = i - dh * Wp * Tp;
+            const int wp = (int)__umulhi((unsigned)rem, mTp), tp = rem - wp * Tp;
+            const int ih = h - 1 + dh, iw = wp - 1, it = tp - 1;
+            const bool ok = ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi && it >= 0 && it < g.Ti;
+            c1_in[i] = ok ? x[(((long)n * g.Hi + ih) * g.Wi + iw) * g.Ti + it] : 0.f;
+        }
+        __syncthreads();
+        float omax = 0.f;
+        float* yrow = y + ((long)n * g.Ho + h) * nv * 32;
+        for (int v = vs; v < nv; v += 32) {
+            const int wo = (int)__umulhi((unsigned)v, mT), t = v - wo * g.To;
+            const float* ip = c1_in + wo * Tp + t;
+            float4 acc = b4;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) {
+                        const float xv = ip[(dh * Wp + dw) * Tp + dt];
+                        const float4 q = wt[(dh * 3 + dw) * 3 + dt];
+                        acc.x = fmaf(xv, q.x, acc.x); acc.y = fmaf(xv, q.y, acc.y); acc.z = fmaf(xv, q.z, acc.z); acc.w = fmaf(xv, q.w, acc.w);
+                    }
+            if (g.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+            *reinterpret_cast<float4*>(yrow + (long)v * 32 + 4 * cg) = acc;
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+        }
+        if (amax) amax_commit(omax, amax + n);
+    }
+}
+
+bool conv3d_cin1_forward_supported(const ConvGeom& g)
+{
+    return g.Cin == 1 && g.Cout == 32 && g.kh == 3 && g.kw == 3 && g.kt == 3 && g.ph == 1 && g.pw == 1 && g.pt == 1 && !g.reflect_hw && !g.reflect_t &&
+           g.Ho == g.Hi && g.Wo == g.Wi && g.To == g.Ti && g.To >= 2 && (g.Wi + 2) * (g.Ti + 2) * 3 * sizeof(float) <= 48 * 1024;
+}
+// amax: per-sample slots of the output (may be null)
+int conv3d_cin1_forward(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, unsigned* amax, hipStream_t s)
+{
+    if (!conv3d_cin1_forward_supported(g)) { set_error("conv3d_cin1_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    const long nrows = (long)g.N * g.Ho;
+    const size_t lds = (size_t)3 * (g.Wi + 2) * (g.Ti + 2) * sizeof(float);
+    hipLaunchKernelGGL(conv3_cin1_fwd_kernel, dim3((unsigned)((nrows + C1_ROWS - 1) / C1_ROWS)), dim3(256), lds, s, g, x, w, bias, y, amax);
+    return check_launch("conv3_cin1_fwd");
 }
 
 int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, const float* w,
@@ -400,8 +473,9 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
         hipLaunchKernelGGL(wgrad_cin1_kernel, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
         int rc = check_launch("wgrad_cin1");
         if (rc) return rc;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((27 * 32 + 31) / 32)), dim3(256), 0, s, partial, dw, (long)27 * 32, slabs);
-        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, pb, db, (long)32, slabs);
+        hipStream_t rs = reduce_fork(s);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((27 * 32 + 31) / 32)), dim3(256), 0, rs, partial, dw, (long)27 * 32, slabs);
+        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, rs, pb, db, (long)32, slabs);
         return check_launch("reduce_partials");
     }
     {
@@ -414,8 +488,9 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
             int rc = check_launch("wgrad2d_small");
             if (rc) return rc;
             const long nw = K * g.Cout;
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, s, partial, dw, nw, slabs);
-            if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), dim3(256), 0, s, pb, db, (long)g.Cout, slabs);
+            hipStream_t rs = reduce_fork(s);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, rs, partial, dw, nw, slabs);
+            if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), dim3(256), 0, rs, pb, db, (long)g.Cout, slabs);
             return check_launch("reduce_partials");
         }
     }
@@ -440,8 +515,9 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     int rc = check_launch("conv_direct_wgrad");
     if (rc) return rc;
     const long nw = K * g.Cout;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), block, 0, s, partial, dw, nw, chunks);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), block, 0, s, partial_b, db, (long)g.Cout, chunks);
+    hipStream_t rs = reduce_fork(s);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), block, 0, rs, partial, dw, nw, chunks);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), block, 0, rs, partial_b, db, (long)g.Cout, chunks);
     return check_launch("reduce_partials");
 }
 

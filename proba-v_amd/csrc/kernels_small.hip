@@ -325,29 +325,33 @@ int tail_backward(const float* dy, float* dtail, int N, int P, int sc, float std
 }
 
 // Gradient of tf.pad(x, 1 on H and W, 'reflect'): padded row 0 mirrors row 1, padded row H+1 mirrors row H-2.
+template <int VEC>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx,
                                                           int N, int H, int W, int TC, unsigned* __restrict__ amax)
 {
+    // VEC = 4: TC % 4 == 0 and 16-byte aligned tensors; indices stay in 32 bits inside a sample (64-bit divisions cost more than the traffic)
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const int n = blockIdx.y;                                       // one sample per grid row: its largest |dx| goes to amax[n]
-    const long per = (long)H * W * TC;
+    const int TCv = TC / VEC, per = H * W * TCv;
+    const float* src = dpad + (long)n * (H + 2) * (W + 2) * TC;
+    float* dst = dx + (long)n * H * W * TC;
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
-        const int e = (int)(i % TC);
-        long r = i / TC;
-        const int w = (int)(r % W);
-        const int h = (int)(r / W);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+        const int r = i / TCv, e = i - r * TCv;
+        const int h = r / W, w = r - h * W;
         int hs[2], ws[2], nh = 1, nw = 1;
         hs[0] = h + 1; ws[0] = w + 1;
         if (h == 1) hs[nh++] = 0;
         if (h == H - 2) hs[nh++] = H + 1;          // H >= 4, so h == 1 and h == H-2 never coincide
         if (w == 1) ws[nw++] = 0;
         if (w == W - 2) ws[nw++] = W + 1;
-        float s = 0.f;
+        vec_t s = 0.f;
         for (int a = 0; a < nh; ++a)
             for (int b = 0; b < nw; ++b)
-                s += dpad[(((long)n * (H + 2) + hs[a]) * (W + 2) + ws[b]) * TC + e];
-        dx[(long)n * per + i] = s;
-        m = fmaxf(m, fabsf(s));
+                s += *reinterpret_cast<const vec_t*>(src + ((long)(hs[a] * (W + 2) + ws[b]) * TCv + e) * VEC);
+        *reinterpret_cast<vec_t*>(dst + (long)i * VEC) = s;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) m = fmaxf(m, fabsf(s[c]));
     }
     if (amax) {                                 // largest |dx| of the sample (H3 operand scale of the next layer's kernels): one guarded atomic per workgroup
 #pragma unroll
@@ -361,6 +365,28 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         }
     }
 }
+static thread_local ReduceSide* g_reduce_side = nullptr;
+void reduce_side_activate(ReduceSide* ctx) { g_reduce_side = ctx; }
+hipStream_t reduce_fork(hipStream_t s)
+{
+    ReduceSide* c = g_reduce_side;
+    if (!c || !c->side) return s;
+    hipEvent_t ev = c->ev[c->k++ & 7];
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->side, ev, 0) != hipSuccess) { (void)hipGetLastError(); return s; }
+    return c->side;
+}
+int reduce_join(hipStream_t s)
+{
+    ReduceSide* c = g_reduce_side;
+    if (!c || !c->side || c->k == 0) return PROBAV_OK;
+    if (hipEventRecord(c->joined, c->side) != hipSuccess || hipStreamWaitEvent(s, c->joined, 0) != hipSuccess) {
+        set_error("reduce_join: event record / wait", hipGetLastError());
+        return PROBAV_EHIP;
+    }
+    c->k = 0;
+    return PROBAV_OK;
+}
+
 int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax, hipStream_t s)
 {
     if (H < 4 || W < 4) { set_error("reflect_fold: H, W must be >= 4", hipSuccess); return PROBAV_EINVAL; }
@@ -368,7 +394,13 @@ int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsi
     long blocks = (per + 255) / 256;
     const long cap = N >= 4096 ? 1 : 4096 / N;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, s, dpad, dx, N, H, W, TC, amax);
+    const bool v4 = TC % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpad) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    if (v4) {
+        blocks = (per / 4 + 255) / 256;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(reflect_fold_kernel<4>, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, s, dpad, dx, N, H, W, TC, amax);
+    } else
+        hipLaunchKernelGGL(reflect_fold_kernel<1>, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, s, dpad, dx, N, H, W, TC, amax);
     return check_launch("reflect_fold");
 }
 

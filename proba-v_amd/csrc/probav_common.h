@@ -56,6 +56,18 @@ int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, 
 size_t wgrad_partial_floats(const ConvGeom& g);
 int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate,
                         float* dw, float* db, float* partial, hipStream_t s);
+// Slab reductions beside the main chain.  The backward-filter kernels leave one slab per workgroup; the few-microsecond kernels that sum
+// them are needed only by the weight-norm backward at the very end, yet on the caller's stream each one sits between two chip-filling
+// launches.  While a ReduceSide is active on the calling thread (the engine's backward pass), reduce_fork(s) records the point on s,
+// makes the engine's side stream wait for it and returns the side stream; the reducing kernels are launched there and run in the
+// gaps of the main chain.  reduce_join(s) makes s wait for everything forked.  Without an active context reduce_fork(s) is s.
+struct ReduceSide { hipStream_t side; hipEvent_t ev[8]; hipEvent_t joined; int k; };
+void reduce_side_activate(ReduceSide* ctx);                 // nullptr deactivates
+hipStream_t reduce_fork(hipStream_t s);
+int reduce_join(hipStream_t s);
+// mainConv1 forward (one input channel -> 32, 3x3x3, zero pads of 1): dedicated store-bound kernel; amax = per-sample slots of y or null
+bool conv3d_cin1_forward_supported(const ConvGeom& g);
+int conv3d_cin1_forward(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, unsigned* amax, hipStream_t s);
 // geometries for which conv3d_direct_wgrad runs a dedicated kernel that beats the matrix kernels (one input channel: mainConv1)
 bool conv3d_direct_wgrad_is_tuned(const ConvGeom& g);
 
