@@ -2080,7 +2080,8 @@ bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
 bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith)
 {
     StripPlan pp;
-    return arith == 2 && pstrip_plan(g, pp);
+    int rvp;
+    return arith == 2 && (pstrip_plan(g, pp) || pp_plan(g, pp, rvp));        // (the alternating-halves form also takes rows shorter than 128 voxels: the later reducers)
 }
 
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
@@ -2106,7 +2107,7 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
 #undef PROBAV_PP
             return check_launch("conv3_pp");
         }
-        (void)pstrip_plan(g, pp);
+        if (!pstrip_plan(g, pp)) { set_error("x6_conv_strip_forward: no piece-ring plan for this geometry (PROBAV_NO_PP set?)", hipSuccess); return PROBAV_EINVAL; }
         static std::once_flag oncep;
         std::call_once(oncep, [] {
             allow_big_lds(conv3_pstrip_kernel<25, false>); allow_big_lds(conv3_pstrip_kernel<25, true>);
