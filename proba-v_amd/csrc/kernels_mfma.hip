@@ -1467,18 +1467,10 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
                 }
                 const int sw = (ra >> 7) & 7;                                // absolute record index & 7, as stored
                 const int cp = cc ^ sw;
-#ifdef PSX_NOA
-                af[0].u = make_uint4(ra, cp, ra, cp); af[1].u = make_uint4(cp, ra, cp, ra);
-#else
                 af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
                 af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
-#endif
                 const uint4* pw = wf + ((long)gg * NST + st) * NP * 64;
-#ifdef PSX_NOW
-                wq[0].u = make_uint4(gg, st, lane, 1); wq[1].u = make_uint4(st, gg, 2, lane);
-#else
                 wq[0].u = pw[0]; wq[1].u = pw[64];
-#endif
             };
 #pragma unroll
             for (int st = 0; st < PF; ++st) request(g0, st, A[st], W[st]);
@@ -1721,7 +1713,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 Frag f[NP];
                 cut8<AR>(sv.v[k], sa, f);
                 unsigned char* rec = slot + s_vd[k] * REC;
-                const int sw = (rec0 + s_vd[k]) & 7;
+                const int sw = ((rec0 + s_vd[k]) >> 1) & 7;
                 *reinterpret_cast<uint4*>(rec + ((s_cc[k] ^ sw) << 4)) = f[0].u;
                 *reinterpret_cast<uint4*>(rec + (((4 + s_cc[k]) ^ sw) << 4)) = f[1].u;
             }
@@ -1736,7 +1728,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 Frag f[NP];
                 cut8<AR>(v8, sa, f);
                 unsigned char* rec = slot + s3_vd * REC;
-                const int sw = (rec0 + s3_vd) & 7;
+                const int sw = ((rec0 + s3_vd) >> 1) & 7;
                 *reinterpret_cast<uint4*>(rec + ((3 ^ sw) << 4)) = f[0].u;
                 *reinterpret_cast<uint4*>(rec + ((7 ^ sw) << 4)) = f[1].u;
             }
@@ -1792,14 +1784,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     };
     auto request_W = [&](int gg, int st, Frag (&wq)[NP]) {
         const uint4* pw = wfrag + ((long)gg * NST + st) * NP * 64;      // wave-uniform base + lane: scalar-base loads
-#ifdef PSX_W1
-        if (st != 0) return;
-#endif
-#ifdef PSX_NOW
-        wq[0].u = make_uint4(gg, st, lane, 1); wq[1].u = make_uint4(st, gg, 2, lane);
-#else
         wq[0].u = pw[lane]; wq[1].u = pw[64 + lane];
-#endif
     };
     // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
     if (grp == 0) {
@@ -1840,21 +1825,11 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                         ra = rec_addr(gg, dt);
                         cc = 2 * kb + half;
                     }
-                    const int sw = (ra >> 7) & 7;
+                    const int sw = (ra >> 8) & 7;
                     const int cp = cc ^ sw;
-#ifdef PSX_A1
-                    if (st != 0) return;
-#endif
-#ifdef PSX_NOA
-                    af[0].u = make_uint4(ra, cp, ra, cp); af[1].u = make_uint4(cp, ra, cp, ra);
-#else
                     af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
                     af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
-#endif
                 };
-#ifdef PPX_PRIO
-                __builtin_amdgcn_s_setprio(PPX_PRIO);
-#endif
 #pragma unroll
                 for (int st = 0; st < PF; ++st) request_A(0, st, A[st]);
                 // One k-block = three MFMAs.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles and whatever else a wave issues in
@@ -1882,9 +1857,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll 1
                 for (int gg = 0; gg < 8; ++gg) group(gg, std::false_type());
                 group(8, std::true_type());
-#endif
-#ifdef PPX_PRIO
-                __builtin_amdgcn_s_setprio(0);
 #endif
 #if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
                 load_skip(tile);
