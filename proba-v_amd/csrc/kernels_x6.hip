@@ -700,7 +700,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     const int li = lane & 15, gcol = (lane >> 4) & 1;
     const int tg = wave & 3, ksel = wave >> 2;
     const int rowbytes = a.Wp * a.Tp * VS;
-    for (int i = tid; i < (3 * rowbytes + 16) / 8; i += 512) reinterpret_cast<uint2*>(lds_raw)[i] = make_uint2(0u, 0u);
+    // H3: the tile's dY row lives in LDS as a piece image too ([voxel][piece][32 channels], 128 B per voxel, rows beyond the tile zero), staged
+    // and cut ONCE per tile by the whole workgroup; the B operand of a k-block is then four transposed reads.  (Before, each of the four
+    // waves of a k-block parity loaded the same 16 x 32 block from memory and cut it for itself.)
+    constexpr bool DYI = AR::SCALED;
+    const int dyrows = (a.nv + 15) & ~15;                  // x6_wgrad_split(): dyrows * 8 <= 512 * NDY
+    unsigned char* dyimg = lds_raw + ((3 * rowbytes + 16 + 15) & ~15);
+    const int zbytes = DYI ? ((3 * rowbytes + 16 + 15) & ~15) + dyrows * 128 : 3 * rowbytes + 16;
+    for (int i = tid; i < zbytes / 8; i += 512) reinterpret_cast<uint2*>(lds_raw)[i] = make_uint2(0u, 0u);
 
     f32x16 acc[7];
 #pragma unroll
@@ -770,11 +777,49 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         Wts = a.W - ws0 < a.Wt ? a.W - ws0 : a.Wt;
     };
 
+    constexpr int NDY = 4;
+    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);         // H3: bias gradient of channels 4 (tid & 7) .. + 3, summed as the rows are staged
+    auto dy_load = [&](int n, int ho, int ws0, int Wts, float4 (&d)[NDY]) {
+        const int ni = Wts * a.T * 8;                      // (voxel, channel quad) items of the row range
+        const long ob = (((long)n * a.H + ho) * a.W + ws0) * a.T * 32;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int i = tid + 512 * k;
+            const int ic = i < ni ? i : 0;
+            d[k] = *reinterpret_cast<const float4*>(dy + ob + ic * 4);
+            if constexpr (GATE) {
+                const float4 m = *reinterpret_cast<const float4*>(gate + ob + ic * 4);       // the layer's own output: ReLU mask of dY
+                d[k].x = m.x > 0.f ? d[k].x : 0.f; d[k].y = m.y > 0.f ? d[k].y : 0.f; d[k].z = m.z > 0.f ? d[k].z : 0.f; d[k].w = m.w > 0.f ? d[k].w : 0.f;
+            }
+        }
+    };
+    auto dy_store = [&](int Wts, const float4 (&d)[NDY]) {
+        const int ni = Wts * a.T * 8;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int i = tid + 512 * k;
+            if (i < dyrows * 8) {
+                const bool live = i < ni;
+                const float4 v = live ? d[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bs4.x += v.x; bs4.y += v.y; bs4.z += v.z; bs4.w += v.w;
+                unsigned q0[NPC], q1[NPC];
+                cut_pair<AR>(v.x, v.y, sd, q0);
+                cut_pair<AR>(v.z, v.w, sd, q1);
+                unsigned char* dst = dyimg + (i >> 3) * 128 + (i & 7) * 8;
+#pragma unroll
+                for (int p = 0; p < NPC; ++p) *reinterpret_cast<uint2*>(dst + p * 64) = make_uint2(q0[p], q1[p]);
+            }
+        }
+    };
+
     const int tbeg = (int)((long)blockIdx.x * a.total_tiles / gridDim.x), tend = (int)((long)(blockIdx.x + 1) * a.total_tiles / gridDim.x);
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     XS_DECL;
     __syncthreads();                                       // ring zeroed
-    if (tbeg < tend) { int n, ws0, Wts, ho; decode(tbeg, n, ws0, Wts, ho); stage_three(n, ho, ws0, Wts); }
+    if (tbeg < tend) {
+        int n, ws0, Wts, ho; decode(tbeg, n, ws0, Wts, ho); stage_three(n, ho, ws0, Wts);
+        if constexpr (DYI) { float4 d0[NDY]; dy_load(n, ho, ws0, Wts, d0); dy_store(Wts, d0); }
+    }
     XS_ACC(1);
 #pragma unroll 1
     for (int tile = tbeg; tile < tend; ++tile) {
@@ -787,8 +832,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         int nn = n, nws0 = ws0, nWts = Wts, nho = ho;
         if (has_next) decode(tile + 1, nn, nws0, nWts, nho);
         const bool consecutive = has_next && nn == n && nws0 == ws0 && nho == ho + 1;    // next tile = next row of the same column range
+        // Nothing of the previous tile is in flight here; saying so explicitly lets the compiler's wait-count model forget loads it still
+        // counts as possibly pending from the loop's back edge (it otherwise puts a vmcnt(0) in front of the k-loop's first transposed
+        // read, which makes the prefetches below synchronous).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
         float nf[NST][2];
         if (consecutive) stage_load(n, ho + 3, ws0, Wts, nf);   // ring row of the next tile's dh = 2, in flight during this tile's MFMAs
+        float4 ndy[NDY];
+        if constexpr (DYI) { if (has_next) dy_load(nn, nho, nws0, nWts, ndy); }       // the next tile's dY row likewise
         const long out_base = (((long)n * a.H + ho) * a.W + ws0) * a.T;
         int tapoff[7];
 #pragma unroll
@@ -826,84 +877,134 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             const int w = (int)__umulhi((unsigned)vi, a.mT), t = vi - w * a.T;
             return (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
         };
-        Frag bf[NPC], bfn[NPC];
-        int va[2], van[2];
-        float rawn[8], rawnn[8];
-        {
-            float raw0[8];
-            load_dy(ksel, raw0);
-            load_dy(ksel + 2 < nkb ? ksel + 2 : ksel, rawn);
-            cut8<AR>(raw0, sd, bf);
-            va[0] = tr_addr(ksel, 0); va[1] = tr_addr(ksel, 1);
-            if (tg == 0 && ksel < nkb) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += raw0[j];
-            }
-        }
         typedef const unsigned char* cptr;
-#pragma unroll 1
-        for (int kb = ksel; kb < nkb; kb += 2) {
-            const int kn = kb + 2 < nkb ? kb + 2 : kb, knn = kb + 4 < nkb ? kb + 4 : kb;
-            load_dy(knn, rawnn);
-            Frag af[2][NPC];
-            auto load_a = [&](int j, Frag (&f)[NPC]) {
-                cptr p0 = lds_raw + tapoff[j] + va[0];
-                cptr p1 = lds_raw + tapoff[j] + va[1];
+        if constexpr (DYI) {
+            // B operand of k-block kb: rows 16 kb + 8 h + 4 jj + (li >> 2) of the dY image, channels 16 gcol + 4 (li & 3) .. + 3 (the read transposes)
+            auto load_b = [&](int kb, Frag (&f)[NPC]) {
+                cptr p0 = dyimg + (16 * kb + 8 * h + (li >> 2)) * 128 + (16 * gcol + 4 * (li & 3)) * 2;
 #pragma unroll
                 for (int p = 0; p < NPC; ++p) {
-                    f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * CB));
-                    f[p].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + p * CB));
+                    f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * 64));
+                    f[p].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * 128 + p * 64));
                 }
             };
-            load_a(0, af[0]);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (slot j = 6 of tg = 3 is clamped: harmless reread)
-                __builtin_amdgcn_sched_barrier(0);
-                if (j < 6 || tg < 3) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);         // wave-uniform
-                // a seventh of the next block's preparation.  The empty volatile asm statements pin it between this tap's
-                // scheduling barriers (pure arithmetic would otherwise be sunk to the end of the loop body).
-                if (j < 4) {
-                    float ra = rawn[2 * j], rb = rawn[2 * j + 1];
-                    asm volatile("" : "+v"(ra), "+v"(rb));
-                    unsigned q[NPC];
-                    cut_pair<AR>(ra, rb, sd, q);
+            Frag bf[NPC], bfn[NPC];
+            int va[2], van[2];
+            load_b(ksel < nkb ? ksel : 0, bf);
+            va[0] = tr_addr(ksel, 0); va[1] = tr_addr(ksel, 1);
+#pragma unroll 1
+            for (int kb = ksel; kb < nkb; kb += 2) {
+                const int kn = kb + 2 < nkb ? kb + 2 : kb;
+                load_b(kn, bfn);
+                Frag af[2][NPC];
+                auto load_a = [&](int j, Frag (&f)[NPC]) {
+                    cptr p0 = lds_raw + tapoff[j] + va[0];
+                    cptr p1 = lds_raw + tapoff[j] + va[1];
 #pragma unroll
                     for (int p = 0; p < NPC; ++p) {
-                        asm volatile("" : "+v"(q[p]));
-                        if (j == 0) bfn[p].u.x = q[p];
-                        if (j == 1) bfn[p].u.y = q[p];
-                        if (j == 2) bfn[p].u.z = q[p];
-                        if (j == 3) bfn[p].u.w = q[p];
+                        f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * CB));
+                        f[p].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + p * CB));
                     }
-                } else if (j < 6) {
-                    int kk = kn;
-                    asm volatile("" : "+v"(kk));
-                    int v = tr_addr(kk, j - 4);
-                    asm volatile("" : "+v"(v));
-                    van[j - 4] = v;
-                } else if (tg == 0 && kb + 2 < nkb) {
+                };
+                load_a(0, af[0]);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) bsum += rawn[i];
+                for (int j = 0; j < 7; ++j) {
+                    if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                   // (slot j = 6 of tg = 3 is clamped: harmless reread)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 6 || tg < 3) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);     // wave-uniform
+                    if (j >= 4 && j < 6) {                                             // the next block's transposed-read addresses, in the shadow of these MFMAs
+                        int kk = kn;
+                        asm volatile("" : "+v"(kk));
+                        int v = tr_addr(kk, j - 4);
+                        asm volatile("" : "+v"(v));
+                        van[j - 4] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int i = 0; i < (AR::SCALED ? 3 : 6); ++i) {                      // one MFMA, then two VALU in its shadow
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int p = 0; p < NPC; ++p) bf[p] = bfn[p];
+                va[0] = van[0]; va[1] = van[1];
             }
-#pragma unroll
-            for (int p = 0; p < NPC; ++p) bf[p] = bfn[p];
-            va[0] = van[0]; va[1] = van[1];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rawn[i] = rawnn[i];
+        } else {
+            Frag bf[NPC], bfn[NPC];
+            int va[2], van[2];
+            float rawn[8], rawnn[8];
+            {
+                float raw0[8];
+                load_dy(ksel, raw0);
+                load_dy(ksel + 2 < nkb ? ksel + 2 : ksel, rawn);
+                cut8<AR>(raw0, sd, bf);
+                va[0] = tr_addr(ksel, 0); va[1] = tr_addr(ksel, 1);
+                if (tg == 0 && ksel < nkb) {
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += raw0[j];
+                }
+            }
+    #pragma unroll 1
+            for (int kb = ksel; kb < nkb; kb += 2) {
+                const int kn = kb + 2 < nkb ? kb + 2 : kb, knn = kb + 4 < nkb ? kb + 4 : kb;
+                load_dy(knn, rawnn);
+                Frag af[2][NPC];
+                auto load_a = [&](int j, Frag (&f)[NPC]) {
+                    cptr p0 = lds_raw + tapoff[j] + va[0];
+                    cptr p1 = lds_raw + tapoff[j] + va[1];
+    #pragma unroll
+                    for (int p = 0; p < NPC; ++p) {
+                        f[p].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + p * CB));
+                        f[p].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + p * CB));
+                    }
+                };
+                load_a(0, af[0]);
+    #pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (slot j = 6 of tg = 3 is clamped: harmless reread)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 6 || tg < 3) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);         // wave-uniform
+                    // a seventh of the next block's preparation.  The empty volatile asm statements pin it between this tap's
+                    // scheduling barriers (pure arithmetic would otherwise be sunk to the end of the loop body).
+                    if (j < 4) {
+                        float ra = rawn[2 * j], rb = rawn[2 * j + 1];
+                        asm volatile("" : "+v"(ra), "+v"(rb));
+                        unsigned q[NPC];
+                        cut_pair<AR>(ra, rb, sd, q);
+    #pragma unroll
+                        for (int p = 0; p < NPC; ++p) {
+                            asm volatile("" : "+v"(q[p]));
+                            if (j == 0) bfn[p].u.x = q[p];
+                            if (j == 1) bfn[p].u.y = q[p];
+                            if (j == 2) bfn[p].u.z = q[p];
+                            if (j == 3) bfn[p].u.w = q[p];
+                        }
+                    } else if (j < 6) {
+                        int kk = kn;
+                        asm volatile("" : "+v"(kk));
+                        int v = tr_addr(kk, j - 4);
+                        asm volatile("" : "+v"(v));
+                        van[j - 4] = v;
+                    } else if (tg == 0 && kb + 2 < nkb) {
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) bsum += rawn[i];
+                    }
+    #pragma unroll
+                    for (int i = 0; i < (AR::SCALED ? 3 : 6); ++i) {                      // one MFMA, then two VALU in its shadow
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    #pragma unroll
+                for (int p = 0; p < NPC; ++p) bf[p] = bfn[p];
+                va[0] = van[0]; va[1] = van[1];
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) rawn[i] = rawnn[i];
+            }
         }
         XS_ACC(3);
         __syncthreads();                                   // every wave is done with this tile's rows
         XS_ACC(4);
         if (consecutive) stage_store(ho + 3, Wts, nf);     // replaces ring row ho
         else if (has_next) stage_three(nn, nho, nws0, nWts);
+        if constexpr (DYI) { if (has_next) dy_store(nWts, ndy); }
         XS_ACC(5);
     }
     // slab of this workgroup: [27 * Cin][Cout] (+ bias sums).  The two k-block parities meet in LDS (the ring is dead now):
@@ -912,6 +1013,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     float* pb = partial_b + (long)blockIdx.x * a.Cout;
     float* xch = reinterpret_cast<float*>(lds_raw) + tg * (7 * 16 + 1) * 64;             // [tg][7 taps x 16 registers + bias][64 lanes]
     __syncthreads();
+    if constexpr (DYI) {                                   // bias sums: 64 threads hold partial sums of each channel quad (fixed order)
+        reinterpret_cast<float4*>(lds_raw)[tid] = bs4;
+        __syncthreads();
+        if (tid < a.Cout) {
+            float b = 0.f;
+            for (int m = 0; m < 64; ++m) b += reinterpret_cast<const float*>(lds_raw)[(8 * m + (tid >> 2)) * 4 + (tid & 3)];
+            pb[tid] = b;
+        }
+        __syncthreads();
+    }
     if (ksel == 1) {
 #pragma unroll
         for (int j = 0; j < 7; ++j)
@@ -937,7 +1048,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
                 if (ci < CIN) pp[((long)tap * CIN + ci) * 32 + col] = v[r];
             }
         }
-        if (tg == 0) {
+        if (tg == 0 && !DYI) {
             float b = bsum + xch[7 * 16 * 64 + lane];
             b += __shfl_xor(b, 32, 64);
             if (h == 0) pb[col] = b;
@@ -957,7 +1068,9 @@ static int x6_wgrad_split(const ConvGeom& g, int arith = 1)              // numb
     const int vs = (g.Cin == 25 ? 56 : 64) * np_, np = (g.Cin + 1) / 2, nst = g.Cin == 25 ? 6 : 7;
     for (int ns = 1; ns <= 4 && ns <= g.Wo; ++ns) {
         const int Wt = (g.Wo + ns - 1) / ns;
-        const size_t lds = (size_t)3 * (Wt + 2) * (g.Ti + 2 * g.pt) * vs + 16;
+        size_t lds = (size_t)3 * (Wt + 2) * (g.Ti + 2 * g.pt) * vs + 16;
+        const int dyrows = (Wt * g.To + 15) & ~15;
+        if (arith == 2) { lds = ((lds + 15) & ~(size_t)15) + (size_t)dyrows * 128; if (dyrows * 8 > 512 * 4) continue; }   // H3: + the dY image
         if (lds <= 160 * 1024 && (Wt + 2) * g.Ti * np <= 512 * nst) return ns;
     }
     return 0;
@@ -969,14 +1082,19 @@ static int x6_wgrad_grid(const ConvGeom& g, int arith = 1)
     const int total = g.N * g.Ho * x6_wgrad_split(g, arith);
     return total < 256 ? total : 256;
 }
-// scratch for either arithmetic (H3 never cuts a row into more column ranges than X6, so its grid is not larger)
-size_t x6_wgrad_partial_floats(const ConvGeom& g) { return (size_t)x6_wgrad_grid(g) * ((size_t)27 * g.Cin * g.Cout + g.Cout); }
+// scratch for either arithmetic
+size_t x6_wgrad_partial_floats(const ConvGeom& g)
+{
+    const int g1 = x6_wgrad_grid(g, 1), g2 = x6_wgrad_split(g, 2) ? x6_wgrad_grid(g, 2) : 0;
+    return (size_t)(g1 > g2 ? g1 : g2) * ((size_t)27 * g.Cin * g.Cout + g.Cout);
+}
 
 int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial,
                   int arith, const Amax& am, hipStream_t s)
 {
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
+    if (arith == 2 && x6_wgrad_split(g, 2) == 0) arith = 1;                  // (the H3 form also needs room for the dY image; the scale-free form serves the rest)
     WgArgs a;
     a.nsplit = x6_wgrad_split(g, arith); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;
     a.N = g.N; a.H = g.Ho; a.W = g.Wo; a.T = g.To; a.Cout = g.Cout; a.Hi = g.Hi; a.Wi = g.Wi; a.Ti = g.Ti;
@@ -990,6 +1108,7 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
     float* partial_b = partial + (size_t)grid * nw;
     const int vs = (g.Cin == 25 ? 56 : 64) * (arith == 2 ? 2 : 3);
     size_t lds = (size_t)3 * a.Wp * a.Tp * vs + 16;
+    if (arith == 2) lds = ((lds + 15) & ~(size_t)15) + (size_t)((a.nv + 15) & ~15) * 128;      // H3: + the dY image
     const size_t xch = (size_t)4 * (7 * 16 + 1) * 64 * sizeof(float);                 // exchange area of the epilogue
     if (lds < xch) lds = xch;
     static std::once_flag once;
