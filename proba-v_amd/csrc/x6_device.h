@@ -109,6 +109,17 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& q0, unsig
     q2 = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
 }
 
+// H3: second pieces of a pair = fp16(v - h0), packed like the first.  The difference is exact in fp32, so one mixed-precision fma per element
+// (fp16 source x -1.0 + fp32 source, fp32 arithmetic, fp16 result written to one half of the destination) gives the same bits as
+// convert-back, subtract, convert in two instructions instead of four.  (Written out: the compiler folds fma(h, -1, v) back into a subtraction.)
+__device__ __forceinline__ unsigned h3_second_pieces(unsigned h0, float va, float vb)
+{
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h0), "v"(va));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h0), "v"(vb));
+    return r;
+}
+
 // ---- arithmetic-generic forms: `s` is the operand tensor's power-of-two scale (ignored by X6) ----
 // pieces of a pair, packed (a -> low half, b -> high half of each dword); q[p] = piece p
 template <class AR>
@@ -117,10 +128,8 @@ __device__ __forceinline__ void cut_pair(float a, float b, float s, unsigned (&q
     if constexpr (AR::SCALED) {
         const f32x2 v = {a * s, b * s};
         const f16x2 h0 = __builtin_convertvector(v, f16x2);                 // v_cvt_pk_f16_f32: round to nearest even
-        const f32x2 r = v - __builtin_convertvector(h0, f32x2);             // exact
-        const f16x2 h1 = __builtin_convertvector(r, f16x2);
         q[0] = __builtin_bit_cast(unsigned, h0);
-        q[1] = __builtin_bit_cast(unsigned, h1);
+        q[1] = h3_second_pieces(q[0], v[0], v[1]);
     } else {
         split_pair(a, b, q[0], q[1], q[2]);
     }
@@ -132,10 +141,8 @@ __device__ __forceinline__ void cut_pair_scaled(float a, float b, unsigned (&q)[
     if constexpr (AR::SCALED) {
         const f32x2 v = {a, b};
         const f16x2 h0 = __builtin_convertvector(v, f16x2);
-        const f32x2 r = v - __builtin_convertvector(h0, f32x2);
-        const f16x2 h1 = __builtin_convertvector(r, f16x2);
         q[0] = __builtin_bit_cast(unsigned, h0);
-        q[1] = __builtin_bit_cast(unsigned, h1);
+        q[1] = h3_second_pieces(q[0], v[0], v[1]);
     } else {
         split_pair(a, b, q[0], q[1], q[2]);
     }
