@@ -709,9 +709,14 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     const int zbytes = DYI ? ((3 * rowbytes + 16 + 15) & ~15) + dyrows * 128 : 3 * rowbytes + 16;
     for (int i = tid; i < zbytes / 8; i += 512) reinterpret_cast<uint2*>(lds_raw)[i] = make_uint2(0u, 0u);
 
-    f32x16 acc[7];
+    // M tiles: the GEMM's rows are the (tap, input channel) pairs, RT rows per tap.  With 25 input channels the H3 form packs them (28
+    // rows per tap = the image's padded channel count, a multiple of the 4-channel granule of a transposed read): 27 x 28 = 756 rows =
+    // 24 tiles instead of 27 tap tiles of which 7 rows in 32 are padding -- 14 % fewer MFMAs and A-operand reads.  Wave (tg, ksel) owns tiles tg + 4 j.
+    constexpr int RT = (AR::SCALED && CIN == 25) ? 28 : 32;
+    constexpr int NT = (27 * RT + 31) / 32, NJ = (NT + 3) / 4;
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 7; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
@@ -841,12 +846,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         float4 ndy[NDY];
         if constexpr (DYI) { if (has_next) dy_load(nn, nho, nws0, nWts, ndy); }       // the next tile's dY row likewise
         const long out_base = (((long)n * a.H + ho) * a.W + ws0) * a.T;
-        int tapoff[7];
+        int tapoff[NJ];                                                                // per lane: its four rows of tile j = channels ci0 .. ci0 + 3 of one tap
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int tap = tg + 4 * j < 27 ? tg + 4 * j : 26;
+        for (int j = 0; j < NJ; ++j) {
+            const int T = tg + 4 * j < NT ? tg + 4 * j : NT - 1;                      // (a slot beyond the last tile: harmless reread)
+            const int R0 = 32 * T + 16 * gcol + 4 * (li & 3);
+            int tap = R0 / RT;
+            const int ci0 = R0 - tap * RT;
+            tap = tap < 27 ? tap : 26;                                                 // (rows beyond the last tap are discarded at the end)
             const int dh = tap / 9, dw = (tap / 3) % 3, dt = tap % 3;
-            tapoff[j] = ((ho + dh) % 3) * rowbytes + (dw * a.Tp + dt) * VS;          // ring row ho + dh
+            tapoff[j] = ((ho + dh) % 3) * rowbytes + (dw * a.Tp + dt) * VS + ci0 * 2; // ring row ho + dh
         }
         // B operand: dY[voxel 16kb + 8h + j][co = col].  Three-stage pipeline over this wave's k-blocks: loads of block i+2 |
         // cutting block i+1 into pieces and its transposed-read addresses | MFMAs of block i.  The second stage is spread over
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             int vi = 16 * kb + 8 * h + 4 * jj + (li >> 2);
             vi = vi < nv ? vi : nv - 1;
             const int w = (int)__umulhi((unsigned)vi, a.mT), t = vi - w * a.T;
-            return (w * a.Tp + t) * VS + (16 * gcol + 4 * (li & 3)) * 2;
+            return (w * a.Tp + t) * VS;                                                  // (the lane's channel offset is part of tapoff[])
         };
         typedef const unsigned char* cptr;
         if constexpr (DYI) {
@@ -908,10 +917,10 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
                 };
                 load_a(0, af[0]);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                   // (slot j = 6 of tg = 3 is clamped: harmless reread)
+                for (int j = 0; j < NJ; ++j) {
+                    if (j + 1 < NJ) load_a(j + 1, af[(j + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j < 6 || tg < 3) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);     // wave-uniform
+                    if (tg + 4 * j < NT) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);     // wave-uniform
                     if (j >= 4 && j < 6) {                                             // the next block's transposed-read addresses, in the shadow of these MFMAs
                         int kk = kn;
                         asm volatile("" : "+v"(kk));
@@ -955,11 +964,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
                     }
                 };
                 load_a(0, af[0]);
-    #pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    if (j + 1 < 7) load_a(j + 1, af[(j + 1) & 1]);                       // (slot j = 6 of tg = 3 is clamped: harmless reread)
+                    static_assert(AR::SCALED || NJ == 7, "the seven-step preparation pipeline below");
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (j + 1 < NJ) load_a(j + 1, af[(j + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j < 6 || tg < 3) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);         // wave-uniform
+                    if (tg + 4 * j < NT) acc[j] = mac<AR>(af[j & 1], bf, acc[j]);         // wave-uniform
                     // a seventh of the next block's preparation.  The empty volatile asm statements pin it between this tap's
                     // scheduling barriers (pure arithmetic would otherwise be sunk to the end of the loop body).
                     if (j < 4) {
@@ -1025,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     }
     if (ksel == 1) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = acc[j][r];
         xch[7 * 16 * 64 + lane] = bsum;
@@ -1033,9 +1043,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     __syncthreads();
     if (ksel == 0) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int tap = tg + 4 * j;
-            if (tap >= 27) continue;
+        for (int j = 0; j < NJ; ++j) {
+            const int T = tg + 4 * j;
+            if (T >= NT) continue;
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1044,8 +1054,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = rowmap(r, h);
-                if (ci < CIN) pp[((long)tap * CIN + ci) * 32 + col] = v[r];
+                const int R = 32 * T + rowmap(r, h);                                   // row of the GEMM -> (tap, input channel)
+                const int tap = R / RT, ci = R - tap * RT;
+                if (tap < 27 && ci < CIN) pp[((long)tap * CIN + ci) * 32 + col] = v[r];
             }
         }
         if (tg == 0 && !DYI) {
