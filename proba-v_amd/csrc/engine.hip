@@ -579,6 +579,26 @@ size_t probav_workspace_bytes(const probav_engine* e, int batch, int training)
     return make_plan(e, batch, training).total * sizeof(float);
 }
 
+static ReduceSide* engine_side(probav_engine* e)
+{
+    if (!e->side_tried) {
+        e->side_tried = true;
+        ReduceSide c = {};
+        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c.joined, hipEventDisableTiming) == hipSuccess;
+        if (ok) e->side = c; else (void)hipGetLastError();          // (without it the sums simply stay on the caller's stream)
+    }
+    return e->side.side ? &e->side : nullptr;
+}
+
+struct SideGuard {          // activates the engine's side stream (probav_common.h: ReduceSide) for the calling thread while a pass is being enqueued
+    ReduceSide* c;
+    explicit SideGuard(ReduceSide* c_) : c(c_) { if (c) { c->k = 0; reduce_side_activate(c); } }
+    ~SideGuard() { if (c) reduce_side_activate(nullptr); }
+};
+static bool side_stream_disabled() { static const bool v = getenv("PROBAV_NO_SIDE_STREAM") != nullptr; return v; }   // diagnostic: everything on the caller's stream
+
 static int forward_impl(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes,
                         int B, int training, const float* WC, void* stream)
 {
@@ -616,6 +636,15 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
         if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
     }
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
+    // the low-frequency residual path (three small 2-D convolutions on the temporal mean) meets the main path only in tail_forward: it runs
+    // on the side stream, in the gaps of the chip-filling launches
+    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e));
+    {
+        hipStream_t rs = reduce_fork(s);
+        CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), rs));
+        CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, Amax(), rs));
+        CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, Amax(), rs));
+    }
     CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
     for (int i = 0; i < R; ++i) {
         if (e->impl >= 1 && e->pw_mfma) {
@@ -647,9 +676,7 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
         cur = W + p.red[k]; acur = A.red((int)k); h = p.redH[k]; t = p.redT[k];
     }
     CK(conv_fwd(e, make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0), cur, nullptr, weff(e->iUp), frag(e->iUp), bias(e->iUp), nullptr, W + p.up, amx(acur, e->iUp, nullptr), s));
-    CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), s));
-    CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, Amax(), s));
-    CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, Amax(), s));
+    CK(reduce_join(s));                                                       // the residual path has arrived
     CK(tail_forward(W + p.up, W + p.r3, y, B, P, c.scale, c.mean, c.std, s));
     return PROBAV_OK;
 }
@@ -664,19 +691,6 @@ int probav_forward_wc(probav_engine* e, const float* params, const float* x, flo
 {
     if (!e || !wcache || wcache_bytes < make_wc_plan(e).total * sizeof(float)) { set_error("probav_forward_wc: weight cache missing / too small", hipSuccess); return PROBAV_EINVAL; }
     return forward_impl(e, params, x, y, ws, ws_bytes, B, training, (const float*)wcache, stream);
-}
-
-static ReduceSide* engine_side(probav_engine* e)
-{
-    if (!e->side_tried) {
-        e->side_tried = true;
-        ReduceSide c = {};
-        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c.joined, hipEventDisableTiming) == hipSuccess;
-        if (ok) e->side = c; else (void)hipGetLastError();          // (without it the sums simply stay on the caller's stream)
-    }
-    return e->side.side ? &e->side : nullptr;
 }
 
 static int backward_impl(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes,
@@ -723,21 +737,20 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     int npart = 0;
     auto next_part = [&]() -> float* { float* q = W + p.partial + (size_t)(npart < p.nparts ? npart : p.nparts - 1) * p.pmax; ++npart; return q; };
-    struct SideGuard { ReduceSide* c; explicit SideGuard(ReduceSide* c_) : c(c_) { if (c) { c->k = 0; reduce_side_activate(c); } } ~SideGuard() { if (c) reduce_side_activate(nullptr); } };
-    static const bool no_side = getenv("PROBAV_NO_SIDE_STREAM") != nullptr;   // diagnostic: slab sums on the caller's stream
-    SideGuard side_guard(no_side ? nullptr : engine_side(e));
+    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e));
 
     CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first
     {
+        hipStream_t rs = reduce_fork(s);                 // beside the main chain: nothing below depends on it until the weight-norm backward
         const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), next_part(), Amax(), s));
-        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, Amax(), s));
+        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), next_part(), Amax(), rs));
+        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, Amax(), rs));
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), next_part(), Amax(), s));
-        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, Amax(), s));
+        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), next_part(), Amax(), rs));
+        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, Amax(), rs));
         const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
-        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), next_part(), Amax(), s));
+        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), next_part(), Amax(), rs));
     }
     // upscale + reducers (models/modelsTF.py:152-164)
     const int nred = (int)e->iRed.size();
@@ -747,7 +760,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     {
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
-        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), next_part(), Amax(), s));
+        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), next_part(), Amax(), reduce_fork(s)));   // (only the weight-norm backward reads it)
         CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
     }
     for (int k = nred - 1; k >= 0; --k) {

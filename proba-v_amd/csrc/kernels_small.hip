@@ -370,7 +370,7 @@ void reduce_side_activate(ReduceSide* ctx) { g_reduce_side = ctx; }
 hipStream_t reduce_fork(hipStream_t s)
 {
     ReduceSide* c = g_reduce_side;
-    if (!c || !c->side) return s;
+    if (!c || !c->side || s == c->side) return s;
     hipEvent_t ev = c->ev[c->k++ & 7];
     if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->side, ev, 0) != hipSuccess) { (void)hipGetLastError(); return s; }
     return c->side;
