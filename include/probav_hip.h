@@ -12,6 +12,11 @@
  *   - every call only ENQUEUES work on `stream` and returns; it never synchronises, allocates or
  *     frees device memory (so calls can be captured in a hipGraph).  probav_engine_create /
  *     _destroy are the only functions that allocate (a few KB for the layer table).
+ *     probav_forward / probav_backward additionally fork work that is off the critical path (the
+ *     low-frequency residual path, the sums of the backward-filter slabs) onto one engine-owned side
+ *     stream by event and join it back into `stream` before returning: the caller sees plain
+ *     stream order.  The side stream is created on the engine's first pass (make that pass outside
+ *     a graph capture); PROBAV_NO_SIDE_STREAM=1 in the environment disables it.
  *   - return value: 0 = ok, PROBAV_EINVAL (-1) bad argument, PROBAV_ENOSPACE (-2) workspace too small,
  *     PROBAV_EHIP (-3) a HIP call failed; probav_last_error() gives the text (thread-local).
  *   - thread-safety: an engine handle and its workspace may be used by one thread at a time;
