@@ -73,6 +73,13 @@ CONV_CASES = [
     ("bwd-data of convReducer_1: full 32->32 gated, 24x24x9 out", 2, (22, 22, 7), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
     ("T=13 normConv same 25->32", 1, (22, 22, 13), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
     ("bwd-data of the T=13 normConv: 32->25 gated (two column ranges in the piece-ring strip kernel)", 2, (22, 22, 13), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 1, 0),
+    # the alternating-halves strip kernel: one patch cut into five row strips (the last one short), the reducers with rows shorter
+    # than 128 voxels, seven frames
+    ("normConv one patch, five strips, relu + skip", 1, (22, 22, 9), 25, 32, (3, 3, 3), (1, 1, 1), 0, 1, 0, 1),
+    ("bwd-data of normConv, one patch: same 32->25", 1, (22, 22, 9), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 0, 0),
+    ("convReducer_3 valid relu", 2, (20, 20, 5), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
+    ("bwd-data of convReducer_3: full 32->32 gated", 2, (18, 18, 3), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
+    ("T=7 normConv same 25->32 + skip", 3, (22, 22, 7), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
 ]
 
 
