@@ -264,11 +264,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     float* sB1 = TbAll + 16 * PB_TB;                              // 256 expand biases
     unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 256);       // [8 waves][NP pieces][32 voxels][72 B] transpose images
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
-#ifdef PWB_WAVE_VGPR
-    const int wave = tid >> 6;
-#else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
     // H3 scales.  Tensors that exist only in registers are scaled from bounds: |H| <= 32 amax(x) amax(w1) + amax(b1) (as in the
     // forward kernel) and |dH| <= D amax(dT) amax(w2), per sample.  W1 as the operand of (c) is cut per cin row (its dX column).
     // A sample's scales are four exponents (scalar registers): ex, ed of X and dT, eh, eg of the hidden tile and its gradient.
