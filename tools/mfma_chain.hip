@@ -29,6 +29,39 @@ __global__ __launch_bounds__(512) void chain(float* out, unsigned long long* cyc
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// the same chain, but every MFMA takes a DIFFERENT operand pair (NOPS random pairs held in registers, rotating): operand buses toggle as in a real kernel
+template <int NOPS>
+__global__ __launch_bounds__(512) void chain_ops(float* out, unsigned long long* cyc, int iters, const f16x8* src)
+{
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    f16x8 a[NOPS], b[NOPS];
+    for (int k = 0; k < NOPS; ++k) { a[k] = src[(k * 2) * 64 + (threadIdx.x & 63)]; b[k] = src[(k * 2 + 1) * 64 + (threadIdx.x & 63)]; }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u % NOPS], b[(u * 5 + 1) % NOPS], acc, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int NOPS> static void run_ops(const char* name, int threads, float* out, unsigned long long* cyc, const f16x8* src)
+{
+    const int iters = 2000;
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((chain_ops<NOPS>), dim3(256), dim3(threads), 0, 0, out, cyc, iters, src);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL((chain_ops<NOPS>), dim3(256), dim3(threads), 0, 0, out, cyc, iters, src);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double nmfma = 256.0 * (threads / 64) * iters * 16.0;
+    printf("%-40s threads %3d: %.1f us, %.0f TFLOP/s, %.1f ns per MFMA per SIMD\n", name, threads, ms * 1e3, nmfma * 32768.0 / (ms * 1e-3) / 1e12, ms * 1e6 / (nmfma / 1024.0));
+}
 template <int NACC, bool BF, int DATA> static void run(const char* name, int threads, float* out, unsigned long long* cyc, const f16x8* src)
 {
     const int iters = 2000;
@@ -48,8 +81,8 @@ template <int NACC, bool BF, int DATA> static void run(const char* name, int thr
 int main()
 {
     float* out; unsigned long long* cyc; f16x8* src;
-    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8); hipMalloc(&src, 128 * 16);
-    _Float16 h[128 * 8]; unsigned s = 12345u;
+    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8); hipMalloc(&src, 2048 * 16);
+    static _Float16 h[2048 * 8]; unsigned s = 12345u;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (_Float16)(((s >> 8) & 0xffff) / 65536.f - 0.5f); }
     hipMemcpy(src, h, sizeof(h), hipMemcpyHostToDevice);
     for (int threads : {256, 512}) {
@@ -59,6 +92,12 @@ int main()
         run<4, false, 1>("f16 4 acc random", threads, out, cyc, src);
         run<1, true, 1>("bf16 1 acc random", threads, out, cyc, src);
         run<4, true, 1>("bf16 4 acc random", threads, out, cyc, src);
+    }
+    for (int threads : {256, 512}) {
+        run_ops<1>("f16 1 operand pair", threads, out, cyc, src);
+        run_ops<4>("f16 4 rotating operand pairs", threads, out, cyc, src);
+        run_ops<8>("f16 8 rotating operand pairs", threads, out, cyc, src);
+        run_ops<16>("f16 16 rotating operand pairs", threads, out, cyc, src);
     }
     return 0;
 }
