@@ -153,9 +153,10 @@ def dry_run(args, world, rank):
     import torch.distributed as dist
     from probav_amd.arch import layer_table
     from probav_amd.trainClass import allreduce_mean_
+    be = "gloo" if args.backend == "nccl" else args.backend          # (the dry run moves CPU tensors: RCCL has nothing to say about those)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        dist.init_process_group(be, rank=rank, world_size=world)
     _, total = layer_table()
     g = torch.full((total,), float(rank + 1))
     t0 = time.perf_counter()
@@ -169,7 +170,7 @@ def dry_run(args, world, rank):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     ok = bool(torch.allclose(g, torch.full_like(g, (world + 1) / 2.0)))
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1, "backend": args.backend,
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1, "backend": be,
                           "steps": args.steps, "allreduce_floats": total, "allreduce_ok": ok, "ms_per_step": round(float(tmax) / max(1, args.steps) * 1e3, 4)}), flush=True)
     if world > 1:
         dist.barrier()

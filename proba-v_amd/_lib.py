@@ -82,6 +82,10 @@ def lib():
             raise RuntimeError(
                 "HIP library %s is missing: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
                 "(there is no CPU/PyTorch fallback for the WDSR-B hot path)" % LIB_PATH)
+        # torch first: its wheel carries its own HIP runtime, and the process must end up with ONE libamdhip64 -- the one torch's
+        # allocator and streams live in.  Loaded the other way round, this library binds to the system copy, which then owns no device
+        # ("no ROCm-capable device is detected" from the first hipMemcpy of probav_engine_create).
+        import torch                                        # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
