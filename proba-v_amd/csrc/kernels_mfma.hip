@@ -1752,6 +1752,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     XS_ACC(1);
 
     const int eq = lane & 7, er = lane >> 3;                                // epilogue coordinates: channel quad, voxel row (mod 8)
+    const int cc4[2] = {half << 4, (2 + half) << 4};                        // 32 channels: k-block kb reads logical chunk 2 kb + half (its byte offset in an unswizzled record)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1807,35 +1808,43 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 const int vox0 = w * a.Tp + t;
                 const int s0 = hrel - fdiv(hrel, NS, a.mNslot) * NS;
                 const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
-                const int sb0 = s0 * rowbytes, sb1 = s1 * rowbytes, sb2 = s2 * rowbytes;
-                auto rec_addr = [&](int gg, int dt) -> int {
-                    const int dh = gg / 3, dw = gg - 3 * dh;                 // wave-uniform
-                    const int sb = dh == 0 ? sb0 : (dh == 1 ? sb1 : sb2);
-                    return sb + (vox0 + dw * a.Tp + dt) * REC;
+                // byte address of the lane's record for tap (dh, dw = 0, dt = 0): ring row hrel + dh
+                const int rb0 = s0 * rowbytes + vox0 * REC, rb1 = s1 * rowbytes + vox0 * REC, rb2 = s2 * rowbytes + vox0 * REC;
+                const int dwb = a.Tp * REC;                                  // one column further
+                // Operand addresses with as little vector arithmetic as the swizzle allows.  Record at byte address ra holds logical chunk c at
+                // ra + ((c ^ key) << 4), key = (ra >> 8) & 7.  Per (dh, dw) group: its base gb and, for dt = 0, 1, 2, key << 4 (K4); per request one
+                // v_xad_u32 ((chunk << 4) ^ K4[dt]) + gb, the dt * 128 in the read's offset field where it is the same for the whole wave, and one
+                // xor for the second piece (chunk ^ 4 = the address ^ 64: records are 128-byte aligned).
+                struct GroupAddr { int gb, k4[3]; };
+                auto group_addr = [&](int base) -> GroupAddr {
+                    GroupAddr q;
+                    q.gb = base;
+                    const int r7 = base >> 7;
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) q.k4[dt] = ((r7 + dt) << 3) & 0x70;
+                    return q;
                 };
-                auto request_A = [&](int gg, int st, Frag (&af)[NP]) {
-                    int ra, cc;
+                auto request_A = [&](const GroupAddr& ga, int st, Frag (&af)[NP]) {
+                    int a0;
                     if constexpr (CIN == 25) {
-                        const int c0 = 2 * st, c1 = 2 * st + 1;
+                        const int c0 = 2 * st, c1 = 2 * st + 1;                 // chunk c of the group's ten: c < 9 -> (dt, cc) = (c / 3, c % 3); c = 9 -> the gathered channel-24 chunk of dt = 0
                         const int dt0 = c0 / 3, cc0 = c0 % 3, dt1 = c1 < 9 ? c1 / 3 : 0, cc1 = c1 < 9 ? c1 % 3 : 3;
-                        ra = rec_addr(gg, 0) + (half ? dt1 : dt0) * REC;
-                        cc = half ? cc1 : cc0;
+                        const int k4 = half ? ga.k4[dt1] : ga.k4[dt0];          // (the halves of the wave read different chunks)
+                        const int cd = half ? (cc1 << 4) + dt1 * REC : (cc0 << 4) + dt0 * REC;
+                        a0 = ((cd & 0x70) ^ k4) + ga.gb + (cd & ~0x7f);
+                        af[0].u = *reinterpret_cast<const uint4*>(plds + a0);
                     } else {
                         const int dt = st >> 1, kb = st & 1;
-                        ra = rec_addr(gg, dt);
-                        cc = 2 * kb + half;
+                        a0 = (cc4[kb] ^ ga.k4[dt]) + ga.gb;
+                        af[0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * REC);
                     }
-                    const int sw = (ra >> 8) & 7;
-                    const int cp = cc ^ sw;
-                    af[0].u = *reinterpret_cast<const uint4*>(plds + ra + (cp << 4));
-                    af[1].u = *reinterpret_cast<const uint4*>(plds + ra + ((cp ^ 4) << 4));
+                    if constexpr (CIN == 25) af[1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64));
+                    else af[1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64) + (st >> 1) * REC);
                 };
-#pragma unroll
-                for (int st = 0; st < PF; ++st) request_A(0, st, A[st]);
                 // One k-block = three MFMAs.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles and whatever else a wave issues in
                 // the gap is hidden only while it fits the other 24 (MI355X_MICROARCH.md, issue costs): the requests of a later k-block are
                 // therefore dealt out over the three gaps instead of standing in front of the first MFMA.
-                auto group = [&](int gg, auto last_tag) {
+                auto group = [&](int gg, const GroupAddr& ga, const GroupAddr& gan, auto last_tag) {
                     constexpr bool LAST = decltype(last_tag)::value;         // the tile's last group requests nothing beyond itself: no load is left in flight at the barrier
 #pragma unroll
                     for (int st = 0; st < NST; ++st) {
@@ -1843,7 +1852,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                         const int gq = same ? gg : gg + 1, sq = same ? st + PF : st + PF - NST;
                         acc = MFMA16H(A[st][1], W[st][0], acc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (same || !LAST) request_A(gq, sq, A[sq]);
+                        if (same || !LAST) request_A(same ? ga : gan, sq, A[sq]);
                         __builtin_amdgcn_sched_barrier(0);
                         acc = MFMA16H(A[st][0], W[st][1], acc);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1853,10 +1862,23 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
+                // the three groups of one ring row (dh); the row base of dh + 1 for the requests that run ahead into it
+                auto row_groups = [&](int dh, int rbh, int rbn, auto last_tag) {
+                    constexpr bool LASTROW = decltype(last_tag)::value;
+                    const GroupAddr g0 = group_addr(rbh), g1 = group_addr(rbh + dwb), g2 = group_addr(rbh + 2 * dwb), gn = group_addr(rbn);
+                    group(3 * dh, g0, g1, std::false_type());
+                    group(3 * dh + 1, g1, g2, std::false_type());
+                    group(3 * dh + 2, g2, gn, std::integral_constant<bool, LASTROW>());
+                };
+                {
+                    const GroupAddr g0 = group_addr(rb0);
+#pragma unroll
+                    for (int st = 0; st < PF; ++st) request_A(g0, st, A[st]);
+                }
 #ifndef PPX_NOTAPS
 #pragma unroll 1
-                for (int gg = 0; gg < 8; ++gg) group(gg, std::false_type());
-                group(8, std::true_type());
+                for (int dh = 0; dh < 2; ++dh) row_groups(dh, dh == 0 ? rb0 : rb1, dh == 0 ? rb1 : rb2, std::false_type());
+                row_groups(2, rb2, rb2, std::true_type());
 #endif
 #if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
                 load_skip(tile);
