@@ -420,6 +420,20 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
     float pdo[4] = {0.f, 0.f, 0.f, 0.f};                              // ... and its dOut values
     auto reduce_prev = [&](int pb) {
         if (pv0 < 0) return;
+        // All sixteen partials are requested before the first is used, and the sums are pinned in front of the store's branch: left alone,
+        // the compiler sinks the reads into the branch and strings them out as read, wait, add, read, wait, add ... -- sixteen LDS round trips
+        // in a row per tile and wave.
+        float t[2][8];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t[k][jj] = TbAll[(pb * 8 + jj) * PB_TB + rv * 33 + col];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) asm volatile("" : "+v"(t[k][jj]));
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
@@ -427,13 +441,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             if constexpr (AR::SCALED) {
                 sacc = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) sacc += TbAll[(pb * 8 + jj) * PB_TB + rv * 33 + col];
+                for (int jj = 0; jj < 8; ++jj) sacc += t[k][jj];
                 sacc = ldexpf(sacc, pkdx) + pdo[k];
             } else {
                 sacc = pdo[k];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) sacc += TbAll[(pb * 8 + jj) * PB_TB + rv * 33 + col];
+                for (int jj = 0; jj < 8; ++jj) sacc += t[k][jj];
             }
+            asm volatile("" : "+v"(sacc));
             if (rv < pnrem) { dX[(pv0 + rv) * 32 + col] = sacc; omax = fmaxf(omax, fabsf(sacc)); }
         }
     };
