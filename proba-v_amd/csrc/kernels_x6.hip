@@ -99,11 +99,14 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
             f32x16 H;
 #pragma unroll
             for (int r = 0; r < 16; ++r) H[r] = 0.f;
+            // one address per chunk; the fragments of the chunk (k-block, piece; W2 behind W1) are immediate offsets from it
+            const unsigned char* wc = reinterpret_cast<const unsigned char*>(sW1) + lane * 16 + c * (2 * NP * 64 * 16);
+            constexpr int W2OFF = 8 * 2 * NP * 64 * 16;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 Frag a[NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) a[p].u = sW1[((c * 2 + kb) * NP + p) * 64 + lane];
+                for (int p = 0; p < NP; ++p) a[p].u = *reinterpret_cast<const uint4*>(wc + (kb * NP + p) * 1024);
                 H = mac<AR>(a, xb[kb], H);
             }
             // bias + ReLU, then split the hidden tile: registers 8kb .. 8kb+7 are k-block kb of the second product
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
             for (int kb = 0; kb < 2; ++kb) {
                 Frag a[NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) a[p].u = sW2[((c * 2 + kb) * NP + p) * 64 + lane];
+                for (int p = 0; p < NP; ++p) a[p].u = *reinterpret_cast<const uint4*>(wc + W2OFF + (kb * NP + p) * 1024);
                 T = mac<AR>(a, hb[kb], T);
             }
         }
