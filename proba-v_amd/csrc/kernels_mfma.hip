@@ -1735,14 +1735,18 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         }
     };
 
-    {   // zero the ring (pads stay zero), then the rows of segment 0: the halves take alternate rows
+    int hiq = nseg > 0 ? need(0) : -1;
+    {   // zero the ring (pads stay zero), then the rows of segment 0: the halves take alternate rows; each half's first row is requested
+        // before the clearing, so that one memory round trip hides under it
+        Staged v0;
+        if (grp <= hiq) stage_load(grp, v0);
         uint4* z = reinterpret_cast<uint4*>(plds);
         for (int i = tid; i < NS * rowbytes / 16; i += 512) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        if (grp <= hiq) stage_store(grp, v0);
     }
-    __syncthreads();
-    int hiq = nseg > 0 ? need(0) : -1;
 #pragma unroll 1
-    for (int q = grp; q <= hiq; q += 2) {
+    for (int q = grp + 2; q <= hiq; q += 2) {
         Staged v;
         stage_load(q, v);
         stage_store(q, v);
