@@ -114,8 +114,8 @@ struct Plan {
     size_t amax; int n_amax, amax_bwd, amax_fwd, B;   // amax slots (one 32-bit word each, x6_device.h): region offset, count, first slot of the backward / forward per-sample arrays
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
-    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, pmax = 0, wpack, total;
-    int nparts = 1;
+    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
+    std::vector<size_t> part_off;      // slab region of the k-th backward-filter launch of a backward pass (relative to `partial`), in launch order
 };
 
 static ConvGeom make_geom(int N, int Hi, int Ti, int Cin, int Ho, int To, int Cout, int kh, int kw, int kt,
@@ -161,6 +161,16 @@ static void reducer_extents(const probav_engine* e, std::vector<int>& hh, std::v
         t += 2 * r.pt - (r.k - 1);
         hh.push_back(h); tt.push_back(t);
     }
+}
+
+// slab floats of the backward-filter launch conv_wgrad() makes for geometry g under the engine's kernel family (the same decisions)
+static size_t wgrad_need(const probav_engine* e, const ConvGeom& g)
+{
+    const bool exotic = g.reflect_t || g.ph > 1 || g.pw > 1 || g.pt > 1 || (g.kh != 3 && g.kh != 1);
+    if (exotic || (e->impl >= 1 && conv3d_direct_wgrad_is_tuned(g))) return wgrad_partial_floats(g);
+    if (e->impl >= 3 && x6_wgrad_supported(g)) return x6_wgrad_partial_floats(g);
+    if (e->impl >= 1 && mfma_wgrad_supported(g)) return mfma_wgrad_partial_floats(g);
+    return wgrad_partial_floats(g);
 }
 
 static Plan make_plan(const probav_engine* e, int B, int training)
@@ -219,36 +229,29 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         p.dr2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
         p.dr1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
         p.dH = take(unfused ? V * E : 0);
-        // every layer's backward-filter geometry, exactly as probav_backward launches it
-        std::vector<ConvGeom> gs;
-        gs.push_back(make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1));
-        gs.push_back(make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1));
-        gs.push_back(make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0));
-        gs.push_back(make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0));
-        {
-            int h = Hin, t = T;
-            for (size_t k = 0; k < e->iRed.size(); ++k) {
-                gs.push_back(red_geom(e, B, k, h, t, F));
-                h = p.redH[k]; t = p.redT[k];
-            }
-            gs.push_back(make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0));
-        }
-        gs.push_back(make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1));
-        gs.push_back(make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0));
-        gs.push_back(make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0));
-        size_t pmax = 0;
-        for (auto& g : gs) {
-            size_t q = wgrad_partial_floats(g);
-            if (mfma_wgrad_supported(g)) { const size_t q2 = mfma_wgrad_partial_floats(g); if (q2 > q) q = q2; }
-            if (x6_wgrad_supported(g)) { const size_t q3 = x6_wgrad_partial_floats(g); if (q3 > q) q = q3; }
-            if (q > pmax) pmax = q;
-        }
-        if (e->pw_mfma && mfma_pw_backward_slab_floats(D) > pmax) pmax = mfma_pw_backward_slab_floats(D);
-        // one region per backward-filter launch (4 outside the blocks + reducers, 2 per block): the slabs of a launch are summed on the
+        // one slab region per backward-filter launch, in the order probav_backward issues them: the slabs of a launch are summed on the
         // side stream while the main chain has moved on, so no two launches may share a region
-        p.pmax = (pmax + 63) & ~(size_t)63;
-        p.nparts = 5 + (int)e->iRed.size() + 3 * R;
-        p.partial = take(p.pmax * p.nparts);
+        {
+            std::vector<size_t> need;
+            const int nred = (int)e->iRed.size();
+            need.push_back(wgrad_need(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0)));           // residConv3, 2, 1
+            need.push_back(wgrad_need(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0)));
+            need.push_back(wgrad_need(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1)));
+            need.push_back(wgrad_need(e, make_geom(B, p.redH[nred - 1], p.redT[nred - 1], F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0)));   // upscaleConv1
+            for (int k = nred - 1; k >= 0; --k)
+                need.push_back(wgrad_need(e, red_geom(e, B, (size_t)k, k ? p.redH[k - 1] : Hin, k ? p.redT[k - 1] : T, F)));
+            const ConvGeom ge = make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1), gd = make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0);
+            const ConvGeom gn = make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0);
+            for (int i = 0; i < R; ++i) {
+                need.push_back(wgrad_need(e, gn));
+                if (!unfused) need.push_back(mfma_pw_backward_slab_floats(D));
+                else { need.push_back(wgrad_need(e, gd)); need.push_back(wgrad_need(e, ge)); }
+            }
+            need.push_back(wgrad_need(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1)));               // mainConv1
+            size_t acc = 0;
+            for (size_t q : need) { p.part_off.push_back(acc); acc += (q + 63) & ~(size_t)63; }
+            p.partial = take(acc);
+        }
     }
     p.total = off;
     return p;
@@ -736,7 +739,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     int npart = 0;
-    auto next_part = [&]() -> float* { float* q = W + p.partial + (size_t)(npart < p.nparts ? npart : p.nparts - 1) * p.pmax; ++npart; return q; };
+    auto next_part = [&]() -> float* { const size_t k = (size_t)npart < p.part_off.size() ? (size_t)npart : p.part_off.size() - 1; ++npart; return W + p.partial + p.part_off[k]; };
     SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e));
 
     CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
