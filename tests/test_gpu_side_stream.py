@@ -1,0 +1,47 @@
+"""The engine's side stream (slab sums, the low-frequency residual path) must not change a single bit: every sum keeps its fixed order
+whichever stream it runs on.  PROBAV_NO_SIDE_STREAM is read once per process, so the two runs are child processes."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import torch
+from probav_amd import synth
+from probav_amd.loss import Losses
+from probav_amd.modelsTF import WDSRConv3D
+dev = torch.device("cuda:0")
+model = WDSRConv3D("s", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True)
+model.load_variables(synth.synth_params(seed=11, perturb=True))
+model = model.to(dev)
+x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(5, seed=12))
+losses = Losses(targetShape=(48, 48, 1))
+h = hashlib.sha256()
+for _ in range(2):                                   # twice: the second pass reuses the pool's workspace and the side stream
+    pred = model(x, training=True)
+    loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
+    model.flat.grad = None
+    loss.backward()
+    torch.cuda.synchronize()
+    h.update(pred.detach().cpu().numpy().tobytes()); h.update(model.flat.grad.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+""" % ROOT
+
+
+def _run(extra_env):
+    env = dict(os.environ)
+    env.pop("PROBAV_NO_SIDE_STREAM", None)
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+
+
+@pytest.mark.gpu
+def test_side_stream_changes_no_bit():
+    assert _run({}) == _run({"PROBAV_NO_SIDE_STREAM": "1"})
