@@ -1,6 +1,8 @@
 // Diagnostic (not part of the product): times the hot H3 kernels in isolation on random data at the benchmark's shapes (batch 128, T = 9).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I proba-v_amd/csrc tools/kbench.hip -o tools/kbench.bin && tools/kbench.bin [iters]
 // -DKB_OLD builds against the round-1 signatures (per-tensor amax slots), for A/B runs of two source trees.
+// Ablation switches of conv3_pp_kernel (timing only, results are wrong): -DPPX_IDLE (the finishing half does nothing: taps alone),
+// -DPPX_NOTAPS (no MFMA loop: finishing + staging alone), -DPPX_NOEPI (no epilogue / skip / stores), -DPPX_NOSTAGE (no row staging).
 #include "../proba-v_amd/csrc/kernels_small.hip"
 #include "../proba-v_amd/csrc/kernels_mfma.hip"
 #include "../proba-v_amd/csrc/kernels_x6.hip"
