@@ -50,28 +50,39 @@ def shuffle_repeat_batch(n, epochs, batchSize, bufferSize, rng, repeat=True):
     """Index stream with tf.data semantics: from_tensor_slices -> shuffle(bufferSize, reshuffle each
     iteration) -> repeat(epochs) -> batch(batchSize) (utils/utils.py:32-34).  The shuffle buffer holds
     `bufferSize` pending elements and emits a uniformly chosen one; batches may straddle epochs because
-    repeat() precedes batch(); the final partial batch is emitted (drop_remainder=False)."""
-    def elements():
-        for _ in range(epochs if repeat else 1):
-            buf = []
-            for i in range(n):
-                buf.append(i)
-                if len(buf) > bufferSize:
-                    k = int(rng.integers(len(buf)))
-                    buf[k], buf[-1] = buf[-1], buf[k]
-                    yield buf.pop()
-            while buf:
-                k = int(rng.integers(len(buf)))
-                buf[k], buf[-1] = buf[-1], buf[k]
-                yield buf.pop()
-    batch = []
-    for i in elements():
-        batch.append(i)
-        if len(batch) == batchSize:
-            yield np.asarray(batch)
-            batch = []
-    if batch:
-        yield np.asarray(batch)
+    repeat() precedes batch(); the final partial batch is emitted (drop_remainder=False).
+    One uniform draw per emitted element, drawn per epoch in bulk: the per-element cost is a few list operations (a generator with
+    a numpy call per ELEMENT cost 3-4 ms per batch of 128 and capped the whole trainer at 70 steps/s)."""
+    def epoch_order():
+        u = rng.random(n).tolist()
+        out = [0] * n
+        m = min(int(bufferSize), n)
+        buf = list(range(m))
+        o = 0
+        for i in range(m, n):                             # steady state: the buffer holds m + 1 elements when it emits
+            buf.append(i)
+            k = int(u[o] * (m + 1))
+            out[o] = buf[k]
+            buf[k] = buf[-1]
+            buf.pop()
+            o += 1
+        while buf:                                        # the source is exhausted: drain
+            k = int(u[o] * len(buf))
+            out[o] = buf[k]
+            buf[k] = buf[-1]
+            buf.pop()
+            o += 1
+        return np.asarray(out, dtype=np.int64)
+
+    pending = np.empty(0, dtype=np.int64)
+    for _ in range(epochs if repeat else 1):
+        pending = np.concatenate([pending, epoch_order()])
+        nb = len(pending) // batchSize
+        for b in range(nb):
+            yield pending[b * batchSize:(b + 1) * batchSize]
+        pending = pending[nb * batchSize:]
+    if len(pending):
+        yield pending
 
 
 class BatchPrefetcher:
@@ -99,7 +110,11 @@ class BatchPrefetcher:
                               for a, dt in zip(self.arrays, self.dtypes)]
         for a, dt, pin in zip(self.arrays, self.dtypes, self._slots[k]):
             view = pin[:len(idx)]
-            view.copy_(torch.as_tensor(np.ascontiguousarray(a[idx])).to(dt))       # host gather + cast into the pinned slot
+            dst = view.numpy()
+            if isinstance(a, np.ndarray) and a.dtype == dst.dtype:
+                np.take(a, idx, axis=0, out=dst)                                    # host gather straight into the pinned slot
+            else:
+                view.copy_(torch.as_tensor(np.ascontiguousarray(a[idx])).to(dt))   # (other containers / dtypes: gather, cast, copy)
             outs.append(view)
         return outs
 
