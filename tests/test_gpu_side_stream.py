@@ -45,3 +45,47 @@ def _run(extra_env):
 @pytest.mark.gpu
 def test_side_stream_changes_no_bit():
     assert _run({}) == _run({"PROBAV_NO_SIDE_STREAM": "1"})
+
+
+@pytest.mark.gpu
+def test_training_step_replays_from_a_captured_graph():
+    """include/probav_hip.h promises calls that only enqueue (graph-capturable): forward + loss + backward captured once (the fork to the
+    side stream and its join are recorded with it), replayed, and compared bit for bit with the eager launches."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from probav_amd import synth
+    from probav_amd.loss import Losses
+    from probav_amd.modelsTF import WDSRConv3D
+    dev = torch.device("cuda:0")
+    model = WDSRConv3D("g", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True)
+    model.load_variables(synth.synth_params(seed=21, perturb=True))
+    model = model.to(dev)
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(3, seed=22))
+    losses = Losses(targetShape=(48, 48, 1))
+
+    def step():
+        pred = model(x, training=True)
+        loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
+        model.flat.grad = None
+        loss.backward()
+        return loss
+
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False) if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch") else None
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):                               # warm-up on the capture stream: engine, side stream, allocator pools
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    model.flat.grad = None
+    with torch.cuda.graph(g):
+        loss_g = step()
+    grad_g = model.flat.grad
+    g.replay()
+    torch.cuda.synchronize()
+    lg, gg = float(loss_g.detach()), grad_g.clone()
+    le = float(step().detach())
+    torch.cuda.synchronize()
+    assert lg == le
+    assert torch.equal(gg, model.flat.grad)
