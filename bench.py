@@ -299,6 +299,24 @@ def run_rank(args):
         dtf, _, _ = timed(step, args.steps, True)
         full = dtf / args.steps * 1e3
 
+    # what the matrix pipe of THIS device sustains (the boxes of a pool differ by ~8 % under fp16-MFMA load): a few milliseconds of
+    # nothing but dependent fp16 MFMAs on every CU, right behind the timed steps (the device is warm)
+    mfma_probe = None
+    if rank == 0:
+        seed = (torch.rand(128 * 8, device=dev) - 0.5).half()
+        sink = torch.empty(256 * 256, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters, launches = 2000, 8
+        _lib.check(L.probav_mfma_probe(_lib.ptr(seed), _lib.ptr(sink), iters, 4, _lib.current_stream()), "probav_mfma_probe")
+        e0.record()
+        _lib.check(L.probav_mfma_probe(_lib.ptr(seed), _lib.ptr(sink), iters, launches, _lib.current_stream()), "probav_mfma_probe")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        mfma_probe = {"tflops": round(launches * 256 * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 3),
+                      "note": "dependent v_mfma_f32_32x32x16_f16 chains, one wave per SIMD on every CU, random operands: the fp16 matrix rate this device "
+                              "sustains (data sheet: 2 500 dense); an H3 kernel issues three such MFMAs per fp32 product"}
+
     fp32_leg = None
     if args.impl >= 3 and not args.no_fp32_mfma_leg:
         model.set_impl(2)
@@ -390,6 +408,8 @@ def run_rank(args):
                 hv["counted_by_rocprof"] = {"GB_per_step": round(bps / 1e9, 2), "GBps": round(bps / 1e9 / (dt / args.steps), 1),
                                             "source": os.path.relpath(hbm_profile, ROOT)}
             out["hbm_view"] = hv
+        if mfma_probe is not None:
+            out["sustained_mfma"] = mfma_probe
         if fp32_leg is not None:
             out["fp32_mfma_path"] = fp32_leg
         if full is not None:

@@ -182,6 +182,13 @@ int probav_wn_forward(probav_engine* e, const float* params, float* weff, float*
 int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm,
                        float* grads, void* stream);
 
+/* ---- measurement aid -------------------------------------------------------------------------------------------------------------- */
+/* Enqueues `launches` launches of nothing but dependent v_mfma_f32_32x32x16_f16 on every compute unit (one wave per SIMD, `iters` x 16
+ * MFMAs per wave, operands from `seed`: 128 x 16 bytes of fp16 data).  Timed by the caller (events on `stream`), it gives the matrix rate
+ * THIS device sustains under load -- the boxes of a pool differ -- as launches * 256 * 4 * iters * 16 * 32768 FLOP / time.
+ * `sink` receives 256 * 256 floats.  bench.py reports it as `sustained_mfma_tflops` beside the step time.                                */
+int probav_mfma_probe(const void* seed, float* sink, int iters, int launches, void* stream);
+
 /* ---- introspection of a training forward pass (parity tests; tf.keras would expose these as layer outputs) -------------------- */
 /* where a saved activation lives inside the caller's workspace after probav_forward(training=1): offset and length in floats.
  * kind: ACT = input of residual block `index` (index num_res_blocks = output of the last block; ACT 0 = relu(mainConv1), models/modelsTF.py:58),

@@ -352,6 +352,11 @@ static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x,
 extern "C" {
 
 int probav_abi_version(void) { return PROBAV_ABI_VERSION; }
+int probav_mfma_probe(const void* seed, float* sink, int iters, int launches, void* stream)
+{
+    if (!seed || !sink || iters < 1 || launches < 1) { set_error("probav_mfma_probe: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    return mfma_probe(seed, sink, iters, launches, (hipStream_t)stream);
+}
 const char* probav_last_error(void) { return probav::last_error(); }
 
 int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)

@@ -365,6 +365,32 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         }
     }
 }
+// nothing but a dependent chain of 32x32x16 fp16 MFMAs: what the matrix pipe of THIS device sustains (probav_mfma_probe)
+typedef _Float16 probe_f16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_probe_kernel(const probe_f16x8* __restrict__ seed, float* __restrict__ sink, int iters)
+{
+    probe_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const probe_f16x8 a = seed[threadIdx.x & 63], b = seed[64 + (threadIdx.x & 63)];
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += acc[i];
+    sink[blockIdx.x * 256 + threadIdx.x] = t;
+}
+int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream_t s)
+{
+    for (int l = 0; l < launches; ++l)
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, s, (const probe_f16x8*)seed, sink, iters);
+    return check_launch("mfma_probe");
+}
+
 static thread_local ReduceSide* g_reduce_side = nullptr;
 void reduce_side_activate(ReduceSide* ctx) { g_reduce_side = ctx; }
 hipStream_t reduce_fork(hipStream_t s)
