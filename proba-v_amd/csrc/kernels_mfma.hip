@@ -2072,6 +2072,7 @@ static StripPlan strip_plan(const ConvGeom& g)
     return p;
 }
 
+static bool pp_disabled() { static const bool v = getenv("PROBAV_NO_PP") != nullptr; return v; }   // diagnostic: the same-program form (conv3_pstrip_kernel) instead
 bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
 // does x6_conv_strip_forward(g, ..., arith) read per-tap fragments (PACK_*_CONV) even for 25 input channels?  (the H3 piece-ring kernel does;
 // the other 25-channel split kernels read the K-concatenated PACK_*_CONVK form)
@@ -2079,7 +2080,7 @@ bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith)
 {
     StripPlan pp;
     int rvp;
-    return arith == 2 && (pstrip_plan(g, pp) || pp_plan(g, pp, rvp));        // (the alternating-halves form also takes rows shorter than 128 voxels: the later reducers)
+    return arith == 2 && (pstrip_plan(g, pp) || (!pp_disabled() && pp_plan(g, pp, rvp)));   // (the alternating-halves form also takes rows shorter than 128 voxels: the later reducers)
 }
 
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
@@ -2089,8 +2090,7 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
     if (arith == 2 && x6_strip_wants_tap_fragments(g, arith)) {               // H3: the piece-ring kernel (filters: PACK_H3_CONV)
         StripPlan pp;
         int rvp = 2;
-        static const bool no_pp = getenv("PROBAV_NO_PP") != nullptr;          // diagnostic: the same-program form (conv3_pstrip_kernel) instead
-        if (!no_pp && pp_plan(g, pp, rvp)) {
+        if (!pp_disabled() && pp_plan(g, pp, rvp)) {
             static std::once_flag onceq;
             std::call_once(onceq, [] {
                 allow_big_lds(conv3_pp_kernel<25, false, 2>); allow_big_lds(conv3_pp_kernel<25, true, 2>);
