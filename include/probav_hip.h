@@ -106,6 +106,9 @@ int probav_backward(probav_engine* e, const float* params, const float* dy, floa
 size_t probav_weight_cache_bytes(const probav_engine* e);
 int probav_optimizer_step_fused(probav_engine* e, float* params, const float* grads, float* m, float* v, float lr, float beta1,
                                 float beta2, float eps, float c_g, float c_m, float c_v, void* wcache, size_t wcache_bytes, void* stream);
+/* The same cache from parameters that nothing is updating (inference, evaluation: `model(x)` many times on fixed weights -- test.py:117,
+ * models/testClass.py:26): weight normalisation + operand packing once, then every probav_forward_wc starts at its first convolution. */
+int probav_weight_cache_build(probav_engine* e, const float* params, void* wcache, size_t wcache_bytes, void* stream);
 int probav_forward_wc(probav_engine* e, const float* params, const float* x, float* y, void* ws, size_t ws_bytes, int batch,
                       int training, const void* wcache, size_t wcache_bytes, void* stream);
 int probav_backward_wc(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes, int batch,

@@ -879,6 +879,22 @@ int probav_optimizer_step_fused(probav_engine* e, float* params, const float* gr
 }
 
 
+int probav_weight_cache_build(probav_engine* e, const float* params, void* wcache, size_t wcache_bytes, void* stream)
+{
+    if (!e || !params || !wcache) { set_error("probav_weight_cache_build: null argument", hipSuccess); return PROBAV_EINVAL; }
+    const WcPlan wc = make_wc_plan(e);
+    if (wcache_bytes < wc.total * sizeof(float)) { set_error("probav_weight_cache_build: weight cache too small", hipSuccess); return PROBAV_ENOSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    float* C = (float*)wcache;
+    unsigned* wam = reinterpret_cast<unsigned*>(C + wc.amax);
+    if (hipMemsetAsync(wam, 0, (size_t)wc.n_wamax * sizeof(unsigned), s) != hipSuccess) { set_error("probav_weight_cache_build: amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    // exactly what a forward pass without a cache does first: weight normalisation (+ per-column / per-row maxima) and operand packing
+    { ProfScope ps(e, CLS_WN, 0.0, s);
+      CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, C + wc.weff, C + wc.weffT, C + wc.invn, wam, s)); }
+    if (!e->jobs.empty()) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), C + wc.weff, C + wc.weffT, C + wc.wpack, wam, s)); }
+    return PROBAV_OK;
+}
+
 // ---- introspection (parity tests) -----------------------------------------------------------------
 int probav_workspace_view(const probav_engine* e, int batch, int training, int kind, int index, int64_t* offset_floats, int64_t* count)
 {

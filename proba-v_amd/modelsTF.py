@@ -96,7 +96,13 @@ class WDSRModel(torch.nn.Module):
             raise RuntimeError("model parameters are on %s but the input is on %s" % (self.flat.device, x.device))
         x = x.contiguous().float()
         need_grad = bool(training) and torch.is_grad_enabled() and self.flat.requires_grad
-        y, ws = torch.ops.probav.wdsr_forward(self.flat, x, int(self._handle().value), self.scale * self.patchSizeLR, need_grad, self.weight_cache())
+        wc = self.weight_cache()
+        if wc is None and not need_grad:
+            # inference on weights nothing is updating (test.py:117 calls the model once per micro-batch of 16): normalise and pack them once
+            wc = self.weight_cache_buffer()
+            torch.ops.probav.weight_cache_build(self.flat, wc, int(self._handle().value))
+            self.mark_weight_cache()
+        y, ws = torch.ops.probav.wdsr_forward(self.flat, x, int(self._handle().value), self.scale * self.patchSizeLR, need_grad, wc)
         self._ws = {(int(x.shape[0]), need_grad, self.flat.device): ws}     # the last call's workspace (saved activations): introspection, tests
         return y
 

@@ -231,6 +231,19 @@ def _(theta, grad, m, v, wcache, engine, lr, beta_1, beta_2, eps, c_g, c_m, c_v)
     return None
 
 
+@torch.library.custom_op("probav::weight_cache_build", mutates_args=("wcache",), device_types="cuda")
+def weight_cache_build(theta: Tensor, wcache: Tensor, engine: int) -> None:
+    """Weight normalisation + operand packing of the CURRENT parameters into `wcache`, for forwards on weights nothing is updating."""
+    _dev(theta, "parameter")
+    _lib.check(_lib.lib().probav_weight_cache_build(c_void_p(engine), _lib.ptr(theta), _lib.ptr(wcache), wcache.numel() * 4, _lib.current_stream()),
+               "probav_weight_cache_build")
+
+
+@weight_cache_build.register_fake
+def _(theta, wcache, engine):
+    return None
+
+
 @torch.library.custom_op("probav::clip_round", mutates_args=(), device_types="cuda")
 def clip_round(x: Tensor, lo: float, hi: float) -> Tensor:
     _dev(x, "clip_round input")
