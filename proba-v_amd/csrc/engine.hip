@@ -602,8 +602,14 @@ static ReduceSide* engine_side(probav_engine* e)
 
 struct SideGuard {          // activates the engine's side stream (probav_common.h: ReduceSide) for the calling thread while a pass is being enqueued
     ReduceSide* c;
-    explicit SideGuard(ReduceSide* c_) : c(c_) { if (c) { c->k = 0; reduce_side_activate(c); } }
-    ~SideGuard() { if (c) reduce_side_activate(nullptr); }
+    hipStream_t s;
+    SideGuard(ReduceSide* c_, hipStream_t s_) : c(c_), s(s_) { if (c) { c->k = 0; reduce_side_activate(c); } }
+    ~SideGuard()
+    {
+        if (!c) return;
+        if (c->k != 0) (void)reduce_join(s);        // a pass that returned early (an error): whatever was forked still rejoins the caller's stream
+        reduce_side_activate(nullptr);
+    }
 };
 static bool side_stream_disabled() { static const bool v = getenv("PROBAV_NO_SIDE_STREAM") != nullptr; return v; }   // diagnostic: everything on the caller's stream
 
@@ -646,7 +652,7 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
     // the low-frequency residual path (three small 2-D convolutions on the temporal mean) meets the main path only in tail_forward: it runs
     // on the side stream, in the gaps of the chip-filling launches
-    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e));
+    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e), s);
     {
         hipStream_t rs = reduce_fork(s);
         CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), rs));
@@ -745,7 +751,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     int npart = 0;
     auto next_part = [&]() -> float* { const size_t k = (size_t)npart < p.part_off.size() ? (size_t)npart : p.part_off.size() - 1; ++npart; return W + p.partial + p.part_off[k]; };
-    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e));
+    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e), s);
 
     CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first
