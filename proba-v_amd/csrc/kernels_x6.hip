@@ -757,22 +757,31 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             const bool ok = rok && iw >= 0 && iw < a.Wi;
             const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
             const long o = ((long)(ok ? iw : 0) * a.Ti + t) * CIN;
-            const float f0 = src[o + c0], f1 = src[o + c1];
-            f[k][0] = ok ? f0 : 0.f;
-            f[k][1] = (ok && c0 + 1 < CIN) ? f1 : 0.f;
+            // raw values (clamped addresses): what must be zero is zeroed in stage_store -- a select right behind the load makes the wave
+            // wait for the load where it is issued, i.e. at the top of the tile instead of under its MFMAs
+            // (32 input channels -- the reducers -- keep the select here: one more item per thread, and the registers do not stretch to it)
+            if constexpr (CIN == 25) { f[k][0] = src[o + c0]; f[k][1] = src[o + c1]; }
+            else { const float f0 = src[o + c0], f1 = src[o + c1]; f[k][0] = ok ? f0 : 0.f; f[k][1] = ok ? f1 : 0.f; }
         }
     };
-    auto stage_store = [&](int key, int Wts, const float (&f)[NST][2]) {
+    auto stage_store = [&](int key, int ws0, int Wts, const float (&f)[NST][2]) {
         unsigned char* slot = lds_raw + (key % 3) * rowbytes;
         const int items = (Wts + 2) * a.Ti * NP;
+        int ih = key - a.ph;
+        if (a.reflect) ih = wg_reflect(ih, a.Hi);
+        const bool rok = ih >= 0 && ih < a.Hi;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + 512 * k;
             if (i < items) {
                 const int vox = i / NP, cp = i - vox * NP;
                 const int lw = (int)__umulhi((unsigned)vox, a.mTi), t = vox - lw * a.Ti;
+                int iw = ws0 + lw - a.pw;
+                if (a.reflect) iw = wg_reflect(iw, a.Wi);
+                const bool ok = rok && iw >= 0 && iw < a.Wi;
                 unsigned q[NPC];
-                cut_pair<AR>(f[k][0], f[k][1], sx, q);
+                if constexpr (CIN == 25) cut_pair<AR>(ok ? f[k][0] : 0.f, (ok && 2 * cp + 1 < CIN) ? f[k][1] : 0.f, sx, q);
+                else cut_pair<AR>(f[k][0], f[k][1], sx, q);
                 unsigned char* d = slot + (lw * a.Tp + t + a.pt) * VS + cp * 4;
 #pragma unroll
                 for (int p = 0; p < NPC; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         for (int rr = 0; rr < 3; ++rr) {
             float f[NST][2];
             stage_load(n, ho + rr, ws0, Wts, f);
-            stage_store(ho + rr, Wts, f);
+            stage_store(ho + rr, ws0, Wts, f);
         }
     };
     auto decode = [&](int tile, int& n, int& ws0, int& Wts, int& ho) {     // tile = (n * nsplit + sp) * H + ho
@@ -1026,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         XS_ACC(3);
         __syncthreads();                                   // every wave is done with this tile's rows
         XS_ACC(4);
-        if (consecutive) stage_store(ho + 3, Wts, nf);     // replaces ring row ho
+        if (consecutive) stage_store(ho + 3, ws0, Wts, nf);     // replaces ring row ho
         else if (has_next) stage_three(nn, nho, nws0, nWts);
         if constexpr (DYI) { if (has_next) dy_store(nWts, ndy); }
         XS_ACC(5);
