@@ -477,7 +477,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             leaves = nn != n;                                          // this is the run's last tile of sample n (wave-uniform)
         }
         float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};
-        stage_load(has_next ? nn : n, has_next ? nj : j, nxv, nd);     // in flight during this tile's MFMAs (after the last tile: a harmless re-read)
         float ch = 1.f, cg = 1.f;                                      // accumulators (a), (b) -> hidden values / hidden gradients at their own scales
         if constexpr (AR::SCALED) {
             const int kh = cur.eh - cur.ex - ew1, kg = cur.eg - ew2 - cur.ed;   // (<= -17 always, see the bounds)
@@ -486,11 +485,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
         const long v0 = (long)n * vps + 32 * j;
         const int nrem = vps - 32 * j < 32 ? vps - 32 * j : 32;
         float cdo[4] = {0.f, 0.f, 0.f, 0.f};                           // dOut of this tile's voxels, consumed by the next iteration's reduction
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
-            cdo[k] = dOut[(v0 + (rv < nrem ? rv : 0)) * 32 + col];
-        }
         const unsigned char* Xb = XA + buf * PB_TILE;
         const unsigned char* Db = DA + buf * PB_TILE;
         Frag xf[2][NP], df[2][NP];
@@ -516,6 +510,15 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
             reduce_prev(buf ^ 1);                          // LDS reads, adds and two stores in the shadow of the 24 MFMAs just issued
             if (pn >= 0 && pn != n) {                      // the previous tile was the last one of its sample: its dX is complete now; the
                 omax_done = omax; n_done = pn; omax = 0.f; // wave-wide maximum and the atomic wait for the next boundary tile (rare code stays out of this loop)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // The next tile's X / dT rows and this tile's dOut values are requested HERE, behind the dX stores of the previous tile: issued
+            // at the top of the tile they sat in front of those stores in the in-order vmcnt queue and the wave waited for them there.
+            stage_load(has_next ? nn : n, has_next ? nj : j, nxv, nd);     // in flight during the rest of this tile (after the last tile: a harmless re-read)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rv = 8 * (wave & 3) + (lane >> 5) + 2 * (k + rk0);
+                cdo[k] = dOut[(v0 + (rv < nrem ? rv : 0)) * 32 + col];
             }
             __builtin_amdgcn_sched_barrier(0);
             XS2(0);
