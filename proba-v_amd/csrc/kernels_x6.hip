@@ -78,6 +78,19 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
     int n = (int)(tb / tps), j = (int)(tb - (long)n * tps);
     float omax = 0.f;
     if (tb < te) sample_scales(n);
+    // The X rows of a tile are requested one tile ahead, BEFORE the previous tile's output stores: consumed at the very top of a tile,
+    // their whole latency was exposed, and behind the stores in the in-order vmcnt queue they also waited for those to retire.
+    float4 nx[2][2];
+    auto load_x = [&](int nn, int jj) {
+        const int vl = 32 * jj + col;
+        const long v = (long)nn * vps + (vl < vps ? vl : vps - 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 16 * kb + 8 * h);
+            nx[kb][0] = xp[0]; nx[kb][1] = xp[1];
+        }
+    };
+    if (tb < te) load_x(n, j);
     for (long tile = tb; tile < te; ++tile) {
         const int vl = 32 * j + col;                                 // voxel inside the sample
         const bool vok = vl < vps;
@@ -86,11 +99,11 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
         Frag xb[2][NP];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 16 * kb + 8 * h);
-            const float4 t0 = xp[0], t1 = xp[1];
+            const float4 t0 = nx[kb][0], t1 = nx[kb][1];
             const float xs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
             cut8<AR>(xs, sx, xb[kb]);
         }
+        if (tile + 1 < te) { const bool wrap = j + 1 == tps; load_x(wrap ? n + 1 : n, wrap ? 0 : j + 1); }
         f32x16 T;
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[r] = 0.f;
