@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     constexpr int NCH = CIN == 25 ? 3 : 4;
     const int lw0 = a.nsplit == 1 ? g.pw : 0, Wl = a.nsplit == 1 ? g.Wi : a.Wt + 2;
     const int nvs = Wl * g.Ti, items = nvs * NCH;                            // pp_plan(): items <= 256 * RVP, nvs <= 256
-    struct Staged { float v[RVP][8]; float g3[3]; };
+    struct Staged { float v[RVP][8]; float g3[3]; float m[GATE ? RVP : 1][8]; float m3[3]; };   // m, m3: the gate tensor's values (GATE), applied in stage_store
     int s_src[RVP], s_vd[RVP], s_cc[RVP], s_live[RVP];                      // source offset (floats) inside an input row, record, chunk, 1 = inside the patch's columns
     int s3_src = 0, s3_vd = 0, s3_m = 0;                                    // gathered chunk: offset of (voxel, channel 24), record, validity bits of depths t-1, t, t+1 (bit 3: item exists)
     {
@@ -1677,13 +1677,13 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
         for (int k = 0; k < RVP; ++k) {
             const f32x4u t0 = *reinterpret_cast<const f32x4u*>(xrow + s_src[k]), t1 = *reinterpret_cast<const f32x4u*>(xrow + s_src[k] + 4);
-            float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            const float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
             if constexpr (GATE) {
                 const float* grow = gate + rbase;
                 const f32x4u m0 = *reinterpret_cast<const f32x4u*>(grow + s_src[k]), m1 = *reinterpret_cast<const f32x4u*>(grow + s_src[k] + 4);
                 const float m[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = m[j] > 0.f ? f[j] : 0.f;
+                for (int j = 0; j < 8; ++j) sv.m[k][j] = m[j];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) sv.v[k][j] = f[j];
@@ -1692,9 +1692,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int o = s3_src + (((s3_m >> j) & 1) ? (j - 1) * CIN : 0);
-                float f = xrow[o];
-                if constexpr (GATE) f = (gate + rbase)[o] > 0.f ? f : 0.f;
-                sv.g3[j] = f;
+                sv.g3[j] = xrow[o];
+                if constexpr (GATE) sv.m3[j] = (gate + rbase)[o];
             }
         }
     };
@@ -1709,7 +1708,11 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if (s_vd[k] >= 0) {
                 const int live = rok & s_live[k];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sv.v[k][j] = live ? sv.v[k][j] : 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    bool keep = live != 0;
+                    if constexpr (GATE) keep = keep && sv.m[k][j] > 0.f;     // ReLU mask of the producing layer (backward-data of a ReLU layer)
+                    sv.v[k][j] = keep ? sv.v[k][j] : 0.f;
+                }
                 Frag f[NP];
                 cut8<AR>(sv.v[k], sa, f);
                 unsigned char* rec = slot + s_vd[k] * REC;
@@ -1724,7 +1727,11 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v8[j] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) v8[j] = (rok & (s3_m >> j) & 1) ? sv.g3[j] : 0.f;
+                for (int j = 0; j < 3; ++j) {
+                    bool keep = (rok & (s3_m >> j) & 1) != 0;
+                    if constexpr (GATE) keep = keep && sv.m3[j] > 0.f;
+                    v8[j] = keep ? sv.g3[j] : 0.f;
+                }
                 Frag f[NP];
                 cut8<AR>(v8, sa, f);
                 unsigned char* rec = slot + s3_vd * REC;
