@@ -592,7 +592,10 @@ static ReduceSide* engine_side(probav_engine* e)
     if (!e->side_tried) {
         e->side_tried = true;
         ReduceSide c = {};
-        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
+        // lowest priority: its kernels are fillers for the gaps of the caller's chain, never competitors
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
+        bool ok = hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, prio_least) == hipSuccess;
         for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c.joined, hipEventDisableTiming) == hipSuccess;
         if (ok) e->side = c; else (void)hipGetLastError();          // (without it the sums simply stay on the caller's stream)
