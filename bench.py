@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--side-stream-mode", type=int, default=2, choices=(0, 1, 2),
+                    help="probav_engine_side_stream: 2 (default) = slab sums, residual path AND the backward-filter kernels on the engine's low-priority "
+                         "side stream; 1 = backward-filter kernels on the launch stream (per-kernel profiles: rocprofv3 / PMC passes); 0 = no side stream")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collective check without a GPU: every rank all-reduces a "
@@ -260,6 +263,7 @@ def run_rank(args):
     opt = make_optimizer("nadam", model, 5e-4)
     step = stepper(model, data, opt)
     h = model._handle()
+    _lib.check(L.probav_engine_side_stream(h, args.side_stream_mode), "probav_engine_side_stream")
     for _ in range(args.warmup):
         step()
     sync()
@@ -279,6 +283,11 @@ def run_rank(args):
     # class, and a second timed run of steps brackets only that class's launches (its average launch time is the roofline's `achieved`).
     prof_all, prof, dom, psteps, rsteps = None, None, None, 2, max(5, min(args.steps, 30))
     if use_events:
+        # per-kernel timings are taken with the backward-filter kernels back on the caller's stream (side-stream mode 1): in the headline
+        # configuration (mode 2) they run on the low-priority side stream BESIDE the other kernels, whose events would then time both
+        _lib.check(L.probav_engine_side_stream(h, min(1, args.side_stream_mode)), "probav_engine_side_stream")
+        for _ in range(2):
+            step()
         _lib.check(L.probav_engine_profile_classes(h, 0xFFFFFFFF), "probav_engine_profile_classes")
         _lib.check(L.probav_engine_profile(h, 1, 512 * psteps), "probav_engine_profile")
         for _ in range(psteps):
@@ -291,6 +300,7 @@ def run_rank(args):
         dtr, _, _ = timed(step, rsteps)
         prof = read_profile()                                                  # the dominant class over rsteps timed steps
         _lib.check(L.probav_engine_profile_classes(h, 0xFFFFFFFF), "probav_engine_profile_classes")
+        _lib.check(L.probav_engine_side_stream(h, args.side_stream_mode), "probav_engine_side_stream")
 
     full = None
     if args.full_step:
@@ -432,7 +442,10 @@ def run_rank(args):
                                "timed_steps": rsteps, "ms_per_step_while_bracketed": round(dtr / rsteps * 1e3, 4),
                                "note": "rank 0, HIP events on the launch stream around every launch of this class during a second timed run of steps "
                                        "right behind the headline one (which carries no kernel events; the other classes are bracketed in two "
-                                       "further steps: kernel_classes); "
+                                       "further steps: kernel_classes); during this leg the backward-filter kernels run on the launch stream "
+                                       "(probav_engine_side_stream mode 1) -- in the headline run they sit on the engine's low-priority side stream "
+                                       "beside this class's launches, and events around those would time both (ms_per_step_while_bracketed shows what "
+                                       "that concurrency is worth); "
                                        "achieved = SURVEY.md §8d's algorithmic fp32 FLOP of the class / its time" + (
                                            "; this class runs split-operand kernels, which issue %d 16-bit MFMA products per fp32 product, so its "
                                            "ceiling is the dense bf16/fp16 MFMA peak (%.0f TFLOP/s) / %d" % (nprod, PEAK_BF16_TFLOPS, nprod) if x6 else
@@ -441,7 +454,8 @@ def run_rank(args):
                 out["roofline"]["issued_incl_recompute_tflops"] = round(ach * PW_BWD_ISSUED_MAC / PW_BWD_ALGO_MAC, 3)
                 out["roofline"]["recompute_note"] = ("the fused pointwise backward also recomputes the 256-channel hidden tile (8 192 MAC/voxel on top of the "
                                                      "29 184 algorithmic ones); the recompute is NOT counted in `achieved`")
-            out["kernel_classes_note"] = "HIP events around every launch of %d untimed steps after the warm-up" % psteps
+            out["kernel_classes_note"] = ("HIP events around every launch of %d untimed steps after the warm-up, backward-filter kernels on the launch "
+                                          "stream (side-stream mode 1); launches on the side stream (slab sums, residual path) are not bracketed" % psteps)
             out["kernel_classes"] = per
             if hbm_profile and T == 9 and B == 128 and args.impl == 4:
                 with open(hbm_profile) as fh:

@@ -185,6 +185,12 @@ int probav_wn_forward(probav_engine* e, const float* params, float* weff, float*
 int probav_wn_backward(probav_engine* e, const float* params, const float* dweff, const float* inv_norm,
                        float* grads, void* stream);
 
+/* What runs on the engine's side stream (see the conventions at the top): 0 = nothing, 1 = the slab sums and the low-frequency residual
+ * path, 2 (default) = also the backward-filter kernels of the 3x3x3 layers, whose results only the weight-norm backward at the very end
+ * reads: at the lowest stream priority they fill the tails of the caller's chain (-3 % per step) -- and share the chip with the kernels
+ * they run beside, so a per-kernel timing (bench.py's roofline leg, a rocprofv3 kernel summary) is taken in mode 1.                        */
+int probav_engine_side_stream(probav_engine* e, int mode);
+
 /* ---- measurement aid -------------------------------------------------------------------------------------------------------------- */
 /* Enqueues `launches` launches of nothing but dependent v_mfma_f32_32x32x16_f16 on every compute unit (one wave per SIMD, `iters` x 16
  * MFMAs per wave, operands from `seed`: 128 x 16 bytes of fp16 data).  Timed by the caller (events on `stream`), it gives the matrix rate

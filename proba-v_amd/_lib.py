@@ -63,6 +63,7 @@ SIGNATURES = {
     "probav_wn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_wn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "probav_workspace_view": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    "probav_engine_side_stream": (c_int, [c_void_p, c_int]),
     "probav_weight_cache_build": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "probav_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -31,6 +31,7 @@ struct probav_engine {
     int iMain = -1, iResid1 = -1, iResid2 = -1, iResid3 = -1, iUp = -1;
     std::vector<int> iExp, iDec, iNorm, iRed;
     ReduceSide side = {};                           // side stream of the slab sums (probav_common.h), created on first use
+    int side_mode = 2;                              // probav_engine_side_stream(): 0 off, 1 small work only, 2 + the backward-filter kernels
     bool side_tried = false;
     struct RedSpec { int k, p, pt, refl, refl_t; };   // one valid convReducer: kernel size, H/W pad, depth pad, mirrored H/W pad, mirrored depth pad
     std::vector<RedSpec> redSpec;
@@ -69,6 +70,7 @@ struct ProfScope {
     ProfScope(const probav_engine* ce, int cls, double macs, hipStream_t st) : e(const_cast<probav_engine*>(ce)), s(st), live(false)
     {
         if (!e->prof_on || !((e->prof_mask >> cls) & 1u) || e->prof_used + 2 > e->prof_ev.size()) return;
+        if (e->side.side && st == e->side.side) return;    // launches on the side stream run in the gaps of the caller's chain: events around them would time the chain, not them
         live = true;
         e->prof_cls.push_back(cls);
         e->prof_macs.push_back(macs);
@@ -115,6 +117,7 @@ struct Plan {
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
     size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
+    std::vector<size_t> gblk, gred;
     std::vector<size_t> part_off;      // slab region of the k-th backward-filter launch of a backward pass (relative to `partial`), in launch order
 };
 
@@ -225,6 +228,12 @@ static Plan make_plan(const probav_engine* e, int B, int training)
             }
         }
         p.gA = take(gmax); p.gB = take(gmax); p.gDec = take(V * D);
+        // every block's input gradient in its own buffer: the block's backward-filter (needed only by the weight-norm backward at the very end)
+        // runs on the low-priority side stream, filling the tails of the main chain's launches, and must find its dY untouched whenever it runs
+        p.gblk.clear();
+        for (int i = 0; i < R; ++i) p.gblk.push_back(take(V * F));
+        p.gred.clear();                                        // the reducers likewise: backward-data output and (mirrored pads) its folded form
+        for (size_t k = 0; k < 2 * e->iRed.size(); ++k) p.gred.push_back(take(gmax));
         p.dtail = take((size_t)B * P * P * s2);
         p.dr2 = take((size_t)B * (Hin - 4) * (Hin - 4) * s2);
         p.dr1 = take((size_t)B * (Hin - 2) * (Hin - 2) * s2);
@@ -352,6 +361,12 @@ static int conv_wgrad(const probav_engine* e, const ConvGeom& g, const float* x,
 extern "C" {
 
 int probav_abi_version(void) { return PROBAV_ABI_VERSION; }
+int probav_engine_side_stream(probav_engine* e, int mode)
+{
+    if (!e || mode < 0 || mode > 2) { set_error("probav_engine_side_stream: bad argument", hipSuccess); return PROBAV_EINVAL; }
+    e->side_mode = mode;
+    return PROBAV_OK;
+}
 int probav_mfma_probe(const void* seed, float* sink, int iters, int launches, void* stream)
 {
     if (!seed || !sink || iters < 1 || launches < 1) { set_error("probav_mfma_probe: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
@@ -655,7 +670,7 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
     CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
     // the low-frequency residual path (three small 2-D convolutions on the temporal mean) meets the main path only in tail_forward: it runs
     // on the side stream, in the gaps of the chip-filling launches
-    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e), s);
+    SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s);
     {
         hipStream_t rs = reduce_fork(s);
         CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), rs));
@@ -754,7 +769,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     int npart = 0;
     auto next_part = [&]() -> float* { const size_t k = (size_t)npart < p.part_off.size() ? (size_t)npart : p.part_off.size() - 1; ++npart; return W + p.partial + p.part_off[k]; };
-    SideGuard side_guard(side_stream_disabled() ? nullptr : engine_side(e), s);
+    SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s);
 
     CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first
@@ -786,22 +801,28 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         const int hi = k ? p.redH[k - 1] : Hin, ti = k ? p.redT[k - 1] : T;
         const float* xin = k ? W + p.red[k - 1] : W + p.act[R];
         const ConvGeom gr = red_geom(e, B, (size_t)k, hi, ti, F);
+        // the backward-filter only feeds the weight-norm backward at the very end: side stream; every tensor it reads stays untouched
+        // (each stage of the chain writes a buffer of its own)
         { Amax m; if (h3) { m.x = k ? A.red(k - 1) : A.act(R); m.w = acur; }
-          CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), next_part(), m, s)); }
+          CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), next_part(), m, e->side_mode >= 2 ? reduce_fork(s) : s)); }
+        float* outA = W + p.gred[2 * k];
+        float* outB = W + p.gred[2 * k + 1];
         unsigned* aoth = new_slot();
-        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, oth, amx(acur, e->iRed[k], aoth), s));
+        CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, outA, amx(acur, e->iRed[k], aoth), s));
         if (refl) {
             acur = new_slot();                      // the folded gradient is a new tensor
-            if (rs.p == 1 && !rs.refl_t) CK(reflect_fold(oth, cur, B, hi, hi, ti * F, acur, s));
+            if (rs.p == 1 && !rs.refl_t) CK(reflect_fold(outA, outB, B, hi, hi, ti * F, acur, s));
             else {
-                CK(reflect_fold3(oth, cur, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
-                if (h3) CK(amax_tensor(cur, (size_t)hi * hi * ti * F, B, acur, s));
+                CK(reflect_fold3(outA, outB, B, hi, hi, ti, F, rs.p, rs.p, rs.refl_t ? rs.pt : 0, s));
+                if (h3) CK(amax_tensor(outB, (size_t)hi * hi * ti * F, B, acur, s));
             }
+            cur = outB;
         } else {
-            float* tmp = cur; cur = oth; oth = tmp;
+            cur = outA;
             acur = aoth;
         }
     }
+    oth = W + p.gB;                                 // (the unfused block path below ping-pongs between `cur` and this)
     // residual blocks (models/modelsTF.py:177-189), last first.  cur = d loss / d act[i+1]
     const ConvGeom ge = make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1);
     const ConvGeom gd = make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0);
@@ -812,8 +833,10 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         float* dH = W + p.dH;
         const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
         // normConv_i: d loss/d w, then d loss/d dec_i
+        const bool fusedp = e->impl >= 1 && e->pw_mfma;
         { Amax m; if (h3) { m.x = A.dec(i); m.w = acur; }
-          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), next_part(), m, s)); }
+          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), next_part(), m, (fusedp && e->side_mode >= 2) ? reduce_fork(s) : s)); }
+        if (fusedp) oth = W + p.gblk[i];                   // this block's dX goes to its own buffer: `cur` stays intact for the late backward-filter
         unsigned* agdec = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, amx(acur, ln, agdec), s));
         if (e->impl >= 1 && e->pw_mfma) {

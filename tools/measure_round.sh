@@ -4,7 +4,9 @@
 R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; O=$R/gpurun_out/round_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-fp32-mfma-leg --no-other-configs --no-kernel-events"
+# per-kernel passes (durations, counters, bytes) with the backward-filter kernels on the launch stream: on the side stream (the default,
+# mode 2) they run beside the other kernels and every per-kernel figure would be a figure of two kernels
+B="--no-cpu-baseline --no-fp32-mfma-leg --no-other-configs --no-kernel-events --side-stream-mode 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py $B --steps 10 --warmup 3 > $O/stats_bench.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_a -o p -- python3 $R/bench.py $B --steps 3 --warmup 1 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/pmc_b -o p -- python3 $R/bench.py $B --steps 3 --warmup 1 > /dev/null 2>&1
