@@ -50,7 +50,7 @@ DTYPES = {3: "f32 (products as 6 bf16-piece MFMA products, f32 accumulate)", 4: 
 
 
 def hbm_profile_path():
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             return p
@@ -77,6 +77,9 @@ def parse_args(argv=None):
                          "side stream; 1 = backward-filter kernels on the launch stream (per-kernel profiles: rocprofv3 / PMC passes); 0 = no side stream")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--force-dp", action="store_true", help="with ONE rank: still initialise a world-size-1 RCCL process group and run the data-parallel "
+                    "step's gradient all-reduce for real (PROBAV_FORCE_DP=1): the N > 1 code path on the one GPU a box has")
+    ap.add_argument("--digest", action="store_true", help="add sha256 of (loss, flat gradient) of the last timed step to the line (bitwise comparisons between modes)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collective check without a GPU: every rank all-reduces a "
                     "gradient-sized buffer over --backend and rank 0 prints a JSON line (CPU test of the N > 1 path)")
     return ap.parse_args(argv)
@@ -194,14 +197,19 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
+    # the library is built BEFORE the process group exists (a cold hipcc build takes minutes: inside the group it would sit in the other
+    # ranks' collective watchdog window); build() serialises the ranks on a file lock, the first one in compiles, the others find it done
+    ge.build()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dp = bool(args.force_dp) or os.environ.get("PROBAV_FORCE_DP") == "1"
+    dp = world > 1 or force_dp
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ["PROBAV_FORCE_DP"] = "1"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if rank == 0:
-        ge.build()
-    if world > 1:
         dist.barrier()
 
     from probav_amd import _lib, synth, testClass
@@ -214,7 +222,7 @@ def run_rank(args):
     L = _lib.lib()
 
     def sync():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +242,7 @@ def run_rank(args):
             loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
             model.flat.grad = None
             loss.backward()
-            if world > 1:
+            if dp:
                 allreduce_mean_(model.flat.grad)
             if full:
                 opt.step()
@@ -254,7 +262,7 @@ def run_rank(args):
         sync()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if dp:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax), [evs[i].elapsed_time(evs[i + 1]) for i in range(k)], loss
 
@@ -278,6 +286,13 @@ def run_rank(args):
 
     # THE timed region: exactly K steps, nothing else on the stream but the K + 1 step-boundary events.
     dt, step_ms, loss = timed(step, args.steps)
+    digest = None
+    if args.digest:
+        import hashlib
+        hsh = hashlib.sha256()
+        hsh.update(loss.detach().cpu().numpy().tobytes())
+        hsh.update(model.flat.grad.detach().cpu().numpy().tobytes())
+        digest = hsh.hexdigest()
     # Roofline leg, right behind it: the same steps with the engine's HIP events around kernel launches.  Events around EVERY launch cost
     # ~6 % of the step (launch ramps no longer overlap), so two steps bracketed in full give the per-class table and name the dominant
     # class, and a second timed run of steps brackets only that class's launches (its average launch time is the roofline's `achieved`).
@@ -387,9 +402,10 @@ def run_rank(args):
             "step_ms": dict(percentiles(step_ms), note="rank 0, HIP events on the launch stream at every step boundary of the timed steps"),
             "config": {"workload": "cfg p16t%dc85r12: %d patches/GPU of [22,22,%d,1] -> [48,48,1], 12 WDSR-B blocks, 32 filters; "
                                    "model fwd + shift-L1 loss + bwd to all parameter gradients%s" %
-                                   (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if world > 1 else ""),
+                                   (T, B, T, "; 1 flat-gradient all-reduce/step (RCCL)" if dp else ""),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "world_size": dist.get_world_size() if world > 1 else 1, "backend": "nccl (RCCL)" if world > 1 else None,
+                       "world_size": dist.get_world_size() if dp else 1, "backend": "nccl (RCCL)" if dp else None,
+                       "forced_dp": bool(force_dp and world == 1),
                        "impl": IMPL_NAMES[args.impl],
                        "arithmetic": ("fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as three exact products of fp16 piece pairs "
                                       "(a = a0 + a1 to 2^-24, power-of-two operand scaling) on the fp16 MFMA pipe (H3 kernels, error of the order of "
@@ -418,6 +434,8 @@ def run_rank(args):
                 hv["counted_by_rocprof"] = {"GB_per_step": round(bps / 1e9, 2), "GBps": round(bps / 1e9 / (dt / args.steps), 1),
                                             "source": os.path.relpath(hbm_profile, ROOT)}
             out["hbm_view"] = hv
+        if digest is not None:
+            out["digest"] = digest
         if mfma_probe is not None:
             out["sustained_mfma"] = mfma_probe
         if fp32_leg is not None:
@@ -468,7 +486,7 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
     return 0

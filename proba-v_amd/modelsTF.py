@@ -10,6 +10,8 @@ torch custom op, `torch.ops.probav.wdsr_forward`, whose registered autograd form
 (the engine's reverse pass) -- probav_amd/ops.py.
 """
 import ctypes
+import os
+import weakref
 from ctypes import c_char, c_int32, c_int64, c_void_p, byref
 
 import torch
@@ -85,6 +87,18 @@ class WDSRModel(torch.nn.Module):
                     if t.numel() != hi - lo:
                         raise ValueError("%s/%s: expected %d values, got %d" % (L.name, key, hi - lo, t.numel()))
                     self.flat[lo:hi] = t.to(self.flat.device)
+        self.invalidate_weight_cache()
+
+    def _apply(self, fn, recurse=True):
+        """`.to(device)` / `.float()` / ... replace the parameter's storage: whatever the cache holds was built from the old one."""
+        out = super()._apply(fn, recurse)
+        self.invalidate_weight_cache()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weight_cache()
+        return out
 
     def forward(self, x, training=False):
         x = _lib.require_device(x, "model input")
@@ -103,7 +117,10 @@ class WDSRModel(torch.nn.Module):
             torch.ops.probav.weight_cache_build(self.flat, wc, int(self._handle().value))
             self.mark_weight_cache()
         y, ws = torch.ops.probav.wdsr_forward(self.flat, x, int(self._handle().value), self.scale * self.patchSizeLR, need_grad, wc)
-        self._ws = {(int(x.shape[0]), need_grad, self.flat.device): ws}     # the last call's workspace (saved activations): introspection, tests
+        # the last call's workspace (saved activations), for introspection and the parity tests: a WEAK reference -- the autograd graph
+        # owns a training workspace until its backward has run; a strong one here would keep the previous step's multi-GB block
+        # resident beside the next one (PROBAV_KEEP_WS=1 pins it, e.g. to inspect an inference pass)
+        self._ws = {(int(x.shape[0]), need_grad, self.flat.device): ws if os.environ.get("PROBAV_KEEP_WS") == "1" else weakref.ref(ws)}
         return y
 
     # -- engine plumbing ---------------------------------------------------------------------------
@@ -152,10 +169,26 @@ class WDSRModel(torch.nn.Module):
         """Called by the fused optimizer right after it has updated `flat` and filled the cache: valid until `flat` changes again."""
         self._wcache_version = (self.flat._version, self.flat.data_ptr())
 
+    def invalidate_weight_cache(self):
+        """Forget the cached effective weights / operand fragments: the next forward normalises and packs the parameters again.
+        Called by `load_variables`, `load_state_dict` and `.to()`; CALL IT YOURSELF after any write to the parameters that torch's version
+        counter of `flat` does not see -- `model.flat.data.copy_(...)` (`.data` carries a counter of its own), a raw-pointer write through
+        the C ABI (`probav_nadam_step` via ctypes), `torch.distributed.broadcast(model.flat.data)`.  In-place writes to `flat` itself
+        (`flat.copy_`, an optimizer's `add_`) are seen without help.  PROBAV_CHECK_WCACHE=1 makes every use of the cache verify it
+        against a fresh build (one extra launch and a device comparison per forward: debugging only)."""
+        self._wcache_version = None
+
     def weight_cache(self):
         """The cache if it still matches the parameters (any in-place change of `flat` bumps its version counter), else None."""
         if self._wcache is not None and self._wcache_version == (self.flat._version, self.flat.data_ptr()) \
                 and self._wcache.device == self.flat.device:
+            if os.environ.get("PROBAV_CHECK_WCACHE") == "1":
+                fresh = torch.empty_like(self._wcache)
+                torch.ops.probav.weight_cache_build(self.flat.detach(), fresh, int(self._handle().value))
+                n = _lib.lib().probav_weight_cache_bytes(self._handle()) // 4
+                if not torch.equal(fresh[:n].view(torch.int32), self._wcache[:n].view(torch.int32)):
+                    raise RuntimeError("stale weight cache: the parameters were written behind torch's version counter "
+                                       "(flat.data / raw pointer / broadcast) without model.invalidate_weight_cache()")
             return self._wcache
         return None
 
@@ -163,6 +196,8 @@ class WDSRModel(torch.nn.Module):
         """The workspace the LAST forward call of this (batch, training) shape produced (every call gets its own: an output of
         torch.ops.probav.wdsr_forward, held by the autograd graph until its backward has run)."""
         ws = self._ws.get((int(batch), bool(training), self.flat.device))
+        if isinstance(ws, weakref.ref):
+            ws = ws()
         if ws is None:
             raise RuntimeError("no forward pass of batch %d (training=%s) has run on this model" % (batch, training))
         return ws

@@ -45,8 +45,31 @@ def _ws_pool(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     pool = _WS_POOLS.get(key)
     if pool is None:
-        pool = _WS_POOLS[key] = torch.cuda.MemPool(no_split=True)
+        try:
+            pool = torch.cuda.MemPool(no_split=True)
+        except TypeError:                                  # (a torch without the keyword: blocks of this pool may then be split)
+            pool = torch.cuda.MemPool()
+        _WS_POOLS[key] = pool
     return pool
+
+
+def release_workspaces(device=None):
+    """Return the workspace blocks to the driver.  Every distinct (batch, training, frames) shape pins its own multi-GB block in the
+    private pool for as long as the pool lives (a trainer alternating training batches, a partial last batch, validation batches and
+    inference micro-batches holds one block each); call this between such phases of a long-lived process.  Blocks still referenced
+    (an un-run backward) are freed when their tensors die."""
+    keys = list(_WS_POOLS) if device is None else [torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()]
+    for k in keys:
+        _WS_POOLS.pop(k, None)
+    torch.cuda.empty_cache()
+
+
+def _scratch_alias(ws):
+    """A second tensor over the workspace's storage with a version counter of its own.  The reverse pass writes gradient buffers and
+    partial-sum slabs into regions of the workspace the forward pass left empty; the saved activations are only read.  Handing THIS
+    tensor to the mutating op keeps the saved workspace's counter still, so a second backward over the same graph (retain_graph, a
+    gradient check) is legal -- and right: it reads the same activations."""
+    return torch.empty(0, dtype=ws.dtype, device=ws.device).set_(ws.untyped_storage(), ws.storage_offset(), ws.shape, ws.stride())
 
 
 def _ws_floats(engine, batch, training):
@@ -122,7 +145,7 @@ def _wdsr_bwd(ctx, dy, dws):
         raise RuntimeError("backward through model(x, training=False): call the model with training=True "
                            "to keep the activations the reverse pass needs")
     flat, ws = ctx.saved_tensors
-    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ws, ctx.engine, ctx.wcache)
+    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), _scratch_alias(ws), ctx.engine, ctx.wcache)
     return g, None, None, None, None, None
 
 

@@ -154,26 +154,79 @@ class BatchPrefetcher:
         return tuple(dev)
 
 
+def dp_state():
+    """(collectives active?, world size).  Active when a process group exists and either spans more than one rank or
+    PROBAV_FORCE_DP=1 is set: a world-size-1 RCCL group then really executes every collective of the data-parallel step (RCCL init
+    with a device id, the stream hand-over between the engine's side-stream join, torch's launch stream and the NCCL stream, the
+    private workspace pool beside RCCL's own buffers) on the one GPU a box has; with one rank a mean over ranks changes no bit."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False, 1
+    world = dist.get_world_size()
+    return (world > 1 or os.environ.get("PROBAV_FORCE_DP", "0") == "1"), world
+
+
 def allreduce_mean_(flat_grad):
     """Average the flat gradient buffer over the data-parallel ranks: one collective per step
     (2.14 MB for p16t9c85r12).  No-op when torch.distributed is not initialised."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        flat_grad.div_(dist.get_world_size())
+    active, world = dp_state()
+    if active:
+        flat_grad.div_(world)
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
 
 def allreduce_metrics_(loss, metric):
     """the scalar reduce of the reference's multi-GPU trainer (debug/trainClassMultiGPU0.py:162-178:
-    `strategy.reduce(MEAN, ...)` of the per-replica loss and metric): ONE 2-float all-reduce per step.  Returns
-    (mean loss, mean metric) as 0-d tensors; without torch.distributed it only takes the local means."""
+    `strategy.reduce(MEAN, ...)` of the per-replica loss and metric): ONE 2-float all-reduce per evaluation step (a training step
+    carries the pair in the tail of its gradient bucket instead: GradBucket).  Returns (mean loss, mean metric) as 0-d tensors;
+    without torch.distributed it only takes the local means."""
     import torch.distributed as dist
     pair = torch.stack([loss.detach().double().mean(), metric.detach().double().mean()])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    active, world = dp_state()
+    if active:
         dist.all_reduce(pair, op=dist.ReduceOp.SUM)
-        pair = pair / dist.get_world_size()
+        pair = pair / world
     return pair[0], pair[1]
+
+
+class GradBucket:
+    """The ONE collective of a data-parallel training step (C1 + C2 in one message): a persistent fp32 buffer
+    [n + 2] = the flat gradient (for the engine's model: one tensor of 535 267 floats) followed by the step's two scalars, the
+    replica's mean loss and mean metric -- what debug/trainClassMultiGPU0.py:162-178 sends as a gradient all-reduce plus two
+    `strategy.reduce(MEAN)` calls.  `reduce_` pre-scales by 1 / world, all-reduces (SUM) once, re-points every `p.grad` at its
+    slice of the bucket (no copy back) and returns the two global means.  At 8 ranks a latency-bound RCCL call costs more than the
+    2 MB of wire time, so the pair rides with the gradient instead of taking a launch of its own."""
+
+    def __init__(self):
+        self.buf = None
+
+    def reduce_(self, params, loss, metric):
+        import torch.distributed as dist
+        active, world = dp_state()
+        ps = [p for p in params if p.grad is not None]
+        n = sum(p.grad.numel() for p in ps)
+        dev = ps[0].grad.device
+        if self.buf is None or self.buf.numel() != n + 2 or self.buf.device != dev:
+            self.buf = torch.empty(n + 2, dtype=torch.float32, device=dev)
+        o = 0
+        for p in ps:
+            k = p.grad.numel()
+            self.buf[o:o + k].copy_(p.grad.reshape(-1))
+            o += k
+        self.buf[n:].copy_(torch.stack([loss.detach().double().mean(), metric.detach().double().mean()]))
+        if active:
+            if world > 1:
+                self.buf.div_(world)
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+        o = 0
+        for p in ps:
+            k = p.grad.numel()
+            p.grad = self.buf[o:o + k].view(p.shape)
+            o += k
+        tail = self.buf[n:].double()                   # (a copy: the bucket is rewritten by the next step)
+        return tail[0], tail[1]
 
 
 class _LateScalars:
@@ -325,21 +378,15 @@ class HipSGD(torch.optim.Optimizer):
 
 def make_optimizer(name, model, learning_rate):
     """train.py:77-83: 'adam' -> Keras Adam, 'nadam' -> Keras Nadam, anything else -> SGD, with the Keras
-    defaults restated (epsilon 1e-7; Nadam schedule_decay 0.004 -- SURVEY.md A.5).  On a HIP device Nadam is the
-    fused kernel (`HipNadam`); on CPU (host-logic tests only) the algebraically identical torch.optim.NAdam."""
+    defaults restated (epsilon 1e-7; Nadam schedule_decay 0.004 -- SURVEY.md A.5), each ONE fused HIP launch over the model's
+    flat parameter buffer.  There is no CPU implementation: `step()` on parameters that do not live on a HIP device raises."""
     params = list(model.parameters())
-    on_gpu = bool(params) and params[0].is_cuda
+    fused = model if hasattr(model, "weight_cache_buffer") else None
     if name == "adam":
-        if on_gpu:
-            return HipAdam(params, lr=learning_rate, model=model if hasattr(model, "weight_cache_buffer") else None)
-        return torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7)
+        return HipAdam(params, lr=learning_rate, model=fused)
     if name == "nadam":
-        if params and params[0].is_cuda:
-            return HipNadam(params, lr=learning_rate, model=model if hasattr(model, "weight_cache_buffer") else None)
-        return torch.optim.NAdam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
-    if on_gpu:
-        return HipSGD(params, lr=learning_rate, model=model if hasattr(model, "weight_cache_buffer") else None)
-    return torch.optim.SGD(params, lr=learning_rate)
+        return HipNadam(params, lr=learning_rate, model=fused)
+    return HipSGD(params, lr=learning_rate, model=fused)
 
 
 class ModelTrainer:
@@ -359,6 +406,7 @@ class ModelTrainer:
         self.multiGPU = multiGPU
         self.strategy = None
         self._log = None
+        self._bucket = GradBucket()
         self.restore()
 
     @property
@@ -375,10 +423,26 @@ class ModelTrainer:
         return os.path.join(self.ckptDir, "checkpoint")
 
     def _read_index(self):
-        if not os.path.exists(self._index_path()):
-            return []
-        with open(self._index_path()) as fh:
-            return [ln.strip() for ln in fh if ln.strip()]
+        if os.path.exists(self._index_path()):
+            with open(self._index_path()) as fh:
+                return [ln.strip() for ln in fh if ln.strip()]
+        # no index of this revision.  A directory written by an earlier revision kept its index in `checkpoint` (lines `ckpt-N.pt`);
+        # failing that, whatever ckpt-N.pt files exist, by N: never restart at ckpt-1.pt over existing files
+        legacy = []
+        if os.path.exists(self._tf_state_path()):
+            with open(self._tf_state_path()) as fh:
+                legacy = [ln.strip() for ln in fh if ln.strip().endswith(".pt")]
+            legacy = [n for n in legacy if os.path.exists(os.path.join(self.ckptDir, n))]
+        if not legacy:
+            import glob
+            import re
+            found = [os.path.basename(f) for f in glob.glob(os.path.join(self.ckptDir, "ckpt-*.pt"))]
+            found = [n for n in found if re.fullmatch(r"ckpt-\d+\.pt", n)]
+            legacy = sorted(found, key=lambda n: int(n[5:-3]))
+            if legacy:
+                logger.warning("[ WARN ] %s holds %d .pt checkpoints but no index (checkpoint.pt-index): taking them in numeric order",
+                               self.ckptDir, len(legacy))
+        return legacy
 
     @property
     def latest_checkpoint(self):
@@ -421,7 +485,7 @@ class ModelTrainer:
             if self.optimizer is not None and state.get("optimizer") is not None:
                 self.optimizer.load_state_dict(state["optimizer"])
             self.step, self.psnr = int(state["step"]), float(state["psnr"])
-            self.save_counter = int(state.get("save_counter", 0))
+            self.save_counter = max(int(state.get("save_counter", 0)), int(os.path.basename(path)[5:-3]))
             print(f"[ INFO ] Model restored from checkpoint at step {self.step}.")
 
     def save(self):
@@ -429,6 +493,7 @@ class ModelTrainer:
             return None
         self.save_counter += 1
         name = "ckpt-%d.pt" % self.save_counter
+        before = [n for n in self._read_index() if n != name]
         names = self._model.variable_names
         tensors = [t.detach().cpu() for t in self._model.trainable_variables]
         model_state = {}
@@ -438,7 +503,7 @@ class ModelTrainer:
         torch.save({"model": model_state, "optimizer": self.optimizer.state_dict() if self.optimizer else None,
                     "step": self.step, "psnr": self.psnr, "save_counter": self.save_counter},
                    os.path.join(self.ckptDir, name))
-        kept = self._read_index() + [name]
+        kept = before + [name]
         for old in kept[:-self.max_to_keep]:
             try:
                 os.remove(os.path.join(self.ckptDir, old))
@@ -545,21 +610,19 @@ class ModelTrainer:
 
     # -- one step (models/trainClass.py:124-143) -----------------------------------------------------------
     def _dp(self):
-        return self.multiGPU and self._world() > 1
+        return self.multiGPU and dp_state()[0]
 
     def trainStep(self, patchLR, patchHR, maskHR):
         predPatchHR = self._model(patchLR, training=True)
         loss = self.loss(patchHR, maskHR, predPatchHR)             # Loss(patchHR, maskHR, predPatchHR)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()                                            # tape.gradient(loss, trainable_variables)
+        metric = self.metric(patchHR, maskHR, predPatchHR.detach())  # (does not depend on the update: evaluated before the exchange)
         if self._dp():
-            for p in self._model.parameters():
-                if p.grad is not None:
-                    allreduce_mean_(p.grad)                        # C1: one flat-gradient all-reduce
+            # C1 + C2 as ONE collective: the flat gradient with the replica's loss / metric means in its tail
+            # (debug/trainClassMultiGPU0.py:153 gradient all-reduce inside apply_gradients, :162-178 strategy.reduce(MEAN))
+            loss, metric = self._bucket.reduce_(list(self._model.parameters()), loss, metric)
         self.optimizer.step()                                      # optimizer.apply_gradients
-        metric = self.metric(patchHR, maskHR, predPatchHR.detach())
-        if self._dp():                                             # C2: strategy.reduce(MEAN) of loss and metric over the replicas
-            loss, metric = allreduce_metrics_(loss, metric)
         self.trainLoss(loss)
         self.trainPSNR(metric)
 

@@ -22,8 +22,8 @@ def _worker(rank, world, port, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from probav_amd.trainClass import ModelTrainer, allreduce_mean_, make_optimizer
-    from tests.test_trainer_host import _stub, _l1, _metric
+    from probav_amd.trainClass import ModelTrainer, allreduce_mean_
+    from tests.test_trainer_host import _stub, _l1, _metric, cpu_optimizer as make_optimizer
     try:
         # 1. the collective itself: mean over ranks of the flat 535 267-element buffer
         g = torch.full((535267,), float(rank + 1))

@@ -157,3 +157,58 @@ def test_fused_optimizer_weight_norm_step(dev):
     with torch.no_grad():
         m.flat.mul_(1.0)                                                # any in-place change of the parameters invalidates the cache
     assert m.weight_cache() is None
+
+
+def test_weight_cache_invalidation_after_writes_behind_the_version_counter(dev, monkeypatch):
+    """`flat.data.copy_()`, a raw-pointer write (ctypes probav_nadam_step) or `dist.broadcast(flat.data)` do not bump the
+    version counter the cache is keyed on.  `invalidate_weight_cache()` is the documented hand-over; `load_variables`,
+    `load_state_dict` and `.to()` call it themselves; PROBAV_CHECK_WCACHE=1 turns a forgotten call into an error instead of a pass on
+    stale weights; a second backward over one graph (retain_graph) is legal (the reverse pass mutates scratch, not saved state)."""
+    m = _model(dev)
+    x = torch.as_tensor(synth.synth_batch(2, seed=81)[0]).to(dev)
+    with torch.no_grad():
+        y0 = m(x)                                                       # inference: builds the cache for the current weights
+    assert m.weight_cache() is not None
+    new = synth.flatten_params(synth.synth_params(seed=82, perturb=True))
+    m.flat.data.copy_(torch.as_tensor(new))                             # behind the counter: the cache still claims to be valid
+    assert m.weight_cache() is not None
+    monkeypatch.setenv("PROBAV_CHECK_WCACHE", "1")
+    with pytest.raises(RuntimeError, match="stale weight cache"):
+        m.weight_cache()
+    monkeypatch.delenv("PROBAV_CHECK_WCACHE")
+    m.invalidate_weight_cache()
+    assert m.weight_cache() is None
+    with torch.no_grad():
+        y1 = m(x)
+    fresh = _model(dev)
+    fresh.load_variables(synth.synth_params(seed=82, perturb=True))
+    with torch.no_grad():
+        y_ref = fresh(x)
+    assert torch.equal(y1, y_ref) and not torch.equal(y1, y0)
+    # the module-level writers invalidate by themselves
+    m.load_variables(synth.synth_params(seed=83, perturb=True))
+    assert m.weight_cache() is None
+    with torch.no_grad():
+        m(x)
+    assert m.weight_cache() is not None
+    m.load_state_dict(fresh.state_dict())
+    assert m.weight_cache() is None
+    with torch.no_grad():
+        assert torch.equal(m(x), y_ref)
+    monkeypatch.setenv("PROBAV_CHECK_WCACHE", "1")
+    with torch.no_grad():
+        assert torch.equal(m(x), y_ref)                                 # a valid cache passes the check
+    monkeypatch.delenv("PROBAV_CHECK_WCACHE")
+    # retain_graph: two reverse passes over one forward give the same gradient
+    y = m(x, training=True)
+    s = y.sum()
+    s.backward(retain_graph=True)
+    g1 = m.flat.grad.clone()
+    m.flat.grad = None
+    s.backward()
+    assert torch.equal(g1, m.flat.grad)
+    from probav_amd import ops
+    del y, s
+    ops.release_workspaces()
+    with torch.no_grad():
+        assert torch.equal(m(x), y_ref)                                 # a released pool is simply rebuilt

@@ -15,6 +15,8 @@ from oracle import wdsr_numpy as on
 from oracle import wdsr_torch as ot
 from probav_amd import synth
 
+os.environ.setdefault("PROBAV_KEEP_WS", "1")     # the gate tests read a pass's workspace after its backward has run (modelsTF.WDSRModel.forward)
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 IMPLS = [0, 1, 2, 3, 4]   # 4 = H3 kernels (three products of scaled fp16 piece pairs), same tolerances; 3 = x6 kernels (fp32 products as six bf16-piece MFMA products), held to the SAME tolerances
@@ -439,13 +441,15 @@ def test_mfma_engine_matches_direct_engine(dev, batch):
             assert float((g0 - g1).norm()) <= tol * float(g0.norm()) + 1e-12, (n, other)
 
 
-def test_full_size_batch128_properties(dev):
-    """BASELINE.json config 2 (batch 128): properties that need no oracle run at that size."""
+@pytest.mark.parametrize("T", [9, 13])
+def test_full_size_batch128_properties(dev, T):
+    """BASELINE.json config 2 (T = 9) and config 3 (T = 13, the reference's longer-T network) at batch 128: properties that need no
+    oracle run at that size, plus the oracle on two samples of the batch (a sample's forward result does not depend on its batch)."""
     from probav_amd.loss import Losses
-    params = synth.synth_params(seed=21, perturb=True)
-    m = _model(dev, params=params)
+    params = synth.synth_params(seed=21, perturb=True, numImgLR=T)
+    m = _model(dev, T, params=params)
     lo = Losses(targetShape=(48, 48, 1))
-    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(128, seed=22))
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(128, seed=22, numImgLR=T))
 
     def step(xs, hs, ms):
         m.flat.grad = None
@@ -462,6 +466,13 @@ def test_full_size_batch128_properties(dev):
     with torch.no_grad():
         p_small = m(x[5:8].contiguous(), training=False)
     assert torch.equal(p_small, p_full[5:8])
+    # ... so two samples of the full batch can be judged by the fp64 oracle at oracle-sized cost (north_star: 1e-3 relative fp32)
+    with torch.no_grad():
+        pick = [77, 127]
+        po = ot.wdsr_forward(torch.tensor(x[pick].cpu().numpy(), dtype=torch.float64), ot.to_torch_params(params, requires_grad=False),
+                             synth.NIR_MEAN, synth.NIR_STD, numImgLR=T).numpy()
+    e = np.abs(p_full[pick].cpu().double().numpy() - po).max() / np.abs(po).max()
+    assert e < 2e-5, e
     # linearity of the gradient in the batch: grad(mean over 128) = mean of the two half-batch gradients
     _, l_a, g_a = step(x[:64].contiguous(), hr[:64].contiguous(), mask[:64].contiguous())
     _, l_b, g_b = step(x[64:].contiguous(), hr[64:].contiguous(), mask[64:].contiguous())
@@ -613,51 +624,33 @@ def test_h3_backward_refuses_a_forward_of_another_family(dev):
 # left is the arithmetic of the kernels, and it is held to SURVEY.md section 8c's bar, 1e-3 of the per-tensor max norm, element-wise.
 # ---------------------------------------------------------------------------------------------------------------------------------
 def _device_gates(m, flat_used, B, T=9):
-    """{layer: bool array}: the ReLU decisions of the last training forward of `m`, read from the saved activations (a post-ReLU value is
-    > 0 exactly where the gate is open) and, for the 256-channel hidden tiles that never reach memory, recomputed by the forward
-    kernel itself (probav_debug_hidden)."""
-    L = _lib()
-    h, ws = m._handle(), m._workspace(B, True)
-    wc = m.weight_cache()                    # the cache the forward pass ran from (None: it recomputed the weights into its workspace)
-    hin = 22
-
-    def view(kind, idx):
-        off, cnt = ctypes.c_int64(), ctypes.c_int64()
-        L.check(L.lib().probav_workspace_view(h, B, 1, kind, idx, ctypes.byref(off), ctypes.byref(cnt)), "probav_workspace_view")
-        return ws[off.value: off.value + cnt.value]
-    gates = {"mainConv1": (view(0, 0) > 0).cpu().numpy(), "residConv1": (view(3, 0) > 0).cpu().numpy()}
-    nvox = B * hin * hin * T
-    hid = torch.empty(nvox * 256, device=ws.device)
-    for i in range(12):
-        L.check(L.lib().probav_debug_hidden(h, L.ptr(flat_used), L.ptr(ws), ws.numel() * 4, B, i, L.ptr(hid), L.ptr(wc), L.current_stream()), "probav_debug_hidden")
-        gates["expConv_%d" % i] = (hid > 0).cpu().numpy()
-    k = 0
-    while True:
-        try:
-            gates["convReducer_%d" % (k + 1)] = (view(2, k) > 0).cpu().numpy()
-        except ValueError:
-            break
-        k += 1
-    return gates
+    from probav_amd.introspect import device_gates
+    return device_gates(m, flat_used, B, T)
 
 
-@pytest.mark.parametrize("impl", [4, 3])
-def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl):
+@pytest.mark.parametrize("impl,T,B", [(4, 9, 2), (3, 9, 2), (4, 13, 2), (4, 9, 5), (4, 7, 3)],
+                         ids=["h3-t9-b2", "x6-t9-b2", "h3-t13-b2", "h3-t9-b5", "h3-t7-b3"])
+def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl, T, B):
+    """T = 9, B = 2: the golden inputs.  T = 13 (reducer v3, rows cut into column ranges), T = 7, and B = 5 (more than two per-sample
+    scale slots behind `amax_over_samples`, a different strip partition): seeded synthetic inputs."""
     from probav_amd.loss import Losses
-    z = np.load(os.path.join(GOLD, "wdsr_t9_b2.npz"))
-    params = synth.synth_params(seed=101, perturb=True)
-    m = _model(dev, 9, params)
+    if (T, B) == (9, 2):
+        z = np.load(os.path.join(GOLD, "wdsr_t9_b2.npz"))
+    else:
+        z = dict(zip(("x", "hr", "mask"), synth.synth_batch(B, seed=300 + 10 * T + B, numImgLR=T)))
+    params = synth.synth_params(seed=101, perturb=True, numImgLR=T)
+    m = _model(dev, T, params)
     m.set_impl(impl)
     lo = Losses(targetShape=(48, 48, 1))
     x, hr, mask = (torch.as_tensor(z[k]).to(dev) for k in ("x", "hr", "mask"))
     pred = m(x, training=True)
     loss = lo.shiftCompensatedL1Loss(hr, mask, pred)
     loss.backward()
-    gates = _device_gates(m, m.flat.detach(), 2)
+    gates = _device_gates(m, m.flat.detach(), B, T)
     report = {}
     pt = ot.to_torch_params(params)
     pred_o, loss_o, grads_o = ot.train_step_grads(torch.tensor(z["x"], dtype=torch.float64), torch.tensor(z["hr"]), torch.tensor(z["mask"]),
-                                                  pt, synth.NIR_MEAN, synth.NIR_STD, gates=gates, gate_report=report)
+                                                  pt, synth.NIR_MEAN, synth.NIR_STD, numImgLR=T, gates=gates, gate_report=report)
     nflip = sum(r[0][0] for r in report.values())
     ngate = sum(int(np.prod(g.shape)) for g in gates.values())
     worst_margin = max((r[0][1] / max(r[0][2], 1e-30)) for r in report.values())
@@ -741,3 +734,30 @@ def test_train_steps_match_oracle(dev, tmp_path):
             print("after one free-running step: max |dtheta| %.3g, fraction beyond 1e-5: %.3g" % (d.max(), (d > 1e-5).mean()))
             assert (d > 1e-5).mean() < 1e-4 and d.max() <= 2.2 * 5e-4
     assert tr.optimizer.state[m.flat]["step"] == 3
+
+
+def test_config4_full_size_inference_is_deterministic_and_micro_batch_independent(dev):
+    """BASELINE.json config 4 at its full size: 32 image sets of 9 registered 128x128 frames -> 2048 patches -> forward -> clip / round
+    -> 32 images of 384x384 (test.py:103-122,149-160).  One batch of 2048, the reference's micro-batches of 16 (test.py:125-134) and a
+    ragged micro-batch (2048 = 5 * 384 + 128) give the same pixels bit for bit; a second pass repeats them; two image sets are judged
+    by the fp64 oracle (a pixel may sit on a rounding boundary: at most one count apart, and only rarely)."""
+    from probav_amd import testClass
+    params = synth.synth_params(seed=77, perturb=True)
+    m = _model(dev, params=params)
+    rng = np.random.default_rng(7)
+    frames = torch.as_tensor(np.clip(rng.normal(synth.NIR_MEAN, synth.NIR_STD, (32, 9, 128, 128)), 0, 16383).astype(np.float32)).to(dev)
+    patches = testClass.unfold_frames(frames)
+    assert tuple(patches.shape) == (32, 64, 22, 22, 9, 1)
+    full = testClass.resolve_images(m, patches, micro_batch=2048)
+    assert tuple(full.shape) == (32, 384, 384) and bool((full == full.round()).all()) and float(full.min()) >= 0 and float(full.max()) <= 65536
+    again = testClass.resolve_images(m, patches, micro_batch=2048)
+    assert torch.equal(full, again)
+    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=16))
+    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=384))
+    pt = ot.to_torch_params(params, requires_grad=False)
+    for s in (0, 31):
+        with torch.no_grad():
+            po = ot.wdsr_forward(torch.tensor(patches[s].cpu().numpy(), dtype=torch.float64), pt, synth.NIR_MEAN, synth.NIR_STD).numpy()
+        want = np.round(np.clip(po, 0, 2 ** 16))[..., 0].reshape(8, 8, 48, 48).transpose(0, 2, 1, 3).reshape(384, 384)       # np.round: half to even, like tf.round
+        d = np.abs(full[s].cpu().numpy().astype(np.float64) - want)
+        assert d.max() <= 1.0 and (d > 0).mean() < 2e-3, (s, d.max(), (d > 0).mean())

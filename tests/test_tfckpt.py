@@ -106,13 +106,13 @@ def test_trainer_restores_nadam_slots_and_leaves_the_tf_state_file_alone(tmp_pat
     np.testing.assert_array_equal(got["m"], opt_state["m"])
     np.testing.assert_array_equal(got["v"], opt_state["v"])
     b = WDSRConv3D("b", "NIR", 1.0, 2.0, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, True, seed=32)
-    opt = make_optimizer("nadam", b, 5e-4)                           # torch.optim.NAdam on CPU (HipNadam on a device: same loader)
+    opt = make_optimizer("nadam", b, 5e-4)                           # HipNadam (its state loads on any device; only step() needs the GPU)
     tr = ModelTrainer(b, None, None, opt, str(ck), str(tmp_path / "logs"))
     assert tr.step == 77 and tr.psnr == 47.25
     st = opt.state[b.flat]
-    assert float(st["step"]) == 4321 and abs(float(st["mu_product"]) - 0.0123) < 1e-7
-    np.testing.assert_array_equal(st["exp_avg"].numpy(), opt_state["m"])
-    np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), opt_state["v"])
+    assert float(st["step"]) == 4321 and abs(float(st["momentum_cache"]) - 0.0123) < 1e-7
+    np.testing.assert_array_equal(st["m"].numpy(), opt_state["m"])
+    np.testing.assert_array_equal(st["v"].numpy(), opt_state["v"])
     tr.save()
     assert (ck / "checkpoint").read_text() == tf_state               # still the reference's own state file
     assert (ck / "checkpoint.pt-index").read_text().split() == ["ckpt-1.pt"]

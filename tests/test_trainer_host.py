@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from probav_amd.modelsTF import WDSRModel
-from probav_amd.trainClass import Mean, ModelTrainer, make_optimizer, shuffle_repeat_batch
+from probav_amd.trainClass import HipNadam, Mean, ModelTrainer, make_optimizer, shuffle_repeat_batch
 
 
 class StubModel(WDSRModel):
@@ -20,6 +20,17 @@ class StubModel(WDSRModel):
 
 def _stub():
     return StubModel("stub", "NIR", 0.0, 1.0, 6, 3, 32, 12, 8, 0.8, 9, 16, seed=0)
+
+
+def cpu_optimizer(name, model, lr):
+    """Test-only stand-in for make_optimizer: the product's optimizers are HIP launches and refuse CPU parameters, the host-logic
+    tests step the stub model with the algebraically identical torch.optim classes."""
+    params = list(model.parameters())
+    if name == "adam":
+        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-7)
+    if name == "nadam":
+        return torch.optim.NAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-7, momentum_decay=0.004)
+    return torch.optim.SGD(params, lr=lr)
 
 
 def _l1(hr, mask, pred):
@@ -53,8 +64,13 @@ def test_mean_metric():
 
 def test_fit_counts_steps_evaluates_and_rotates_checkpoints(tmp_path):
     model = _stub()
-    opt = make_optimizer("nadam", model, 5e-4)
-    assert isinstance(opt, torch.optim.NAdam) and opt.defaults["eps"] == 1e-7 and opt.defaults["momentum_decay"] == 0.004
+    hip = make_optimizer("nadam", model, 5e-4)               # the product's optimizer: Keras defaults, and no CPU arithmetic behind it
+    assert isinstance(hip, HipNadam) and hip.defaults["epsilon"] == 1e-7 and hip.defaults["schedule_decay"] == 0.004
+    model.flat.grad = torch.zeros_like(model.flat)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip.step()
+    model.flat.grad = None
+    opt = cpu_optimizer("nadam", model, 5e-4)
     tr = ModelTrainer(model, _l1, _metric, opt, str(tmp_path / "ckpt"), str(tmp_path / "logs"), evalStep=2)
     n = 16
     X = np.zeros((n, 22, 22, 9, 1), np.float32)
@@ -75,11 +91,11 @@ def test_fit_counts_steps_evaluates_and_rotates_checkpoints(tmp_path):
     assert tags.index("Test loss") > [i for i, e in enumerate(events) if e["tag"] == "Train loss" and e["step"] == 2][0]
     # restore picks up step, psnr and the weights
     model2 = _stub()
-    tr2 = ModelTrainer(model2, _l1, _metric, make_optimizer("adam", model2, 1e-3), str(tmp_path / "ckpt"), str(tmp_path / "logs2"))
+    tr2 = ModelTrainer(model2, _l1, _metric, cpu_optimizer("adam", model2, 1e-3), str(tmp_path / "ckpt"), str(tmp_path / "logs2"))
     assert tr2.step == 16 and torch.equal(model2.flat.detach(), model.flat.detach())
     # saveBestOnly keeps the checkpoint only when the validation metric improves (models/trainClass.py:117-122)
     tr3 = ModelTrainer(_stub(), _l1, _metric, None, str(tmp_path / "c3"), str(tmp_path / "l3"), evalStep=1)
-    tr3.optimizer = make_optimizer("sgd", tr3.model, 0.0)
+    tr3.optimizer = cpu_optimizer("sgd", tr3.model, 0.0)
     tr3.psnr = 1e9
     tr3.fitTrainData(X, [y, msk], 8, 1, [X[:8], y[:8], msk[:8]], valSteps=1, saveBestOnly=True)
     assert not os.path.exists(tmp_path / "c3" / "checkpoint.pt-index")
@@ -103,3 +119,36 @@ def test_batch_prefetcher_preserves_order_and_values():
         raise RuntimeError("index stream failed")
     with pytest.raises(RuntimeError):
         list(BatchPrefetcher((X,), (torch.float32,), boom(), "cpu"))
+
+
+def test_legacy_checkpoint_directories_are_recognised(tmp_path):
+    """the .pt index moved from `checkpoint` to `checkpoint.pt-index`.  A directory of the earlier revision (index lines
+    `ckpt-N.pt` in `checkpoint`), or one with .pt files and no index at all, restores its newest checkpoint, continues the numbering
+    and keeps pruning -- instead of starting from scratch and overwriting ckpt-1.pt."""
+    model = _stub()
+    tr = ModelTrainer(model, _l1, _metric, cpu_optimizer("sgd", model, 0.1), str(tmp_path / "ck"), str(tmp_path / "lg"))
+    with torch.no_grad():
+        model.flat.add_(1.0)
+    tr.step = 7
+    for _ in range(3):
+        tr.save()
+    idx = tmp_path / "ck" / "checkpoint.pt-index"
+    names = idx.read_text().split()
+    assert names == ["ckpt-1.pt", "ckpt-2.pt", "ckpt-3.pt"]
+    # (a) earlier revision: the index lived in `checkpoint`
+    (tmp_path / "ck" / "checkpoint").write_text(idx.read_text())
+    idx.unlink()
+    m2 = _stub()
+    tr2 = ModelTrainer(m2, _l1, _metric, cpu_optimizer("sgd", m2, 0.1), str(tmp_path / "ck"), str(tmp_path / "lg2"))
+    assert tr2.step == 7 and tr2.save_counter == 3 and torch.equal(m2.flat.detach(), model.flat.detach())
+    assert tr2.save() == "ckpt-4.pt"
+    assert idx.read_text().split() == ["ckpt-1.pt", "ckpt-2.pt", "ckpt-3.pt", "ckpt-4.pt"]
+    # (b) no index at all: the files themselves, by number
+    idx.unlink()
+    (tmp_path / "ck" / "checkpoint").unlink()
+    m3 = _stub()
+    tr3 = ModelTrainer(m3, _l1, _metric, cpu_optimizer("sgd", m3, 0.1), str(tmp_path / "ck"), str(tmp_path / "lg3"))
+    assert tr3.step == 7 and tr3.save_counter == 4
+    tr3.save(); tr3.save()
+    assert idx.read_text().split() == ["ckpt-2.pt", "ckpt-3.pt", "ckpt-4.pt", "ckpt-5.pt", "ckpt-6.pt"]
+    assert not (tmp_path / "ck" / "ckpt-1.pt").exists()

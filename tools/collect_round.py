@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Copy the summaries tools/measure_round.sh left under gpurun_out/round_<tag>/ into profiles/<tag>_* (tracked).
 
-    python tools/collect_round.py r02"""
+    python tools/collect_round.py r03"""
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "round_" + tag)
 dst = os.path.join(ROOT, "profiles")
 for name, out in (("kernel_stats.csv", "bench_kernel_stats.csv"), ("hbm_traffic.json", "hbm_traffic.json"),
