@@ -185,8 +185,8 @@ class WDSRModel(torch.nn.Module):
             if os.environ.get("PROBAV_CHECK_WCACHE") == "1":
                 fresh = torch.empty_like(self._wcache)
                 torch.ops.probav.weight_cache_build(self.flat.detach(), fresh, int(self._handle().value))
-                n = _lib.lib().probav_weight_cache_bytes(self._handle()) // 4
-                if not torch.equal(fresh[:n].view(torch.int32), self._wcache[:n].view(torch.int32)):
+                n = _lib.lib().probav_weff_count(self._handle())       # the cache's first block: the effective weights of all layers (the
+                if not torch.equal(fresh[:n].view(torch.int32), self._wcache[:n].view(torch.int32)):      # blocks behind it have alignment gaps nobody writes)
                     raise RuntimeError("stale weight cache: the parameters were written behind torch's version counter "
                                        "(flat.data / raw pointer / broadcast) without model.invalidate_weight_cache()")
             return self._wcache

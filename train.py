@@ -37,9 +37,11 @@ def patchNet(config, opt):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get("PROBAV_FORCE_DP") == "1":     # (PROBAV_FORCE_DP=1: the data-parallel step on ONE GPU, over a world-size-1 RCCL group)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=int(os.environ.get("RANK", "0")), world_size=world, device_id=torch.device("cuda", local))
     logger.info("[ INFO ] Loading data...")
     dataDir = os.path.join(config["preprocessing_out"], "augmentedPatchesDir")
     load = lambda n: np.load(os.path.join(dataDir, n % opt.band), allow_pickle=True)
