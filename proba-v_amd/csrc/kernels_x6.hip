@@ -17,6 +17,7 @@
 #include "kernels_x6.h"
 #include "x6_device.h"
 #include <type_traits>
+#include <cstdlib>
 
 #include <mutex>
 
@@ -664,6 +665,649 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Alternating-halves form of the fused pointwise backward (H3 arithmetic): the same products in the same order as pw_bwd_x6_kernel<H3>
+// (its results are bit for bit those of that kernel), on another schedule.  There, all eight waves run one program behind one barrier
+// per tile: the two waves of a SIMD reach their MFMA phases together (one matrix pipe: each phase takes twice its length) and their
+// gate / cut phases together (the stamps: the younger wave's 170 vector instructions take 1 640 cycles, the older one's 780), and the
+// matrix pipe idles through every vector phase -- 6 400 cycles per tile around 2 x 960 cycles of MFMA.  Here the halves of the workgroup
+// (waves 0-3 / 4-7: one wave of each on every SIMD) TAKE TURNS, half B one segment behind half A:
+//      segment:   2i              2i+1            2i+2             2i+3
+//      half A:    Y(i)            X(i)            Y(i+1)           X(i+1)
+//      half B:    X(i-1)          Y(i)            X(i)             Y(i+1)
+//   Y(i) = the matrix phase: (c), (d), (e) of tile i-1 (from the pieces the wave cut in X(i-1): registers and its transpose images),
+//          the dX partial of tile i-1 to LDS, then (a), (b) of tile i: 30 MFMAs;
+//   X(i) = the vector phase: bias / ReLU / gate / cut of tile i's hidden tile and its gradient, pieces to the transpose images; half A
+//          also cuts and stages tile i+1 (its rows were requested at the start of Y(i)), half B sums the eight dX partials of tile i-1
+//          (+ dOut, requested at the start of Y(i)) and stores dX.
+// One barrier per segment, waiting for LDS traffic only.  A staged tile is read over four segments (A's and B's (a),(b), then their
+// (d),(e)): three staging buffers; the partials of tile i are complete after segment 2i+3, summed in 2i+4 and overwritten in 2i+6: two
+// parities.  To make room (160 KB exactly) the transpose images and the partials lose their padding columns and are swizzled instead:
+// 8-byte chunk c of voxel row r of an image at chunk c ^ key(r), key(r) = (r ^ (r >> 3)) & 7; 16-byte chunk q of row r of a partial at
+// chunk q ^ (r & 7) -- conflict-free for the stores, the transposed reads and the 16-byte reads of the sums alike.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PS_IMG = 32 * 64;                     // bytes of one transpose image [32 voxels][32 fp16]
+constexpr int PS_TB = 32 * 32;                      // floats of one dX partial [32 voxels][32 cin]
+__device__ __forceinline__ int ps_key(int row) { return (row ^ (row >> 3)) & 7; }
+__device__ __forceinline__ void tr_frag_sw(const unsigned char* img, int o0, int o1, Frag& f)
+{
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + o0));
+    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + o1));
+}
+
+__global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
+    const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
+    const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
+    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int vps, int D, PwAmax am)
+{
+    using AR = H3;
+    constexpr int NP = 2;
+    constexpr int PB_TILE = NP * PB_IMG;                          // one staged tensor tile: NP piece images
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* XA = lds_raw;                                  // [3 buffers][NP pieces][32 voxels][80 B]
+    unsigned char* DA = XA + 3 * PB_TILE;                         // same for dT (channels D..31 stay zero)
+    float* TbAll = reinterpret_cast<float*>(DA + 3 * PB_TILE);   // [2 parities][8 waves][32][32] dX partials (swizzled)
+    float* sB1 = TbAll + 16 * PS_TB;                              // [2 sample parities][256] expand biases at the hidden tile's scale
+    unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 512);       // [8 waves][dH' | H'][NP pieces][32 voxels][64 B] (swizzled)
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hb = wave >> 2;                                     // 0: half A (stages), 1: half B (one segment behind; sums the partials)
+    const int c = wave;                                           // this wave's hidden chunk
+    const unsigned aw1 = *am.w1, aw2 = *am.w2, ab1 = *am.b1;
+    const int ew1 = h3_exp_w(aw1), ew2 = h3_exp_w(aw2);
+    // a tile: sample, tile inside it, and the sample's four exponents (X, dT, hidden tile, its gradient; each in [-113, 60]) packed into one
+    // scalar register -- three tiles are in flight (being staged / computed / summed) and scalar registers are scarce
+    struct Cur {
+        int n, j, e4;
+        __device__ __forceinline__ int ex() const { return (int)(signed char)(e4 & 0xff); }
+        __device__ __forceinline__ int ed() const { return (int)(signed char)((e4 >> 8) & 0xff); }
+        __device__ __forceinline__ int eh() const { return (int)(signed char)((e4 >> 16) & 0xff); }
+        __device__ __forceinline__ int eg() const { return e4 >> 24; }
+    };
+    auto load_scales = [&](Cur& q) {
+        const unsigned ax = am.x[q.n], ad = am.dt[q.n];
+        const int ex = h3_exp(ax), ed = h3_exp(ad);
+        const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1));
+        const int eg = h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2));
+        q.e4 = __builtin_amdgcn_readfirstlane((ex & 0xff) | ((ed & 0xff) << 8) | ((eh & 0xff) << 16) | (eg << 24));
+    };
+    const int tps = (vps + 31) >> 5;                              // tiles per sample
+    auto advance = [&](Cur& q) { if (++q.j == tps) { q.j = 0; ++q.n; load_scales(q); } };
+
+    Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            w1[kb][p].u = w1f[((c * 2 + kb) * NP + p) * 64 + lane];
+            w2[kb][p].u = w2kf[((c * 2 + kb) * NP + p) * 64 + lane];
+            w3[kb][p].u = w1cf[((c * 2 + kb) * NP + p) * 64 + lane];
+        }
+    unsigned char* Ti = TiAll + wave * 2 * NP * PS_IMG;           // dH' pieces
+    unsigned char* Th = Ti + NP * PS_IMG;                          // H' pieces
+    // Per-lane addresses inside a swizzled image / partial: ONE register each, the variants by an xor with a constant (registers are what
+    // this kernel is short of).  Transposed read q of k-block kb: row r = 16 kb + 8 q + r0, r0 = 4 half + (li >> 2) < 8, so key(r) = r0 ^ (2 kb + q)
+    // and the byte offset is (t0 ^ ((2 kb + q) << 3)) + 1024 kb + 512 q.  Store G of a lane's row (voxel col): chunk (half + 2 G) ^ key(col)
+    // = s0 ^ (G << 4) in bytes; its 16-byte chunk of the dX partial: w0 ^ (G << 5).
+    int t0, s0, w0;
+    {
+        const int li = lane & 15, gcol = (lane >> 4) & 1, r0 = 4 * half + (li >> 2);
+        t0 = r0 * 64 + (((4 * gcol + (li & 3)) ^ r0) << 3);
+        s0 = col * 64 + ((half ^ ps_key(col)) << 3);                              // (the key's bits 1, 2 meet G's: (half + 2 G) ^ key = (half ^ key) ^ (2 G))
+        w0 = col * 128 + ((half ^ (col & 7)) << 4);
+    }
+    auto toff = [&](int kb, int q) { return (t0 ^ ((2 * kb + q) << 3)) + 1024 * kb + 512 * q; };
+    f32x16 dW1, dW2t;
+    float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
+    for (int i = tid; i < 3 * PB_TILE / 16; i += 512) reinterpret_cast<uint4*>(DA)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    const int ntiles = (int)(nvox / vps) * tps;
+    const int tbeg = (int)((long)ntiles * blockIdx.x / gridDim.x), tend = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);   // this workgroup's run of tiles
+    const int nt = tend - tbeg;
+    // ---- per-thread state of the two roles, in the SAME registers (the role is wave-uniform, and registers are what this kernel is short of):
+    //   half A (stages): rc[k] = byte offset of its dT element f = t + 256 k inside a piece image ([voxel][80 B]); rf[k] = running sum of that
+    //                    element (db2); ro = byte offset of its float4 of the X tile in memory, rs = in the piece image
+    //   half B (sums):   rc[k] = exponent of W1's cin row 4 rq + k (W1 as the operand of (c) is cut per cin row: its dX column);
+    //                    rf[0] = largest |dX| so far; ro = byte offset of its (voxel row, 4 cin) of a dX / dOut tile, rs = float offset in a partial
+    const int t8 = tid & 255, rrow = t8 >> 3, rq = t8 & 7;
+    int rc[4]; float rf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = t8 + 256 * k, dv = f / D;
+        rc[k] = hb ? h3_exp_w(am.w1r[4 * rq + k]) : (f < 32 * D ? dv * PB_ROW + (f - dv * D) * 2 : D * 2);      // (an unused slot: voxel 0's zero pad, D < 32 there)
+    }
+    const unsigned ro = rrow * 128u + rq * 16u;                        // (both roles: row t8 >> 3, 16-byte column t8 & 7 of a [32][32] fp32 tile)
+    const int rs = hb ? rrow * 32 + ((rq ^ (rrow & 7)) << 2) : rrow * PB_ROW + rq * 8;
+    // staging: raw, clamped, unconditional loads (zeroing happens at the store); scalar base + 32-bit lane offset.  FULL: the tile is known
+    // to have all 32 voxels (the hot loop): no clamps, no selects.  A dT element slot beyond 32 D (the last of the four when D < 32) is
+    // branch-free: it writes a zero into the zero pad of voxel 0 (rc[] points there).
+    const bool dvalid3 = t8 + 768 < 32 * D;
+    auto stage_load = [&](auto full_tag, const Cur& q, float4& xv, float (&d)[4]) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const long v0 = (long)q.n * vps + 32 * q.j;
+        const int nrem = FULL ? 32 : (vps - 32 * q.j < 32 ? vps - 32 * q.j : 32);
+        const char* xb = reinterpret_cast<const char*>(x + v0 * 32);
+        xv = *reinterpret_cast<const float4*>(xb + (FULL || rrow < nrem ? ro : rq * 16u));
+        const char* db = reinterpret_cast<const char*>(dT + v0 * D);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned f = t8 + 256 * k;
+            d[k] = *reinterpret_cast<const float*>(db + ((int)f < nrem * D ? 4u * f : 0u));
+        }
+    };
+    auto stage_store = [&](auto full_tag, int buf, const Cur& q, const float4& xv, const float (&d)[4]) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int nrem = FULL ? 32 : (vps - 32 * q.j < 32 ? vps - 32 * q.j : 32);
+        const float sx = pow2i(q.ex()), sd = pow2i(q.ed());
+        {
+            const bool xl = FULL || rrow < nrem;
+            unsigned a[NP], b[NP];
+            cut_pair<AR>(xl ? xv.x : 0.f, xl ? xv.y : 0.f, sx, a);
+            cut_pair<AR>(xl ? xv.z : 0.f, xl ? xv.w : 0.f, sx, b);
+            unsigned char* dst = XA + buf * PB_TILE + rs;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(dst + p * PB_IMG) = make_uint2(a[p], b[p]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live = (k < 3 ? (D >= 24 || t8 + 256 * k < 32 * D) : dvalid3) && (FULL || t8 + 256 * k < nrem * D);
+            const float dv = live ? d[k] : 0.f;
+            unsigned short qq[NP];
+            cut_one<AR>(dv, sd, qq);
+            unsigned char* dst = DA + buf * PB_TILE + rc[k];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<unsigned short*>(dst + p * PB_IMG) = qq[p];
+            rf[k] += dv;
+        }
+    };
+    // ---- the workgroup's slab: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]; (d), (e) and the db1 sums are added to it at true scale when a
+    // jump of the scales is too large to carry the sums along, and at the end; the first flush stores ----
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    float* sl = slabs + (long)blockIdx.x * slab_floats;
+    bool flushed = false;                                             // wave-uniform
+    auto flush = [&](const Cur& q) {
+        asm volatile("" ::: "memory");                                // a rare path: nothing of it may be speculated into the tile loop
+        float a1[16], a2[16], a3[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a1[r] = ldexpf(dW1[r], -(q.ex() + q.eg())); a2[r] = ldexpf(dW2t[r], -(q.ed() + q.eh()));
+            float v = bs1v[r];                                        // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+            a3[r] = ldexpf(v, -q.eg());
+            dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f;
+        }
+        if (flushed) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = rowmap(r, half);
+                a1[r] += sl[(long)rw * 256 + 32 * c + col];
+                if (rw < D) a2[r] += sl[8192 + (long)(32 * c + col) * D + rw];
+                if (col == 0) a3[r] += sl[8192 + 256 * (long)D + 32 * c + rw];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = rowmap(r, half);
+            sl[(long)rw * 256 + 32 * c + col] = a1[r];                                        // [cin][hidden]
+            if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = a2[r];                     // [hidden][out]
+            if (col == 0) sl[8192 + 256 * (long)D + 32 * c + rw] = a3[r];
+        }
+        flushed = true;
+    };
+    int on = -1;                                                       // half B: the sample whose largest |dX| rf[0] is collecting
+
+    // tiles i-2 (its partials get summed), i-1 ((c), (d), (e)), i ((a), (b), gate), i+1 (staged), i+2 (requested)
+    Cur c2p = {0, 0, 0}, cprev = c2p, ccur = c2p, cnext = c2p, cnn = c2p;
+    if (nt > 0) {
+        ccur.n = tbeg / tps; ccur.j = tbeg - ccur.n * tps; load_scales(ccur);
+        cnext = ccur; if (nt > 1) advance(cnext);
+        cnn = cnext; if (nt > 2) advance(cnn);
+    }
+    __syncthreads();                                   // the dT pads of all three buffers are zero
+    float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};      // half A: the raw rows of the tile staged next
+    float4 rdo = make_float4(0.f, 0.f, 0.f, 0.f);                                          // half B: dOut of the tile summed next
+    if (nt > 0 && hb == 0) {
+        stage_load(std::false_type(), ccur, nxv, nd);
+        stage_store(std::false_type(), 0, ccur, nxv, nd);
+        sB1[(ccur.n & 1) * 256 + t8] = b1[t8] * pow2i(ccur.eh());
+        if (nt > 1) stage_load(std::false_type(), cnext, nxv, nd);
+    }
+    // LDS only: requested rows and dX stores stay in flight; nothing (an MFMA least of all) may be scheduled across a segment boundary
+    auto bar = [] { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    int b0 = 0;                                                    // staging buffer of tile i (i mod 3)
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    float hs[16];                                                  // relu(H) of tile i at the hidden tile's scale, from Y(i) to X(i)
+    f32x16 dH = zero;                                              // its gradient (accumulator of (b)), likewise
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hs[r] = 0.f;
+
+    XS_DECL;
+#ifdef PROBAV_STAMP
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // One iteration = the wave's Y(i) and X(i).  HOT: tiles i-2 .. i+3 exist, are full and belong to one sample -- every condition below is
+    // true and nothing that happens once per sample or once per run is compiled into the instance; ROLE = 0 / 1: the instance of half A / B
+    // (straight-line code: one scheduling region per phase, so that the vector work can be dealt out between the MFMAs), 2: by `hb`.
+    auto iter = [&](auto hot_tag, auto role_tag, int i) {
+        constexpr bool HOT = decltype(hot_tag)::value;
+        constexpr int ROLE = decltype(role_tag)::value;
+        const bool roleA = ROLE == 2 ? hb == 0 : ROLE == 0, roleB = ROLE == 2 ? hb != 0 : ROLE == 1;
+        if constexpr (HOT) {                                       // (all five tiles share sample and scales: only ccur is carried by the loop)
+            c2p = ccur; c2p.j -= 2; cprev = ccur; cprev.j -= 1; cnext = ccur; cnext.j += 1; cnn = ccur; cnn.j += 2;
+        }
+        const bool hp2 = HOT || i >= 2, hp = HOT || (i >= 1 && i <= nt), hc = HOT || i < nt, hn = HOT || i + 1 < nt, hnn = HOT || i + 2 < nt;
+        const int bprev = b0 == 0 ? 2 : b0 - 1, bnext = b0 == 2 ? 0 : b0 + 1;
+        bar();
+        XS_ACC(1);
+        // the matrix phase at priority 1: its MFMAs and the work in their gaps go ahead of the partner wave's vector phase in the SIMD's
+        // arbitration (measured: -3...5 % of the kernel; the phases of the two waves of a SIMD do not overlap on gfx950 -- tools/coissue.hip --
+        // so what the arbitration decides is who idles, and an idle matrix pipe is the expensive kind)
+#ifndef H3S_NOPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        // ================================ Y(i) ================================
+        f32x16 H = zero;
+        if constexpr (HOT) {
+            // The hot loop's matrix phase, scheduled by hand: 30 MFMAs in the order (a), (d)/(e) k-block 0, k-block 1, (c), (b); behind each
+            // MFMA a "gap" with a small piece of the phase's other work -- LDS reads of operands a few MFMAs ahead, and vector work that runs
+            // while that MFMA executes (the partner wave of the SIMD is in its X phase).  Every gap is fenced by sched_barrier(0), the only
+            // form every scheduling pass respects: what is written in a gap stays in it.  None of the vector work depends on (d), (e), (c),
+            // (b); relu(H) needs (a): its pieces start a few gaps behind (a)'s last MFMA.
+            const unsigned char* Xb = XA + b0 * PB_TILE;
+            const unsigned char* Db = DA + b0 * PB_TILE;
+            const unsigned char* Xp = XA + bprev * PB_TILE;
+            const unsigned char* Dp = DA + bprev * PB_TILE;
+            // ---- pieces of vector work ----
+            // half A: cut and stage tile i+1 (X float4: two pair cuts; four dT elements)
+            const float sx = pow2i(cnext.ex()), sd = pow2i(cnext.ed());
+            unsigned char* sXd = XA + bnext * PB_TILE + rs;
+            unsigned char* sDd = DA + bnext * PB_TILE;
+            auto stageX = [&](float u, float v, int off) {
+                unsigned q[NP];
+                cut_pair<AR>(u, v, sx, q);
+                *reinterpret_cast<unsigned*>(sXd + off) = q[0];
+                *reinterpret_cast<unsigned*>(sXd + PB_IMG + off) = q[1];
+            };
+            auto stageD = [&](int k) {
+                const float dv = (k < 3 ? (D >= 24 || t8 + 256 * k < 32 * D) : dvalid3) ? nd[k] : 0.f;
+                unsigned short qq[NP];
+                cut_one<AR>(dv, sd, qq);
+                *reinterpret_cast<unsigned short*>(sDd + rc[k]) = qq[0];
+                *reinterpret_cast<unsigned short*>(sDd + PB_IMG + rc[k]) = qq[1];
+                rf[k] += dv;
+            };
+            // half B: dX of tile i-2 = dOut + its eight chunk partials, in the order of the chunks (partial jj is requested two gaps ahead)
+            const float* Tp = TbAll + (i & 1) * 8 * PS_TB + rs;
+            float4 tq[3];                                                  // (three in flight)
+            float sa[4] = {0.f, 0.f, 0.f, 0.f};
+            auto sums_read = [&](int jj) { tq[jj % 3] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); };
+            auto sums_add = [&](int jj) { sa[0] += tq[jj % 3].x; sa[1] += tq[jj % 3].y; sa[2] += tq[jj % 3].z; sa[3] += tq[jj % 3].w; };
+            auto sums_out = [&]() {
+                const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sa[k] = ldexpf(sa[k], -(rc[k] + c2p.eg())) + od[k];      // (c) partials -> true values: W1's cin row and the sample's dH scale
+                const long sv0 = (long)c2p.n * vps + 32 * c2p.j;
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX + sv0 * 32) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+            };
+            auto sums_max = [&]() { rf[0] = fmaxf(fmaxf(rf[0], fmaxf(fabsf(sa[0]), fabsf(sa[1]))), fmaxf(fabsf(sa[2]), fabsf(sa[3]))); };
+            // both: bias, ReLU and cut of the hidden tile, four registers (one 8-byte chunk of the lane's H' image row, both pieces) at a time
+            const int kh = ccur.eh() - ccur.ex() - ew1;                            // (<= -17 always, see the bounds)
+            const float ch = pow2i(kh < -126 ? -126 : kh);
+            const float* sB = sB1 + (ccur.n & 1) * 256 + 32 * c + 4 * half;
+            float4 bbq[4];
+            auto relu2 = [&](int g, int e0) {                          // registers 4g + e0, 4g + e0 + 1
+                const float bv[4] = {bbq[g].x, bbq[g].y, bbq[g].z, bbq[g].w};
+                hs[4 * g + e0] = fmaxf(fmaf(H[4 * g + e0], ch, bv[e0]), 0.f);
+                hs[4 * g + e0 + 1] = fmaxf(fmaf(H[4 * g + e0 + 1], ch, bv[e0 + 1]), 0.f);
+            };
+            unsigned hq[2][NP];
+            auto hcut = [&](int g, int pr) { cut_pair_scaled<AR>(hs[4 * g + 2 * pr], hs[4 * g + 2 * pr + 1], hq[pr]); };
+            auto hstore = [&](int g) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ (g << 4))) = make_uint2(hq[0][p], hq[1][p]);
+            };
+            // ---- operands, requested in the gaps ahead of their MFMAs ----
+            Frag xf[2][NP], df[2][NP], gq[2][NP];
+            Frag at[2][NP], bt[2][NP], ae[2][NP], be[2][NP];          // [k-block][piece]
+            uint2 glo[2][NP], ghi[2][NP];
+            auto rd_de = [&](int kb, int which) {                      // two fragments = four transposed reads
+                if (which == 0) { tr_frag<PB_ROW>(Xp, lane, kb, at[kb][0]); tr_frag_sw(Ti, toff(kb, 0), toff(kb, 1), bt[kb][0]); }
+                if (which == 1) { tr_frag<PB_ROW>(Xp + PB_IMG, lane, kb, at[kb][1]); tr_frag_sw(Ti + PS_IMG, toff(kb, 0), toff(kb, 1), bt[kb][1]); }
+                if (which == 2) { tr_frag<PB_ROW>(Dp, lane, kb, ae[kb][0]); tr_frag_sw(Th, toff(kb, 0), toff(kb, 1), be[kb][0]); }
+                if (which == 3) { tr_frag<PB_ROW>(Dp + PB_IMG, lane, kb, ae[kb][1]); tr_frag_sw(Th + PS_IMG, toff(kb, 0), toff(kb, 1), be[kb][1]); }
+            };
+            auto rd_gq = [&](int kb, int p) {
+                glo[kb][p] = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4)));
+                ghi[kb][p] = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4)));
+            };
+            auto rd_df = [&](int kb, int p) { df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16); };
+            // gap `S` of the schedule
+            auto gap = [&](auto slot_tag) {
+                constexpr int S = decltype(slot_tag)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                // operand requests
+                if constexpr (S >= 0 && S <= 3) rd_de(0, S);
+                if constexpr (S >= 6 && S <= 9) rd_de(1, S - 6);
+                if constexpr (S >= 12 && S <= 15) rd_gq((S - 12) >> 1, (S - 12) & 1);
+                if constexpr (S >= 19 && S <= 22) rd_df((S - 19) >> 1, (S - 19) & 1);
+                if constexpr (ROLE == 0) {
+#ifndef H3S_NOSTAGE
+                    if constexpr (S == 0) stageX(nxv.x, nxv.y, 0);
+                    if constexpr (S == 1) stageX(nxv.z, nxv.w, 4);
+                    if constexpr (S >= 2 && S <= 5) stageD(S - 2);
+#endif
+                } else {
+#ifndef H3S_NOSUMS
+                    if constexpr (S + 2 <= 7) sums_read(S + 2);
+                    if constexpr (S <= 7) sums_add(S);
+                    if constexpr (S == 8) sums_out();
+                    if constexpr (S == 9) sums_max();
+#endif
+                }
+#ifndef H3S_NOGATE
+                constexpr int H0 = ROLE == 0 ? 8 : 11;                  // the first gap of the relu(H) work (four gaps per group of four registers)
+                if constexpr (S >= H0 && S < H0 + 16) {
+                    constexpr int g = (S - H0) >> 2, c4 = (S - H0) & 3;
+                    if constexpr (c4 == 0) relu2(g, 0);
+                    if constexpr (c4 == 1) { relu2(g, 2); hcut(g, 0); }
+                    if constexpr (c4 == 2) hcut(g, 1);
+                    if constexpr (c4 == 3) hstore(g);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#define GAP(n) gap(std::integral_constant<int, n>())
+            // ahead of the first MFMA: (a)'s operands, the biases, half B's first two partials
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bbq[g] = *reinterpret_cast<const float4*>(sB + 8 * g);
+#ifndef H3S_NOSUMS
+            if constexpr (ROLE == 1) { sums_read(0); sums_read(1); }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef H3S_NOY
+            // (a)
+            H = MFMA16H(w1[0][1], xf[0][0], H); GAP(0);
+            H = MFMA16H(w1[0][0], xf[0][1], H); GAP(1);
+            H = MFMA16H(w1[0][0], xf[0][0], H); GAP(2);
+            H = MFMA16H(w1[1][1], xf[1][0], H); GAP(3);
+            H = MFMA16H(w1[1][0], xf[1][1], H); GAP(4);
+            H = MFMA16H(w1[1][0], xf[1][0], H); GAP(5);
+            // (d), (e): dW1c[cin][hidden] += X^T dH', dW2c^T[out][hidden] += dT^T H'
+            dW1 = MFMA16H(at[0][1], bt[0][0], dW1); GAP(6);
+            dW2t = MFMA16H(ae[0][1], be[0][0], dW2t); GAP(7);
+            dW1 = MFMA16H(at[0][0], bt[0][1], dW1); GAP(8);
+            dW2t = MFMA16H(ae[0][0], be[0][1], dW2t); GAP(9);
+            dW1 = MFMA16H(at[0][0], bt[0][0], dW1); GAP(10);
+            dW2t = MFMA16H(ae[0][0], be[0][0], dW2t); GAP(11);
+            dW1 = MFMA16H(at[1][1], bt[1][0], dW1); GAP(12);
+            dW2t = MFMA16H(ae[1][1], be[1][0], dW2t); GAP(13);
+            dW1 = MFMA16H(at[1][0], bt[1][1], dW1); GAP(14);
+            dW2t = MFMA16H(ae[1][0], be[1][1], dW2t); GAP(15);
+            dW1 = MFMA16H(at[1][0], bt[1][0], dW1); GAP(16);
+            dW2t = MFMA16H(ae[1][0], be[1][0], dW2t); GAP(17);
+            // (c): its B operand is the cut gradient tile as this lane stored it, read back instead of held in 16 registers across the segments
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) gq[kb][p].u = make_uint4(glo[kb][p].x, glo[kb][p].y, ghi[kb][p].x, ghi[kb][p].y);
+            f32x16 dx = zero;
+            dx = MFMA16H(w3[0][1], gq[0][0], dx); GAP(18);
+            dx = MFMA16H(w3[0][0], gq[0][1], dx); GAP(19);
+            dx = MFMA16H(w3[0][0], gq[0][0], dx); GAP(20);
+            dx = MFMA16H(w3[1][1], gq[1][0], dx); GAP(21);
+            dx = MFMA16H(w3[1][0], gq[1][1], dx); GAP(22);
+            dx = MFMA16H(w3[1][0], gq[1][0], dx); GAP(23);
+            // (b)
+            dH = zero;
+            dH = MFMA16H(w2[0][1], df[0][0], dH); GAP(24);
+            dH = MFMA16H(w2[0][0], df[0][1], dH); GAP(25);
+            dH = MFMA16H(w2[0][0], df[0][0], dH); GAP(26);
+            {
+                unsigned char* Tb = reinterpret_cast<unsigned char*>(TbAll + (((i - 1) & 1) * 8 + wave) * PS_TB);
+#pragma unroll
+                for (int G = 0; G < 4; ++G) *reinterpret_cast<float4*>(Tb + (w0 ^ (G << 5))) = make_float4(dx[4 * G], dx[4 * G + 1], dx[4 * G + 2], dx[4 * G + 3]);
+            }
+            dH = MFMA16H(w2[1][1], df[1][0], dH); GAP(27);
+            dH = MFMA16H(w2[1][0], df[1][1], dH); GAP(28);
+            dH = MFMA16H(w2[1][0], df[1][0], dH); GAP(29);
+#else
+            GAP(0); GAP(1); GAP(2); GAP(3); GAP(4); GAP(5); GAP(6); GAP(7); GAP(8); GAP(9); GAP(10); GAP(11); GAP(12); GAP(13); GAP(14); GAP(15); GAP(16); GAP(17);
+            GAP(18); GAP(19); GAP(20); GAP(21); GAP(22); GAP(23); GAP(24); GAP(25); GAP(26);
+#endif
+#undef GAP
+        } else {
+        // (a) first: relu(H) and its pieces are vector work for the shadow of the 24 MFMAs that follow
+#ifndef H3S_NOY
+        if (hc) {
+            const unsigned char* Xb = XA + b0 * PB_TILE;
+            Frag xf[2][NP];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
+            H = mac<AR>(w1[0], xf[0], H); H = mac<AR>(w1[1], xf[1], H);               // (a)
+        }
+        if (hp) {
+            const unsigned char* Xp = XA + bprev * PB_TILE;
+            const unsigned char* Dp = DA + bprev * PB_TILE;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {                               // (d) and (e) side by side
+                Frag at[NP], bt[NP], ae[NP], be[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    tr_frag<PB_ROW>(Xp + p * PB_IMG, lane, kb, at[p]); tr_frag_sw(Ti + p * PS_IMG, toff(kb, 0), toff(kb, 1), bt[p]);
+                    tr_frag<PB_ROW>(Dp + p * PB_IMG, lane, kb, ae[p]); tr_frag_sw(Th + p * PS_IMG, toff(kb, 0), toff(kb, 1), be[p]);
+                }
+                dW1 = mac<AR>(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
+                dW2t = mac<AR>(ae, be, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
+            }
+            // (c): its B operand is the cut gradient tile as this lane stored it (the accumulator registers of (b) in order: the pieces of
+            // k-block kb are the lane's chunks G = 2 kb, 2 kb + 1), read back instead of held in 16 registers across the segments
+            Frag gq[2][NP];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4)));
+                    const uint2 hi = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4)));
+                    gq[kb][p].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            f32x16 dx = zero;
+            dx = mac<AR>(w3[0], gq[0], dx); dx = mac<AR>(w3[1], gq[1], dx);
+            unsigned char* Tb = reinterpret_cast<unsigned char*>(TbAll + (((i - 1) & 1) * 8 + wave) * PS_TB);
+#pragma unroll
+            for (int G = 0; G < 4; ++G) *reinterpret_cast<float4*>(Tb + (w0 ^ (G << 5))) = make_float4(dx[4 * G], dx[4 * G + 1], dx[4 * G + 2], dx[4 * G + 3]);
+        }
+        if (hc) {
+            const unsigned char* Db = DA + b0 * PB_TILE;
+            Frag df[2][NP];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
+            dH = zero;
+            dH = mac<AR>(w2[0], df[0], dH); dH = mac<AR>(w2[1], df[1], dH);           // (b)
+        }
+#endif
+        // ---- the vector work of the phase (the scheduler deals it out between the MFMAs above: none of it depends on (d), (e), (c), (b)) ----
+#ifndef H3S_NOSUMS
+        if (roleB && hp2) {
+            // dX of tile i-2 = dOut + its eight chunk partials (complete since two segments), in the order of the chunks
+            if constexpr (!HOT) {
+                if (on != c2p.n) {                                     // the sums enter another sample: commit the finished one's largest |dX|
+                    if (on >= 0 && am.y) amax_commit(rf[0], am.y + on);
+                    on = c2p.n; rf[0] = 0.f;
+                }
+            }
+            const long sv0 = (long)c2p.n * vps + 32 * c2p.j;
+            const int snrem = HOT ? 32 : (vps - 32 * c2p.j < 32 ? vps - 32 * c2p.j : 32);
+            const float* Tp = TbAll + (i & 1) * 8 * PS_TB + rs;
+            float sa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float4 t = *reinterpret_cast<const float4*>(Tp + jj * PS_TB);
+                sa[0] += t.x; sa[1] += t.y; sa[2] += t.z; sa[3] += t.w;
+            }
+            const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sa[k] = ldexpf(sa[k], -(rc[k] + c2p.eg())) + od[k];      // (c) partials -> true values: W1's cin row and the sample's dH scale
+            if (HOT || rrow < snrem) {
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX + sv0 * 32) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+                rf[0] = fmaxf(fmaxf(rf[0], fmaxf(fabsf(sa[0]), fabsf(sa[1]))), fmaxf(fabsf(sa[2]), fabsf(sa[3])));
+            }
+        }
+#endif
+#ifndef H3S_NOSTAGE
+        // half A cuts and stages tile i+1 (requested one X phase ago): its buffer was last read two segments ago
+        if (roleA && hn) stage_store(hot_tag, bnext, cnext, nxv, nd);
+#endif
+#if !defined(H3S_NOGATE) && !defined(H3S_NOY)
+        if (hc) {
+            // bias, ReLU and cut of the hidden tile; its pieces go to the wave's H' image (whose previous content (e) has read above),
+            // relu(H) itself stays in registers for the gate in X(i)
+            const int kh = ccur.eh() - ccur.ex() - ew1;                            // (<= -17 always, see the bounds)
+            const float ch = pow2i(kh < -126 ? -126 : kh);
+            const float* sB = sB1 + (ccur.n & 1) * 256 + 32 * c + 4 * half;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Frag hf[NP];
+                float hk[8];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {                          // registers 4G .. 4G+3 <-> hidden 32c + 8G + 4h + (0..3)
+                    const float4 bb = *reinterpret_cast<const float4*>(sB + 8 * (2 * kb + g));
+                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * kb + 4 * g + e;
+                        hs[r] = fmaxf(fmaf(H[r], ch, bv[e]), 0.f);
+                        hk[4 * g + e] = hs[r];
+                    }
+                }
+                cut8_scaled<AR>(hk, hf);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ ((2 * kb) << 4))) = make_uint2(hf[p].u.x, hf[p].u.y);
+                    *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4))) = make_uint2(hf[p].u.z, hf[p].u.w);
+                }
+            }
+        }
+#endif
+        }
+        XS_ACC(2);
+#ifndef H3S_NOPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        bar();
+        XS_ACC(3);
+        // ================================ X(i) ================================
+        // requested here, used one phase on: the rows of tile i+2 (half A) / dOut of tile i-1, summed in Y(i+1) (half B)
+        if (roleA) { if (hnn) stage_load(hot_tag, cnn, nxv, nd); }
+        else if (hp) {
+            const long pv0 = (long)cprev.n * vps + 32 * cprev.j;
+            const int pnrem = HOT ? 32 : (vps - 32 * cprev.j < 32 ? vps - 32 * cprev.j : 32);
+            rdo = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dOut + pv0 * 32) + (HOT || rrow < pnrem ? ro : rq * 16u));
+        }
+#ifndef H3S_NOGATE
+        if (hc) {
+            if constexpr (!HOT) {
+                if (hp && ccur.n != cprev.n) {
+                    // (d), (e) and the db1 sums of tile i run at another sample's scales.  The running sums (tiles <= i-1, all three) move to
+                    // the new scales by an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright
+                    // one -- banks them in the slab instead and starts over.
+                    const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
+                    const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
+                    if (big > 40) flush(cprev);
+                    else if (big != 0) {
+                        const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
+                    }
+                }
+            }
+            const int kg = ccur.eg() - ew2 - ccur.ed();
+            const float cg = pow2i(kg < -126 ? -126 : kg);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Frag gf[NP];
+                float gs[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * kb + e;
+                    gs[e] = hs[r] > 0.f ? dH[r] * cg : 0.f;            // (relu(hv) > 0 exactly where hv > 0)
+                    bs1v[r] += gs[e];
+                }
+                cut8_scaled<AR>(gs, gf);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {                         // dH' pieces to the wave's transpose image: (d) reads it transposed, (c) as stored
+                    *reinterpret_cast<uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4))) = make_uint2(gf[p].u.x, gf[p].u.y);
+                    *reinterpret_cast<uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4))) = make_uint2(gf[p].u.z, gf[p].u.w);
+                }
+            }
+        }
+#endif
+        if constexpr (!HOT) {
+            // the biases at the next sample's hidden scale, in that sample's parity (first read in Y(i+1); the last reader of what this overwrites
+            // -- the sample before the current one -- was a Y phase before this segment)
+            if (hb == 0 && hn && cnext.n != ccur.n) sB1[(cnext.n & 1) * 256 + t8] = b1[t8] * pow2i(cnext.eh());
+        }
+        XS_ACC(5);
+        if constexpr (HOT) ++ccur.j;
+        else {
+            c2p = cprev; cprev = ccur; ccur = cnext; cnext = cnn;
+            if (i + 3 < nt) advance(cnn);
+        }
+        b0 = bnext;
+    };
+    if (hb) bar();                                                 // half B starts one segment late ...
+    {
+        int i = 0;
+        while (i < nt + 2) {
+            // tiles i-2 .. i+3 inside one sample and inside the run: 3 <= j(i) <= tps - 4 and 2 <= i <= nt - 4 -- a stretch of the hot loop
+            // (tps - 4: the sample's last tile, the only one that may be partial, stays outside)
+            int cnt = (i >= 2 && i < nt && ccur.j >= 3) ? min(tps - 3 - ccur.j, nt - 3 - i) : 0;
+            if (cnt > 0) {
+                if (hb) for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 1>(), i);
+                else for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 0>(), i);
+                // back to separate cursors: all of them still inside the sample
+                c2p = ccur; c2p.j -= 2; cprev = ccur; cprev.j -= 1; cnext = ccur; cnext.j += 1; cnn = ccur; cnn.j += 2;
+            } else {
+                iter(std::false_type(), std::integral_constant<int, 2>(), i);
+                ++i;
+            }
+        }
+    }
+    if (!hb) bar();                                                // ... and half A waits for its last one
+    __syncthreads();
+    if (hb && on >= 0 && am.y) amax_commit(rf[0], am.y + on);
+    flush(cprev);                                          // the sums of the run's last sample(s), at that sample's scales
+    // db2[out] = sum of the staged dT values: thread t < 256 always staged out (t % D), ((t + 256) % D), ...; fixed-order sum
+    float* R = TbAll;                                                 // R[f] = column sum of staged element f (f < 1024)
+    if (hb == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R[tid + 256 * k] = (tid + 256 * k < 32 * D) ? rf[k] : 0.f;
+    }
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int jj = tid; jj < 1024; jj += D) t += R[jj];
+        sl[8192 + 256 * (long)D + 256 + tid] = t;
+    }
+#ifdef PROBAV_STAMP
+    xs_acc[6] = __builtin_amdgcn_s_memrealtime() - rt0;      // (100 MHz ticks of the wave's life: life in cycles / this = clock / 100 MHz)
+#endif
+    XS_OUT;
+}
+
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
                    const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
                    int arith, const PwAmax& am, hipStream_t s)
@@ -671,11 +1315,21 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     static std::once_flag once;
     std::call_once(once, [] {
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_h3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     if (vps <= 0 || vps > nvox) vps = nvox;
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_backward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+        static const bool same_program = getenv("PROBAV_PW_BWD_V1") != nullptr;      // diagnostic / A-B runs: the one-program form (same bits)
+        if (!same_program) {
+            const size_t lds = (size_t)6 * H3::NP * PB_IMG + ((size_t)16 * PS_TB + 512) * sizeof(float) + (size_t)8 * 2 * H3::NP * PS_IMG;       // = 160 KB
+            hipLaunchKernelGGL(pw_bwd_h3s_kernel, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
+                               (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);
+            int rc = check_launch("pw_bwd_h3s");
+            if (rc) return rc;
+            return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
+        }
         const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 2 * H3::NP * PT_IMG;   // (two transpose images per wave)
         hipLaunchKernelGGL(pw_bwd_x6_kernel<H3>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
                            (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);

@@ -94,3 +94,12 @@ def test_training_step_replays_from_a_captured_graph():
     torch.cuda.synchronize()
     assert lg == le
     assert torch.equal(gg, model.flat.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
+def test_pointwise_backward_schedules_agree_bit_for_bit(B, T):
+    """The alternating-halves form of the fused pointwise backward (pw_bwd_h3s_kernel, the default) evaluates the same products in the
+    same order as the one-program form (pw_bwd_x6_kernel<H3>, PROBAV_PW_BWD_V1=1): predictions and all 132 gradients of the whole
+    network are identical, bit for bit."""
+    assert _run({}, B, T, 2) == _run({"PROBAV_PW_BWD_V1": "1"}, B, T, 2)

@@ -77,7 +77,9 @@ int main()
             x6_pw_backward(xx, dT, dO, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, dX, dW1, dW2, db1, db2, slabs, nvox, 22 * 22 * 9, D, ARITH, pam, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-#ifdef PROBAV_STAMP2
+#ifdef PROBAV_STAMP_H3S
+        const char* nm[8] = {"t0", "wait: barrier before Y", "Y: (d),(e),(c) of tile i-1, (a),(b) of tile i", "wait: barrier before X", "X: dX sums (half B)", "X: gate + cut + transpose stores", "X: stage store (half A)", "t_end"};
+#elif defined(PROBAV_STAMP2)
         const char* nm[8] = {"t0", "(a),(b) + dX reduce of the previous tile", "gate + cut", "(c)", "Tb store, dH' transpose, (d)", "H' transpose, (e)", "-", "t_end"};
 #else
         const char* nm[8] = {"t0", "wait: tile staged", "compute", "stage store", "wait: partials", "dX reduce", "epilogue", "t_end"};
@@ -89,7 +91,7 @@ int main()
                 for (int k = 1; k < 7; ++k) acc[k] += (double)s[k];
                 life += (double)(s[7] - s[0]);
             }
-            printf("pw_bwd wave %d: life %.0f cyc/WG (%.0f per tile) |", wave, life / 256, life / 256 / 68.06);
+            printf("pw_bwd wave %d: life %.0f cyc/WG (%.0f per tile), in-kernel clock %.2f GHz |", wave, life / 256, life / 256 / 68.06, acc[6] > 0 ? life / acc[6] * 0.1 : 0.0);
             for (int k = 1; k < 7; ++k) printf(" %s %.1f%%", nm[k], 100.0 * acc[k] / life);
             printf("\n");
         }
