@@ -143,8 +143,10 @@ def cpu_baseline(seconds=20.0):
         if time.perf_counter() - t0 >= seconds or n >= 40:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(8 * n / dt, 3), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": "oracle/wdsr_torch.py fp32, batch 8 (cfg p16t9c85r12 on CPU), fwd + L1 loss + bwd, %d steps in %.1f s" % (n, dt)}
+    return {"value": round(8 * n / dt, 3), "unit": "patches/s", "cores": cores, "threads": cores, "host_cores": avail, "kind": "port",
+            "sample": "oracle/wdsr_torch.py fp32, batch 8 (cfg p16t9c85r12 on CPU), fwd + L1 loss + bwd, %d steps in %.1f s; `cores` = `threads` = "
+                      "the torch thread count used (the fastest of 8 / 16 / 32 / 64 in a short calibration: oneDNN does not scale further at "
+                      "this size), `host_cores` = os.cpu_count() of the box" % (n, dt)}
 
 
 def percentiles(ms):
@@ -330,17 +332,22 @@ def run_rank(args):
     if rank == 0:
         seed = (torch.rand(128 * 8, device=dev) - 0.5).half()
         sink = torch.empty(256 * 256, device=dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         iters, launches = 2000, 8
-        _lib.check(L.probav_mfma_probe(_lib.ptr(seed), _lib.ptr(sink), iters, 4, _lib.current_stream()), "probav_mfma_probe")
-        e0.record()
-        _lib.check(L.probav_mfma_probe(_lib.ptr(seed), _lib.ptr(sink), iters, launches, _lib.current_stream()), "probav_mfma_probe")
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        mfma_probe = {"tflops": round(launches * 256 * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 3),
-                      "note": "dependent v_mfma_f32_32x32x16_f16 chains, one wave per SIMD on every CU, random operands: the fp16 matrix rate this device "
-                              "sustains (data sheet: 2 500 dense); an H3 kernel issues three such MFMAs per fp32 product"}
+        shapes = {}
+        for shape, name in ((0, "32x32x16"), (1, "16x16x32")):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            _lib.check(L.probav_mfma_probe_shape(_lib.ptr(seed), _lib.ptr(sink), iters, 4, shape, _lib.current_stream()), "probav_mfma_probe_shape")
+            e0.record()
+            _lib.check(L.probav_mfma_probe_shape(_lib.ptr(seed), _lib.ptr(sink), iters, launches, shape, _lib.current_stream()), "probav_mfma_probe_shape")
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            shapes[name] = {"tflops": round(launches * 256 * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 3)}
+        mfma_probe = {"tflops": shapes["32x32x16"]["tflops"], "ms": shapes["32x32x16"]["ms"], "by_shape": shapes,
+                      "note": "dependent fp16 MFMA chains, one wave per SIMD on every CU, random operands: the fp16 matrix rate this device "
+                              "sustains (data sheet: 2 500 dense) with v_mfma_f32_32x32x16_f16 (the shape the H3 kernels issue, three per fp32 "
+                              "product) and with v_mfma_f32_16x16x32_f16 (same cycles per FLOP; the chip holds a higher clock on it when the "
+                              "matrix pipe alone is what limits the power)"}
 
     fp32_leg = None
     if args.impl >= 3 and not args.no_fp32_mfma_leg:
@@ -440,6 +447,11 @@ def run_rank(args):
             out["sustained_mfma"] = mfma_probe
         if fp32_leg is not None:
             out["fp32_mfma_path"] = fp32_leg
+            # the pool's boxes fall into two classes under fp16-MFMA load (~8 % apart on the H3 kernels, < 1 % apart on the fp32-MFMA path):
+            # the ratio of the two step times tells a reader which class produced this line
+            ratio = (dt / args.steps * 1e3) / fp32_leg["ms_per_step"]
+            out["box_class"] = {"h3_step_over_fp32_step": round(ratio, 4), "class": "faster" if ratio < 0.405 else "slower",
+                                "note": "same build on both classes; DESIGN.md section 5 lists the per-class numbers"}
         if full is not None:
             out["full_step"] = {"ms_per_step": round(full, 4), "patches_per_s": round(world * B / full * 1e3, 2),
                                 "includes": "fwd + L1 loss + bwd + Nadam update + cPSNR metric"}

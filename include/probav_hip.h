@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROBAV_ABI_VERSION 3
+#define PROBAV_ABI_VERSION 4
 
 /* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
  * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale=True)   (models/modelsTF.py:8-17) */
@@ -197,6 +197,10 @@ int probav_engine_side_stream(probav_engine* e, int mode);
  * THIS device sustains under load -- the boxes of a pool differ -- as launches * 256 * 4 * iters * 16 * 32768 FLOP / time.
  * `sink` receives 256 * 256 floats.  bench.py reports it as `sustained_mfma_tflops` beside the step time.                                */
 int probav_mfma_probe(const void* seed, float* sink, int iters, int launches, void* stream);
+/* The same with the MFMA shape as a parameter (ABI 4): shape 0 = v_mfma_f32_32x32x16_f16 (iters x 16 MFMAs of 32 768 FLOP per wave), shape 1 =
+ * v_mfma_f32_16x16x32_f16 (iters x 32 MFMAs of 16 384 FLOP: the same FLOP per wave, the same cycles per FLOP).  Where the chip lowers its clock
+ * under matrix load the clock it holds depends on the shape (MI355X_MICROARCH.md, DVFS give-back, item 7): bench.py reports both rates. */
+int probav_mfma_probe_shape(const void* seed, float* sink, int iters, int launches, int shape, void* stream);
 
 /* ---- introspection of a training forward pass (parity tests; tf.keras would expose these as layer outputs) -------------------- */
 /* where a saved activation lives inside the caller's workspace after probav_forward(training=1): offset and length in floats.

@@ -66,6 +66,7 @@ SIGNATURES = {
     "probav_engine_side_stream": (c_int, [c_void_p, c_int]),
     "probav_weight_cache_build": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "probav_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "probav_mfma_probe_shape": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "probav_weight_cache_bytes": (c_size_t, [c_void_p]),
     "probav_optimizer_step_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
@@ -93,7 +94,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if L.probav_abi_version() != 3:
+        if L.probav_abi_version() != 4:
             raise RuntimeError("libprobav_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -372,6 +372,11 @@ int probav_mfma_probe(const void* seed, float* sink, int iters, int launches, vo
     if (!seed || !sink || iters < 1 || launches < 1) { set_error("probav_mfma_probe: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     return mfma_probe(seed, sink, iters, launches, (hipStream_t)stream);
 }
+int probav_mfma_probe_shape(const void* seed, float* sink, int iters, int launches, int shape, void* stream)
+{
+    if (!seed || !sink || iters < 1 || launches < 1 || shape < 0 || shape > 1) { set_error("probav_mfma_probe_shape: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    return mfma_probe(seed, sink, iters, launches, (hipStream_t)stream, shape);
+}
 const char* probav_last_error(void) { return probav::last_error(); }
 
 int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)

@@ -384,10 +384,24 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(const probe_f16x8* __re
     for (int i = 0; i < 16; ++i) t += acc[i];
     sink[blockIdx.x * 256 + threadIdx.x] = t;
 }
-int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream_t s)
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_probe16_kernel(const probe_f16x8* __restrict__ seed, float* __restrict__ sink, int iters)
 {
-    for (int l = 0; l < launches; ++l)
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, s, (const probe_f16x8*)seed, sink, iters);
+    probe_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const probe_f16x8 a = seed[threadIdx.x & 63], b = seed[64 + (threadIdx.x & 63)];
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+    sink[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream_t s, int shape)
+{
+    for (int l = 0; l < launches; ++l) {
+        if (shape == 1) hipLaunchKernelGGL(mfma_probe16_kernel, dim3(256), dim3(256), 0, s, (const probe_f16x8*)seed, sink, iters);
+        else hipLaunchKernelGGL(mfma_probe_kernel, dim3(256), dim3(256), 0, s, (const probe_f16x8*)seed, sink, iters);
+    }
     return check_launch("mfma_probe");
 }
 

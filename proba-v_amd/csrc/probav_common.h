@@ -56,7 +56,7 @@ int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, 
 size_t wgrad_partial_floats(const ConvGeom& g);
 int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate,
                         float* dw, float* db, float* partial, hipStream_t s);
-int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream_t s);
+int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream_t s, int shape = 0);      // shape 0: 32x32x16, 1: 16x16x32 (fp16)
 // Slab reductions beside the main chain.  The backward-filter kernels leave one slab per workgroup; the few-microsecond kernels that sum
 // them are needed only by the weight-norm backward at the very end, yet on the caller's stream each one sits between two chip-filling
 // launches.  While a ReduceSide is active on the calling thread (the engine's backward pass), reduce_fork(s) records the point on s,
