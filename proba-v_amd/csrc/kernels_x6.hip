@@ -858,6 +858,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
         }
         flushed = true;
     };
+    auto flush_cold = [&](const Cur& q) { flush(q); };
     int on = -1;                                                       // half B: the sample whose largest |dX| rf[0] is collecting
 
     // tiles i-2 (its partials get summed), i-1 ((c), (d), (e)), i ((a), (b), gate), i+1 (staged), i+2 (requested)
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     // One iteration = the wave's Y(i) and X(i).  HOT: tiles i-2 .. i+3 exist, are full and belong to one sample -- every condition below is
     // true and nothing that happens once per sample or once per run is compiled into the instance; ROLE = 0 / 1: the instance of half A / B
     // (straight-line code: one scheduling region per phase, so that the vector work can be dealt out between the MFMAs), 2: by `hb`.
-    auto iter = [&](auto hot_tag, auto role_tag, int i) {
+    auto iter = [&](auto hot_tag, auto role_tag, int i, auto&& between) {
         constexpr bool HOT = decltype(hot_tag)::value;
         constexpr int ROLE = decltype(role_tag)::value;
         const bool roleA = ROLE == 2 ? hb == 0 : ROLE == 0, roleB = ROLE == 2 ? hb != 0 : ROLE == 1;
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
 #endif
         bar();
         XS_ACC(3);
+        between();
         // ================================ X(i) ================================
         // requested here, used one phase on: the rows of tile i+2 (half A) / dOut of tile i-1, summed in Y(i+1) (half B)
         if (roleA) { if (hnn) stage_load(hot_tag, cnn, nxv, nd); }
@@ -1220,14 +1222,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
 #ifndef H3S_NOGATE
         if (hc) {
             if constexpr (!HOT) {
+                // (d), (e) and the db1 sums of tile i run at another sample's scales.  The running sums (tiles <= i-1, all three) move to the
+                // new scales by an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright one --
+                // banks them in the slab instead and starts over (`big_jump`: done by the caller, between two iterations' code, so that the
+                // slab code's registers are not part of this body)
                 if (hp && ccur.n != cprev.n) {
-                    // (d), (e) and the db1 sums of tile i run at another sample's scales.  The running sums (tiles <= i-1, all three) move to
-                    // the new scales by an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright
-                    // one -- banks them in the slab instead and starts over.
                     const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
                     const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
-                    if (big > 40) flush(cprev);
-                    else if (big != 0) {
+                    if (big <= 40 && big != 0) {
                         const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
@@ -1276,12 +1278,18 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             // (tps - 4: the sample's last tile, the only one that may be partial, stays outside)
             int cnt = (i >= 2 && i < nt && ccur.j >= 3) ? min(tps - 3 - ccur.j, nt - 3 - i) : 0;
             if (cnt > 0) {
-                if (hb) for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 1>(), i);
-                else for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 0>(), i);
+                if (hb) for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 1>(), i, [] {});
+                else for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 0>(), i, [] {});
                 // back to separate cursors: all of them still inside the sample
                 c2p = ccur; c2p.j -= 2; cprev = ccur; cprev.j -= 1; cnext = ccur; cnext.j += 1; cnn = ccur; cnn.j += 2;
             } else {
-                iter(std::false_type(), std::integral_constant<int, 2>(), i);
+                iter(std::false_type(), std::integral_constant<int, 2>(), i, [&] {
+                    // between Y(i) and X(i): the running sums hold tiles <= i-1; a jump of the scales too large to carry them along banks them
+                    if (i >= 1 && i < nt && ccur.n != cprev.n) {
+                        const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
+                        if (max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3) > 40) flush_cold(cprev);
+                    }
+                });
                 ++i;
             }
         }

@@ -278,3 +278,214 @@ def clip_round(x: Tensor, lo: float, hi: float) -> Tensor:
 @clip_round.register_fake
 def _(x, lo, hi):
     return torch.empty_like(x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# per-layer operators (SURVEY.md section 8b's minimum op set): what the engine is made of, as torch ops of their own, so that a variant
+# network (another block order, an iWDSR-style head) can be composed from them.  Each has its autograd formula registered in terms of
+# the other ops of the set; the whole-network op above stays the fast path (one workspace, fused scales, side stream).
+# Layouts are the reference's: activations [N, H, W, T, C] (channels last), filters in Keras layout [kh, kw, kt, Cin, Cout].
+# ---------------------------------------------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+def _geom17(N, hwt, cin, out_hwt, cout, k, pad, reflect, relu):
+    return (_ct.c_int32 * 17)(N, hwt[0], hwt[1], hwt[2], cin, out_hwt[0], out_hwt[1], out_hwt[2], cout, k[0], k[1], k[2], pad[0], pad[1], pad[2],
+                              1 if reflect else 0, 1 if relu else 0)
+
+
+def _conv_out(x, w, pad):
+    k = tuple(w.shape[:3])
+    out = tuple(int(x.shape[1 + i]) + 2 * pad[i] - k[i] + 1 for i in range(3))
+    return k, out
+
+
+@torch.library.custom_op("probav::conv3d_k3_fwd", mutates_args=(), device_types="cuda")
+def conv3d_k3_fwd(x: Tensor, w: Tensor, bias: Tensor, pad: list[int], reflect_hw: bool, relu: bool, skip: Optional[Tensor] = None,
+                  gate: Optional[Tensor] = None, impl: int = 4) -> Tensor:
+    """y = act(conv(x * [gate > 0], w) + bias) + skip: Conv3D of models/modelsTF.py:168-183,187-203 (`same`: pad 1, `valid`: pad 0; reflect_hw: the
+    tf.pad(REFLECT) of the height / width axes in front of convReducer_1) -- and, with flipped taps and swapped channels, its backward-data."""
+    _dev(x, "conv input")
+    k, out = _conv_out(x, w, pad)
+    y = torch.empty((x.shape[0],) + out + (w.shape[4],), dtype=torch.float32, device=x.device)
+    g = _geom17(x.shape[0], x.shape[1:4], x.shape[4], out, w.shape[4], k, pad, reflect_hw, relu)
+    rc = _lib.lib().probav_conv3d_forward(_ct.byref(g), _lib.ptr(x), _lib.ptr(gate), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(y), impl,
+                                          _lib.current_stream())
+    if rc == _lib.PROBAV_EINVAL and impl != 0:             # a geometry this MFMA family does not cover: the shape-agnostic kernels, as the engine does
+        rc = _lib.lib().probav_conv3d_forward(_ct.byref(g), _lib.ptr(x), _lib.ptr(gate), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(y), 0,
+                                              _lib.current_stream())
+    _lib.check(rc, "probav_conv3d_forward")
+    return y
+
+
+@conv3d_k3_fwd.register_fake
+def _(x, w, bias, pad, reflect_hw, relu, skip=None, gate=None, impl=4):
+    k, out = _conv_out(x, w, pad)
+    return x.new_empty((x.shape[0],) + out + (w.shape[4],), dtype=torch.float32)
+
+
+@torch.library.custom_op("probav::conv3d_k3_bwd_weight", mutates_args=(), device_types="cuda")
+def conv3d_k3_bwd_weight(x: Tensor, dy: Tensor, ksize: list[int], pad: list[int], reflect_hw: bool, gate: Optional[Tensor] = None,
+                         impl: int = 4) -> tuple[Tensor, Tensor]:
+    """(dw [kh, kw, kt, Cin, Cout], db [Cout]) of the same layer from its input and the gradient of its output (gate: the layer's own
+    post-ReLU output, when it has one)."""
+    _dev(x, "conv input")
+    out = tuple(int(dy.shape[1 + i]) for i in range(3))
+    g = _geom17(x.shape[0], x.shape[1:4], x.shape[4], out, dy.shape[4], ksize, pad, reflect_hw, gate is not None)
+    L = _lib.lib()
+    use = impl
+    nbytes = L.probav_conv3d_wgrad_scratch_bytes(_ct.byref(g), use)
+    if nbytes == 0 and use != 0:
+        use = 0
+        nbytes = L.probav_conv3d_wgrad_scratch_bytes(_ct.byref(g), 0)
+    scratch = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+    dw = torch.empty(tuple(ksize) + (x.shape[4], dy.shape[4]), dtype=torch.float32, device=x.device)
+    db = torch.empty((dy.shape[4],), dtype=torch.float32, device=x.device)
+    _lib.check(L.probav_conv3d_wgrad(_ct.byref(g), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(gate), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nbytes, use,
+                                     _lib.current_stream()), "probav_conv3d_wgrad")
+    return dw, db
+
+
+@conv3d_k3_bwd_weight.register_fake
+def _(x, dy, ksize, pad, reflect_hw, gate=None, impl=4):
+    return x.new_empty(tuple(ksize) + (x.shape[4], dy.shape[4]), dtype=torch.float32), x.new_empty((dy.shape[4],), dtype=torch.float32)
+
+
+def _conv_setup(ctx, inputs, output):
+    x, w, bias, pad, reflect_hw, relu, skip, gate, impl = inputs
+    if gate is not None:
+        raise RuntimeError("probav::conv3d_k3_fwd: the `gate` form is the backward-data operator of another layer and has no autograd formula")
+    ctx.save_for_backward(x, w, output if relu else None)
+    ctx.pad, ctx.reflect_hw, ctx.relu, ctx.impl, ctx.has_skip = list(pad), reflect_hw, relu, impl, skip is not None
+
+
+def _conv_bwd(ctx, dy):
+    x, w, y = ctx.saved_tensors
+    dy = dy.contiguous().float()
+    k = tuple(w.shape[:3])
+    gate = None
+    if ctx.relu:                                            # y = relu(z) + skip: the gate is z > 0; with a skip the saved output no longer shows it
+        if ctx.has_skip:
+            raise RuntimeError("probav::conv3d_k3_fwd: relu together with skip has no autograd formula (the network never combines them on one layer)")
+        gate = y
+    dw, db = torch.ops.probav.conv3d_k3_bwd_weight(x, dy, list(k), ctx.pad, ctx.reflect_hw, gate, ctx.impl)
+    dx = None
+    if ctx.needs_input_grad[0]:
+        if ctx.reflect_hw:
+            raise RuntimeError("probav::conv3d_k3_fwd: the input gradient of a reflect-padded layer goes through the engine (fold of the mirrored border)")
+        wT = torch.flip(w, dims=(0, 1, 2)).transpose(3, 4).contiguous()                 # flipped taps, swapped channels
+        bpad = [k[i] - 1 - ctx.pad[i] for i in range(3)]                                 # "full" correlation minus the forward padding
+        zero = torch.zeros(w.shape[3], dtype=torch.float32, device=x.device)
+        dx = torch.ops.probav.conv3d_k3_fwd(dy, wT, zero, bpad, False, False, None, gate, ctx.impl)
+    return dx, dw, db, None, None, None, (dy if ctx.has_skip else None), None, None
+
+
+conv3d_k3_fwd.register_autograd(_conv_bwd, setup_context=_conv_setup)
+
+
+@torch.library.custom_op("probav::pw_expand_relu_decay_fwd", mutates_args=(), device_types="cuda")
+def pw_expand_relu_decay_fwd(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, vox_per_sample: int = 0, impl: int = 4) -> Tensor:
+    """expConv_i (1x1x1, 32 -> 256) + ReLU + decConv_i (1x1x1, 256 -> D), fused: models/modelsTF.py:179-183.  x [..., 32] -> [..., D]; the
+    256-channel tensor never reaches memory.  vox_per_sample: voxels of one patch (the unit the H3 arithmetic scales by; 0 = one sample)."""
+    _dev(x, "pointwise input")
+    nvox = x.numel() // x.shape[-1]
+    dec = torch.empty(tuple(x.shape[:-1]) + (w2.shape[-1],), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().probav_pw_forward(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(dec), nvox, vox_per_sample,
+                                            w2.shape[-1], impl, _lib.current_stream()), "probav_pw_forward")
+    return dec
+
+
+@pw_expand_relu_decay_fwd.register_fake
+def _(x, w1, b1, w2, b2, vox_per_sample=0, impl=4):
+    return x.new_empty(tuple(x.shape[:-1]) + (w2.shape[-1],), dtype=torch.float32)
+
+
+@torch.library.custom_op("probav::pw_expand_relu_decay_bwd", mutates_args=(), device_types="cuda")
+def pw_expand_relu_decay_bwd(x: Tensor, d_dec: Tensor, d_skip: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, vox_per_sample: int = 0,
+                             impl: int = 4) -> tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """The fused reverse pass: (dx = d_skip + dL/dx, dw1, db1, dw2, db2); the hidden tile is recomputed, never stored."""
+    _dev(x, "pointwise input")
+    nvox, D = x.numel() // x.shape[-1], w2.shape[-1]
+    L = _lib.lib()
+    nbytes = L.probav_pw_backward_scratch_bytes(D)
+    scratch = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dw1, db1, dw2, db2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty((D,), dtype=torch.float32, device=x.device)
+    _lib.check(L.probav_pw_backward(_lib.ptr(x), _lib.ptr(d_dec), _lib.ptr(d_skip), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(dx), _lib.ptr(dw1),
+                                    _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2), _lib.ptr(scratch), nbytes, nvox, vox_per_sample, D, impl,
+                                    _lib.current_stream()), "probav_pw_backward")
+    return dx, dw1, db1, dw2, db2
+
+
+@pw_expand_relu_decay_bwd.register_fake
+def _(x, d_dec, d_skip, w1, b1, w2, vox_per_sample=0, impl=4):
+    return torch.empty_like(x), torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), x.new_empty((w2.shape[-1],), dtype=torch.float32)
+
+
+def _pw_setup(ctx, inputs, output):
+    x, w1, b1, w2, b2, vps, impl = inputs
+    ctx.save_for_backward(x, w1, b1, w2)
+    ctx.vps, ctx.impl = vps, impl
+
+
+def _pw_bwd(ctx, d_dec):
+    x, w1, b1, w2 = ctx.saved_tensors
+    d_dec = d_dec.contiguous().float()
+    dx, dw1, db1, dw2, db2 = torch.ops.probav.pw_expand_relu_decay_bwd(x, d_dec, torch.zeros_like(x), w1, b1, w2, ctx.vps, ctx.impl)
+    return dx, dw1, db1, dw2, db2, None, None
+
+
+pw_expand_relu_decay_fwd.register_autograd(_pw_bwd, setup_context=_pw_setup)
+
+
+@torch.library.custom_op("probav::wn_weight_fwd", mutates_args=(), device_types="cuda")
+def wn_weight_fwd(flat: Tensor, engine: int) -> tuple[Tensor, Tensor, Tensor]:
+    """TFA WeightNormalization of every layer of the engine's flat parameter buffer (w = g v / ||v||, per output channel):
+    -> (weff: layers in order, Keras layout; weffT: flipped taps / swapped channels for the backward-data operators; inv_norm per output channel)."""
+    _dev(flat, "parameter")
+    L, h = _lib.lib(), c_void_p(engine)
+    nw, nc = L.probav_weff_count(h), L.probav_cout_total(h)
+    weff, weffT = torch.empty(nw, dtype=torch.float32, device=flat.device), torch.empty(nw, dtype=torch.float32, device=flat.device)
+    inv = torch.empty(nc, dtype=torch.float32, device=flat.device)
+    _lib.check(L.probav_wn_forward(h, _lib.ptr(flat), _lib.ptr(weff), _lib.ptr(weffT), _lib.ptr(inv), _lib.current_stream()), "probav_wn_forward")
+    return weff, weffT, inv
+
+
+@wn_weight_fwd.register_fake
+def _(flat, engine):
+    L, h = _lib.lib(), c_void_p(engine)
+    nw, nc = L.probav_weff_count(h), L.probav_cout_total(h)
+    return flat.new_empty((nw,)), flat.new_empty((nw,)), flat.new_empty((nc,))
+
+
+@torch.library.custom_op("probav::wn_weight_bwd", mutates_args=(), device_types="cuda")
+def wn_weight_bwd(flat: Tensor, dweff: Tensor, inv_norm: Tensor, engine: int) -> Tensor:
+    """Gradient of the flat parameter buffer (g, v of every layer; the bias slots are left to the caller) from the gradient of `weff`."""
+    _dev(flat, "parameter")
+    grads = torch.zeros_like(flat)
+    _lib.check(_lib.lib().probav_wn_backward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dweff), _lib.ptr(inv_norm), _lib.ptr(grads), _lib.current_stream()),
+               "probav_wn_backward")
+    return grads
+
+
+@wn_weight_bwd.register_fake
+def _(flat, dweff, inv_norm, engine):
+    return torch.zeros_like(flat)
+
+
+def _wn_setup(ctx, inputs, output):
+    flat, engine = inputs
+    ctx.save_for_backward(flat, output[2])
+    ctx.engine = engine
+    ctx.mark_non_differentiable(output[1], output[2])
+    ctx.set_materialize_grads(False)
+
+
+def _wn_bwd(ctx, dweff, dweffT, dinv):
+    if dweff is None:
+        return None, None
+    flat, inv = ctx.saved_tensors
+    return torch.ops.probav.wn_weight_bwd(flat, dweff.contiguous().float(), inv, ctx.engine), None
+
+
+wn_weight_fwd.register_autograd(_wn_bwd, setup_context=_wn_setup)
