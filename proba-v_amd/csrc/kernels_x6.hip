@@ -762,8 +762,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
-    for (int i = tid; i < 3 * PB_TILE / 16; i += 512) reinterpret_cast<uint4*>(DA)[i] = make_uint4(0u, 0u, 0u, 0u);
-
     const int ntiles = (int)(nvox / vps) * tps;
     const int tbeg = (int)((long)ntiles * blockIdx.x / gridDim.x), tend = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);   // this workgroup's run of tiles
     const int nt = tend - tbeg;
@@ -781,16 +779,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     }
     const unsigned ro = rrow * 128u + rq * 16u;                        // (both roles: row t8 >> 3, 16-byte column t8 & 7 of a [32][32] fp32 tile)
     const int rs = hb ? rrow * 32 + ((rq ^ (rrow & 7)) << 2) : rrow * PB_ROW + rq * 8;
-    // staging: raw, clamped, unconditional loads (zeroing happens at the store); scalar base + 32-bit lane offset.  FULL: the tile is known
-    // to have all 32 voxels (the hot loop): no clamps, no selects.  A dT element slot beyond 32 D (the last of the four when D < 32) is
-    // branch-free: it writes a zero into the zero pad of voxel 0 (rc[] points there).
+    // staging: raw, clamped, unconditional loads (zeroing happens at the store); scalar base + 32-bit lane offset.  A dT element slot
+    // beyond 32 D (the last of the four when D < 32) is branch-free: it writes a zero into the zero pad of voxel 0 (rc[] points there).
     const bool dvalid3 = t8 + 768 < 32 * D;
-    auto stage_load = [&](auto full_tag, const Cur& q, float4& xv, float (&d)[4]) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    auto stage_load = [&](const Cur& q, float4& xv, float (&d)[4]) {
         const long v0 = (long)q.n * vps + 32 * q.j;
-        const int nrem = FULL ? 32 : (vps - 32 * q.j < 32 ? vps - 32 * q.j : 32);
+        const int nrem = vps - 32 * q.j < 32 ? vps - 32 * q.j : 32;
         const char* xb = reinterpret_cast<const char*>(x + v0 * 32);
-        xv = *reinterpret_cast<const float4*>(xb + (FULL || rrow < nrem ? ro : rq * 16u));
+        xv = *reinterpret_cast<const float4*>(xb + (rrow < nrem ? ro : rq * 16u));
         const char* db = reinterpret_cast<const char*>(dT + v0 * D);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -798,12 +794,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             d[k] = *reinterpret_cast<const float*>(db + ((int)f < nrem * D ? 4u * f : 0u));
         }
     };
-    auto stage_store = [&](auto full_tag, int buf, const Cur& q, const float4& xv, const float (&d)[4]) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int nrem = FULL ? 32 : (vps - 32 * q.j < 32 ? vps - 32 * q.j : 32);
+    auto stage_store = [&](int buf, const Cur& q, const float4& xv, const float (&d)[4]) {         // (the prologue's; the loop stages in the gaps of its MFMAs)
+        const int nrem = vps - 32 * q.j < 32 ? vps - 32 * q.j : 32;
         const float sx = pow2i(q.ex()), sd = pow2i(q.ed());
         {
-            const bool xl = FULL || rrow < nrem;
+            const bool xl = rrow < nrem;
             unsigned a[NP], b[NP];
             cut_pair<AR>(xl ? xv.x : 0.f, xl ? xv.y : 0.f, sx, a);
             cut_pair<AR>(xl ? xv.z : 0.f, xl ? xv.w : 0.f, sx, b);
@@ -813,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool live = (k < 3 ? (D >= 24 || t8 + 256 * k < 32 * D) : dvalid3) && (FULL || t8 + 256 * k < nrem * D);
+            const bool live = (k < 3 ? (D >= 24 || t8 + 256 * k < 32 * D) : dvalid3) && t8 + 256 * k < nrem * D;
             const float dv = live ? d[k] : 0.f;
             unsigned short qq[NP];
             cut_one<AR>(dv, sd, qq);
@@ -828,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
     float* sl = slabs + (long)blockIdx.x * slab_floats;
     bool flushed = false;                                             // wave-uniform
-    auto flush = [&](const Cur& q) {
+    auto flush = [&](const Cur& q) __attribute__((always_inline)) {
         asm volatile("" ::: "memory");                                // a rare path: nothing of it may be speculated into the tile loop
         float a1[16], a2[16], a3[16];
 #pragma unroll
@@ -858,51 +853,49 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
         }
         flushed = true;
     };
-    auto flush_cold = [&](const Cur& q) { flush(q); };
     int on = -1;                                                       // half B: the sample whose largest |dX| rf[0] is collecting
 
     // tiles i-2 (its partials get summed), i-1 ((c), (d), (e)), i ((a), (b), gate), i+1 (staged), i+2 (requested)
+    // ONE program for every iteration i = 0 .. nt+1 of the run: tiles outside 0 .. nt-1 are GHOSTS.  A ghost in front of the run finds
+    // zeros in the staging buffers, the transpose images and the partials (all of LDS is cleared first): (d), (e), (c) add zeros, its sums
+    // are not stored.  A ghost behind the run is staged as zeros: dT = 0 makes its gradient tile, its db1 / dW terms and its partial
+    // vanish whatever relu(bias) is.  So no iteration needs a program of its own (a separate cold instance spilled 200 registers and
+    // took 1.7x a hot iteration: a tenth of the kernel).  A ghost's cursor is a copy of the nearest real tile's.
     Cur c2p = {0, 0, 0}, cprev = c2p, ccur = c2p, cnext = c2p, cnn = c2p;
     if (nt > 0) {
         ccur.n = tbeg / tps; ccur.j = tbeg - ccur.n * tps; load_scales(ccur);
         cnext = ccur; if (nt > 1) advance(cnext);
         cnn = cnext; if (nt > 2) advance(cnn);
+        c2p = cprev = ccur;
     }
-    __syncthreads();                                   // the dT pads of all three buffers are zero
+    for (int k = tid; k < 160 * 1024 / 16; k += 512) reinterpret_cast<uint4*>(lds_raw)[k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
     float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};      // half A: the raw rows of the tile staged next
     float4 rdo = make_float4(0.f, 0.f, 0.f, 0.f);                                          // half B: dOut of the tile summed next
     if (nt > 0 && hb == 0) {
-        stage_load(std::false_type(), ccur, nxv, nd);
-        stage_store(std::false_type(), 0, ccur, nxv, nd);
-        sB1[(ccur.n & 1) * 256 + t8] = b1[t8] * pow2i(ccur.eh());
-        if (nt > 1) stage_load(std::false_type(), cnext, nxv, nd);
+        stage_load(ccur, nxv, nd);
+        stage_store(0, ccur, nxv, nd);
+        stage_load(cnext, nxv, nd);                                                        // (nt == 1: tile 0 again; staged as a ghost = zeros)
     }
+    if (hb == 0) sB1[(ccur.n & 1) * 256 + t8] = b1[t8] * pow2i(ccur.eh());
     // LDS only: requested rows and dX stores stay in flight; nothing (an MFMA least of all) may be scheduled across a segment boundary
     auto bar = [] { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
     int b0 = 0;                                                    // staging buffer of tile i (i mod 3)
     f32x16 zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    float hs[16];                                                  // relu(H) of tile i at the hidden tile's scale, from Y(i) to X(i)
+    f32x16 H = zero;                                               // accumulator of (a), then IN PLACE relu(H) of tile i at the hidden tile's scale: from Y(i) to X(i)
     f32x16 dH = zero;                                              // its gradient (accumulator of (b)), likewise
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hs[r] = 0.f;
 
     XS_DECL;
 #ifdef PROBAV_STAMP
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // One iteration = the wave's Y(i) and X(i).  HOT: tiles i-2 .. i+3 exist, are full and belong to one sample -- every condition below is
-    // true and nothing that happens once per sample or once per run is compiled into the instance; ROLE = 0 / 1: the instance of half A / B
-    // (straight-line code: one scheduling region per phase, so that the vector work can be dealt out between the MFMAs), 2: by `hb`.
-    auto iter = [&](auto hot_tag, auto role_tag, int i, auto&& between) {
-        constexpr bool HOT = decltype(hot_tag)::value;
+    // One iteration = the wave's Y(i) and X(i); ROLE = 0 / 1: the instance of half A / B (straight-line code: one scheduling region per
+    // phase, so that the vector work can be dealt out between the MFMAs).
+    auto iter = [&](auto role_tag, int i) __attribute__((always_inline)) {
         constexpr int ROLE = decltype(role_tag)::value;
-        const bool roleA = ROLE == 2 ? hb == 0 : ROLE == 0, roleB = ROLE == 2 ? hb != 0 : ROLE == 1;
-        if constexpr (HOT) {                                       // (all five tiles share sample and scales: only ccur is carried by the loop)
-            c2p = ccur; c2p.j -= 2; cprev = ccur; cprev.j -= 1; cnext = ccur; cnext.j += 1; cnn = ccur; cnn.j += 2;
-        }
-        const bool hp2 = HOT || i >= 2, hp = HOT || (i >= 1 && i <= nt), hc = HOT || i < nt, hn = HOT || i + 1 < nt, hnn = HOT || i + 2 < nt;
+        const bool real_p2 = i >= 2, real_p = i >= 1 && i <= nt, real_c = i < nt, real_n = i + 1 < nt, real_nn = i + 2 < nt;      // which of the five tiles exist
         const int bprev = b0 == 0 ? 2 : b0 - 1, bnext = b0 == 2 ? 0 : b0 + 1;
         bar();
         XS_ACC(1);
@@ -913,30 +906,33 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
         __builtin_amdgcn_s_setprio(1);
 #endif
         // ================================ Y(i) ================================
-        f32x16 H = zero;
-        if constexpr (HOT) {
-            // The hot loop's matrix phase, scheduled by hand: 30 MFMAs in the order (a), (d)/(e) k-block 0, k-block 1, (c), (b); behind each
-            // MFMA a "gap" with a small piece of the phase's other work -- LDS reads of operands a few MFMAs ahead, and vector work that runs
-            // while that MFMA executes (the partner wave of the SIMD is in its X phase).  Every gap is fenced by sched_barrier(0), the only
-            // form every scheduling pass respects: what is written in a gap stays in it.  None of the vector work depends on (d), (e), (c),
-            // (b); relu(H) needs (a): its pieces start a few gaps behind (a)'s last MFMA.
+        H = zero;
+        {
+            // The matrix phase, scheduled by hand: 30 MFMAs in the order (a), (d)/(e) k-block 0, k-block 1, (c), (b); behind each MFMA a "gap"
+            // with a small piece of the phase's other work -- LDS reads of operands a few MFMAs ahead, and vector work that runs while that
+            // MFMA executes.  Every gap is fenced by sched_barrier(0), the only form every scheduling pass respects: what is written in a
+            // gap stays in it.  None of the vector work depends on (d), (e), (c), (b); relu(H) needs (a): its pieces start a few gaps behind
+            // (a)'s last MFMA.
             const unsigned char* Xb = XA + b0 * PB_TILE;
             const unsigned char* Db = DA + b0 * PB_TILE;
             const unsigned char* Xp = XA + bprev * PB_TILE;
             const unsigned char* Dp = DA + bprev * PB_TILE;
             // ---- pieces of vector work ----
-            // half A: cut and stage tile i+1 (X float4: two pair cuts; four dT elements)
+            // half A: cut and stage tile i+1 (X float4: two pair cuts; four dT elements); a ghost is staged as zeros
             const float sx = pow2i(cnext.ex()), sd = pow2i(cnext.ed());
+            const int nnrem = real_n ? (vps - 32 * cnext.j < 32 ? vps - 32 * cnext.j : 32) : 0;
+            const int nlim = __builtin_amdgcn_readfirstlane(nnrem * D);
             unsigned char* sXd = XA + bnext * PB_TILE + rs;
             unsigned char* sDd = DA + bnext * PB_TILE;
             auto stageX = [&](float u, float v, int off) {
+                const bool xl = rrow < nnrem;
                 unsigned q[NP];
-                cut_pair<AR>(u, v, sx, q);
+                cut_pair<AR>(xl ? u : 0.f, xl ? v : 0.f, sx, q);
                 *reinterpret_cast<unsigned*>(sXd + off) = q[0];
                 *reinterpret_cast<unsigned*>(sXd + PB_IMG + off) = q[1];
             };
             auto stageD = [&](int k) {
-                const float dv = (k < 3 ? (D >= 24 || t8 + 256 * k < 32 * D) : dvalid3) ? nd[k] : 0.f;
+                const float dv = t8 + 256 * k < nlim ? nd[k] : 0.f;           // (nlim <= 32 D: a slot beyond the tile's elements stores a zero)
                 unsigned short qq[NP];
                 cut_one<AR>(dv, sd, qq);
                 *reinterpret_cast<unsigned short*>(sDd + rc[k]) = qq[0];
@@ -945,6 +941,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             };
             // half B: dX of tile i-2 = dOut + its eight chunk partials, in the order of the chunks (partial jj is requested two gaps ahead)
             const float* Tp = TbAll + (i & 1) * 8 * PS_TB + rs;
+            const int snrem = real_p2 ? (vps - 32 * c2p.j < 32 ? vps - 32 * c2p.j : 32) : 0;
             float4 tq[3];                                                  // (three in flight)
             float sa[4] = {0.f, 0.f, 0.f, 0.f};
             auto sums_read = [&](int jj) { tq[jj % 3] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); };
@@ -954,9 +951,12 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sa[k] = ldexpf(sa[k], -(rc[k] + c2p.eg())) + od[k];      // (c) partials -> true values: W1's cin row and the sample's dH scale
                 const long sv0 = (long)c2p.n * vps + 32 * c2p.j;
-                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX + sv0 * 32) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+                if (rrow < snrem) *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX + sv0 * 32) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
             };
-            auto sums_max = [&]() { rf[0] = fmaxf(fmaxf(rf[0], fmaxf(fabsf(sa[0]), fabsf(sa[1]))), fmaxf(fabsf(sa[2]), fabsf(sa[3]))); };
+            auto sums_max = [&]() {
+                const float m = fmaxf(fmaxf(fabsf(sa[0]), fabsf(sa[1])), fmaxf(fabsf(sa[2]), fabsf(sa[3])));
+                rf[0] = fmaxf(rf[0], rrow < snrem ? m : 0.f);
+            };
             // both: bias, ReLU and cut of the hidden tile, four registers (one 8-byte chunk of the lane's H' image row, both pieces) at a time
             const int kh = ccur.eh() - ccur.ex() - ew1;                            // (<= -17 always, see the bounds)
             const float ch = pow2i(kh < -126 ? -126 : kh);
@@ -964,11 +964,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             float4 bbq[4];
             auto relu2 = [&](int g, int e0) {                          // registers 4g + e0, 4g + e0 + 1
                 const float bv[4] = {bbq[g].x, bbq[g].y, bbq[g].z, bbq[g].w};
-                hs[4 * g + e0] = fmaxf(fmaf(H[4 * g + e0], ch, bv[e0]), 0.f);
-                hs[4 * g + e0 + 1] = fmaxf(fmaf(H[4 * g + e0 + 1], ch, bv[e0 + 1]), 0.f);
+                H[4 * g + e0] = fmaxf(fmaf(H[4 * g + e0], ch, bv[e0]), 0.f);
+                H[4 * g + e0 + 1] = fmaxf(fmaf(H[4 * g + e0 + 1], ch, bv[e0 + 1]), 0.f);
             };
             unsigned hq[2][NP];
-            auto hcut = [&](int g, int pr) { cut_pair_scaled<AR>(hs[4 * g + 2 * pr], hs[4 * g + 2 * pr + 1], hq[pr]); };
+            auto hcut = [&](int g, int pr) { cut_pair_scaled<AR>(H[4 * g + 2 * pr], H[4 * g + 2 * pr + 1], hq[pr]); };
             auto hstore = [&](int g) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ (g << 4))) = make_uint2(hq[0][p], hq[1][p]);
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 // operand requests
                 if constexpr (S >= 0 && S <= 3) rd_de(0, S);
-                if constexpr (S >= 6 && S <= 9) rd_de(1, S - 6);
+                if constexpr (S >= 8 && S <= 11) rd_de(1, S - 8);
                 if constexpr (S >= 12 && S <= 15) rd_gq((S - 12) >> 1, (S - 12) & 1);
                 if constexpr (S >= 19 && S <= 22) rd_df((S - 19) >> 1, (S - 19) & 1);
                 if constexpr (ROLE == 0) {
@@ -1013,6 +1013,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
                 }
 #ifndef H3S_NOGATE
                 constexpr int H0 = ROLE == 0 ? 8 : 11;                  // the first gap of the relu(H) work (four gaps per group of four registers)
+                if constexpr (S >= H0 - 2 && S < H0 + 14 && ((S - H0 + 2) & 3) == 0) bbq[(S - H0 + 2) >> 2] = *reinterpret_cast<const float4*>(sB + 8 * ((S - H0 + 2) >> 2));      // its biases, two gaps ahead
                 if constexpr (S >= H0 && S < H0 + 16) {
                     constexpr int g = (S - H0) >> 2, c4 = (S - H0) & 3;
                     if constexpr (c4 == 0) relu2(g, 0);
@@ -1029,8 +1030,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bbq[g] = *reinterpret_cast<const float4*>(sB + 8 * g);
 #ifndef H3S_NOSUMS
             if constexpr (ROLE == 1) { sums_read(0); sums_read(1); }
 #endif
@@ -1086,123 +1085,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             GAP(18); GAP(19); GAP(20); GAP(21); GAP(22); GAP(23); GAP(24); GAP(25); GAP(26);
 #endif
 #undef GAP
-        } else {
-        // (a) first: relu(H) and its pieces are vector work for the shadow of the 24 MFMAs that follow
-#ifndef H3S_NOY
-        if (hc) {
-            const unsigned char* Xb = XA + b0 * PB_TILE;
-            Frag xf[2][NP];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
-            H = mac<AR>(w1[0], xf[0], H); H = mac<AR>(w1[1], xf[1], H);               // (a)
-        }
-        if (hp) {
-            const unsigned char* Xp = XA + bprev * PB_TILE;
-            const unsigned char* Dp = DA + bprev * PB_TILE;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {                               // (d) and (e) side by side
-                Frag at[NP], bt[NP], ae[NP], be[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    tr_frag<PB_ROW>(Xp + p * PB_IMG, lane, kb, at[p]); tr_frag_sw(Ti + p * PS_IMG, toff(kb, 0), toff(kb, 1), bt[p]);
-                    tr_frag<PB_ROW>(Dp + p * PB_IMG, lane, kb, ae[p]); tr_frag_sw(Th + p * PS_IMG, toff(kb, 0), toff(kb, 1), be[p]);
-                }
-                dW1 = mac<AR>(at, bt, dW1);                                // dW1c[cin][hidden] += X^T dH'
-                dW2t = mac<AR>(ae, be, dW2t);                              // dW2c^T[out][hidden] += dT^T H'
-            }
-            // (c): its B operand is the cut gradient tile as this lane stored it (the accumulator registers of (b) in order: the pieces of
-            // k-block kb are the lane's chunks G = 2 kb, 2 kb + 1), read back instead of held in 16 registers across the segments
-            Frag gq[2][NP];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const uint2 lo = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4)));
-                    const uint2 hi = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4)));
-                    gq[kb][p].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-            f32x16 dx = zero;
-            dx = mac<AR>(w3[0], gq[0], dx); dx = mac<AR>(w3[1], gq[1], dx);
-            unsigned char* Tb = reinterpret_cast<unsigned char*>(TbAll + (((i - 1) & 1) * 8 + wave) * PS_TB);
-#pragma unroll
-            for (int G = 0; G < 4; ++G) *reinterpret_cast<float4*>(Tb + (w0 ^ (G << 5))) = make_float4(dx[4 * G], dx[4 * G + 1], dx[4 * G + 2], dx[4 * G + 3]);
-        }
-        if (hc) {
-            const unsigned char* Db = DA + b0 * PB_TILE;
-            Frag df[2][NP];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
-            dH = zero;
-            dH = mac<AR>(w2[0], df[0], dH); dH = mac<AR>(w2[1], df[1], dH);           // (b)
-        }
-#endif
-        // ---- the vector work of the phase (the scheduler deals it out between the MFMAs above: none of it depends on (d), (e), (c), (b)) ----
-#ifndef H3S_NOSUMS
-        if (roleB && hp2) {
-            // dX of tile i-2 = dOut + its eight chunk partials (complete since two segments), in the order of the chunks
-            if constexpr (!HOT) {
-                if (on != c2p.n) {                                     // the sums enter another sample: commit the finished one's largest |dX|
-                    if (on >= 0 && am.y) amax_commit(rf[0], am.y + on);
-                    on = c2p.n; rf[0] = 0.f;
-                }
-            }
-            const long sv0 = (long)c2p.n * vps + 32 * c2p.j;
-            const int snrem = HOT ? 32 : (vps - 32 * c2p.j < 32 ? vps - 32 * c2p.j : 32);
-            const float* Tp = TbAll + (i & 1) * 8 * PS_TB + rs;
-            float sa[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float4 t = *reinterpret_cast<const float4*>(Tp + jj * PS_TB);
-                sa[0] += t.x; sa[1] += t.y; sa[2] += t.z; sa[3] += t.w;
-            }
-            const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sa[k] = ldexpf(sa[k], -(rc[k] + c2p.eg())) + od[k];      // (c) partials -> true values: W1's cin row and the sample's dH scale
-            if (HOT || rrow < snrem) {
-                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX + sv0 * 32) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
-                rf[0] = fmaxf(fmaxf(rf[0], fmaxf(fabsf(sa[0]), fabsf(sa[1]))), fmaxf(fabsf(sa[2]), fabsf(sa[3])));
-            }
-        }
-#endif
-#ifndef H3S_NOSTAGE
-        // half A cuts and stages tile i+1 (requested one X phase ago): its buffer was last read two segments ago
-        if (roleA && hn) stage_store(hot_tag, bnext, cnext, nxv, nd);
-#endif
-#if !defined(H3S_NOGATE) && !defined(H3S_NOY)
-        if (hc) {
-            // bias, ReLU and cut of the hidden tile; its pieces go to the wave's H' image (whose previous content (e) has read above),
-            // relu(H) itself stays in registers for the gate in X(i)
-            const int kh = ccur.eh() - ccur.ex() - ew1;                            // (<= -17 always, see the bounds)
-            const float ch = pow2i(kh < -126 ? -126 : kh);
-            const float* sB = sB1 + (ccur.n & 1) * 256 + 32 * c + 4 * half;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                Frag hf[NP];
-                float hk[8];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {                          // registers 4G .. 4G+3 <-> hidden 32c + 8G + 4h + (0..3)
-                    const float4 bb = *reinterpret_cast<const float4*>(sB + 8 * (2 * kb + g));
-                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 8 * kb + 4 * g + e;
-                        hs[r] = fmaxf(fmaf(H[r], ch, bv[e]), 0.f);
-                        hk[4 * g + e] = hs[r];
-                    }
-                }
-                cut8_scaled<AR>(hk, hf);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ ((2 * kb) << 4))) = make_uint2(hf[p].u.x, hf[p].u.y);
-                    *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4))) = make_uint2(hf[p].u.z, hf[p].u.w);
-                }
-            }
-        }
-#endif
         }
         XS_ACC(2);
 #ifndef H3S_NOPRIO
@@ -1210,32 +1092,43 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
 #endif
         bar();
         XS_ACC(3);
-        between();
         // ================================ X(i) ================================
-        // requested here, used one phase on: the rows of tile i+2 (half A) / dOut of tile i-1, summed in Y(i+1) (half B)
-        if (roleA) { if (hnn) stage_load(hot_tag, cnn, nxv, nd); }
-        else if (hp) {
+        // requested here, used one phase on: the rows of tile i+2 (half A) / dOut of tile i-1, summed in Y(i+1) (half B); a ghost's
+        // request goes to the nearest real tile (its cursor) and is not used
+        if constexpr (ROLE == 0) stage_load(cnn, nxv, nd);
+        else {
             const long pv0 = (long)cprev.n * vps + 32 * cprev.j;
-            const int pnrem = HOT ? 32 : (vps - 32 * cprev.j < 32 ? vps - 32 * cprev.j : 32);
-            rdo = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dOut + pv0 * 32) + (HOT || rrow < pnrem ? ro : rq * 16u));
+            const int pnrem = vps - 32 * cprev.j < 32 ? vps - 32 * cprev.j : 32;
+            rdo = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dOut + pv0 * 32) + (rrow < pnrem ? ro : rq * 16u));
+        }
+        // ---- once per sample (scalar branches, rarely taken) ----
+        if (real_p && real_c && ccur.n != cprev.n) {
+            // (d), (e) and the db1 sums of tile i run at another sample's scales.  The running sums (tiles <= i-1, all three) move to the new
+            // scales by an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright one -- banks them
+            // in the slab instead and starts over.
+            const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
+            const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
+            if (big > 40) flush(cprev);
+            else if (big != 0) {
+                const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
+            }
+        }
+        if constexpr (ROLE == 0) {
+            // the biases at the next sample's hidden scale, in that sample's parity (first read in Y(i+1); the last reader of what this
+            // overwrites -- the sample before the current one -- was a Y phase before this segment)
+            if (real_n && cnext.n != ccur.n) sB1[(cnext.n & 1) * 256 + t8] = b1[t8] * pow2i(cnext.eh());
+        } else {
+            // Y(i+1) sums tile i-1: when that enters another sample, the finished one's largest |dX| is committed here
+            if (real_p && on != cprev.n) {
+                if (on >= 0 && am.y) amax_commit(rf[0], am.y + on);
+                on = cprev.n; rf[0] = 0.f;
+            }
         }
 #ifndef H3S_NOGATE
-        if (hc) {
-            if constexpr (!HOT) {
-                // (d), (e) and the db1 sums of tile i run at another sample's scales.  The running sums (tiles <= i-1, all three) move to the
-                // new scales by an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright one --
-                // banks them in the slab instead and starts over (`big_jump`: done by the caller, between two iterations' code, so that the
-                // slab code's registers are not part of this body)
-                if (hp && ccur.n != cprev.n) {
-                    const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
-                    const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
-                    if (big <= 40 && big != 0) {
-                        const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
-                    }
-                }
-            }
+        {
+            // gate of tile i (a ghost: dH = 0, so its gradient tile is zero whatever relu(bias) is)
             const int kg = ccur.eg() - ew2 - ccur.ed();
             const float cg = pow2i(kg < -126 ? -126 : kg);
 #pragma unroll
@@ -1245,7 +1138,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = 8 * kb + e;
-                    gs[e] = hs[r] > 0.f ? dH[r] * cg : 0.f;            // (relu(hv) > 0 exactly where hv > 0)
+                    gs[e] = H[r] > 0.f ? dH[r] * cg : 0.f;             // (H holds relu(hv) by now: > 0 exactly where hv > 0)
                     bs1v[r] += gs[e];
                 }
                 cut8_scaled<AR>(gs, gf);
@@ -1257,43 +1150,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             }
         }
 #endif
-        if constexpr (!HOT) {
-            // the biases at the next sample's hidden scale, in that sample's parity (first read in Y(i+1); the last reader of what this overwrites
-            // -- the sample before the current one -- was a Y phase before this segment)
-            if (hb == 0 && hn && cnext.n != ccur.n) sB1[(cnext.n & 1) * 256 + t8] = b1[t8] * pow2i(cnext.eh());
-        }
         XS_ACC(5);
-        if constexpr (HOT) ++ccur.j;
-        else {
-            c2p = cprev; cprev = ccur; ccur = cnext; cnext = cnn;
-            if (i + 3 < nt) advance(cnn);
-        }
+        c2p = cprev; cprev = ccur; ccur = cnext; cnext = cnn;
+        if (i + 3 < nt) advance(cnn);
         b0 = bnext;
     };
     if (hb) bar();                                                 // half B starts one segment late ...
-    {
-        int i = 0;
-        while (i < nt + 2) {
-            // tiles i-2 .. i+3 inside one sample and inside the run: 3 <= j(i) <= tps - 4 and 2 <= i <= nt - 4 -- a stretch of the hot loop
-            // (tps - 4: the sample's last tile, the only one that may be partial, stays outside)
-            int cnt = (i >= 2 && i < nt && ccur.j >= 3) ? min(tps - 3 - ccur.j, nt - 3 - i) : 0;
-            if (cnt > 0) {
-                if (hb) for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 1>(), i, [] {});
-                else for (; cnt > 0; --cnt, ++i) iter(std::true_type(), std::integral_constant<int, 0>(), i, [] {});
-                // back to separate cursors: all of them still inside the sample
-                c2p = ccur; c2p.j -= 2; cprev = ccur; cprev.j -= 1; cnext = ccur; cnext.j += 1; cnn = ccur; cnn.j += 2;
-            } else {
-                iter(std::false_type(), std::integral_constant<int, 2>(), i, [&] {
-                    // between Y(i) and X(i): the running sums hold tiles <= i-1; a jump of the scales too large to carry them along banks them
-                    if (i >= 1 && i < nt && ccur.n != cprev.n) {
-                        const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
-                        if (max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3) > 40) flush_cold(cprev);
-                    }
-                });
-                ++i;
-            }
-        }
-    }
+    if (hb) for (int i = 0; i < nt + 2; ++i) iter(std::integral_constant<int, 1>(), i);
+    else for (int i = 0; i < nt + 2; ++i) iter(std::integral_constant<int, 0>(), i);
     if (!hb) bar();                                                // ... and half A waits for its last one
     __syncthreads();
     if (hb && on >= 0 && am.y) amax_commit(rf[0], am.y + on);
