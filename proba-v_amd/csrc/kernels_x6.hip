@@ -1108,8 +1108,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
             // in the slab instead and starts over.
             const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
             const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
+#ifndef H3S_NOFLUSH              /* (instruction-count builds only: tools/isa_budget.py) */
             if (big > 40) flush(cprev);
-            else if (big != 0) {
+            else
+#endif
+            if (big != 0) {
                 const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
