@@ -31,6 +31,11 @@ namespace probav {
 // ---------------------------------------------------------------------------------------------------
 // Workgroup shape: the X6 weight images (2 x 48 KB) leave room for one workgroup per CU, so it is 12 waves wide; the H3 images
 // (2 x 32 KB) fit twice: two workgroups of 8 waves = 4 waves per SIMD instead of 3.
+#ifdef PROBAV_STAMP
+#define PF_ACC(k) do { __builtin_amdgcn_sched_barrier(0); XS_ACC(k); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PF_ACC(k) do { } while (0)
+#endif
 template <class AR> struct PwfShape { static constexpr int WAVES = 12, WGS = 1; };
 template <> struct PwfShape<H3> { static constexpr int WAVES = 8, WGS = 2; };
 
@@ -92,7 +97,12 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
         }
     };
     if (tb < te) load_x(n, j);
+    XS_DECL;
+#ifdef PROBAV_STAMP
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (long tile = tb; tile < te; ++tile) {
+        PF_ACC(5);
         const int vl = 32 * j + col;                                 // voxel inside the sample
         const bool vok = vl < vps;
         const long v = (long)n * vps + (vok ? vl : vps - 1);
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
             cut8<AR>(xs, sx, xb[kb]);
         }
         if (tile + 1 < te) { const bool wrap = j + 1 == tps; load_x(wrap ? n + 1 : n, wrap ? 0 : j + 1); }
+        PF_ACC(1);
         f32x16 T;
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[r] = 0.f;
@@ -123,6 +134,10 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
                 for (int p = 0; p < NP; ++p) a[p].u = *reinterpret_cast<const uint4*>(wc + (kb * NP + p) * 1024);
                 H = mac<AR>(a, xb[kb], H);
             }
+#ifdef PROBAV_STAMP
+            asm volatile("s_nop 0" :: "v"(H[0]));
+#endif
+            PF_ACC(2);
             // bias + ReLU, then split the hidden tile: registers 8kb .. 8kb+7 are k-block kb of the second product
             Frag hb[2][NP];
 #pragma unroll
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
                     }
                 }
             }
+            PF_ACC(3);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 Frag a[NP];
@@ -152,6 +168,7 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
                 for (int p = 0; p < NP; ++p) a[p].u = *reinterpret_cast<const uint4*>(wc + W2OFF + (kb * NP + p) * 1024);
                 T = mac<AR>(a, hb[kb], T);
             }
+            PF_ACC(4);
         }
         if (vok) {
             // registers 4g .. 4g+3 are the four CONSECUTIVE output channels 8g + 4h + (0..3) of this lane's voxel: one 16-byte store each
@@ -185,6 +202,10 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
         }
     }
     if (am.y && j != 0 && tb < te) amax_commit(omax, am.y + n);
+#ifdef PROBAV_STAMP
+    xs_acc[6] = __builtin_amdgcn_s_memrealtime() - rt0;
+#endif
+    XS_OUT;
 }
 
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     // a tile: sample, tile inside it, and the sample's four exponents (X, dT, hidden tile, its gradient; each in [-113, 60]) packed into one
     // scalar register -- three tiles are in flight (being staged / computed / summed) and scalar registers are scarce
     struct Cur {
-        int n, j, e4;
+        int n, j, e4, v0;                                           // v0: the tile's first voxel (nvox < 2^31: checked by the launcher)
         __device__ __forceinline__ int ex() const { return (int)(signed char)(e4 & 0xff); }
         __device__ __forceinline__ int ed() const { return (int)(signed char)((e4 >> 8) & 0xff); }
         __device__ __forceinline__ int eh() const { return (int)(signed char)((e4 >> 16) & 0xff); }
@@ -733,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
         q.e4 = __builtin_amdgcn_readfirstlane((ex & 0xff) | ((ed & 0xff) << 8) | ((eh & 0xff) << 16) | (eg << 24));
     };
     const int tps = (vps + 31) >> 5;                              // tiles per sample
-    auto advance = [&](Cur& q) { if (++q.j == tps) { q.j = 0; ++q.n; load_scales(q); } };
+    auto advance = [&](Cur& q) { if (++q.j == tps) { q.j = 0; ++q.n; q.v0 = q.n * vps; load_scales(q); } else q.v0 += 32; };
 
     Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
 #pragma unroll
@@ -783,11 +804,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     // beyond 32 D (the last of the four when D < 32) is branch-free: it writes a zero into the zero pad of voxel 0 (rc[] points there).
     const bool dvalid3 = t8 + 768 < 32 * D;
     auto stage_load = [&](const Cur& q, float4& xv, float (&d)[4]) {
-        const long v0 = (long)q.n * vps + 32 * q.j;
         const int nrem = vps - 32 * q.j < 32 ? vps - 32 * q.j : 32;
-        const char* xb = reinterpret_cast<const char*>(x + v0 * 32);
+        const char* xb = reinterpret_cast<const char*>(x) + ((unsigned long)(unsigned)q.v0 << 7);
         xv = *reinterpret_cast<const float4*>(xb + (rrow < nrem ? ro : rq * 16u));
-        const char* db = reinterpret_cast<const char*>(dT + v0 * D);
+        const char* db = reinterpret_cast<const char*>(dT) + ((unsigned long)(unsigned)(q.v0 * D) << 2);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned f = t8 + 256 * k;
@@ -861,9 +881,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     // are not stored.  A ghost behind the run is staged as zeros: dT = 0 makes its gradient tile, its db1 / dW terms and its partial
     // vanish whatever relu(bias) is.  So no iteration needs a program of its own (a separate cold instance spilled 200 registers and
     // took 1.7x a hot iteration: a tenth of the kernel).  A ghost's cursor is a copy of the nearest real tile's.
-    Cur c2p = {0, 0, 0}, cprev = c2p, ccur = c2p, cnext = c2p, cnn = c2p;
+    Cur c2p = {0, 0, 0, 0}, cprev = c2p, ccur = c2p, cnext = c2p, cnn = c2p;
     if (nt > 0) {
-        ccur.n = tbeg / tps; ccur.j = tbeg - ccur.n * tps; load_scales(ccur);
+        ccur.n = tbeg / tps; ccur.j = tbeg - ccur.n * tps; ccur.v0 = ccur.n * vps + 32 * ccur.j; load_scales(ccur);
         cnext = ccur; if (nt > 1) advance(cnext);
         cnn = cnext; if (nt > 2) advance(cnn);
         c2p = cprev = ccur;
@@ -950,8 +970,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
                 const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sa[k] = ldexpf(sa[k], -(rc[k] + c2p.eg())) + od[k];      // (c) partials -> true values: W1's cin row and the sample's dH scale
-                const long sv0 = (long)c2p.n * vps + 32 * c2p.j;
-                if (rrow < snrem) *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX + sv0 * 32) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+                if (rrow < snrem) *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX) + ((unsigned long)(unsigned)c2p.v0 << 7) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
             };
             auto sums_max = [&]() {
                 const float m = fmaxf(fmaxf(fabsf(sa[0]), fabsf(sa[1])), fmaxf(fabsf(sa[2]), fabsf(sa[3])));
@@ -1097,9 +1116,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
         // request goes to the nearest real tile (its cursor) and is not used
         if constexpr (ROLE == 0) stage_load(cnn, nxv, nd);
         else {
-            const long pv0 = (long)cprev.n * vps + 32 * cprev.j;
             const int pnrem = vps - 32 * cprev.j < 32 ? vps - 32 * cprev.j : 32;
-            rdo = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dOut + pv0 * 32) + (rrow < pnrem ? ro : rq * 16u));
+            rdo = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dOut) + ((unsigned long)(unsigned)cprev.v0 << 7) + (rrow < pnrem ? ro : rq * 16u));
         }
         // ---- once per sample (scalar branches, rarely taken) ----
         if (real_p && real_c && ccur.n != cprev.n) {
@@ -1196,7 +1214,8 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_backward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
-        static const bool same_program = getenv("PROBAV_PW_BWD_V1") != nullptr;      // diagnostic / A-B runs: the one-program form (same bits)
+        static const bool v1_env = getenv("PROBAV_PW_BWD_V1") != nullptr;      // diagnostic / A-B runs: the one-program form (same bits)
+        const bool same_program = v1_env || nvox * 32 >= (1L << 31);            // (the alternating-halves kernel keeps voxel indices in 32-bit scalars)
         if (!same_program) {
             const size_t lds = (size_t)6 * H3::NP * PB_IMG + ((size_t)16 * PS_TB + 512) * sizeof(float) + (size_t)8 * 2 * H3::NP * PS_IMG;       // = 160 KB
             hipLaunchKernelGGL(pw_bwd_h3s_kernel, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,

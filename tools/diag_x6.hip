@@ -61,6 +61,29 @@ int main()
             printf("\n");
         }
     }
+    {   // fused pointwise forward (stamps: 1 cut of X, 2 W1 reads + (a), 3 bias / ReLU / cut, 4 W2 reads + decay product, 5 epilogue + stores)
+        const long nvox = (long)B * 22 * 22 * 9;
+        const int D = 25;
+        float *xx, *dec, *w, *b1, *b2;
+        hipMalloc(&xx, nvox * 32 * 4); hipMalloc(&dec, nvox * D * 4); hipMalloc(&w, 3 * X6_PW_FRAG_WORDS * 4); hipMalloc(&b1, 256 * 4); hipMalloc(&b2, 32 * 4);
+        hipMemcpy(xx, h.data(), nvox * 32 * 4, hipMemcpyHostToDevice);
+        hipMemset(w, 0x3c, 3 * X6_PW_FRAG_WORDS * 4); hipMemset(b1, 0, 256 * 4); hipMemset(b2, 0, 32 * 4);
+        for (int it = 0; it < 3; ++it) x6_pw_forward(xx, w, w + X6_PW_FRAG_WORDS, b1, b2, dec, nvox, 22 * 22 * 9, D, ARITH, pam, 0);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+        const char* nm[8] = {"t0", "cut of X", "W1 reads + (a)", "bias / ReLU / cut", "W2 reads + decay product", "epilogue + stores (+ loop)", "-", "t_end"};
+        for (int wave = 0; wave < 8; wave += 3) {
+            double acc[8] = {0}; double life = 0;
+            for (int b = 0; b < 512; ++b) {
+                const unsigned long long* s = &st[(b * 8 + wave) * 8];
+                for (int k = 1; k < 7; ++k) acc[k] += (double)s[k];
+                life += (double)(s[7] - s[0]);
+            }
+            printf("pw_fwd wave %d: life %.0f cyc/WG, in-kernel clock %.2f GHz |", wave, life / 512, acc[6] > 0 ? life / acc[6] * 0.1 : 0.0);
+            for (int k = 1; k < 6; ++k) printf(" %s %.1f%%", nm[k], 100.0 * acc[k] / life);
+            printf("\n");
+        }
+    }
     {   // fused pointwise backward
         const long nvox = (long)B * 22 * 22 * 9;
         const int D = 25;
