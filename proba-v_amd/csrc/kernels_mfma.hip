@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pstrip_kernel(StripArgs a, const
 // Ring: `nslot` rows (pp_plan(): the rows of two consecutive segments never collide); records, swizzle, filter fragments and the
 // gathered channel-24 chunk are those of conv3_pstrip_kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int CIN, bool GATE, int RVP>
+template <int CIN, bool GATE, int RVP, bool K32 = false>
 __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const float* __restrict__ x, const float* __restrict__ gate,
                                                          const uint4* __restrict__ wfrag, const float* __restrict__ bias,
                                                          const float* __restrict__ skip, float* __restrict__ y, Amax am)
@@ -1615,6 +1615,19 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     float* ybase = y + out_base * g.Cout;
     const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
     const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
+    // K32 form (v_mfma_f32_16x16x32_f16, 32 input channels = ONE k-block per tap): the 32 x 32 tile is four 16 x 16 accumulators (voxel
+    // half u, channel half v); a lane holds column 16 v + m16 of both channel halves, so the filter column's exponent and the bias come in pairs
+    const int m16 = lane & 15, kq = lane >> 4;
+    int eun16[2] = {0, 0};
+    float bv16[2] = {0.f, 0.f};
+    if constexpr (K32) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int c = 16 * v + m16;
+            eun16[v] = -(ea + h3_exp_w(am.w[c < g.Cout ? c : 0]));
+            bv16[v] = (bias && c < g.Cout) ? bias[c] : 0.f;
+        }
+    }
     auto elem_off_ch = [&](int vi, int ch) -> int {
         if (a.nsplit == 1) return vi * g.Cout + ch;
         const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
@@ -1798,10 +1811,26 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         const uint4* pw = wfrag + ((long)gg * NST + st) * NP * 64;      // wave-uniform base + lane: scalar-base loads
         wq[0].u = pw[lane]; wq[1].u = pw[64 + lane];
     };
+    // K32 form: the fragments of PACK_H3_CONV are read with another lane order.  A 16x16x32 B operand wants, in lane (m16, kq), k = 8 kq .. 8 kq + 7 of
+    // column 16 v + m16: that is lane (16 v + m16) + 32 (kq & 1) of the 32x32x16 fragment kb = kq >> 1 -- the same 16 bytes, no second packed copy.
+    // Ring of THREE taps: slot dt of every (dh, dw) group; W[2 dt + v], A[2 dt + u].
+    const int wl16 = ((kq >> 1) * 128 + 32 * (kq & 1) + m16) << 4;          // byte offset inside a tap's 4 KB (piece: + 1024, channel half v: + 256)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wfrag), 0, 27 * 4096, 0x00020000);   // (K32: scalar base + 32-bit lane offset + immediate)
+    typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+    auto wload16 = [&](int tap, int off) -> uint4 {
+        const u32x4b r = __builtin_amdgcn_raw_buffer_load_b128(wrs, wl16 + off, tap * 4096, 0);
+        return make_uint4(r[0], r[1], r[2], r[3]);
+    };
+    auto request_W16_p0 = [&](int tap, int sl) { W[2 * sl][0].u = wload16(tap, 0); W[2 * sl + 1][0].u = wload16(tap, 256); };       // piece 0 of both channel halves
+    auto request_W16_p1 = [&](int tap, int sl) { W[2 * sl][1].u = wload16(tap, 1024); W[2 * sl + 1][1].u = wload16(tap, 1280); };
+    auto request_W16 = [&](int tap, int sl) { request_W16_p0(tap, sl); request_W16_p1(tap, sl); };
     // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
     if (grp == 0) {
+        if constexpr (K32) { request_W16(0, 0); request_W16(1, 1); }
+        else {
 #pragma unroll
-        for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
+            for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
+        }
     }
 #pragma unroll 1
     for (int sg = 0; sg <= nseg; ++sg) {
@@ -1809,6 +1838,105 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         if (grp == (sg & 1)) {
             // ---- taps of one whole tile ----
             const int tile = 4 * sg + tsel;
+            if constexpr (K32) {
+              if (sg < nseg && tile < NTL) {
+                typedef float f32x4a __attribute__((ext_vector_type(4)));
+                f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: voxels 16 u + 4 kq + i, channel 16 v + m16
+                const int dwb = a.Tp * REC;
+                int rbu[2][3];                                               // byte address of the lane's record (voxel half u) in ring row hrel + dh, tap (dw, dt) = (0, 0)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int vi = tile * 32 + 16 * u + m16;
+                    vi = vi < NV ? vi : NV - 1;
+                    const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+                    const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+                    const int vox0 = w * a.Tp + t;
+                    const int s0 = hrel - fdiv(hrel, NS, a.mNslot) * NS;
+                    const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
+                    rbu[u][0] = s0 * rowbytes + vox0 * REC; rbu[u][1] = s1 * rowbytes + vox0 * REC; rbu[u][2] = s2 * rowbytes + vox0 * REC;
+                }
+                struct GroupAddr { int gb, k4[3]; };
+                auto group_addr = [&](int base) -> GroupAddr {
+                    GroupAddr q;
+                    q.gb = base;
+                    const int r7 = base >> 7;
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) q.k4[dt] = ((r7 + dt) << 3) & 0x70;
+                    return q;
+                };
+                const int cq = kq << 4;                                      // the lane's chunk (8 channels) of its record, unswizzled byte offset
+                auto addr_A16 = [&](const GroupAddr& ga, int dt) -> int { return (cq ^ ga.k4[dt]) + ga.gb; };
+                auto request_A16 = [&](const GroupAddr& ga, int dt, Frag (&af)[NP]) {
+                    const int a0 = addr_A16(ga, dt);
+                    af[0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * REC);
+                    af[1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64) + dt * REC);
+                };
+#define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[AF][pa].h, W[WF][pb].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+                // One tap = one k-block = twelve MFMAs (three piece pairs x four accumulators, never the same accumulator twice in a row).  A 16x16x32
+                // MFMA leaves the wave 12 issue cycles: the requests of the tap after next (ring slot of the tap before this one) go out two at a time
+                // in the gaps after the first six -- filters first (the longer latency), in the order the MFMAs will want them (pieces (1, 0) first).
+                auto group = [&](int gg, const GroupAddr (&ga)[2], const GroupAddr (&gan)[2], auto last_tag) {
+                    constexpr bool LAST = decltype(last_tag)::value;
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) {
+                        const bool same = dt == 0;                            // tap after next: (gg, 2) from tap 0, (gg + 1, dt - 1) otherwise
+                        const int sq = same ? 2 : dt - 1;
+                        const bool req = same || !LAST;
+                        const int tq_ = (same ? gg : gg + 1) * 3 + sq;
+                        const int a0 = 2 * dt, a1 = 2 * dt + 1;
+                        int ad0 = 0, ad1 = 0;
+                        PP_MM(a0, a0, c00, 1, 0);
+                        if (req) request_W16_p0(tq_, sq);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(a0, a1, c01, 1, 0);
+                        if (req) request_W16_p1(tq_, sq);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(a1, a0, c10, 1, 0);
+                        if (req) { ad0 = addr_A16(same ? ga[0] : gan[0], sq); ad1 = addr_A16(same ? ga[1] : gan[1], sq); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(a1, a1, c11, 1, 0);
+                        if (req) { A[2 * sq][1].u = *reinterpret_cast<const uint4*>(plds + (ad0 ^ 64) + sq * REC); A[2 * sq + 1][1].u = *reinterpret_cast<const uint4*>(plds + (ad1 ^ 64) + sq * REC); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(a0, a0, c00, 0, 1);
+                        if (req) { A[2 * sq][0].u = *reinterpret_cast<const uint4*>(plds + ad0 + sq * REC); A[2 * sq + 1][0].u = *reinterpret_cast<const uint4*>(plds + ad1 + sq * REC); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(a0, a1, c01, 0, 1); PP_MM(a1, a0, c10, 0, 1); PP_MM(a1, a1, c11, 0, 1);
+                        PP_MM(a0, a0, c00, 0, 0); PP_MM(a0, a1, c01, 0, 0); PP_MM(a1, a0, c10, 0, 0); PP_MM(a1, a1, c11, 0, 0);
+                    }
+                };
+                auto row_groups = [&](int dh, const int (&rbh)[2], const int (&rbn)[2], auto last_tag) {
+                    constexpr bool LASTROW = decltype(last_tag)::value;
+                    const GroupAddr g0[2] = {group_addr(rbh[0]), group_addr(rbh[1])}, g1[2] = {group_addr(rbh[0] + dwb), group_addr(rbh[1] + dwb)};
+                    const GroupAddr g2[2] = {group_addr(rbh[0] + 2 * dwb), group_addr(rbh[1] + 2 * dwb)}, gn[2] = {group_addr(rbn[0]), group_addr(rbn[1])};
+                    group(3 * dh, g0, g1, std::false_type());
+                    group(3 * dh + 1, g1, g2, std::false_type());
+                    group(3 * dh + 2, g2, gn, std::integral_constant<bool, LASTROW>());
+                };
+                {
+                    const GroupAddr gu0 = group_addr(rbu[0][0]), gu1 = group_addr(rbu[1][0]);
+                    request_A16(gu0, 0, A[0]); request_A16(gu1, 0, A[1]);
+                    request_A16(gu0, 1, A[2]); request_A16(gu1, 1, A[3]);
+                }
+#ifndef PPX_NOTAPS
+#pragma unroll 1
+                for (int dh = 0; dh < 2; ++dh) {
+                    const int rh[2] = {dh == 0 ? rbu[0][0] : rbu[0][1], dh == 0 ? rbu[1][0] : rbu[1][1]};
+                    const int rn[2] = {dh == 0 ? rbu[0][1] : rbu[0][2], dh == 0 ? rbu[1][1] : rbu[1][2]};
+                    row_groups(dh, rh, rn, std::false_type());
+                }
+                {
+                    const int rh[2] = {rbu[0][2], rbu[1][2]};
+                    row_groups(2, rh, rh, std::true_type());
+                }
+#endif
+#undef PP_MM
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i] = c00[i]; acc[4 + i] = c01[i]; acc[8 + i] = c10[i]; acc[12 + i] = c11[i]; }
+#if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
+                load_skip(tile);
+#endif
+              }
+            } else
             if (sg < nseg && tile < NTL) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1931,11 +2059,21 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if (do_load && !have_nv) stage_load(hiq + 1, nv_);               // (only the very first finishing segment: no taps came before it)
             have_nv = false;
             if (fin) {
+                if constexpr (K32) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = ldexpf(acc[i], eun) + bv;                       // the filter column's exponent and the bias are per lane in the accumulator layout
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    turn[rowmap(i, half) * 32 + col] = v;
+                    for (int i = 0; i < 16; ++i) {                            // acc[4 (2 u + v) + r]: voxel 16 u + 4 kq + r, channel 16 v + m16
+                        const int u = i >> 3, v_ = (i >> 2) & 1, r = i & 3;
+                        float v = ldexpf(acc[i], eun16[v_]) + bv16[v_];
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        turn[(16 * u + 4 * kq + r) * 32 + 16 * v_ + m16] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float v = ldexpf(acc[i], eun) + bv;                   // the filter column's exponent and the bias are per lane in the accumulator layout
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        turn[rowmap(i, half) * 32 + col] = v;
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (a wave's LDS operations execute in order: the wait orders the compiler)
                 float4 tq[4];
@@ -1970,8 +2108,11 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 }
             }
             if (sg + 1 < nseg) {
+                if constexpr (K32) { request_W16(0, 0); request_W16(1, 1); }
+                else {
 #pragma unroll
-                for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
+                    for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
+                }
             }
             XS_ACC(3);
         }
@@ -2090,6 +2231,8 @@ bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith)
     return arith == 2 && (pstrip_plan(g, pp) || (!pp_disabled() && pp_plan(g, pp, rvp)));   // (the alternating-halves form also takes rows shorter than 128 voxels: the later reducers)
 }
 
+int g_pp_k16 = -1;     // 1: 32 input channels through the 32x32x16 form (PROBAV_PP_K16; diagnostics flip it between launches)
+
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
                         const float* skip, float* y, int arith, const Amax& am, hipStream_t s)
 {
@@ -2103,11 +2246,23 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
                 allow_big_lds(conv3_pp_kernel<25, false, 2>); allow_big_lds(conv3_pp_kernel<25, true, 2>);
                 allow_big_lds(conv3_pp_kernel<32, false, 2>); allow_big_lds(conv3_pp_kernel<32, true, 2>);
                 allow_big_lds(conv3_pp_kernel<25, false, 3>); allow_big_lds(conv3_pp_kernel<25, true, 3>);
-                allow_big_lds(conv3_pp_kernel<32, false, 3>); allow_big_lds(conv3_pp_kernel<32, true, 3>); });
+                allow_big_lds(conv3_pp_kernel<32, false, 3>); allow_big_lds(conv3_pp_kernel<32, true, 3>);
+                allow_big_lds(conv3_pp_kernel<32, false, 2, true>); allow_big_lds(conv3_pp_kernel<32, true, 2, true>);
+                allow_big_lds(conv3_pp_kernel<32, false, 3, true>); allow_big_lds(conv3_pp_kernel<32, true, 3, true>); });
+            // 32 input channels: the 16x16x32 MFMA form (one k-block per tap) unless PROBAV_PP_K16 asks for the 32x32x16 one (A/B runs; bit-identical sums are not
+            // expected between the two: the order of the k-partial sums inside the matrix pipe differs)
+            if (g_pp_k16 < 0) g_pp_k16 = getenv("PROBAV_PP_K16") != nullptr ? 1 : 0;
+            const bool k16_env = g_pp_k16 == 1;
 #define PROBAV_PP(C, G, R) hipLaunchKernelGGL((conv3_pp_kernel<C, G, R>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
 #define PROBAV_PP_R(C, G) do { if (rvp == 2) PROBAV_PP(C, G, 2); else PROBAV_PP(C, G, 3); } while (0)
             if (g.Cin == 25) { if (gate) PROBAV_PP_R(25, true); else PROBAV_PP_R(25, false); }
-            else             { if (gate) PROBAV_PP_R(32, true); else PROBAV_PP_R(32, false); }
+            else if (k16_env) { if (gate) PROBAV_PP_R(32, true); else PROBAV_PP_R(32, false); }
+            else {
+#define PROBAV_PPK(G, R) hipLaunchKernelGGL((conv3_pp_kernel<32, G, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
+                if (gate) { if (rvp == 2) PROBAV_PPK(true, 2); else PROBAV_PPK(true, 3); }
+                else      { if (rvp == 2) PROBAV_PPK(false, 2); else PROBAV_PPK(false, 3); }
+#undef PROBAV_PPK
+            }
 #undef PROBAV_PP_R
 #undef PROBAV_PP
             return check_launch("conv3_pp");
