@@ -31,14 +31,17 @@ for _ in range(REPS):                                # repeatedly: later passes 
     torch.cuda.synchronize()
     h.update(pred.detach().cpu().numpy().tobytes()); h.update(model.flat.grad.cpu().numpy().tobytes())
 print("DIGEST", h.hexdigest())
+if len(sys.argv) > 4:                                # the last pass' values, for comparisons with a tolerance
+    import numpy as np
+    np.savez(sys.argv[4], pred=pred.detach().cpu().numpy(), grad=model.flat.grad.cpu().numpy())
 """ % ROOT
 
 
-def _run(extra_env, B=5, T=9, reps=2):
+def _run(extra_env, B=5, T=9, reps=2, dump=None):
     env = dict(os.environ)
     env.pop("PROBAV_NO_SIDE_STREAM", None)
     env.update(extra_env)
-    out = subprocess.run([sys.executable, "-c", SCRIPT, str(B), str(T), str(reps)], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", SCRIPT, str(B), str(T), str(reps)] + ([dump] if dump else []), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     return [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
 
@@ -103,3 +106,18 @@ def test_pointwise_backward_schedules_agree_bit_for_bit(B, T):
     same order as the one-program form (pw_bwd_x6_kernel<H3>, PROBAV_PW_BWD_V1=1): predictions and all 132 gradients of the whole
     network are identical, bit for bit."""
     assert _run({}, B, T, 2) == _run({"PROBAV_PW_BWD_V1": "1"}, B, T, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
+def test_mfma_shapes_of_the_32_channel_strip_kernel_agree(B, T, tmp_path):
+    """conv3_pp_kernel with 32 input channels (backward-data of the residual blocks, the reducers) runs on v_mfma_f32_16x16x32_f16 by default and
+    on v_mfma_f32_32x32x16_f16 under PROBAV_PP_K16=1.  Same pieces, same products; the matrix pipe sums 32 against 16 of them per instruction,
+    so the fp32 results may differ in the last bits and no more: predictions to 1e-6 of their range, the flat gradient vector to 1e-5 of its max-norm."""
+    import numpy as np
+    a, b = str(tmp_path / "k32.npz"), str(tmp_path / "k16.npz")
+    _run({}, B, T, 1, a)
+    _run({"PROBAV_PP_K16": "1"}, B, T, 1, b)
+    A, Bv = np.load(a), np.load(b)
+    assert np.abs(A["pred"] - Bv["pred"]).max() <= 1e-6 * np.abs(Bv["pred"]).max()
+    assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-5 * np.abs(Bv["grad"]).max()
