@@ -29,6 +29,9 @@ namespace probav {
 
 // In-kernel phase stamps for tools/diag_conv.hip (a separate diagnostic build defines PROBAV_STAMP; the product
 // library never does, so no stamp executes in it).  Stamps go to a buffer nothing else reads.
+#if defined(PROBAV_STAMP_CLOCK) && !defined(PROBAV_STAMP)
+__device__ unsigned long long g_stamps[8192 * 8];
+#endif
 #ifdef PROBAV_STAMP
 __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1649,6 +1652,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     const int nvs = Wl * g.Ti, items = nvs * NCH;                            // pp_plan(): items <= 256 * RVP, nvs <= 256
     struct Staged { float v[RVP][8]; float g3[3]; float m[GATE ? RVP : 1][8]; float m3[3]; };   // m, m3: the gate tensor's values (GATE), applied in stage_store
     int s_src[RVP], s_vd[RVP], s_cc[RVP], s_live[RVP];                      // source offset (floats) inside an input row, record, chunk, 1 = inside the patch's columns
+    int s_key[RVP], s3_key = 0;                                              // the records' swizzle keys (stage_store)
     int s3_src = 0, s3_vd = 0, s3_m = 0;                                    // gathered chunk: offset of (voxel, channel 24), record, validity bits of depths t-1, t, t+1 (bit 3: item exists)
     {
         auto locate = [&](int lv, int& lw, int& t, int& iwc, int& colok) {
@@ -1668,6 +1672,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             locate(lv, lw, t, iwc, colok);
             s_src[k] = (iwc * g.Ti + t) * CIN + 8 * cc;
             s_vd[k] = it < items ? lw * a.Tp + t + g.pt : -1;
+            s_key[k] = K32 ? (((lw * (a.Tp - 2) + t + g.pt) >> 1) & 3) << 1 : ((lw * (a.Tp - 2) + t + g.pt) >> 1) & 7;
             s_cc[k] = cc;
             s_live[k] = colok;
         }
@@ -1677,6 +1682,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             locate(lv, lw, t, iwc, colok);
             s3_src = (iwc * g.Ti + t) * CIN + 24;
             s3_vd = lw * a.Tp + t;                                             // (indexed by PADDED depth t' = t: the chunk holds padded depths t', t'+1, t'+2 = input depths t-1, t, t+1)
+            s3_key = ((lw * (a.Tp - 2) + t) >> 1) & 7;
             s3_m = (colok && t - 1 >= 0 ? 1 : 0) | (colok ? 2 : 0) | (colok && t + 1 < g.Ti ? 4 : 0) | (gtid < nvs ? 8 : 0);
         }
     }
@@ -1713,7 +1719,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     auto stage_store = [&](int q, Staged& sv) {
         const int sl = q - fdiv(q, NS, a.mNslot) * NS;
         unsigned char* slot = plds + sl * rowbytes;
-        const int rec0 = sl * a.Wp * a.Tp;                                   // absolute record index of the slot's first record (the swizzle key)
         const int ih = hb - g.ph + q;
         const int rok = (ih >= 0 && ih < g.Hi) ? 1 : 0;
 #pragma unroll
@@ -1729,7 +1734,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 Frag f[NP];
                 cut8<AR>(sv.v[k], sa, f);
                 unsigned char* rec = slot + s_vd[k] * REC;
-                const int sw = ((rec0 + s_vd[k]) >> 1) & 7;
+                // Swizzle key of a record at padded coordinates (w', t'): made of x = w' (Tp - 2) + t', NOT of the record index w' Tp + t'.  x runs on through
+                // a tile's voxels (t fastest) where the record index jumps by 3 at every column change, and its parity is the record's (address bit 7), so the
+                // sixteen lanes of a ds_read_b128 group -- voxels {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a tile reading ONE chunk (32x32x16 forms) --
+                // get sixteen different bank groups from key = (x >> 1) & 7 on the three chunk bits.  (With the record index in x's place 62 % of the LDS
+                // cycles of these kernels were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; 11 % now, at tile rows that wrap.)
+                // K32 form: a lane group holds 16 voxels of which eight read chunk c and eight chunk c ^ 1, so bit 0 stays the chunk's own and the key is
+                // the two bits (x >> 1) & 3 on chunk bits 1..2: any eight consecutive voxels get eight bank groups.
+                const int sw = s_key[k];
                 *reinterpret_cast<uint4*>(rec + ((s_cc[k] ^ sw) << 4)) = f[0].u;
                 *reinterpret_cast<uint4*>(rec + (((4 + s_cc[k]) ^ sw) << 4)) = f[1].u;
             }
@@ -1748,7 +1760,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 Frag f[NP];
                 cut8<AR>(v8, sa, f);
                 unsigned char* rec = slot + s3_vd * REC;
-                const int sw = ((rec0 + s3_vd) >> 1) & 7;
+                const int sw = s3_key;
                 *reinterpret_cast<uint4*>(rec + ((3 ^ sw) << 4)) = f[0].u;
                 *reinterpret_cast<uint4*>(rec + ((7 ^ sw) << 4)) = f[1].u;
             }
@@ -1821,12 +1833,21 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         const u32x4b r = __builtin_amdgcn_raw_buffer_load_b128(wrs, wl16 + off, tap * 4096, 0);
         return make_uint4(r[0], r[1], r[2], r[3]);
     };
-    auto request_W16_p0 = [&](int tap, int sl) { W[2 * sl][0].u = wload16(tap, 0); W[2 * sl + 1][0].u = wload16(tap, 256); };       // piece 0 of both channel halves
-    auto request_W16_p1 = [&](int tap, int sl) { W[2 * sl][1].u = wload16(tap, 1024); W[2 * sl + 1][1].u = wload16(tap, 1280); };
-    auto request_W16 = [&](int tap, int sl) { request_W16_p0(tap, sl); request_W16_p1(tap, sl); };
+#ifdef PPX_WD
+    constexpr int WD = PPX_WD;
+#else
+    constexpr int WD = 4;                                                    // depth of the K32 form's filter ring (taps)
+#endif
+    Frag WK[K32 ? 2 * WD : 1][NP];
+    auto request_W16_p0 = [&](int tap, int sl) { WK[2 * sl][0].u = wload16(tap, 0); WK[2 * sl + 1][0].u = wload16(tap, 256); };       // piece 0 of both channel halves
+    auto request_W16_p1 = [&](int tap, int sl) { WK[2 * sl][1].u = wload16(tap, 1024); WK[2 * sl + 1][1].u = wload16(tap, 1280); };
+    auto request_W16_first = [&]() {                                         // the first WD - 1 taps of a tile
+#pragma unroll
+        for (int T = 0; T < WD - 1; ++T) { request_W16_p0(T, T); request_W16_p1(T, T); }
+    };
     // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
     if (grp == 0) {
-        if constexpr (K32) { request_W16(0, 0); request_W16(1, 1); }
+        if constexpr (K32) request_W16_first();
         else {
 #pragma unroll
             for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
@@ -1843,7 +1864,10 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 typedef float f32x4a __attribute__((ext_vector_type(4)));
                 f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: voxels 16 u + 4 kq + i, channel 16 v + m16
                 const int dwb = a.Tp * REC;
+                const int Tu = a.Tp - 2;
+                const int cq = kq << 4;                                      // the lane's chunk (8 channels) of its record, unswizzled byte offset
                 int rbu[2][3];                                               // byte address of the lane's record (voxel half u) in ring row hrel + dh, tap (dw, dt) = (0, 0)
+                int ck[2][3][3];                                             // [u][dw][dt]: cq ^ (swizzle key of the record of tap (dw, dt)), the same in every ring row
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     int vi = tile * 32 + 16 * u + m16;
@@ -1854,79 +1878,52 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     const int s0 = hrel - fdiv(hrel, NS, a.mNslot) * NS;
                     const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
                     rbu[u][0] = s0 * rowbytes + vox0 * REC; rbu[u][1] = s1 * rowbytes + vox0 * REC; rbu[u][2] = s2 * rowbytes + vox0 * REC;
-                }
-                struct GroupAddr { int gb, k4[3]; };
-                auto group_addr = [&](int base) -> GroupAddr {
-                    GroupAddr q;
-                    q.gb = base;
-                    const int r7 = base >> 7;
+                    const int x = w * Tu + t;                                // key index of the (dw, dt) = (0, 0) record (stage_store)
 #pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) q.k4[dt] = ((r7 + dt) << 3) & 0x70;
-                    return q;
-                };
-                const int cq = kq << 4;                                      // the lane's chunk (8 channels) of its record, unswizzled byte offset
-                auto addr_A16 = [&](const GroupAddr& ga, int dt) -> int { return (cq ^ ga.k4[dt]) + ga.gb; };
-                auto request_A16 = [&](const GroupAddr& ga, int dt, Frag (&af)[NP]) {
-                    const int a0 = addr_A16(ga, dt);
-                    af[0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * REC);
-                    af[1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64) + dt * REC);
-                };
-#define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[AF][pa].h, W[WF][pb].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
-                // One tap = one k-block = twelve MFMAs (three piece pairs x four accumulators, never the same accumulator twice in a row).  A 16x16x32
-                // MFMA leaves the wave 12 issue cycles: the requests of the tap after next (ring slot of the tap before this one) go out two at a time
-                // in the gaps after the first six -- filters first (the longer latency), in the order the MFMAs will want them (pieces (1, 0) first).
-                auto group = [&](int gg, const GroupAddr (&ga)[2], const GroupAddr (&gan)[2], auto last_tag) {
-                    constexpr bool LAST = decltype(last_tag)::value;
+                    for (int dw = 0; dw < 3; ++dw)
 #pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) {
-                        const bool same = dt == 0;                            // tap after next: (gg, 2) from tap 0, (gg + 1, dt - 1) otherwise
-                        const int sq = same ? 2 : dt - 1;
-                        const bool req = same || !LAST;
-                        const int tq_ = (same ? gg : gg + 1) * 3 + sq;
-                        const int a0 = 2 * dt, a1 = 2 * dt + 1;
-                        int ad0 = 0, ad1 = 0;
-                        PP_MM(a0, a0, c00, 1, 0);
-                        if (req) request_W16_p0(tq_, sq);
-                        __builtin_amdgcn_sched_barrier(0);
-                        PP_MM(a0, a1, c01, 1, 0);
-                        if (req) request_W16_p1(tq_, sq);
-                        __builtin_amdgcn_sched_barrier(0);
-                        PP_MM(a1, a0, c10, 1, 0);
-                        if (req) { ad0 = addr_A16(same ? ga[0] : gan[0], sq); ad1 = addr_A16(same ? ga[1] : gan[1], sq); }
-                        __builtin_amdgcn_sched_barrier(0);
-                        PP_MM(a1, a1, c11, 1, 0);
-                        if (req) { A[2 * sq][1].u = *reinterpret_cast<const uint4*>(plds + (ad0 ^ 64) + sq * REC); A[2 * sq + 1][1].u = *reinterpret_cast<const uint4*>(plds + (ad1 ^ 64) + sq * REC); }
-                        __builtin_amdgcn_sched_barrier(0);
-                        PP_MM(a0, a0, c00, 0, 1);
-                        if (req) { A[2 * sq][0].u = *reinterpret_cast<const uint4*>(plds + ad0 + sq * REC); A[2 * sq + 1][0].u = *reinterpret_cast<const uint4*>(plds + ad1 + sq * REC); }
-                        __builtin_amdgcn_sched_barrier(0);
-                        PP_MM(a0, a1, c01, 0, 1); PP_MM(a1, a0, c10, 0, 1); PP_MM(a1, a1, c11, 0, 1);
-                        PP_MM(a0, a0, c00, 0, 0); PP_MM(a0, a1, c01, 0, 0); PP_MM(a1, a0, c10, 0, 0); PP_MM(a1, a1, c11, 0, 0);
-                    }
-                };
-                auto row_groups = [&](int dh, const int (&rbh)[2], const int (&rbn)[2], auto last_tag) {
-                    constexpr bool LASTROW = decltype(last_tag)::value;
-                    const GroupAddr g0[2] = {group_addr(rbh[0]), group_addr(rbh[1])}, g1[2] = {group_addr(rbh[0] + dwb), group_addr(rbh[1] + dwb)};
-                    const GroupAddr g2[2] = {group_addr(rbh[0] + 2 * dwb), group_addr(rbh[1] + 2 * dwb)}, gn[2] = {group_addr(rbn[0]), group_addr(rbn[1])};
-                    group(3 * dh, g0, g1, std::false_type());
-                    group(3 * dh + 1, g1, g2, std::false_type());
-                    group(3 * dh + 2, g2, gn, std::integral_constant<bool, LASTROW>());
-                };
-                {
-                    const GroupAddr gu0 = group_addr(rbu[0][0]), gu1 = group_addr(rbu[1][0]);
-                    request_A16(gu0, 0, A[0]); request_A16(gu1, 0, A[1]);
-                    request_A16(gu0, 1, A[2]); request_A16(gu1, 1, A[3]);
+                        for (int dt = 0; dt < 3; ++dt) ck[u][dw][dt] = cq ^ (((x + dw * Tu + dt) << 4) & 0x60);      // (((x') >> 1) & 3) << 5: chunk bits 1..2 as a byte offset
                 }
+                // tap T = 9 dh + 3 dw + dt.  A ring: three taps (slot T % 3, A[2 slot + u]); filter ring: WD taps (slot T % WD, WK[2 slot + v]) -- the filters come
+                // from L2 (110 KB of fragments go round the 32 KB L1 once per tile): requested two taps ahead the loop ran at that latency, not at the pipe's rate
+                auto request_A16 = [&](int T, int u, bool hi_piece, bool lo_piece) {
+                    const int dh = T / 9, dw = (T / 3) % 3, dt = T % 3, sl = T % 3;
+                    const int a0 = ck[u][dw][dt] + rbu[u][dh] + dw * dwb;
+                    if (hi_piece) A[2 * sl + u][1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64) + dt * REC);
+                    if (lo_piece) A[2 * sl + u][0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * REC);
+                };
+#define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[AF][pa].h, WK[WF][pb].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+                request_A16(0, 0, true, true); request_A16(0, 1, true, true);
+                request_A16(1, 0, true, true); request_A16(1, 1, true, true);
 #ifndef PPX_NOTAPS
-#pragma unroll 1
-                for (int dh = 0; dh < 2; ++dh) {
-                    const int rh[2] = {dh == 0 ? rbu[0][0] : rbu[0][1], dh == 0 ? rbu[1][0] : rbu[1][1]};
-                    const int rn[2] = {dh == 0 ? rbu[0][1] : rbu[0][2], dh == 0 ? rbu[1][1] : rbu[1][2]};
-                    row_groups(dh, rh, rn, std::false_type());
-                }
-                {
-                    const int rh[2] = {rbu[0][2], rbu[1][2]};
-                    row_groups(2, rh, rh, std::true_type());
+                // One tap = one k-block = twelve MFMAs (three piece pairs x four accumulators, never the same accumulator twice in a row); the requests go out
+                // in the gaps after the first ones, filters first, in the order the MFMAs will want them (pieces (1, 0) first)
+#pragma unroll
+                for (int T = 0; T < 27; ++T) {
+                    const int a0 = 2 * (T % 3), a1 = a0 + 1, w0 = 2 * (T % WD), w1 = w0 + 1;
+                    const int TW = T + WD - 1, TA = T + 2;                   // the taps whose operands are requested now (their ring slots held tap T - 1)
+                    PP_MM(a0, w0, c00, 1, 0);
+#ifndef PPX_NOW
+                    if (TW < 27) request_W16_p0(TW, TW % WD);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_MM(a0, w1, c01, 1, 0);
+#ifndef PPX_NOW
+                    if (TW < 27) request_W16_p1(TW, TW % WD);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_MM(a1, w0, c10, 1, 0);
+#ifndef PPX_NOA
+                    if (TA < 27) { request_A16(TA, 0, true, false); request_A16(TA, 1, true, false); }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_MM(a1, w1, c11, 1, 0);
+#ifndef PPX_NOA
+                    if (TA < 27) { request_A16(TA, 0, false, true); request_A16(TA, 1, false, true); }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_MM(a0, w0, c00, 0, 1); PP_MM(a0, w1, c01, 0, 1); PP_MM(a1, w0, c10, 0, 1); PP_MM(a1, w1, c11, 0, 1);
+                    PP_MM(a0, w0, c00, 0, 0); PP_MM(a0, w1, c01, 0, 0); PP_MM(a1, w0, c10, 0, 0); PP_MM(a1, w1, c11, 0, 0);
                 }
 #endif
 #undef PP_MM
@@ -1955,12 +1952,12 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 // v_xad_u32 ((chunk << 4) ^ K4[dt]) + gb, the dt * 128 in the read's offset field where it is the same for the whole wave, and one
                 // xor for the second piece (chunk ^ 4 = the address ^ 64: records are 128-byte aligned).
                 struct GroupAddr { int gb, k4[3]; };
-                auto group_addr = [&](int base) -> GroupAddr {
+                const int Tu = a.Tp - 2, x0 = w * Tu + t;                    // the key index of the lane's (dw, dt) = (0, 0) record (stage_store)
+                auto group_addr = [&](int base, int xg) -> GroupAddr {
                     GroupAddr q;
                     q.gb = base;
-                    const int r7 = base >> 7;
 #pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) q.k4[dt] = ((r7 + dt) << 3) & 0x70;
+                    for (int dt = 0; dt < 3; ++dt) q.k4[dt] = ((xg + dt) << 3) & 0x70;      // (((xg + dt) >> 1) & 7) << 4
                     return q;
                 };
                 auto request_A = [&](const GroupAddr& ga, int st, Frag (&af)[NP]) {
@@ -2004,13 +2001,13 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 // the three groups of one ring row (dh); the row base of dh + 1 for the requests that run ahead into it
                 auto row_groups = [&](int dh, int rbh, int rbn, auto last_tag) {
                     constexpr bool LASTROW = decltype(last_tag)::value;
-                    const GroupAddr g0 = group_addr(rbh), g1 = group_addr(rbh + dwb), g2 = group_addr(rbh + 2 * dwb), gn = group_addr(rbn);
+                    const GroupAddr g0 = group_addr(rbh, x0), g1 = group_addr(rbh + dwb, x0 + Tu), g2 = group_addr(rbh + 2 * dwb, x0 + 2 * Tu), gn = group_addr(rbn, x0);
                     group(3 * dh, g0, g1, std::false_type());
                     group(3 * dh + 1, g1, g2, std::false_type());
                     group(3 * dh + 2, g2, gn, std::integral_constant<bool, LASTROW>());
                 };
                 {
-                    const GroupAddr g0 = group_addr(rb0);
+                    const GroupAddr g0 = group_addr(rb0, x0);
 #pragma unroll
                     for (int st = 0; st < PF; ++st) request_A(g0, st, A[st]);
                 }
@@ -2108,7 +2105,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 }
             }
             if (sg + 1 < nseg) {
-                if constexpr (K32) { request_W16(0, 0); request_W16(1, 1); }
+                if constexpr (K32) request_W16_first();
                 else {
 #pragma unroll
                     for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);

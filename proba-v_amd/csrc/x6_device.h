@@ -25,6 +25,12 @@ namespace probav {
 #define XS_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[8] = {xs_t, 0, 0, 0, 0, 0, 0, 0}
 #define XS_ACC(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[k] += t_ - xs_t; xs_t = t_; } while (0)
 #define XS_OUT do { xs_acc[7] = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 8; ++k_) g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k_] = xs_acc[k_]; } while (0)
+#elif defined(PROBAV_STAMP_CLOCK)
+// clock-only build (tools/kbench.hip -DPROBAV_STAMP_CLOCK): two stamps per wave, none inside the loops; in-kernel clock = cycles / (100 MHz ticks) * 0.1 GHz
+#define XS_DECL const unsigned long long xs_c0 = __builtin_amdgcn_s_memtime(), xs_r0 = __builtin_amdgcn_s_memrealtime()
+#define XS_ACC(k) do { } while (0)
+#define XS_OUT do { const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime(); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8] = c1_ - xs_c0; g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 1] = r1_ - xs_r0; } } while (0)
 #else
 #define XS_DECL do { } while (0)
 #define XS_ACC(k) do { } while (0)

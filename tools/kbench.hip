@@ -1,5 +1,6 @@
 // Diagnostic (not part of the product): times the hot H3 kernels in isolation on random data at the benchmark's shapes (batch 128, T = 9).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I proba-v_amd/csrc tools/kbench.hip -o tools/kbench.bin && tools/kbench.bin [iters]
+// -DPROBAV_STAMP_CLOCK adds each kernel's in-kernel clock (two stamps per wave, none inside the loops).
 // -DKB_OLD builds against the round-1 signatures (per-tensor amax slots), for A/B runs of two source trees.
 // Ablation switches of conv3_pp_kernel (timing only, results are wrong): -DPPX_IDLE (the finishing half does nothing: taps alone),
 // -DPPX_NOTAPS (no MFMA loop: finishing + staging alone), -DPPX_NOEPI (no epilogue / skip / stores), -DPPX_NOSTAGE (no row staging).
@@ -9,6 +10,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 using namespace probav;
 
 static int g_pass = 0;
@@ -23,7 +25,20 @@ template <class F> static float timeit(const char* name, int iters, double gflop
     hipEventSynchronize(b);
     float ms = 0; hipEventElapsedTime(&ms, a, b);
     const float us = ms * 1e3f / iters;
-    if (g_pass) printf("%-44s %8.1f us   %7.1f TFLOP/s (algorithmic fp32)\n", name, us, gflop / us * 1e3);
+    if (g_pass) printf("%-44s %8.1f us   %7.1f TFLOP/s (algorithmic fp32)", name, us, gflop / us * 1e3);
+#ifdef PROBAV_STAMP_CLOCK
+    if (g_pass) {       // in-kernel clock of the LAST launch: per wave cycles / 100 MHz ticks between the kernel's two stamps; median over the waves that wrote them
+        static std::vector<unsigned long long> st(8192 * 8);
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+        std::vector<double> clk, cyc;
+        for (size_t w = 0; w < 8192; ++w) if (st[w * 8 + 1] > 0) { clk.push_back((double)st[w * 8] / (double)st[w * 8 + 1] * 0.1); cyc.push_back((double)st[w * 8]); }
+        if (!clk.empty()) { std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+            printf("   clock %.2f GHz (p10 %.2f, p90 %.2f), %.0f cycles between the stamps", clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10], cyc[cyc.size() / 2]); }
+        std::fill(st.begin(), st.end(), 0ull);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), st.data(), st.size() * 8);
+    }
+#endif
+    if (g_pass) printf("\n");
     if (hipGetLastError() != hipSuccess) printf("   !! HIP error\n");
     return us;
 }
