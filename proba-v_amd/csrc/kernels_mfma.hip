@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #ifdef PPX_WD
     constexpr int WD = PPX_WD;
 #else
-    constexpr int WD = 4;                                                    // depth of the K32 form's filter ring (taps)
+    constexpr int WD = 3;                                                    // depth of the K32 form's filter ring (taps; 4 and 5 measured no faster: the L1 is bandwidth-, not latency-bound)
 #endif
     Frag WK[K32 ? 2 * WD : 1][NP];
     auto request_W16_p0 = [&](int tap, int sl) { WK[2 * sl][0].u = wload16(tap, 0); WK[2 * sl + 1][0].u = wload16(tap, 256); };       // piece 0 of both channel halves
