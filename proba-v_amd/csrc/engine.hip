@@ -840,7 +840,9 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         // normConv_i: d loss/d w, then d loss/d dec_i
         const bool fusedp = e->impl >= 1 && e->pw_mfma;
         { Amax m; if (h3) { m.x = A.dec(i); m.w = acur; }
-          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), next_part(), m, (fusedp && e->side_mode >= 2) ? reduce_fork(s) : s)); }
+          // (from the second block on, the last thing enqueued on s was the previous block's pointwise backward, whose slab sums forked right behind it)
+          CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), next_part(), m,
+                        (fusedp && e->side_mode >= 2) ? (i < R - 1 ? reduce_fork_adjacent(s) : reduce_fork(s)) : s)); }
         if (fusedp) oth = W + p.gblk[i];                   // this block's dX goes to its own buffer: `cur` stays intact for the late backward-filter
         unsigned* agdec = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, amx(acur, ln, agdec), s));

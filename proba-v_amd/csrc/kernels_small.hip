@@ -6,6 +6,7 @@
 //   clip + round-half-even                              (test.py:117-119, models/testClass.py:27-28)
 //   shift-compensated L1 / L2 / cPSNR fwd + bwd         (models/loss.py:37-84, 140-187, 226-238)
 #include "probav_common.h"
+#include <cstdlib>
 #include <atomic>
 #include <stdio.h>
 #include <string.h>
@@ -413,6 +414,16 @@ hipStream_t reduce_fork(hipStream_t s)
     if (!c || !c->side || s == c->side) return s;
     hipEvent_t ev = c->ev[c->k++ & 7];
     if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->side, ev, 0) != hipSuccess) { (void)hipGetLastError(); return s; }
+    return c->side;
+}
+// The caller guarantees that nothing has been enqueued on s since its last reduce_fork(s): the side stream, being in order, already waits for
+// that point -- no second event (an event record between two kernels of the launch stream costs it about 6 us of bubble).
+hipStream_t reduce_fork_adjacent(hipStream_t s)
+{
+    ReduceSide* c = g_reduce_side;
+    if (!c || !c->side || s == c->side) return s;
+    static const bool always_record = getenv("PROBAV_FORK_EVENTS") != nullptr;     // A/B runs: an event at every fork
+    if (c->k == 0 || always_record) return reduce_fork(s);   // (nothing forked yet in this pass: there is no earlier point)
     return c->side;
 }
 int reduce_join(hipStream_t s)

@@ -65,6 +65,7 @@ int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream
 struct ReduceSide { hipStream_t side; hipEvent_t ev[8]; hipEvent_t joined; int k; };
 void reduce_side_activate(ReduceSide* ctx);                 // nullptr deactivates
 hipStream_t reduce_fork(hipStream_t s);
+hipStream_t reduce_fork_adjacent(hipStream_t s);           // the same point as the caller's previous reduce_fork(s) (nothing enqueued on s in between): no new event
 int reduce_join(hipStream_t s);
 // mainConv1 forward (one input channel -> 32, 3x3x3, zero pads of 1): dedicated store-bound kernel; amax = per-sample slots of y or null
 bool conv3d_cin1_forward_supported(const ConvGeom& g);
