@@ -626,7 +626,7 @@ static ReduceSide* engine_side(probav_engine* e)
 struct SideGuard {          // activates the engine's side stream (probav_common.h: ReduceSide) for the calling thread while a pass is being enqueued
     ReduceSide* c;
     hipStream_t s;
-    SideGuard(ReduceSide* c_, hipStream_t s_) : c(c_), s(s_) { if (c) { c->k = 0; reduce_side_activate(c); } }
+    SideGuard(ReduceSide* c_, hipStream_t s_) : c(c_), s(s_) { if (c) { c->k = 0; c->last = nullptr; reduce_side_activate(c); } }
     ~SideGuard()
     {
         if (!c) return;

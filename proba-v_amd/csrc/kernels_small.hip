@@ -413,7 +413,8 @@ hipStream_t reduce_fork(hipStream_t s)
     ReduceSide* c = g_reduce_side;
     if (!c || !c->side || s == c->side) return s;
     hipEvent_t ev = c->ev[c->k++ & 7];
-    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->side, ev, 0) != hipSuccess) { (void)hipGetLastError(); return s; }
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->side, ev, 0) != hipSuccess) { (void)hipGetLastError(); c->last = nullptr; return s; }
+    c->last = s;
     return c->side;
 }
 // The caller guarantees that nothing has been enqueued on s since its last reduce_fork(s): the side stream, being in order, already waits for
@@ -423,7 +424,7 @@ hipStream_t reduce_fork_adjacent(hipStream_t s)
     ReduceSide* c = g_reduce_side;
     if (!c || !c->side || s == c->side) return s;
     static const bool always_record = getenv("PROBAV_FORK_EVENTS") != nullptr;     // A/B runs: an event at every fork
-    if (c->k == 0 || always_record) return reduce_fork(s);   // (nothing forked yet in this pass: there is no earlier point)
+    if (c->k == 0 || c->last != s || always_record) return reduce_fork(s);   // (nothing forked yet in this pass, or the last fork did not take: there is no earlier point)
     return c->side;
 }
 int reduce_join(hipStream_t s)
@@ -435,6 +436,7 @@ int reduce_join(hipStream_t s)
         return PROBAV_EHIP;
     }
     c->k = 0;
+    c->last = nullptr;
     return PROBAV_OK;
 }
 

@@ -62,7 +62,7 @@ int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream
 // launches.  While a ReduceSide is active on the calling thread (the engine's backward pass), reduce_fork(s) records the point on s,
 // makes the engine's side stream wait for it and returns the side stream; the reducing kernels are launched there and run in the
 // gaps of the main chain.  reduce_join(s) makes s wait for everything forked.  Without an active context reduce_fork(s) is s.
-struct ReduceSide { hipStream_t side; hipEvent_t ev[8]; hipEvent_t joined; int k; };
+struct ReduceSide { hipStream_t side; hipEvent_t ev[8]; hipEvent_t joined; int k; hipStream_t last; };   // last: the stream of the latest SUCCESSFUL fork since the join (reduce_fork_adjacent)
 void reduce_side_activate(ReduceSide* ctx);                 // nullptr deactivates
 hipStream_t reduce_fork(hipStream_t s);
 hipStream_t reduce_fork_adjacent(hipStream_t s);           // the same point as the caller's previous reduce_fork(s) (nothing enqueued on s in between): no new event
