@@ -55,10 +55,20 @@ __device__ __forceinline__ double wave_sum(double v)
 //   weff  [tap][ci][co]                      forward / backward-filter
 //   weffT [taps-1-tap][co][ci]               backward-data (flipped taps, channels swapped)
 // ---------------------------------------------------------------------------------------------------
+// the layer whose channel range [n_off, next n_off) holds `chan` (offsets ascending).  One wave, up to 64 layers: lane i looks at layer i, a ballot
+// counts the layers that start at or before the channel -- one round trip instead of a chain of up to nl dependent loads (which was most of
+// these kernels' 40 us).  More layers than lanes: the chain, from layer 63 on.
+__device__ __forceinline__ int find_by_offset(const WnLayer* L, int nl, int chan, bool rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int mine = lane < nl ? (rows ? L[lane].r_off : L[lane].n_off) : 0x7fffffff;
+    int i = __popcll(__ballot(mine <= chan)) - 1;                    // (layer 0 starts at 0: at least one)
+    if (nl > 64) while (i + 1 < nl && chan >= (rows ? L[i + 1].r_off : L[i + 1].n_off)) ++i;
+    return __builtin_amdgcn_readfirstlane(i);
+}
 __device__ __forceinline__ int find_layer(const WnLayer* L, int nl, int chan, int& co)
 {
-    int i = 0;
-    while (i + 1 < nl && chan >= L[i + 1].n_off) ++i;
+    const int i = find_by_offset(L, nl, chan, false);
     co = chan - L[i].n_off;
     return i;
 }
@@ -106,19 +116,44 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
             om[i] = mi; ov[i] = vi;
         }
     }
-    float ss = 0.f;
-    for (int k = lane; k < L.K; k += 64) { const float q = v[(long)k * L.Cout + co]; ss = fmaf(q, q, ss); }
-    ss = wave_sum(ss);
-    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));            // tf.nn.l2_normalize epsilon
-    const float scale = gain * inv;
-    if (lane == 0) inv_norm[L.n_off + co] = inv;
-    float wmax = 0.f;
-    for (int k = lane; k < L.K; k += 64) {
-        const float q = v[(long)k * L.Cout + co] * scale;
-        weff[L.w_off + (long)k * L.Cout + co] = q;
-        const int tap = k / L.Cin, ci = k - tap * L.Cin;
-        weffT[L.w_off + ((long)(L.taps - 1 - tap) * L.Cout + co) * L.Cin + ci] = q;
-        wmax = fmaxf(wmax, fabsf(q));
+    // The column lives in registers between the norm and the scaled stores: all of its loads are in flight together (a loop over a runtime K
+    // waited for each in turn -- 14 round trips for a 3x3x3x32 column, twice).  Columns longer than WN_Q * 64 (none in this network) take the loop.
+    constexpr int WN_Q = 14;
+    float ss = 0.f, wmax = 0.f;
+    if (L.K <= WN_Q * 64) {
+        float q[WN_Q];
+#pragma unroll
+        for (int j = 0; j < WN_Q; ++j) { const int k = lane + 64 * j; q[j] = k < L.K ? v[(long)k * L.Cout + co] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < WN_Q; ++j) ss = fmaf(q[j], q[j], ss);              // (the same order as the loop: zeros beyond the column add nothing)
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));            // tf.nn.l2_normalize epsilon
+        const float scale = gain * inv;
+        if (lane == 0) inv_norm[L.n_off + co] = inv;
+#pragma unroll
+        for (int j = 0; j < WN_Q; ++j) {
+            const int k = lane + 64 * j;
+            if (k < L.K) {
+                const float w = q[j] * scale;
+                weff[L.w_off + (long)k * L.Cout + co] = w;
+                const int tap = k / L.Cin, ci = k - tap * L.Cin;
+                weffT[L.w_off + ((long)(L.taps - 1 - tap) * L.Cout + co) * L.Cin + ci] = w;
+                wmax = fmaxf(wmax, fabsf(w));
+            }
+        }
+    } else {
+        for (int k = lane; k < L.K; k += 64) { const float q = v[(long)k * L.Cout + co]; ss = fmaf(q, q, ss); }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        const float scale = gain * inv;
+        if (lane == 0) inv_norm[L.n_off + co] = inv;
+        for (int k = lane; k < L.K; k += 64) {
+            const float q = v[(long)k * L.Cout + co] * scale;
+            weff[L.w_off + (long)k * L.Cout + co] = q;
+            const int tap = k / L.Cin, ci = k - tap * L.Cin;
+            weffT[L.w_off + ((long)(L.taps - 1 - tap) * L.Cout + co) * L.Cin + ci] = q;
+            wmax = fmaxf(wmax, fabsf(q));
+        }
     }
     if (amax) {     // largest |effective weight| and |bias| of the layer (slots li and nl + li) and of this output column: operand scales of the H3 kernels
 #pragma unroll
@@ -135,14 +170,23 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
 __global__ __launch_bounds__(64) void wn_rowmax_kernel(const WnLayer* __restrict__ layers, int nl, const float* __restrict__ weff,
                                                       unsigned* __restrict__ arow)
 {
-    int i = 0;
-    while (i + 1 < nl && (int)blockIdx.x >= layers[i + 1].r_off) ++i;
+    const int i = find_by_offset(layers, nl, (int)blockIdx.x, true);
     const WnLayer L = layers[i];
     const int ci = blockIdx.x - L.r_off, lane = threadIdx.x;
     float m = 0.f;
-    for (int e = lane; e < L.taps * L.Cout; e += 64) {
-        const int tap = e / L.Cout, co = e - tap * L.Cout;
-        m = fmaxf(m, fabsf(weff[L.w_off + ((long)tap * L.Cin + ci) * L.Cout + co]));
+    const int ne = L.taps * L.Cout;
+    for (int e0 = 0; e0 < ne; e0 += 64 * 8) {                         // eight independent loads per round trip
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + 64 * j + lane;
+            const int ec = e < ne ? e : 0;
+            const int tap = ec / L.Cout, co = ec - tap * L.Cout;
+            q[j] = weff[L.w_off + ((long)tap * L.Cin + ci) * L.Cout + co];
+            q[j] = e < ne ? fabsf(q[j]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, q[j]);
     }
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
