@@ -1618,18 +1618,22 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     float* ybase = y + out_base * g.Cout;
     const float* sbase = skip ? skip + out_base * g.Cout : nullptr;
     const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
-    // K32 form (v_mfma_f32_16x16x32_f16, 32 input channels = ONE k-block per tap): the 32 x 32 tile is four 16 x 16 accumulators (voxel
-    // half u, channel half v); a lane holds column 16 v + m16 of both channel halves, so the filter column's exponent and the bias come in pairs
+    // K32 form (v_mfma_f32_16x16x32_f16, 32 input channels = ONE k-block per tap): the 32 x 32 tile is four 16 x 16 accumulators (voxel half u,
+    // channel half v), computed TRANSPOSED -- the filter fragment is the instruction's A operand, the records its B -- so that a lane's four accumulator
+    // registers are four CONSECUTIVE channels 16 v + 4 kq .. + 3 of one voxel 16 u + m16: skip and output are 16-byte accesses straight from / to
+    // memory, with no turn-around through LDS.  The filter columns' exponents and the biases of the lane's eight channels:
     const int m16 = lane & 15, kq = lane >> 4;
-    int eun16[2] = {0, 0};
-    float bv16[2] = {0.f, 0.f};
+    int eun8[2][4];
+    float bv8[2][4];
     if constexpr (K32) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int c = 16 * v + m16;
-            eun16[v] = -(ea + h3_exp_w(am.w[c < g.Cout ? c : 0]));
-            bv16[v] = (bias && c < g.Cout) ? bias[c] : 0.f;
-        }
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 16 * v + 4 * kq + i;
+                eun8[v][i] = -(ea + h3_exp_w(am.w[c < g.Cout ? c : 0]));
+                bv8[v][i] = (bias && c < g.Cout) ? bias[c] : 0.f;
+            }
     }
     auto elem_off_ch = [&](int vi, int ch) -> int {
         if (a.nsplit == 1) return vi * g.Cout + ch;
@@ -1803,8 +1807,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     auto load_skip = [&](int tile) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int vi = tile * 32 + er + 8 * jj;
-            eoff[jj] = vi < NV ? elem_off_ch(vi, 4 * eq) : -1;
+            const int vi = K32 ? tile * 32 + 16 * (jj >> 1) + m16 : tile * 32 + er + 8 * jj;       // K32: jj = 2 u + v
+            eoff[jj] = vi < NV ? elem_off_ch(vi, K32 ? 16 * (jj & 1) + 4 * kq : 4 * eq) : -1;
             skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
         }
         if (sbase) {
@@ -1815,7 +1819,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || 4 * eq + c >= g.Cout) ? 0 : eoff[jj] + c];
+                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || (K32 ? 16 * (jj & 1) + 4 * kq : 4 * eq) + c >= g.Cout) ? 0 : eoff[jj] + c];
             }
         }
     };
@@ -1862,7 +1866,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if constexpr (K32) {
               if (sg < nseg && tile < NTL) {
                 typedef float f32x4a __attribute__((ext_vector_type(4)));
-                f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: voxels 16 u + 4 kq + i, channel 16 v + m16
+                f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: channels 16 v + 4 kq + i of voxel 16 u + m16
                 const int dwb = a.Tp * REC;
                 const int Tu = a.Tp - 2;
                 const int cq = kq << 4;                                      // the lane's chunk (8 channels) of its record, unswizzled byte offset
@@ -1892,7 +1896,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     if (hi_piece) A[2 * sl + u][1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64) + dt * REC);
                     if (lo_piece) A[2 * sl + u][0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * REC);
                 };
-#define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[AF][pa].h, WK[WF][pb].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+#define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(WK[WF][pb].h, A[AF][pa].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)      // (transposed: rows = channels)
                 request_A16(0, 0, true, true); request_A16(0, 1, true, true);
                 request_A16(1, 0, true, true); request_A16(1, 1, true, true);
 #ifndef PPX_NOTAPS
@@ -2056,21 +2060,38 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if (do_load && !have_nv) stage_load(hiq + 1, nv_);               // (only the very first finishing segment: no taps came before it)
             have_nv = false;
             if (fin) {
-                if constexpr (K32) {
+              if constexpr (K32) {
+                // acc[4 (2 u + v) + i]: channel 16 v + 4 kq + i of voxel 16 u + m16 -- the layout of the 16-byte skip loads and output stores themselves
+                const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {                            // acc[4 (2 u + v) + r]: voxel 16 u + 4 kq + r, channel 16 v + m16
-                        const int u = i >> 3, v_ = (i >> 2) & 1, r = i & 3;
-                        float v = ldexpf(acc[i], eun16[v_]) + bv16[v_];
-                        if (g.relu) v = fmaxf(v, 0.f);
-                        turn[(16 * u + 4 * kq + r) * 32 + 16 * v_ + m16] = v;
-                    }
-                } else {
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int v_ = jj & 1, c0 = 16 * v_ + 4 * kq;
+                    f32x4u o;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float v = ldexpf(acc[i], eun) + bv;                   // the filter column's exponent and the bias are per lane in the accumulator layout
+                    for (int i = 0; i < 4; ++i) {
+                        float v = ldexpf(acc[4 * jj + i], eun8[v_][i]) + bv8[v_][i];
                         if (g.relu) v = fmaxf(v, 0.f);
-                        turn[rowmap(i, half) * 32 + col] = v;
+                        o[i] = v + skq[jj][i];
                     }
+                    if (full) {
+                        *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    } else if (eoff[jj] >= 0) {
+                        if (c0 + 4 <= g.Cout) {
+                            *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (c0 + c < g.Cout) { ybase[eoff[jj] + c] = o[c]; omax = fmaxf(omax, fabsf(o[c])); }
+                        }
+                    }
+                }
+              } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = ldexpf(acc[i], eun) + bv;                       // the filter column's exponent and the bias are per lane in the accumulator layout
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    turn[rowmap(i, half) * 32 + col] = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (a wave's LDS operations execute in order: the wait orders the compiler)
                 float4 tq[4];
@@ -2095,6 +2116,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the turn buffer is free again before the partner wave can reach its own epilogue (next barrier)
+              }
             }
             if (do_load) {
                 stage_store(hiq + 1, nv_);
