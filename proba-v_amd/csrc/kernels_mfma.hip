@@ -1829,7 +1829,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     };
     // K32 form: the fragments of PACK_H3_CONV are read with another lane order.  A 16x16x32 B operand wants, in lane (m16, kq), k = 8 kq .. 8 kq + 7 of
     // column 16 v + m16: that is lane (16 v + m16) + 32 (kq & 1) of the 32x32x16 fragment kb = kq >> 1 -- the same 16 bytes, no second packed copy.
-    // Ring of THREE taps: slot dt of every (dh, dw) group; W[2 dt + v], A[2 dt + u].
+    // (The kernel issues it as the A operand: the tile is computed transposed, see eun8 above.)  Rings: WK[2 (tap % WD) + v] here, A[2 (tap % 3) + u] for the records.
     const int wl16 = ((kq >> 1) * 128 + 32 * (kq & 1) + m16) << 4;          // byte offset inside a tap's 4 KB (piece: + 1024, channel half v: + 256)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wfrag), 0, 27 * 4096, 0x00020000);   // (K32: scalar base + 32-bit lane offset + immediate)
     typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
@@ -1889,7 +1889,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                         for (int dt = 0; dt < 3; ++dt) ck[u][dw][dt] = cq ^ (((x + dw * Tu + dt) << 4) & 0x60);      // (((x') >> 1) & 3) << 5: chunk bits 1..2 as a byte offset
                 }
                 // tap T = 9 dh + 3 dw + dt.  A ring: three taps (slot T % 3, A[2 slot + u]); filter ring: WD taps (slot T % WD, WK[2 slot + v]) -- the filters come
-                // from L2 (110 KB of fragments go round the 32 KB L1 once per tile): requested two taps ahead the loop ran at that latency, not at the pipe's rate
+                // from L2 through the 64 B/clk L1 (110 KB of fragments go round the 32 KB cache once per tile): that bandwidth, not the ring's depth, sets the tap's 256 cycles
                 auto request_A16 = [&](int T, int u, bool hi_piece, bool lo_piece) {
                     const int dh = T / 9, dw = (T / 3) % 3, dt = T % 3, sl = T % 3;
                     const int a0 = ck[u][dw][dt] + rbu[u][dh] + dw * dwb;
