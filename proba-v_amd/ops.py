@@ -194,8 +194,24 @@ def _(hr, mask, pred, arg, upstream, border, which):
 @torch.library.custom_op("probav::shift_loss", mutates_args=(), device_types="cuda")
 def shift_loss(pred: Tensor, hr: Tensor, mask: Tensor, border: int, bit_depth: int, which: int) -> tuple[Tensor, Tensor, Tensor]:
     """which = 1: L1 (models/loss.py:73-84), 2: L2 (:55-71) -> (batch-mean loss [scalar], arg-min shift per sample [B], per-sample minima [B])."""
-    f, arg, means = torch.ops.probav.shift_metrics(hr, mask, pred, border, bit_depth)
-    return means[which - 1].clone(), arg[which - 1].clone(), f[which - 1].clone()
+    # the launch writes through seven separate pointers: the three results asked for go straight into tensors of their own (no copies: three
+    # launches less per step), the other four into one scratch allocation
+    _dev(pred, "predPatchHR")
+    B, S = pred.shape[0], pred.shape[1]
+    dev = pred.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    amin = torch.empty((B,), dtype=torch.int32, device=dev)
+    per = torch.empty((B,), dtype=torch.float32, device=dev)
+    scr = torch.empty((2 * B + 1,), dtype=torch.float32, device=dev)        # the other per-sample loss, cPSNR, the other mean
+    sarg = torch.empty((B,), dtype=torch.int32, device=dev)
+    l1 = which == 1
+    _lib.check(_lib.lib().probav_shift_loss_forward(
+        _lib.ptr(hr), _lib.ptr(mask), _lib.ptr(pred), B, S, border, bit_depth,
+        _lib.ptr(per if l1 else scr[0:B]), _lib.ptr(scr[0:B] if l1 else per), _lib.ptr(scr[B:2 * B]),
+        _lib.ptr(amin if l1 else sarg), _lib.ptr(sarg if l1 else amin),
+        _lib.ptr(loss if l1 else scr[2 * B:]), _lib.ptr(scr[2 * B:] if l1 else loss),
+        _lib.current_stream()), "probav_shift_loss_forward")
+    return loss, amin, per
 
 
 @shift_loss.register_fake
