@@ -1606,8 +1606,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     const int eun = -(ea + ew);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tsel = wave & 3, grp = wave >> 2;
-    const int rowbytes = a.Wp * a.Tp * REC, NS = a.nslot;
-    float* turn = reinterpret_cast<float*>(plds + NS * rowbytes) + tsel * 1024;      // [32 voxels][32 channels], shared by waves tsel and tsel + 4 (never in the same role)
+    // Ring row.  32x32x16 forms: Wp * Tp records of 128 bytes ([piece][chunk of 8 channels], swizzled: stage_store).  K32 form: PLANAR -- eight planes
+    // (piece, chunk) of Wp * Tp 16-byte entries each, plane pitch PS = 16 * (a count that is 2 mod 16): a tap is then a constant byte offset from the lane's
+    // (dw, dt) = (0, 0) entry -- no swizzle key that changes with the tap, no per-tap address arithmetic -- and the banks work out by parity: entry e of plane c
+    // sits in bank group (e + 2 c) mod 16; a ds_read_b128 lane group holds eight lanes of chunk kq and eight of kq + 1 (MI355X_MICROARCH.md, LDS), the kernel
+    // gives the former the tile's even voxels and the latter the odd ones (pm16 below), consecutive voxels alternate entry parity (Tp - 2 and Tp differ by 2), so
+    // the two sets fall into bank groups of different parity whatever the tap; the staging stores (two voxels x four chunks per lane group) spread the same way.
+    const int NS = a.nslot;
+    const int PS = K32 ? 16 * ((((a.Wp * a.Tp) + 13) & ~15) + 2) : 0;
+    const int rowbytes = K32 ? 8 * PS : a.Wp * a.Tp * REC;
+    float* turn = reinterpret_cast<float*>(plds + NS * rowbytes) + tsel * 1024;      // [32 voxels][32 channels], shared by waves tsel and tsel + 4 (never in the same role; K32: unused)
     const int strip = srem / a.nsplit, sp = srem - strip * a.nsplit;
     const int ws0 = sp * a.Wt;
     const int hb = strip * a.SR;
@@ -1620,9 +1628,12 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     const float bv = (bias && col < g.Cout) ? bias[col] : 0.f;
     // K32 form (v_mfma_f32_16x16x32_f16, 32 input channels = ONE k-block per tap): the 32 x 32 tile is four 16 x 16 accumulators (voxel half u,
     // channel half v), computed TRANSPOSED -- the filter fragment is the instruction's A operand, the records its B -- so that a lane's four accumulator
-    // registers are four CONSECUTIVE channels 16 v + 4 kq .. + 3 of one voxel 16 u + m16: skip and output are 16-byte accesses straight from / to
+    // registers are four CONSECUTIVE channels 16 v + 4 kq .. + 3 of one voxel 16 u + pm16: skip and output are 16-byte accesses straight from / to
     // memory, with no turn-around through LDS.  The filter columns' exponents and the biases of the lane's eight channels:
     const int m16 = lane & 15, kq = lane >> 4;
+    // voxel of the 16 of a sub-tile that operand row / column m16 stands for: the lanes that share a ds_read_b128 group with the NEXT chunk's lanes
+    // (m16 = 4..11) take the odd voxels, the others the even ones (the planar ring's bank argument above)
+    const int pm16 = (m16 >= 4 && m16 < 12) ? 2 * (m16 - 4) + 1 : (m16 < 4 ? 2 * m16 : 2 * (m16 - 12) + 8);
     int eun8[2][4];
     float bv8[2][4];
     if constexpr (K32) {
@@ -1676,7 +1687,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             locate(lv, lw, t, iwc, colok);
             s_src[k] = (iwc * g.Ti + t) * CIN + 8 * cc;
             s_vd[k] = it < items ? lw * a.Tp + t + g.pt : -1;
-            s_key[k] = K32 ? (((lw * (a.Tp - 2) + t + g.pt) >> 1) & 3) << 1 : ((lw * (a.Tp - 2) + t + g.pt) >> 1) & 7;
+            s_key[k] = ((lw * (a.Tp - 2) + t + g.pt) >> 1) & 7;
             s_cc[k] = cc;
             s_live[k] = colok;
         }
@@ -1737,14 +1748,18 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 }
                 Frag f[NP];
                 cut8<AR>(sv.v[k], sa, f);
+                if constexpr (K32) {                                         // planar ring: entry s_vd of planes (piece, chunk)
+                    unsigned char* ent = slot + s_vd[k] * 16 + s_cc[k] * PS;
+                    *reinterpret_cast<uint4*>(ent) = f[0].u;
+                    *reinterpret_cast<uint4*>(ent + 4 * PS) = f[1].u;
+                    continue;
+                }
                 unsigned char* rec = slot + s_vd[k] * REC;
                 // Swizzle key of a record at padded coordinates (w', t'): made of x = w' (Tp - 2) + t', NOT of the record index w' Tp + t'.  x runs on through
                 // a tile's voxels (t fastest) where the record index jumps by 3 at every column change, and its parity is the record's (address bit 7), so the
                 // sixteen lanes of a ds_read_b128 group -- voxels {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a tile reading ONE chunk (32x32x16 forms) --
                 // get sixteen different bank groups from key = (x >> 1) & 7 on the three chunk bits.  (With the record index in x's place 62 % of the LDS
                 // cycles of these kernels were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; 11 % now, at tile rows that wrap.)
-                // K32 form: a lane group holds 16 voxels of which eight read chunk c and eight chunk c ^ 1, so bit 0 stays the chunk's own and the key is
-                // the two bits (x >> 1) & 3 on chunk bits 1..2: any eight consecutive voxels get eight bank groups.
                 const int sw = s_key[k];
                 *reinterpret_cast<uint4*>(rec + ((s_cc[k] ^ sw) << 4)) = f[0].u;
                 *reinterpret_cast<uint4*>(rec + (((4 + s_cc[k]) ^ sw) << 4)) = f[1].u;
@@ -1807,7 +1822,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     auto load_skip = [&](int tile) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int vi = K32 ? tile * 32 + 16 * (jj >> 1) + m16 : tile * 32 + er + 8 * jj;       // K32: jj = 2 u + v
+            const int vi = K32 ? tile * 32 + 16 * (jj >> 1) + pm16 : tile * 32 + er + 8 * jj;      // K32: jj = 2 u + v
             eoff[jj] = vi < NV ? elem_off_ch(vi, K32 ? 16 * (jj & 1) + 4 * kq : 4 * eq) : -1;
             skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
         }
@@ -1866,35 +1881,27 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if constexpr (K32) {
               if (sg < nseg && tile < NTL) {
                 typedef float f32x4a __attribute__((ext_vector_type(4)));
-                f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: channels 16 v + 4 kq + i of voxel 16 u + m16
-                const int dwb = a.Tp * REC;
-                const int Tu = a.Tp - 2;
-                const int cq = kq << 4;                                      // the lane's chunk (8 channels) of its record, unswizzled byte offset
-                int rbu[2][3];                                               // byte address of the lane's record (voxel half u) in ring row hrel + dh, tap (dw, dt) = (0, 0)
-                int ck[2][3][3];                                             // [u][dw][dt]: cq ^ (swizzle key of the record of tap (dw, dt)), the same in every ring row
+                f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: channels 16 v + 4 kq + i of voxel 16 u + pm16
+                const int dwb = a.Tp * 16;                                   // one column further: Tp entries
+                int rbu[2][3];                                               // byte address of the lane's entry (voxel half u, its chunk's plane, piece 0) in ring row hrel + dh, tap (dw, dt) = (0, 0)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    int vi = tile * 32 + 16 * u + m16;
+                    int vi = tile * 32 + 16 * u + pm16;
                     vi = vi < NV ? vi : NV - 1;
                     const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
                     const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
-                    const int vox0 = w * a.Tp + t;
+                    const int e0 = (w * a.Tp + t) * 16 + kq * PS;
                     const int s0 = hrel - fdiv(hrel, NS, a.mNslot) * NS;
                     const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
-                    rbu[u][0] = s0 * rowbytes + vox0 * REC; rbu[u][1] = s1 * rowbytes + vox0 * REC; rbu[u][2] = s2 * rowbytes + vox0 * REC;
-                    const int x = w * Tu + t;                                // key index of the (dw, dt) = (0, 0) record (stage_store)
-#pragma unroll
-                    for (int dw = 0; dw < 3; ++dw)
-#pragma unroll
-                        for (int dt = 0; dt < 3; ++dt) ck[u][dw][dt] = cq ^ (((x + dw * Tu + dt) << 4) & 0x60);      // (((x') >> 1) & 3) << 5: chunk bits 1..2 as a byte offset
+                    rbu[u][0] = s0 * rowbytes + e0; rbu[u][1] = s1 * rowbytes + e0; rbu[u][2] = s2 * rowbytes + e0;
                 }
                 // tap T = 9 dh + 3 dw + dt.  A ring: three taps (slot T % 3, A[2 slot + u]); filter ring: WD taps (slot T % WD, WK[2 slot + v]) -- the filters come
                 // from L2 through the 64 B/clk L1 (110 KB of fragments go round the 32 KB cache once per tile): that bandwidth, not the ring's depth, sets the tap's 256 cycles
                 auto request_A16 = [&](int T, int u, bool hi_piece, bool lo_piece) {
                     const int dh = T / 9, dw = (T / 3) % 3, dt = T % 3, sl = T % 3;
-                    const int a0 = ck[u][dw][dt] + rbu[u][dh] + dw * dwb;
-                    if (hi_piece) A[2 * sl + u][1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64) + dt * REC);
-                    if (lo_piece) A[2 * sl + u][0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * REC);
+                    const int a0 = rbu[u][dh] + dw * dwb;                     // (the same for the three dt of a (dh, dw) group: the depth step is the read's immediate offset)
+                    if (hi_piece) A[2 * sl + u][1].u = *reinterpret_cast<const uint4*>(plds + a0 + 4 * PS + dt * 16);
+                    if (lo_piece) A[2 * sl + u][0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * 16);
                 };
 #define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(WK[WF][pb].h, A[AF][pa].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)      // (transposed: rows = channels)
                 request_A16(0, 0, true, true); request_A16(0, 1, true, true);
@@ -2061,7 +2068,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             have_nv = false;
             if (fin) {
               if constexpr (K32) {
-                // acc[4 (2 u + v) + i]: channel 16 v + 4 kq + i of voxel 16 u + m16 -- the layout of the 16-byte skip loads and output stores themselves
+                // acc[4 (2 u + v) + i]: channel 16 v + 4 kq + i of voxel 16 u + pm16 -- the layout of the 16-byte skip loads and output stores themselves
                 const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -2167,7 +2174,9 @@ static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
         auto needf = [&](int sg) { const int vl = std::min(NV - 1, (sg + 1) * 128 - 1); return vl / nvr + 2; };
         int nslot = needf(0) + 1;
         for (int sg = 0; sg + 1 < nseg; ++sg) nslot = std::max(nslot, needf(sg + 1) - (sg * 128) / nvr + 1);
-        const size_t need = (size_t)nslot * (wt + 2) * Tp * 128 + (size_t)4 * 1024 * sizeof(float);
+        size_t rowb = (size_t)(wt + 2) * Tp * 128;
+        if (g.Cin == 32) rowb = std::max(rowb, (size_t)8 * 16 * (((size_t)((wt + 2) * Tp + 13) & ~(size_t)15) + 2));     // the K32 form's planar row (conv3_pp_kernel)
+        const size_t need = (size_t)nslot * rowb + (size_t)4 * 1024 * sizeof(float);
         if (need > 163840) continue;
         p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = need; p.grid = g.N * nstrips * ns;
         p.a.g = g; p.a.Wp = wt + 2; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips; p.a.nsplit = ns; p.a.Wt = wt;
