@@ -1855,15 +1855,33 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #ifdef PPX_WD
     constexpr int WD = PPX_WD;
 #else
-    constexpr int WD = 3;                                                    // depth of the K32 form's filter ring (taps; 4 and 5 measured no faster: the L1 is bandwidth-, not latency-bound)
+    constexpr int WD = 2;                                                    // depth of the K32 form's filter ring (taps of 24 MFMAs; the L1 is bandwidth-, not latency-bound)
 #endif
-    Frag WK[K32 ? 2 * WD : 1][NP];
+    // K32: the two waves of a PAIR (tsel >> 1) share a 64-voxel tile and split its TAPS -- member 0 taps 0..13, member 1 taps 14..26 -- so that a tap's
+    // 4 KB of filter fragments feed 24 MFMAs instead of 12: four waves x 4 KB per 12-MFMA tap are exactly the 64 B/clk of the vector L1 and made that tap
+    // 256 cycles long instead of 192 (tools/mfma_feed.hip).  Each member ends with partial sums of all 64 voxels, keeps the 32 it finishes
+    // and hands the other 32 to its partner through LDS (xbuf: the 16 KB behind the ring; second barrier at the end of the segment).
+    constexpr int KT0 = 14;                                                  // first tap of member 1
+#ifdef PPX_AD
+    constexpr int AD = PPX_AD;
+#else
+    constexpr int AD = 2;                                                    // depth of the K32 form's record ring (taps of 24 MFMAs)
+#endif
+    const int pr = tsel >> 1, tr = tsel & 1;
+    Frag WK[K32 ? 2 * WD : 1][NP], AK[K32 ? 4 * AD : 1][NP];                 // WK[2 (L % WD) + v], AK[4 (L % AD) + u], L = tap - the member's first tap
     auto request_W16_p0 = [&](int tap, int sl) { WK[2 * sl][0].u = wload16(tap, 0); WK[2 * sl + 1][0].u = wload16(tap, 256); };       // piece 0 of both channel halves
     auto request_W16_p1 = [&](int tap, int sl) { WK[2 * sl][1].u = wload16(tap, 1024); WK[2 * sl + 1][1].u = wload16(tap, 1280); };
-    auto request_W16_first = [&]() {                                         // the first WD - 1 taps of a tile
+    auto request_W16_first = [&]() {                                         // the member's first WD - 1 taps
+        const int T0 = tr ? KT0 : 0;
 #pragma unroll
-        for (int T = 0; T < WD - 1; ++T) { request_W16_p0(T, T); request_W16_p1(T, T); }
+        for (int L = 0; L < WD - 1; ++L) { request_W16_p0(T0 + L, L); request_W16_p1(T0 + L, L); }
     };
+    typedef float f32x4a __attribute__((ext_vector_type(4)));
+    f32x4a keep[4], xsend[4];                                                // K32: partial sums of the 32 voxels this wave finishes ([2 u' + v]) / of the partner's 32, from the end of the taps to the hand-over
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { keep[k] = (f32x4a){0.f, 0.f, 0.f, 0.f}; xsend[k] = keep[k]; }
+    bool xvalid = false;
+    float* xbuf = reinterpret_cast<float*>(plds + NS * rowbytes);            // [4 waves][16 registers][64 lanes]
     // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
     if (grp == 0) {
         if constexpr (K32) request_W16_first();
@@ -1879,14 +1897,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             // ---- taps of one whole tile ----
             const int tile = 4 * sg + tsel;
             if constexpr (K32) {
-              if (sg < nseg && tile < NTL) {
-                typedef float f32x4a __attribute__((ext_vector_type(4)));
-                f32x4a c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[u][v]: channels 16 v + 4 kq + i of voxel 16 u + pm16
-                const int dwb = a.Tp * 16;                                   // one column further: Tp entries
-                int rbu[2][3];                                               // byte address of the lane's entry (voxel half u, its chunk's plane, piece 0) in ring row hrel + dh, tap (dw, dt) = (0, 0)
+              const int ptile = 2 * sg + pr;                                 // the pair's 64-voxel tile
+              xvalid = sg < nseg && ptile * 64 < NV;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    int vi = tile * 32 + 16 * u + pm16;
+              for (int k = 0; k < 4; ++k) { keep[k] = (f32x4a){0.f, 0.f, 0.f, 0.f}; xsend[k] = keep[k]; }      // (unconditionally: what they held is dead here)
+              if (xvalid) {
+                const int dwb = a.Tp * 16;                                   // one column further: Tp entries
+                int rbu[4][3];                                               // byte address of the lane's entry (voxels 16 u .., its chunk's plane, piece 0) in ring row hrel + dh, tap (dw, dt) = (0, 0)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int vi = ptile * 64 + 16 * u + pm16;
                     vi = vi < NV ? vi : NV - 1;
                     const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
                     const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
@@ -1895,53 +1915,61 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
                     rbu[u][0] = s0 * rowbytes + e0; rbu[u][1] = s1 * rowbytes + e0; rbu[u][2] = s2 * rowbytes + e0;
                 }
-                // tap T = 9 dh + 3 dw + dt.  A ring: three taps (slot T % 3, A[2 slot + u]); filter ring: WD taps (slot T % WD, WK[2 slot + v]) -- the filters come
-                // from L2 through the 64 B/clk L1 (110 KB of fragments go round the 32 KB cache once per tile): that bandwidth, not the ring's depth, sets the tap's 256 cycles
-                auto request_A16 = [&](int T, int u, bool hi_piece, bool lo_piece) {
-                    const int dh = T / 9, dw = (T / 3) % 3, dt = T % 3, sl = T % 3;
+                // tap T = 9 dh + 3 dw + dt, L = T - the member's first tap; rings AK[4 (L % AD) + u], WK[2 (L % WD) + v]
+                auto request_A16 = [&](int T, int L, int u, int piece) {
+                    const int dh = T / 9, dw = (T / 3) % 3, dt = T % 3, sl = L % AD;
                     const int a0 = rbu[u][dh] + dw * dwb;                     // (the same for the three dt of a (dh, dw) group: the depth step is the read's immediate offset)
-                    if (hi_piece) A[2 * sl + u][1].u = *reinterpret_cast<const uint4*>(plds + a0 + 4 * PS + dt * 16);
-                    if (lo_piece) A[2 * sl + u][0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * 16);
+                    if (piece) AK[4 * sl + u][1].u = *reinterpret_cast<const uint4*>(plds + a0 + 4 * PS + dt * 16);
+                    else AK[4 * sl + u][0].u = *reinterpret_cast<const uint4*>(plds + a0 + dt * 16);
                 };
-#define PP_MM(AF, WF, C, pa, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(WK[WF][pb].h, A[AF][pa].h, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)      // (transposed: rows = channels)
-                request_A16(0, 0, true, true); request_A16(0, 1, true, true);
-                request_A16(1, 0, true, true); request_A16(1, 1, true, true);
+                // accumulator of voxels 16 u .. and channel half v (transposed: a lane holds channels 16 v + 4 kq + i of voxel 16 u + pm16): member 0 finishes
+                // u = 0, 1 and hands over u = 2, 3; member 1 the other way round
+#define PP_CU(u, v) ((((u) >= 2) == R1) ? keep[2 * ((u) & 1) + (v)] : xsend[2 * ((u) & 1) + (v)])
+#define PP_MM(u, v, pa, pb) PP_CU(u, v) = __builtin_amdgcn_mfma_f32_16x16x32_f16(WK[2 * (L % WD) + v][pb].h, AK[4 * (L % AD) + u][pa].h, PP_CU(u, v), 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+                // One tap = one k-block = 24 MFMAs (three piece pairs x eight accumulators); the requests go out in the gaps behind the first ones,
+                // filters first, then the records' second pieces (the pair (1, 0) is the first the next tap multiplies), then their first pieces
+                auto run_taps = [&](auto t0_tag, auto t1_tag) __attribute__((always_inline)) {
+                    constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
+                    constexpr bool R1 = T0 != 0;
+#pragma unroll
+                    for (int L = 0; L < AD - 1; ++L)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { request_A16(T0 + L, L, u, 1); request_A16(T0 + L, L, u, 0); }
 #ifndef PPX_NOTAPS
-                // One tap = one k-block = twelve MFMAs (three piece pairs x four accumulators, never the same accumulator twice in a row); the requests go out
-                // in the gaps after the first ones, filters first, in the order the MFMAs will want them (pieces (1, 0) first)
 #pragma unroll
-                for (int T = 0; T < 27; ++T) {
-                    const int a0 = 2 * (T % 3), a1 = a0 + 1, w0 = 2 * (T % WD), w1 = w0 + 1;
-                    const int TW = T + WD - 1, TA = T + 2;                   // the taps whose operands are requested now (their ring slots held tap T - 1)
-                    PP_MM(a0, w0, c00, 1, 0);
-#ifndef PPX_NOW
-                    if (TW < 27) request_W16_p0(TW, TW % WD);
+                    for (int T = T0; T < T1; ++T) {
+                        const int L = T - T0;
+                        const int TW = T + WD - 1, LW = L + WD - 1, TA = T + AD - 1, LA = L + AD - 1;     // the taps whose operands are requested now
+                        PP_MM(0, 0, 1, 0);
+                        if (TW < T1) request_W16_p0(TW, LW % WD);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(0, 1, 1, 0);
+                        if (TW < T1) request_W16_p1(TW, LW % WD);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(1, 0, 1, 0);
+                        if (TA < T1) { request_A16(TA, LA, 0, 1); request_A16(TA, LA, 1, 1); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(1, 1, 1, 0);
+                        if (TA < T1) { request_A16(TA, LA, 2, 1); request_A16(TA, LA, 3, 1); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(2, 0, 1, 0);
+                        if (TA < T1) { request_A16(TA, LA, 0, 0); request_A16(TA, LA, 1, 0); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(2, 1, 1, 0);
+                        if (TA < T1) { request_A16(TA, LA, 2, 0); request_A16(TA, LA, 3, 0); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_MM(3, 0, 1, 0); PP_MM(3, 1, 1, 0);
+                        PP_MM(0, 0, 0, 1); PP_MM(0, 1, 0, 1); PP_MM(1, 0, 0, 1); PP_MM(1, 1, 0, 1); PP_MM(2, 0, 0, 1); PP_MM(2, 1, 0, 1); PP_MM(3, 0, 0, 1); PP_MM(3, 1, 0, 1);
+                        PP_MM(0, 0, 0, 0); PP_MM(0, 1, 0, 0); PP_MM(1, 0, 0, 0); PP_MM(1, 1, 0, 0); PP_MM(2, 0, 0, 0); PP_MM(2, 1, 0, 0); PP_MM(3, 0, 0, 0); PP_MM(3, 1, 0, 0);
+                    }
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    PP_MM(a0, w1, c01, 1, 0);
-#ifndef PPX_NOW
-                    if (TW < 27) request_W16_p1(TW, TW % WD);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    PP_MM(a1, w0, c10, 1, 0);
-#ifndef PPX_NOA
-                    if (TA < 27) { request_A16(TA, 0, true, false); request_A16(TA, 1, true, false); }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    PP_MM(a1, w1, c11, 1, 0);
-#ifndef PPX_NOA
-                    if (TA < 27) { request_A16(TA, 0, false, true); request_A16(TA, 1, false, true); }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    PP_MM(a0, w0, c00, 0, 1); PP_MM(a0, w1, c01, 0, 1); PP_MM(a1, w0, c10, 0, 1); PP_MM(a1, w1, c11, 0, 1);
-                    PP_MM(a0, w0, c00, 0, 0); PP_MM(a0, w1, c01, 0, 0); PP_MM(a1, w0, c10, 0, 0); PP_MM(a1, w1, c11, 0, 0);
-                }
-#endif
+                };
+                if (tr == 0) run_taps(std::integral_constant<int, 0>(), std::integral_constant<int, KT0>());
+                else run_taps(std::integral_constant<int, KT0>(), std::integral_constant<int, 27>());
 #undef PP_MM
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { acc[i] = c00[i]; acc[4 + i] = c01[i]; acc[8 + i] = c10[i]; acc[12 + i] = c11[i]; }
+#undef PP_CU
 #if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
-                load_skip(tile);
+                if (tile < NTL) load_skip(tile);
 #endif
               }
             } else
@@ -2068,15 +2096,17 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             have_nv = false;
             if (fin) {
               if constexpr (K32) {
-                // acc[4 (2 u + v) + i]: channel 16 v + 4 kq + i of voxel 16 u + pm16 -- the layout of the 16-byte skip loads and output stores themselves
+                // keep[2 u + v][i] (+ the partner's share): channel 16 v + 4 kq + i of voxel 16 u + pm16 -- the layout of the 16-byte skip loads and output stores themselves
                 const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int v_ = jj & 1, c0 = 16 * v_ + 4 * kq;
                     f32x4u o;
+                    const float4 xp = *reinterpret_cast<const float4*>(xbuf + tsel * 1024 + (jj * 64 + lane) * 4);      // the partner's partial sums of these four values (its taps)
+                    const float xq[4] = {xp.x, xp.y, xp.z, xp.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = ldexpf(acc[4 * jj + i], eun8[v_][i]) + bv8[v_][i];
+                        float v = ldexpf(keep[jj][i] + xq[i], eun8[v_][i]) + bv8[v_][i];
                         if (g.relu) v = fmaxf(v, 0.f);
                         o[i] = v + skq[jj][i];
                     }
@@ -2144,6 +2174,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         }
         hiq = hi_next;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: global loads requested for the next segment and the output stores stay in flight
+        if constexpr (K32) {
+            // hand-over of the partial sums: the half that finished tiles has read its share of the previous hand-over (barrier above); the half that ran taps
+            // leaves, in its PARTNER's slot, what it summed for the partner's 32 voxels; second barrier; the partner adds it in its finishing segment
+            if (grp == (sg & 1) && xvalid) {
+                float* xs = xbuf + (tsel ^ 1) * 1024;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(xs + (k * 64 + lane) * 4) = make_float4(xsend[k][0], xsend[k][1], xsend[k][2], xsend[k][3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         XS_ACC(4);
     }
     if (am.y) amax_commit(omax, am.y + n);
