@@ -1595,6 +1595,9 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
     using AR = H3;
     constexpr int NP = 2, REC = 128, PF = 3;
+    // K32 (the fourth template argument) = the NEW FORM: planar ring, the two waves of a pair split a 64-voxel tile's k-blocks.  With 32 input channels it
+    // also means the 16x16x32 MFMA shape (S16); with 25 (P25) the k-blocks stay v_mfma_f32_32x32x16_f16 ones (75 k-slots per (dh, dw) group = 5 of 16).
+    constexpr bool S16 = K32 && CIN == 32, P25 = K32 && CIN == 25;
     const ConvGeom& g = a.g;
     float omax = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -1613,8 +1616,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     // gives the former the tile's even voxels and the latter the odd ones (pm16 below), consecutive voxels alternate entry parity (Tp - 2 and Tp differ by 2), so
     // the two sets fall into bank groups of different parity whatever the tap; the staging stores (two voxels x four chunks per lane group) spread the same way.
     const int NS = a.nslot;
-    const int PS = K32 ? 16 * ((((a.Wp * a.Tp) + 13) & ~15) + 2) : 0;
-    const int rowbytes = K32 ? 8 * PS : a.Wp * a.Tp * REC;
+    const int PS = S16 ? 16 * ((((a.Wp * a.Tp) + 13) & ~15) + 2) : 0;
+    const int rowbytes = S16 ? 8 * PS : a.Wp * a.Tp * REC;
     float* turn = reinterpret_cast<float*>(plds + NS * rowbytes) + tsel * 1024;      // [32 voxels][32 channels], shared by waves tsel and tsel + 4 (never in the same role; K32: unused)
     const int strip = srem / a.nsplit, sp = srem - strip * a.nsplit;
     const int ws0 = sp * a.Wt;
@@ -1636,7 +1639,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     const int pm16 = (m16 >= 4 && m16 < 12) ? 2 * (m16 - 4) + 1 : (m16 < 4 ? 2 * m16 : 2 * (m16 - 12) + 8);
     int eun8[2][4];
     float bv8[2][4];
-    if constexpr (K32) {
+    if constexpr (S16) {
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -1748,7 +1751,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 }
                 Frag f[NP];
                 cut8<AR>(sv.v[k], sa, f);
-                if constexpr (K32) {                                         // planar ring: entry s_vd of planes (piece, chunk)
+                if constexpr (S16) {                                         // planar ring: entry s_vd of planes (piece, chunk)
                     unsigned char* ent = slot + s_vd[k] * 16 + s_cc[k] * PS;
                     *reinterpret_cast<uint4*>(ent) = f[0].u;
                     *reinterpret_cast<uint4*>(ent + 4 * PS) = f[1].u;
@@ -1822,8 +1825,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     auto load_skip = [&](int tile) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int vi = K32 ? tile * 32 + 16 * (jj >> 1) + pm16 : tile * 32 + er + 8 * jj;      // K32: jj = 2 u + v
-            eoff[jj] = vi < NV ? elem_off_ch(vi, K32 ? 16 * (jj & 1) + 4 * kq : 4 * eq) : -1;
+            const int vi = S16 ? tile * 32 + 16 * (jj >> 1) + pm16 : tile * 32 + er + 8 * jj;      // S16: jj = 2 u + v
+            eoff[jj] = vi < NV ? elem_off_ch(vi, S16 ? 16 * (jj & 1) + 4 * kq : 4 * eq) : -1;
             skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
         }
         if (sbase) {
@@ -1834,7 +1837,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || (K32 ? 16 * (jj & 1) + 4 * kq : 4 * eq) + c >= g.Cout) ? 0 : eoff[jj] + c];
+                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || (S16 ? 16 * (jj & 1) + 4 * kq : 4 * eq) + c >= g.Cout) ? 0 : eoff[jj] + c];
             }
         }
     };
@@ -1868,7 +1871,22 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     constexpr int AD = 2;                                                    // depth of the K32 form's record ring (taps of 24 MFMAs)
 #endif
     const int pr = tsel >> 1, tr = tsel & 1;
-    Frag WK[K32 ? 2 * WD : 1][NP], AK[K32 ? 4 * AD : 1][NP];                 // WK[2 (L % WD) + v], AK[4 (L % AD) + u], L = tap - the member's first tap
+    Frag WK[S16 ? 2 * WD : 1][NP], AK[S16 ? 4 * AD : 1][NP];                 // WK[2 (L % WD) + v], AK[4 (L % AD) + u], L = tap - the member's first tap
+    // P25: 45 k-blocks of 16 (nine (dh, dw) groups x five), member 0 k-blocks 0..22, member 1 23..44; rings of RK k-blocks: WP[L % RK], AP[2 (L % RK) + voxel half]
+    constexpr int KB0 = 23, RK = 3;
+    Frag WP[P25 ? RK : 1][NP], AP[P25 ? 2 * RK : 1][NP];
+    const __amdgpu_buffer_rsrc_t wrp = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wfrag), 0, 9 * 5 * NP * 1024, 0x00020000);
+    auto request_WP = [&](int K, int sl) {                                   // k-block K = 5 group + st: the fragments' own order; scalar base + lane offset (no 64-bit address per k-block)
+        const u32x4b r0 = __builtin_amdgcn_raw_buffer_load_b128(wrp, lane * 16, K * (NP * 1024), 0);
+        const u32x4b r1 = __builtin_amdgcn_raw_buffer_load_b128(wrp, lane * 16 + 1024, K * (NP * 1024), 0);
+        WP[sl][0].u = make_uint4(r0[0], r0[1], r0[2], r0[3]); WP[sl][1].u = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+    };
+    auto request_WP_first = [&]() {
+        const int K0 = tr ? KB0 : 0;
+#pragma unroll
+        for (int L = 0; L < RK - 1; ++L) request_WP(K0 + L, L);
+    };
+    f32x16 keep16, send16;                                                   // P25: partial sums of the 32 voxels this wave finishes / of the partner's 32
     auto request_W16_p0 = [&](int tap, int sl) { WK[2 * sl][0].u = wload16(tap, 0); WK[2 * sl + 1][0].u = wload16(tap, 256); };       // piece 0 of both channel halves
     auto request_W16_p1 = [&](int tap, int sl) { WK[2 * sl][1].u = wload16(tap, 1024); WK[2 * sl + 1][1].u = wload16(tap, 1280); };
     auto request_W16_first = [&]() {                                         // the member's first WD - 1 taps
@@ -1884,7 +1902,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     float* xbuf = reinterpret_cast<float*>(plds + NS * rowbytes);            // [4 waves][16 registers][64 lanes]
     // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
     if (grp == 0) {
-        if constexpr (K32) request_W16_first();
+        if constexpr (S16) request_W16_first();
+        else if constexpr (P25) request_WP_first();
         else {
 #pragma unroll
             for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
@@ -1896,6 +1915,96 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         if (grp == (sg & 1)) {
             // ---- taps of one whole tile ----
             const int tile = 4 * sg + tsel;
+            if constexpr (P25) {
+              const int ptile = 2 * sg + pr;                                 // the pair's 64-voxel tile
+              xvalid = sg < nseg && ptile * 64 < NV;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) { keep16[i] = 0.f; send16[i] = 0.f; }
+              if (xvalid) {
+                const int dwb = a.Tp * REC;                                  // one column further
+                const int Tu = a.Tp - 2;
+                int rbp[2][3], xp0[2];                                       // byte address of the lane's record (voxel half uh: voxel 32 uh + col) in ring row hrel + dh, tap (0, 0); its key index (stage_store)
+#pragma unroll
+                for (int uh = 0; uh < 2; ++uh) {
+                    int vi = ptile * 64 + 32 * uh + col;
+                    vi = vi < NV ? vi : NV - 1;
+                    const int hrel = fdiv(vi, nvr, a.mNvr), rem = vi - hrel * nvr;
+                    const int w = fdiv(rem, g.To, a.mTo), t = rem - w * g.To;
+                    const int e0 = (w * a.Tp + t) * REC;
+                    const int s0 = hrel - fdiv(hrel, NS, a.mNslot) * NS;
+                    const int s1 = s0 + 1 < NS ? s0 + 1 : s0 + 1 - NS, s2 = s1 + 1 < NS ? s1 + 1 : s1 + 1 - NS;
+                    rbp[uh][0] = s0 * rowbytes + e0; rbp[uh][1] = s1 * rowbytes + e0; rbp[uh][2] = s2 * rowbytes + e0;
+                    xp0[uh] = w * Tu + t;
+                }
+                // k-block st of a group covers its chunks 2 st (lanes 0..31) and 2 st + 1 (lanes 32..63): chunk c < 9 -> depth dt = c / 3, chunk c % 3 of the
+                // record; c = 9 -> the gathered chunk 3 of the dt = 0 record.  Record at byte address ra holds chunk c at ra + ((c ^ key) << 4) (stage_store).
+                // per (dh, dw) group and voxel half: the group's base and, for dt = 0, 1, 2, key << 4; set when the requests reach a group's first k-block
+                int gab[2], gak[2][3];
+                auto set_group = [&](int gg) {
+                    const int dh = gg / 3, dw = gg % 3;
+#pragma unroll
+                    for (int uh = 0; uh < 2; ++uh) {
+                        gab[uh] = rbp[uh][dh] + dw * dwb;
+                        const int xg = xp0[uh] + dw * Tu;
+#pragma unroll
+                        for (int dt = 0; dt < 3; ++dt) gak[uh][dt] = ((xg + dt) << 3) & 0x70;      // (((x') >> 1) & 7) << 4 of the record of depth step dt
+                    }
+                };
+                auto request_AP = [&](int K, int L, int uh0 = 0, int uh1 = 2) {
+                    const int gg = K / NST, st = K % NST, sl = L % RK;
+                    if (st == 0 && uh0 == 0) set_group(gg);
+                    const int c0 = 2 * st, c1 = 2 * st + 1;
+                    const int dt0 = c0 / 3, cc0 = c0 % 3, dt1 = c1 < 9 ? c1 / 3 : 0, cc1 = c1 < 9 ? c1 % 3 : 3;
+#pragma unroll
+                    for (int uh = uh0; uh < uh1; ++uh) {
+                        const int k4 = half ? gak[uh][dt1] : gak[uh][dt0];      // (the halves of the wave read different chunks)
+                        const int cd = half ? (cc1 << 4) + dt1 * REC : (cc0 << 4) + dt0 * REC;
+                        const int a0 = ((cd & 0x70) ^ k4) + gab[uh] + (cd & ~0x7f);
+                        AP[2 * sl + uh][0].u = *reinterpret_cast<const uint4*>(plds + a0);
+                        AP[2 * sl + uh][1].u = *reinterpret_cast<const uint4*>(plds + (a0 ^ 64));
+                    }
+                };
+                // member 0 finishes voxel half 0 and hands over half 1; member 1 the other way round
+#define PP_C25(uh) (((uh) == 1) == R1 ? keep16 : send16)
+                auto run_kb = [&](auto k0_tag, auto k1_tag) __attribute__((always_inline)) {
+                    constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+                    constexpr bool R1 = K0 != 0;
+                    if (K0 % NST != 0) set_group(K0 / NST);
+#pragma unroll
+                    for (int L = 0; L < RK - 1; ++L) request_AP(K0 + L, L);
+#ifndef PPX_NOTAPS
+#pragma unroll
+                    for (int K = K0; K < K1; ++K) {
+                        const int L = K - K0, sl = L % RK, KN = K + RK - 1, LN = L + RK - 1;       // k-block requested now (its ring slot held k-block K - 1)
+                        PP_C25(0) = MFMA16H(AP[2 * sl][1], WP[sl][0], PP_C25(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (KN < K1) request_WP(KN, LN % RK);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_C25(1) = MFMA16H(AP[2 * sl + 1][1], WP[sl][0], PP_C25(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (KN < K1) request_AP(KN, LN, 0, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_C25(0) = MFMA16H(AP[2 * sl][0], WP[sl][1], PP_C25(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (KN < K1) request_AP(KN, LN, 1, 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_C25(1) = MFMA16H(AP[2 * sl + 1][0], WP[sl][1], PP_C25(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_C25(0) = MFMA16H(AP[2 * sl][0], WP[sl][0], PP_C25(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_C25(1) = MFMA16H(AP[2 * sl + 1][0], WP[sl][0], PP_C25(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+                };
+                if (tr == 0) run_kb(std::integral_constant<int, 0>(), std::integral_constant<int, KB0>());
+                else run_kb(std::integral_constant<int, KB0>(), std::integral_constant<int, 9 * NST>());
+#undef PP_C25
+#if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
+                if (tile < NTL) load_skip(tile);
+#endif
+              }
+            } else
             if constexpr (K32) {
               const int ptile = 2 * sg + pr;                                 // the pair's 64-voxel tile
               xvalid = sg < nseg && ptile * 64 < NV;
@@ -2095,7 +2204,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if (do_load && !have_nv) stage_load(hiq + 1, nv_);               // (only the very first finishing segment: no taps came before it)
             have_nv = false;
             if (fin) {
-              if constexpr (K32) {
+              if constexpr (P25) {
+                // the partner's partial sums of this wave's 32 voxels (accumulator layout, in this wave's slot of xbuf, which then serves as the turn-around buffer)
+                float4 xp[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xp[k] = *reinterpret_cast<const float4*>(xbuf + tsel * 1024 + (k * 64 + lane) * 4);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (read before the slot is rewritten below)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { acc[4 * k] = keep16[4 * k] + xp[k].x; acc[4 * k + 1] = keep16[4 * k + 1] + xp[k].y; acc[4 * k + 2] = keep16[4 * k + 2] + xp[k].z; acc[4 * k + 3] = keep16[4 * k + 3] + xp[k].w; }
+              }
+              if constexpr (S16) {
                 // keep[2 u + v][i] (+ the partner's share): channel 16 v + 4 kq + i of voxel 16 u + pm16 -- the layout of the 16-byte skip loads and output stores themselves
                 const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
 #pragma unroll
@@ -2164,7 +2282,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                 }
             }
             if (sg + 1 < nseg) {
-                if constexpr (K32) request_W16_first();
+                if constexpr (S16) request_W16_first();
+                else if constexpr (P25) request_WP_first();
                 else {
 #pragma unroll
                     for (int st = 0; st < PF; ++st) request_W(0, st, W[st]);
@@ -2180,7 +2299,10 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             if (grp == (sg & 1) && xvalid) {
                 float* xs = xbuf + (tsel ^ 1) * 1024;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(xs + (k * 64 + lane) * 4) = make_float4(xsend[k][0], xsend[k][1], xsend[k][2], xsend[k][3]);
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (P25) *reinterpret_cast<float4*>(xs + (k * 64 + lane) * 4) = make_float4(send16[4 * k], send16[4 * k + 1], send16[4 * k + 2], send16[4 * k + 3]);
+                    else *reinterpret_cast<float4*>(xs + (k * 64 + lane) * 4) = make_float4(xsend[k][0], xsend[k][1], xsend[k][2], xsend[k][3]);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -2215,7 +2337,7 @@ static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
         int nslot = needf(0) + 1;
         for (int sg = 0; sg + 1 < nseg; ++sg) nslot = std::max(nslot, needf(sg + 1) - (sg * 128) / nvr + 1);
         size_t rowb = (size_t)(wt + 2) * Tp * 128;
-        if (g.Cin == 32) rowb = std::max(rowb, (size_t)8 * 16 * (((size_t)((wt + 2) * Tp + 13) & ~(size_t)15) + 2));     // the K32 form's planar row (conv3_pp_kernel)
+        if (g.Cin == 32) rowb = std::max(rowb, (size_t)8 * 16 * (((size_t)((wt + 2) * Tp + 13) & ~(size_t)15) + 2));     // the 32-channel new form's planar row (conv3_pp_kernel)
         const size_t need = (size_t)nslot * rowb + (size_t)4 * 1024 * sizeof(float);
         if (need > 163840) continue;
         p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = need; p.grid = g.N * nstrips * ns;
@@ -2316,14 +2438,21 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
                 allow_big_lds(conv3_pp_kernel<25, false, 3>); allow_big_lds(conv3_pp_kernel<25, true, 3>);
                 allow_big_lds(conv3_pp_kernel<32, false, 3>); allow_big_lds(conv3_pp_kernel<32, true, 3>);
                 allow_big_lds(conv3_pp_kernel<32, false, 2, true>); allow_big_lds(conv3_pp_kernel<32, true, 2, true>);
-                allow_big_lds(conv3_pp_kernel<32, false, 3, true>); allow_big_lds(conv3_pp_kernel<32, true, 3, true>); });
+                allow_big_lds(conv3_pp_kernel<32, false, 3, true>); allow_big_lds(conv3_pp_kernel<32, true, 3, true>);
+                allow_big_lds(conv3_pp_kernel<25, false, 2, true>); allow_big_lds(conv3_pp_kernel<25, false, 3, true>); });
             // 32 input channels: the 16x16x32 MFMA form (one k-block per tap) unless PROBAV_PP_K16 asks for the 32x32x16 one (A/B runs; bit-identical sums are not
             // expected between the two: the order of the k-partial sums inside the matrix pipe differs)
             if (g_pp_k16 < 0) g_pp_k16 = getenv("PROBAV_PP_K16") != nullptr ? 1 : 0;
             const bool k16_env = g_pp_k16 == 1;
 #define PROBAV_PP(C, G, R) hipLaunchKernelGGL((conv3_pp_kernel<C, G, R>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
 #define PROBAV_PP_R(C, G) do { if (rvp == 2) PROBAV_PP(C, G, 2); else PROBAV_PP(C, G, 3); } while (0)
-            if (g.Cin == 25) { if (gate) PROBAV_PP_R(25, true); else PROBAV_PP_R(25, false); }
+            static const bool old25_env = getenv("PROBAV_PP_OLD25") != nullptr;          // A/B runs: the 25-channel layers (the forward pass) on the one-wave-per-tile form
+            if (g.Cin == 25 && (old25_env || gate)) { if (gate) PROBAV_PP_R(25, true); else PROBAV_PP_R(25, false); }    // (a gated 25-channel layer does not occur in this network: the old form, whose gated instance has the registers)
+            else if (g.Cin == 25) {
+#define PROBAV_PPN(R) hipLaunchKernelGGL((conv3_pp_kernel<25, false, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
+                if (rvp == 2) PROBAV_PPN(2); else PROBAV_PPN(3);
+#undef PROBAV_PPN
+            }
             else if (k16_env) { if (gate) PROBAV_PP_R(32, true); else PROBAV_PP_R(32, false); }
             else {
 #define PROBAV_PPK(G, R) hipLaunchKernelGGL((conv3_pp_kernel<32, G, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
