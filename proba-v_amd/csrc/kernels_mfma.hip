@@ -1825,8 +1825,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     auto load_skip = [&](int tile) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int vi = S16 ? tile * 32 + 16 * (jj >> 1) + pm16 : tile * 32 + er + 8 * jj;      // S16: jj = 2 u + v
-            eoff[jj] = vi < NV ? elem_off_ch(vi, S16 ? 16 * (jj & 1) + 4 * kq : 4 * eq) : -1;
+            const int vi = S16 ? tile * 32 + 16 * (jj >> 1) + pm16 : (P25 ? tile * 32 + col : tile * 32 + er + 8 * jj);      // S16: jj = 2 u + v; P25: jj = channel group g
+            eoff[jj] = vi < NV ? elem_off_ch(vi, S16 ? 16 * (jj & 1) + 4 * kq : (P25 ? 8 * jj + 4 * half : 4 * eq)) : -1;
             skq[jj] = (f32x4u){0.f, 0.f, 0.f, 0.f};
         }
         if (sbase) {
@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || (S16 ? 16 * (jj & 1) + 4 * kq : 4 * eq) + c >= g.Cout) ? 0 : eoff[jj] + c];
+                    for (int c = 0; c < 4; ++c) skq[jj][c] = sbase[(eoff[jj] < 0 || (S16 ? 16 * (jj & 1) + 4 * kq : (P25 ? 8 * jj + 4 * half : 4 * eq)) + c >= g.Cout) ? 0 : eoff[jj] + c];
             }
         }
     };
@@ -1900,6 +1900,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     for (int k = 0; k < 4; ++k) { keep[k] = (f32x4a){0.f, 0.f, 0.f, 0.f}; xsend[k] = keep[k]; }
     bool xvalid = false;
     float* xbuf = reinterpret_cast<float*>(plds + NS * rowbytes);            // [4 waves][16 registers][64 lanes]
+    // P25 computes its tiles transposed as well (a lane then holds channels 8 g + 4 half + i of ONE voxel: 16-byte skip loads and stores, no turn-around);
+    // the 16 channels' exponents and biases do not fit its registers: two 32-entry tables behind xbuf
+    int* tabE = reinterpret_cast<int*>(xbuf + 4096);
+    float* tabB = reinterpret_cast<float*>(tabE + 32);
+    if constexpr (P25) {
+        if (tid < 32) {
+            tabE[tid] = -(ea + h3_exp_w(am.w[tid < g.Cout ? tid : 0]));
+            tabB[tid] = (bias && tid < g.Cout) ? bias[tid] : 0.f;
+        }
+    }
     // the filter fragments of a tile's first k-blocks are requested BEFORE the barrier that opens its segment (an L2 round trip per segment otherwise)
     if (grp == 0) {
         if constexpr (S16) request_W16_first();
@@ -1976,23 +1986,23 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #pragma unroll
                     for (int K = K0; K < K1; ++K) {
                         const int L = K - K0, sl = L % RK, KN = K + RK - 1, LN = L + RK - 1;       // k-block requested now (its ring slot held k-block K - 1)
-                        PP_C25(0) = MFMA16H(AP[2 * sl][1], WP[sl][0], PP_C25(0));
+                        PP_C25(0) = MFMA16H(WP[sl][0], AP[2 * sl][1], PP_C25(0));
                         __builtin_amdgcn_sched_barrier(0);
                         if (KN < K1) request_WP(KN, LN % RK);
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_C25(1) = MFMA16H(AP[2 * sl + 1][1], WP[sl][0], PP_C25(1));
+                        PP_C25(1) = MFMA16H(WP[sl][0], AP[2 * sl + 1][1], PP_C25(1));
                         __builtin_amdgcn_sched_barrier(0);
                         if (KN < K1) request_AP(KN, LN, 0, 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_C25(0) = MFMA16H(AP[2 * sl][0], WP[sl][1], PP_C25(0));
+                        PP_C25(0) = MFMA16H(WP[sl][1], AP[2 * sl][0], PP_C25(0));
                         __builtin_amdgcn_sched_barrier(0);
                         if (KN < K1) request_AP(KN, LN, 1, 2);
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_C25(1) = MFMA16H(AP[2 * sl + 1][0], WP[sl][1], PP_C25(1));
+                        PP_C25(1) = MFMA16H(WP[sl][1], AP[2 * sl + 1][0], PP_C25(1));
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_C25(0) = MFMA16H(AP[2 * sl][0], WP[sl][0], PP_C25(0));
+                        PP_C25(0) = MFMA16H(WP[sl][0], AP[2 * sl][0], PP_C25(0));
                         __builtin_amdgcn_sched_barrier(0);
-                        PP_C25(1) = MFMA16H(AP[2 * sl + 1][0], WP[sl][0], PP_C25(1));
+                        PP_C25(1) = MFMA16H(WP[sl][0], AP[2 * sl + 1][0], PP_C25(1));
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #endif
@@ -2184,6 +2194,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             { float t_ = 0.f;
 #pragma unroll
               for (int i = 0; i < 16; ++i) t_ += acc[i];
+              if constexpr (S16) {                              // (the new forms keep their sums elsewhere: without this the ablation would drop half of the MFMAs as dead code)
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) t_ += keep[k][0] + keep[k][1] + keep[k][2] + keep[k][3];
+              }
+              if constexpr (P25) {
+#pragma unroll
+                  for (int i = 0; i < 16; ++i) t_ += keep16[i];
+              }
               if (t_ == 1234.5f) ybase[lane] = t_; }
 #else
 #ifdef PPX_NOEPI
@@ -2191,6 +2209,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             { float t_ = 0.f;
 #pragma unroll
               for (int i = 0; i < 16; ++i) t_ += acc[i];
+              if constexpr (S16) {                              // (the new forms keep their sums elsewhere: without this the ablation would drop half of the MFMAs as dead code)
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) t_ += keep[k][0] + keep[k][1] + keep[k][2] + keep[k][3];
+              }
+              if constexpr (P25) {
+#pragma unroll
+                  for (int i = 0; i < 16; ++i) t_ += keep16[i];
+              }
               if (t_ == 1234.5f) ybase[lane] = t_; }
 #else
             const bool fin = sg >= 1 && tile < NTL;                          // wave-uniform
@@ -2205,14 +2231,38 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
             have_nv = false;
             if (fin) {
               if constexpr (P25) {
-                // the partner's partial sums of this wave's 32 voxels (accumulator layout, in this wave's slot of xbuf, which then serves as the turn-around buffer)
-                float4 xp[4];
+                // keep16[4 g + i] (+ the partner's share, accumulator layout, in this wave's slot of xbuf): channel 8 g + 4 half + i of voxel `col` -- the
+                // layout of the 16-byte skip loads and output stores themselves
+                const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xp[k] = *reinterpret_cast<const float4*>(xbuf + tsel * 1024 + (k * 64 + lane) * 4);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (read before the slot is rewritten below)
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c0 = 8 * jj + 4 * half;
+                    const float4 xp = *reinterpret_cast<const float4*>(xbuf + tsel * 1024 + (jj * 64 + lane) * 4);
+                    const int4 e4 = *reinterpret_cast<const int4*>(tabE + c0);
+                    const float4 b4 = *reinterpret_cast<const float4*>(tabB + c0);
+                    const float xq[4] = {xp.x, xp.y, xp.z, xp.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const int eq4[4] = {e4.x, e4.y, e4.z, e4.w};
+                    f32x4u o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { acc[4 * k] = keep16[4 * k] + xp[k].x; acc[4 * k + 1] = keep16[4 * k + 1] + xp[k].y; acc[4 * k + 2] = keep16[4 * k + 2] + xp[k].z; acc[4 * k + 3] = keep16[4 * k + 3] + xp[k].w; }
-              }
+                    for (int i = 0; i < 4; ++i) {
+                        float v = ldexpf(keep16[4 * jj + i] + xq[i], eq4[i]) + bq[i];
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        o[i] = v + skq[jj][i];
+                    }
+                    if (full) {
+                        *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    } else if (eoff[jj] >= 0) {
+                        if (c0 + 4 <= g.Cout) {
+                            *reinterpret_cast<f32x4u*>(ybase + eoff[jj]) = o;
+                            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (c0 + c < g.Cout) { ybase[eoff[jj] + c] = o[c]; omax = fmaxf(omax, fabsf(o[c])); }
+                        }
+                    }
+                }
+              } else
               if constexpr (S16) {
                 // keep[2 u + v][i] (+ the partner's share): channel 16 v + 4 kq + i of voxel 16 u + pm16 -- the layout of the 16-byte skip loads and output stores themselves
                 const bool full = (tile * 32 + 32 <= NV) && g.Cout == 32;
@@ -2338,7 +2388,7 @@ static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
         for (int sg = 0; sg + 1 < nseg; ++sg) nslot = std::max(nslot, needf(sg + 1) - (sg * 128) / nvr + 1);
         size_t rowb = (size_t)(wt + 2) * Tp * 128;
         if (g.Cin == 32) rowb = std::max(rowb, (size_t)8 * 16 * (((size_t)((wt + 2) * Tp + 13) & ~(size_t)15) + 2));     // the 32-channel new form's planar row (conv3_pp_kernel)
-        const size_t need = (size_t)nslot * rowb + (size_t)4 * 1024 * sizeof(float);
+        const size_t need = (size_t)nslot * rowb + (size_t)4 * 1024 * sizeof(float) + 256;          // ring, hand-over / turn-around buffer, two 32-entry tables
         if (need > 163840) continue;
         p.ok = true; p.CC = g.Cin; p.KS = 16; p.lds_bytes = need; p.grid = g.N * nstrips * ns;
         p.a.g = g; p.a.Wp = wt + 2; p.a.Tp = Tp; p.a.SR = SR; p.a.nstrips = nstrips; p.a.nsplit = ns; p.a.Wt = wt;
