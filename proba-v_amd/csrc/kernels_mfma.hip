@@ -2007,8 +2007,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     }
 #endif
                 };
+#ifndef PPX_NOPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 if (tr == 0) run_kb(std::integral_constant<int, 0>(), std::integral_constant<int, KB0>());
                 else run_kb(std::integral_constant<int, KB0>(), std::integral_constant<int, 9 * NST>());
+#ifndef PPX_NOPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #undef PP_C25
 #if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
                 if (tile < NTL) load_skip(tile);
@@ -2083,8 +2089,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                     }
 #endif
                 };
+#ifndef PPX_NOPRIO
+                __builtin_amdgcn_s_setprio(1);                               // the matrix phase before the other half's finishing work: an idle matrix pipe is the expensive kind of idle
+#endif
                 if (tr == 0) run_taps(std::integral_constant<int, 0>(), std::integral_constant<int, KT0>());
                 else run_taps(std::integral_constant<int, KT0>(), std::integral_constant<int, 27>());
+#ifndef PPX_NOPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #undef PP_MM
 #undef PP_CU
 #if !defined(PPX_IDLE) && !defined(PPX_NOEPI)
