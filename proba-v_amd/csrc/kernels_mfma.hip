@@ -2500,7 +2500,7 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
                 allow_big_lds(conv3_pp_kernel<25, false, 3>); allow_big_lds(conv3_pp_kernel<25, true, 3>);
                 allow_big_lds(conv3_pp_kernel<32, false, 3>); allow_big_lds(conv3_pp_kernel<32, true, 3>);
                 allow_big_lds(conv3_pp_kernel<32, false, 2, true>); allow_big_lds(conv3_pp_kernel<32, true, 2, true>);
-                allow_big_lds(conv3_pp_kernel<32, false, 3, true>); allow_big_lds(conv3_pp_kernel<32, true, 3, true>);
+                allow_big_lds(conv3_pp_kernel<32, false, 3, true>);
                 allow_big_lds(conv3_pp_kernel<25, false, 2, true>); allow_big_lds(conv3_pp_kernel<25, false, 3, true>); });
             // 32 input channels: the 16x16x32 MFMA form (one k-block per tap) unless PROBAV_PP_K16 asks for the 32x32x16 one (A/B runs; bit-identical sums are not
             // expected between the two: the order of the k-partial sums inside the matrix pipe differs)
@@ -2518,7 +2518,7 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
             else if (k16_env) { if (gate) PROBAV_PP_R(32, true); else PROBAV_PP_R(32, false); }
             else {
 #define PROBAV_PPK(G, R) hipLaunchKernelGGL((conv3_pp_kernel<32, G, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
-                if (gate) { if (rvp == 2) PROBAV_PPK(true, 2); else PROBAV_PPK(true, 3); }
+                if (gate) { if (rvp == 2) PROBAV_PPK(true, 2); else PROBAV_PP(32, true, 3); }    // (gated with three items per thread -- reducers at T = 13: the new form's instance would spill 42 registers; the one-wave-per-tile form has them, same step time)
                 else      { if (rvp == 2) PROBAV_PPK(false, 2); else PROBAV_PPK(false, 3); }
 #undef PROBAV_PPK
             }
