@@ -1304,7 +1304,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     constexpr int NST = CIN <= 28 ? 6 : 7;                 // x6_wgrad_supported(): (Wt + 2) * Ti * NP <= 512 * NST
     // a tile = (patch n, column range sp, output row ho).  Ring row `key` = ho + dh holds input row key - ph (mirrored / zero outside),
     // local column lw <-> input column ws0 + lw - pw, local depth lt <-> input depth lt - pt (depth pads stay zero from the init).
-    auto stage_load = [&](int n, int key, int ws0, int Wts, float (&f)[NST][2]) {
+    // meta[k]: what stage_store needs of the item's index arithmetic, so that it is done once per item and not twice -- bits 0..23 the byte offset of the
+    // item's pair inside a ring row, bit 29: the pair's second channel exists, bit 30: the item exists, bit 31: inside the patch (row and column)
+    auto stage_load = [&](int n, int key, int ws0, int Wts, float (&f)[NST][2], int (&meta)[NST]) {
         int ih = key - a.ph;
         if (a.reflect) ih = wg_reflect(ih, a.Hi);
         const bool rok = ih >= 0 && ih < a.Hi;
@@ -1321,6 +1323,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             const bool ok = rok && iw >= 0 && iw < a.Wi;
             const int c0 = 2 * cp, c1 = c0 + 1 < CIN ? c0 + 1 : c0;
             const long o = ((long)(ok ? iw : 0) * a.Ti + t) * CIN;
+            meta[k] = ((lw * a.Tp + t + a.pt) * VS + cp * 4) | (c0 + 1 < CIN ? 1 << 29 : 0) | (i < items ? 1 << 30 : 0) | (ok ? (int)0x80000000u : 0);
             // raw values (clamped addresses): what must be zero is zeroed in stage_store -- a select right behind the load makes the wave
             // wait for the load where it is issued, i.e. at the top of the tile instead of under its MFMAs
             // (32 input channels -- the reducers -- keep the select here: one more item per thread, and the registers do not stretch to it)
@@ -1328,25 +1331,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
             else { const float f0 = src[o + c0], f1 = src[o + c1]; f[k][0] = ok ? f0 : 0.f; f[k][1] = ok ? f1 : 0.f; }
         }
     };
-    auto stage_store = [&](int key, int ws0, int Wts, const float (&f)[NST][2]) {
+    auto stage_store = [&](int key, const float (&f)[NST][2], const int (&meta)[NST]) {
         unsigned char* slot = lds_raw + (key % 3) * rowbytes;
-        const int items = (Wts + 2) * a.Ti * NP;
-        int ih = key - a.ph;
-        if (a.reflect) ih = wg_reflect(ih, a.Hi);
-        const bool rok = ih >= 0 && ih < a.Hi;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int i = tid + 512 * k;
-            if (i < items) {
-                const int vox = i / NP, cp = i - vox * NP;
-                const int lw = (int)__umulhi((unsigned)vox, a.mTi), t = vox - lw * a.Ti;
-                int iw = ws0 + lw - a.pw;
-                if (a.reflect) iw = wg_reflect(iw, a.Wi);
-                const bool ok = rok && iw >= 0 && iw < a.Wi;
+            if (meta[k] & (1 << 30)) {
+                const bool ok = meta[k] < 0;
                 unsigned q[NPC];
-                if constexpr (CIN == 25) cut_pair<AR>(ok ? f[k][0] : 0.f, (ok && 2 * cp + 1 < CIN) ? f[k][1] : 0.f, sx, q);
+                if constexpr (CIN == 25) cut_pair<AR>(ok ? f[k][0] : 0.f, (ok && (meta[k] & (1 << 29))) ? f[k][1] : 0.f, sx, q);
                 else cut_pair<AR>(f[k][0], f[k][1], sx, q);
-                unsigned char* d = slot + (lw * a.Tp + t + a.pt) * VS + cp * 4;
+                unsigned char* d = slot + (meta[k] & 0xffffff);
 #pragma unroll
                 for (int p = 0; p < NPC; ++p) *reinterpret_cast<unsigned*>(d + p * CB) = q[p];
             }
@@ -1356,8 +1350,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
 #pragma unroll 1
         for (int rr = 0; rr < 3; ++rr) {
             float f[NST][2];
-            stage_load(n, ho + rr, ws0, Wts, f);
-            stage_store(ho + rr, ws0, Wts, f);
+            int mt[NST];
+            stage_load(n, ho + rr, ws0, Wts, f, mt);
+            stage_store(ho + rr, f, mt);
         }
     };
     auto decode = [&](int tile, int& n, int& ws0, int& Wts, int& ho) {     // tile = (n * nsplit + sp) * H + ho
@@ -1429,7 +1424,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         // read, which makes the prefetches below synchronous).
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
         float nf[NST][2];
-        if (consecutive) stage_load(n, ho + 3, ws0, Wts, nf);   // ring row of the next tile's dh = 2, in flight during this tile's MFMAs
+        int nmeta[NST];
+        if (consecutive) stage_load(n, ho + 3, ws0, Wts, nf, nmeta);   // ring row of the next tile's dh = 2, in flight during this tile's MFMAs
         float4 ndy[NDY];
         if constexpr (DYI) { if (has_next) dy_load(nn, nho, nws0, nWts, ndy); }       // the next tile's dY row likewise
         const long out_base = (((long)n * a.H + ho) * a.W + ws0) * a.T;
@@ -1599,7 +1595,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
         XS_ACC(3);
         __syncthreads();                                   // every wave is done with this tile's rows
         XS_ACC(4);
-        if (consecutive) stage_store(ho + 3, ws0, Wts, nf);     // replaces ring row ho
+        if (consecutive) stage_store(ho + 3, nf, nmeta);     // replaces ring row ho
         else if (has_next) stage_three(nn, nho, nws0, nWts);
         if constexpr (DYI) { if (has_next) dy_store(nWts, ndy); }
         XS_ACC(5);
