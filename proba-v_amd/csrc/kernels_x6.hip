@@ -1256,6 +1256,7 @@ struct WgArgs {
     int ph, pw, pt, reflect;    // pads (0 or 1 each); reflect: H/W pads mirror the input (tf.pad REFLECT) instead of zeros
     int Wp, Tp, nv, total_tiles;
     int nsplit, Wt;             // output rows are cut into nsplit column ranges of Wt columns when three full rows do not fit the LDS
+    int tab;                    // byte offset of the staging table in LDS (nsplit == 1 and room for it), 0 = none
     unsigned mT, mTi;           // ceil(2^32 / T), ceil(2^32 / Ti): floor(v / d) = umulhi(v, m) for the small v used here (d >= 2)
 };
 
@@ -1306,11 +1307,42 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     // local column lw <-> input column ws0 + lw - pw, local depth lt <-> input depth lt - pt (depth pads stay zero from the init).
     // meta[k]: what stage_store needs of the item's index arithmetic, so that it is done once per item and not twice -- bits 0..23 the byte offset of the
     // item's pair inside a ring row, bit 29: the pair's second channel exists, bit 30: the item exists, bit 31: inside the patch (row and column)
+    // With one column range per row (nsplit == 1) a thread's items are the same for every row: their index arithmetic is done ONCE, at the start of the
+    // kernel, and kept in LDS ([NST][512] pairs: source offset inside an input row, meta without the row's validity) -- six 8-byte reads per row instead of
+    // some 25 vector instructions per item.
+    int2* stab = a.tab ? reinterpret_cast<int2*>(lds_raw + a.tab) : nullptr;
+    if (stab) {
+        const int items = (a.W + 2) * a.Ti * NP;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + 512 * k;
+            const int ic = i < items ? i : 0;
+            const int vox = ic / NP, cp = ic - vox * NP;
+            const int lw = (int)__umulhi((unsigned)vox, a.mTi), t = vox - lw * a.Ti;
+            int iw = lw - a.pw;
+            if (a.reflect) iw = wg_reflect(iw, a.Wi);
+            const bool cok = iw >= 0 && iw < a.Wi;
+            const int c0 = 2 * cp;
+            stab[k * 512 + tid] = make_int2(((cok ? iw : 0) * a.Ti + t) * CIN + c0,
+                                            ((lw * a.Tp + t + a.pt) * VS + cp * 4) | (c0 + 1 < CIN ? 1 << 29 : 0) | (i < items ? 1 << 30 : 0) | (cok ? (int)0x80000000u : 0));
+        }
+    }
     auto stage_load = [&](int n, int key, int ws0, int Wts, float (&f)[NST][2], int (&meta)[NST]) {
         int ih = key - a.ph;
         if (a.reflect) ih = wg_reflect(ih, a.Hi);
         const bool rok = ih >= 0 && ih < a.Hi;
         const float* src = x + ((long)n * a.Hi + (rok ? ih : 0)) * (long)a.Wi * a.Ti * CIN;
+        if (stab) {
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int2 c = stab[k * 512 + tid];
+                meta[k] = rok ? c.y : c.y & 0x7fffffff;
+                const float f0 = src[c.x], f1 = src[c.x + ((c.y >> 29) & 1)];
+                if constexpr (CIN == 25) { f[k][0] = f0; f[k][1] = f1; }
+                else { const bool ok = meta[k] < 0; f[k][0] = ok ? f0 : 0.f; f[k][1] = ok ? f1 : 0.f; }
+            }
+            return;
+        }
         const int items = (Wts + 2) * a.Ti * NP;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -1705,6 +1737,11 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
     if (arith == 2) lds = ((lds + 15) & ~(size_t)15) + (size_t)((a.nv + 15) & ~15) * 128;      // H3: + the dY image
     const size_t xch = (size_t)4 * (7 * 16 + 1) * 64 * sizeof(float);                 // exchange area of the epilogue
     if (lds < xch) lds = xch;
+    a.tab = 0;
+    {   // the staging table (kernel: stab): one column range per row, and room behind the images
+        const size_t tb = (lds + 15) & ~(size_t)15, tsz = (size_t)(g.Cin == 25 ? 6 : 7) * 512 * 8;
+        if (a.nsplit == 1 && tb + tsz <= 160 * 1024) { a.tab = (int)tb; lds = tb + tsz; }
+    }
     static std::once_flag once;
     std::call_once(once, [] {
 #define PROBAV_WGA(C, G, A) note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x6_kernel<C, G, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
