@@ -1676,7 +1676,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
         auto locate = [&](int lv, int& lw, int& t, int& iwc, int& colok) {
             const int lwr = fdiv(lv, g.Ti, a.mTi);
             t = lv - lwr * g.Ti; lw = lw0 + lwr;
-            const int iw = ws0 + lw - g.pw;
+            int iw = ws0 + lw - g.pw;
+            if (g.reflect_hw) iw = iw < 0 ? -iw : (iw >= g.Wi ? 2 * g.Wi - 2 - iw : iw);     // tf.pad REFLECT: the H / W pads mirror the input (convReducer_1)
             colok = (iw >= 0 ? 1 : 0) & (iw < g.Wi ? 1 : 0);
             iwc = iw < 0 ? 0 : (iw < g.Wi ? iw : g.Wi - 1);
         };
@@ -1707,7 +1708,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     // stage_load only REQUESTS (clamped addresses, nothing consumed): what must be zero -- rows and columns outside the patch, the dead
     // depths of the gathered chunk -- is zeroed in stage_store, so that the loads stay in flight across the barrier
     auto stage_load = [&](int q, Staged& sv) {
-        const int ih = hb - g.ph + q;
+        int ih = hb - g.ph + q;
+        if (g.reflect_hw) ih = ih < 0 ? -ih : (ih >= g.Hi ? 2 * g.Hi - 2 - ih : ih);
         const bool rok = ih >= 0 && ih < g.Hi;
         const long rbase = (((long)n * g.Hi + (rok ? ih : 0)) * g.Wi) * (long)g.Ti * CIN;
         const float* xrow = x + rbase;
@@ -1737,7 +1739,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     auto stage_store = [&](int q, Staged& sv) {
         const int sl = q - fdiv(q, NS, a.mNslot) * NS;
         unsigned char* slot = plds + sl * rowbytes;
-        const int ih = hb - g.ph + q;
+        int ih = hb - g.ph + q;
+        if (g.reflect_hw) ih = ih < 0 ? -ih : (ih >= g.Hi ? 2 * g.Hi - 2 - ih : ih);
         const int rok = (ih >= 0 && ih < g.Hi) ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < RVP; ++k) {
@@ -2378,7 +2381,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
 {
     p.ok = false;
-    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.Cout > 32 || (g.Cin != 25 && g.Cin != 32)) return false;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.Cout > 32 || (g.Cin != 25 && g.Cin != 32)) return false;
+    if (g.reflect_hw && (g.ph != 1 || g.pw != 1 || g.Hi < 2 || g.Wi < 2)) return false;        // mirrored pads of 1: the staging mirrors its source row / column (convReducer_1)
     if (g.Ho != g.Hi + 2 * g.ph - 2 || g.Wo != g.Wi + 2 * g.pw - 2 || g.To != g.Ti + 2 * g.pt - 2) return false;
     if (g.Cin == 25 && (g.pt != 1 || g.To != g.Ti)) return false;
     if (g.Ho < 3) return false;
