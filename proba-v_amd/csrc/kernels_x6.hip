@@ -208,6 +208,160 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
     XS_OUT;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same fused forward on v_mfma_f32_16x16x32_f16 (H3 only): 32 input channels are ONE k-block of that shape, a hidden chunk of 32 is
+// one k-block of the second product.  The kernel is the one above with another register tiling -- the LDS images of the two weight sets are
+// read IN PLACE with another lane order, nothing is packed twice:
+//   first product   H^T[hidden 16 s + .][voxel 16 u + .]: A = W1^T, lane (m, kq) wants k = cin 8 kq .. + 7 of hidden row 16 s + m =
+//                   lane (16 s + m) + 32 (kq & 1) of the 32x32x16 fragment kb = kq >> 1 (one ds_read_b128); B = X^T, lane (n, kq): cin 8 kq .. of voxel 16 u + n
+//   its accumulator lane (n, kq), register i = hidden 16 s + 4 kq + i of voxel 16 u + n: registers (s, i) of a lane are k-slots j = 4 s + i of
+//                   the second product's B operand (k = 8 kq + j) once the matching A operand is packed with that order: hidden 16 (j >> 2) + 4 kq + (j & 3),
+//                   which in the W2 image (k-slot kp = rowmap(8 kb + j', half)) is fragment kb = j >> 2, lane (16 o + m) + 32 (kq & 1), bytes 8 (kq >> 1) .. + 7
+//                   (two ds_read_b64 per fragment)
+//   second product  T^T[out 16 o + 4 kq + i][voxel 16 u + n]: a lane holds four consecutive output channels of one voxel -> 16-byte stores
+// Why: cycles per FLOP are the same, but the chip holds a higher clock on this shape, and this kernel ran at the lowest clock of the set.
+// The hidden tile's sums are NOT bit-identical to the 32x32x16 kernel's (32 against 16 products per instruction); the backward pass recomputes the tile
+// with the 32x32x16 arrangement, and so does probav_debug_hidden: gates of pre-activations that sit at zero to the last bit can differ between the passes.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag, const uint4* __restrict__ w2frag,
+                                                            const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ dec,
+                                                            long nvox, int vps, int D, PwAmax am)
+{
+    using AR = H3;
+    constexpr int NP = 2, WAVES = 8;
+    typedef float f32x4k __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4* sW1 = reinterpret_cast<uint4*>(lds_raw);             // [8 chunks][2 kb][NP pieces][64 lanes]  32 KB
+    uint4* sW2 = sW1 + 8 * 2 * NP * 64;                          // same
+    float* sB1 = reinterpret_cast<float*>(sW2 + 8 * 2 * NP * 64);    // 256
+    float* sB2 = sB1 + 256;                                      // 32
+    int* sE2 = reinterpret_cast<int*>(sB2 + 32);                 // 32: H3 exponent of decConv's output column d
+    const int tid = threadIdx.x, lane = tid & 63, m16 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
+    if (tid < 256) sB1[tid] = b1[tid];
+    if (tid < 32) { sB2[tid] = tid < D ? b2[tid] : 0.f; sE2[tid] = tid < D ? h3_exp_w(am.w2c[tid]) : 0; }
+    __syncthreads();
+    float sx = 1.f, sbias = 1.f, c1 = 1.f; int eh = 0;
+    const unsigned aw1 = *am.w1, ab1 = *am.b1;
+    const int ew1 = h3_exp_w(aw1);
+    auto sample_scales = [&](int n) {
+        const unsigned ax = am.x[n];
+        const int ex = h3_exp(ax);
+        eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1));
+        sx = pow2i(ex); sbias = pow2i(eh);
+        const int k1 = -(ex + ew1);
+        c1 = pow2i(k1 < -126 ? -126 : k1);
+    };
+    const int tps = (vps + 31) >> 5;
+    const long ntiles = (nvox / vps) * tps;
+    const long gw = (long)blockIdx.x * WAVES + wave, nw = (long)gridDim.x * WAVES;
+    const long tb = ntiles * gw / nw, te = ntiles * (gw + 1) / nw;
+    int n = (int)(tb / tps), j = (int)(tb - (long)n * tps);
+    float omax = 0.f;
+    if (tb < te) sample_scales(n);
+    float4 nx[2][2];                                             // [u][two float4]: cin 8 kq .. 8 kq + 7 of voxel 16 u + m16
+    auto load_x = [&](int nn, int jj) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int vl = 32 * jj + 16 * u + m16;
+            const long v = (long)nn * vps + (vl < vps ? vl : vps - 1);
+            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 8 * kq);
+            nx[u][0] = xp[0]; nx[u][1] = xp[1];
+        }
+    };
+    if (tb < te) load_x(n, j);
+    // lane parts of the operand addresses inside the weight images (bytes)
+    const int a1l = ((kq >> 1) * NP * 64 + m16 + 32 * (kq & 1)) * 16;                 // + s * 256 + piece * 1024 + chunk * (2 NP 1024)
+    const int a2l = (m16 + 32 * (kq & 1)) * 16 + 8 * (kq >> 1);                      // + o * 256 + piece * 1024 + kb * (NP 1024) + chunk * (2 NP 1024)
+    const unsigned char* w1b = reinterpret_cast<const unsigned char*>(sW1) + a1l;
+    const unsigned char* w2b = reinterpret_cast<const unsigned char*>(sW2) + a2l;
+    for (long tile = tb; tile < te; ++tile) {
+        Frag xb[2][NP];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 t0 = nx[u][0], t1 = nx[u][1];
+            const float xs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            cut8<AR>(xs, sx, xb[u]);
+        }
+        if (tile + 1 < te) { const bool wrap = j + 1 == tps; load_x(wrap ? n + 1 : n, wrap ? 0 : j + 1); }
+        f32x4k T[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) { T[o][0] = (f32x4k){0.f, 0.f, 0.f, 0.f}; T[o][1] = T[o][0]; }
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            const unsigned char* wc1 = w1b + c * (2 * NP * 1024);
+            const unsigned char* wc2 = w2b + c * (2 * NP * 1024);
+            Frag a1[2][NP];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) a1[s][p].u = *reinterpret_cast<const uint4*>(wc1 + s * 256 + p * 1024);
+            f32x4k H[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { H[s][0] = (f32x4k){0.f, 0.f, 0.f, 0.f}; H[s][1] = H[s][0]; }
+#define PWK(C, a, pa, b, pb) C = __builtin_amdgcn_mfma_f32_16x16x32_f16((a)[pa].h, (b)[pb].h, C, 0, 0, 0)
+            PWK(H[0][0], a1[0], 1, xb[0], 0); PWK(H[0][1], a1[0], 1, xb[1], 0); PWK(H[1][0], a1[1], 1, xb[0], 0); PWK(H[1][1], a1[1], 1, xb[1], 0);
+            PWK(H[0][0], a1[0], 0, xb[0], 1); PWK(H[0][1], a1[0], 0, xb[1], 1); PWK(H[1][0], a1[1], 0, xb[0], 1); PWK(H[1][1], a1[1], 0, xb[1], 1);
+            PWK(H[0][0], a1[0], 0, xb[0], 0); PWK(H[0][1], a1[0], 0, xb[1], 0); PWK(H[1][0], a1[1], 0, xb[0], 0); PWK(H[1][1], a1[1], 0, xb[1], 0);
+            // the second product's A operand: k-slots j < 4 from the kb = 0 fragment, j >= 4 from kb = 1 (8 bytes each)
+            Frag a2[2][NP];
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(wc2 + o * 256 + p * 1024), hi = *reinterpret_cast<const uint2*>(wc2 + o * 256 + p * 1024 + NP * 1024);
+                    a2[o][p].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            // bias + ReLU + cut: registers (s, i) of H[s][u] are k-slots 4 s + i
+            const float4 bq0 = *reinterpret_cast<const float4*>(sB1 + 32 * c + 4 * kq), bq1 = *reinterpret_cast<const float4*>(sB1 + 32 * c + 16 + 4 * kq);
+            const float bv[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+            Frag hb[2][NP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float hs[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { hs[i] = fmaxf(fmaf(H[0][u][i], c1, bv[i]), 0.f); hs[4 + i] = fmaxf(fmaf(H[1][u][i], c1, bv[4 + i]), 0.f); }
+                cut8<AR>(hs, sbias, hb[u]);
+            }
+            PWK(T[0][0], a2[0], 1, hb[0], 0); PWK(T[0][1], a2[0], 1, hb[1], 0); PWK(T[1][0], a2[1], 1, hb[0], 0); PWK(T[1][1], a2[1], 1, hb[1], 0);
+            PWK(T[0][0], a2[0], 0, hb[0], 1); PWK(T[0][1], a2[0], 0, hb[1], 1); PWK(T[1][0], a2[1], 0, hb[0], 1); PWK(T[1][1], a2[1], 0, hb[1], 1);
+            PWK(T[0][0], a2[0], 0, hb[0], 0); PWK(T[0][1], a2[0], 0, hb[1], 0); PWK(T[1][0], a2[1], 0, hb[0], 0); PWK(T[1][1], a2[1], 0, hb[1], 0);
+#undef PWK
+        }
+        // T[o][u][i]: output channel 16 o + 4 kq + i of voxel 16 u + m16
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int vl = 32 * j + 16 * u + m16;
+            if (vl < vps) {
+                float* op = dec + ((long)n * vps + vl) * D;
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int c0 = 16 * o + 4 * kq;
+                    float t[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = ldexpf(T[o][u][i], -(sE2[c0 + i] + eh)) + sB2[c0 + i];
+                    if (c0 + 4 <= D) {
+                        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                        f32x4u q = {t[0], t[1], t[2], t[3]};
+                        *reinterpret_cast<f32x4u*>(op + c0) = q;
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (c0 + i < D) { op[c0 + i] = t[i]; omax = fmaxf(omax, fabsf(t[i])); }
+                    }
+                }
+            }
+        }
+        if (++j == tps) {
+            if (am.y) amax_commit(omax, am.y + n);
+            omax = 0.f; j = 0; ++n;
+            if (tile + 1 < te) sample_scales(n);
+        }
+    }
+    if (am.y && j != 0 && tb < te) amax_commit(omax, am.y + n);
+}
+
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                   long nvox, long vps, int D, int arith, const PwAmax& am, hipStream_t s, float* hdump)
 {
@@ -216,14 +370,17 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_h3k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     if (vps <= 0 || vps > nvox) vps = nvox;                          // one "sample"
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_forward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2c || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
         const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32) * sizeof(float);
+        static const bool v1_env = getenv("PROBAV_PW_FWD_V1") != nullptr;      // A/B runs: the 32x32x16 kernel
         if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                                       b1, b2, dec, nvox, (int)vps, D, am, hdump);
+        else if (!v1_env) hipLaunchKernelGGL(pw_fwd_h3k_kernel, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am);
         else hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, false>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                                 b1, b2, dec, nvox, (int)vps, D, am, hdump);
     } else {
