@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROBAV_ABI_VERSION 4
+#define PROBAV_ABI_VERSION 5
 
 /* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
  * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale=True)   (models/modelsTF.py:8-17) */
@@ -94,6 +94,15 @@ int probav_forward(probav_engine* e, const float* params, const float* x, float*
  * (training=1) on the same ws / batch.                                                              */
 int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws,
                     size_t ws_bytes, int batch, void* stream);
+/* The same in two buffers (ABI 5).  probav_workspace_bytes(e, batch, 1) = saved_bytes + scratch_bytes: the first part is the SAVED STATE of a
+ * training forward pass (what `tf.GradientTape` keeps: models/trainClass.py:126-131) -- probav_forward(training=1) needs no more than that --,
+ * the second is what only the reverse pass writes on its way (gradient buffers, partial-sum slabs, its amax slots; meaningless before and
+ * after).  probav_backward_split READS `saved` and writes `scratch`: the saved state of one forward pass can serve any number of reverse
+ * passes (a retained graph, a gradient check), and a framework that tracks which operator writes which of its arguments sees a functional
+ * operator.  wcache: the weight cache the forward pass ran from, or NULL.  probav_backward(ws) = probav_backward_split(ws, ws + saved_bytes). */
+int probav_workspace_split(const probav_engine* e, int batch, size_t* saved_bytes, size_t* scratch_bytes);
+int probav_backward_split(probav_engine* e, const float* params, const float* dy, float* grads, const void* saved, size_t saved_bytes,
+                          void* scratch, size_t scratch_bytes, int batch, const void* wcache, size_t wcache_bytes, void* stream);
 
 /* ---- optimizer update fused with the weight normalisation of the next step ---------------------------------
  * replaces  optimizer.apply_gradients(...)  +  the WeightNormalization kernel recomputation of the NEXT model call
@@ -214,7 +223,8 @@ int probav_workspace_view(const probav_engine* e, int batch, int training, int k
 /* the post-ReLU hidden tile relu(expConv_block(x)) [B*(P+s)^2*T][256] (models/modelsTF.py:179-180) exactly as the fused forward kernel
  * of the current kernel family (3 or 4) evaluates it -- that tensor never reaches memory otherwise.  Call after probav_forward(training=1)
  * with the same workspace; the ReLU gates of the reverse pass are the signs of these values.                                          */
-int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int batch, int block, float* hidden,
+int probav_debug_hidden(probav_engine* e, const float* params, const void* ws /* saved state: read only */, size_t ws_bytes, int batch, int block, float* hidden,
+                        float* dec_scratch /* [voxels][dec channels] floats: the launch's regular output, discarded */,
                         const void* wcache /* the weight cache the forward pass ran from, or NULL */, void* stream);
 
 #ifdef __cplusplus

@@ -67,7 +67,9 @@ SIGNATURES = {
     "probav_weight_cache_build": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "probav_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "probav_mfma_probe_shape": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "probav_workspace_split": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "probav_backward_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
     "probav_weight_cache_bytes": (c_size_t, [c_void_p]),
     "probav_optimizer_step_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
                                             c_void_p, c_size_t, c_void_p]),
@@ -94,7 +96,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if L.probav_abi_version() != 4:
+        if L.probav_abi_version() != 5:
             raise RuntimeError("libprobav_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -112,11 +112,14 @@ static int add_layer(probav_engine* e, const std::string& name, int kh, int kw, 
 static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }      // 64 floats = 256 B
 
 struct Plan {
-    size_t weff, weffT, invn, dweff, xn, mn;
+    size_t weff, weffT, invn, xn, mn;
     size_t amax; int n_amax, amax_bwd, amax_fwd, B;   // amax slots (one 32-bit word each, x6_device.h): region offset, count, first slot of the backward / forward per-sample arrays
     std::vector<size_t> act, dec, red;
     std::vector<int> redH, redT;              // output extent of each reducer
-    size_t up, r1, r2, r3, H, dH, gA, gB, gDec, dtail, dr2, dr1, partial, wpack, total;
+    size_t up, r1, r2, r3, H, wpack;
+    // --- what only the reverse pass writes (offsets relative to the SCRATCH base: the tail of a one-piece workspace, or the caller's second buffer) ---
+    size_t bamax, dweff2, Hb, dH, gA, gB, gDec, dtail, dr2, dr1, partial;
+    size_t fwd_total, bwd_total, total;       // floats: the saved state of a forward pass | the reverse pass's scratch | both
     std::vector<size_t> gblk, gred;
     std::vector<size_t> part_off;      // slab region of the k-th backward-filter launch of a backward pass (relative to `partial`), in launch order
 };
@@ -193,9 +196,8 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         p.amax_fwd = 2 * L + (int)e->cout_total + (int)e->cin_total;
         p.amax_bwd = p.amax_fwd + B * (2 * R + 1 + nred);
         p.n_amax = p.amax_bwd + (training ? B * (2 * R + 2 * nred + 8) : 0);
-        p.amax = take((size_t)p.n_amax);
+        p.amax = take((size_t)p.amax_bwd);
     }
-    p.dweff = take(training ? e->weff_count : 0);
     p.wpack = take(e->wpack_count);
     p.xn = take(V); p.mn = take((size_t)B * Hin * Hin);
     if (training) {
@@ -215,8 +217,13 @@ static Plan make_plan(const probav_engine* e, int B, int training)
     // the 256-channel hidden tensor (1 KB per voxel) only exists in memory when the pointwise pair runs UNfused (generic kernels, impl 0)
     const bool unfused = !(e->impl >= 1 && e->pw_mfma);
     p.H = take(unfused ? V * E : 0);
-    p.dH = p.gA = p.gB = p.gDec = p.dtail = p.dr2 = p.dr1 = p.partial = 0;
+    p.fwd_total = off;
+    off = 0;
+    p.bamax = p.dweff2 = p.Hb = p.dH = p.gA = p.gB = p.gDec = p.dtail = p.dr2 = p.dr1 = p.partial = 0;
     if (training) {
+        p.bamax = take((size_t)(p.n_amax - p.amax_bwd));
+        p.dweff2 = take(e->weff_count);
+        p.Hb = take(unfused ? V * E : 0);              // the recomputed hidden tensor of the unfused path (the forward pass's own copy is saved state: read-only here)
         size_t gmax = (size_t)B * (Hin + 2) * (Hin + 2) * T * F;
         {   // gradients of the (mirror-padded) reducer inputs
             int h = Hin, t = T;
@@ -262,7 +269,8 @@ static Plan make_plan(const probav_engine* e, int B, int training)
             p.partial = take(acc);
         }
     }
-    p.total = off;
+    p.bwd_total = off;
+    p.total = p.fwd_total + p.bwd_total;
     return p;
 }
 
@@ -286,10 +294,11 @@ struct Frags { const float* f32 = nullptr; const float* x6 = nullptr; const floa
 
 // amax slot addresses inside the workspace (layout: make_plan)
 struct AmaxSlots {
-    const probav_engine* e; unsigned* base; unsigned* wbase; int L, R, B, fwd, bwd;
-    // wslots: where the weights' slots live -- the head of the workspace's amax region, or the weight cache's
-    AmaxSlots(const probav_engine* e_, const Plan& p, float* W, int R_, unsigned* wslots = nullptr)
-        : e(e_), base(reinterpret_cast<unsigned*>(W + p.amax)), wbase(wslots ? wslots : reinterpret_cast<unsigned*>(W + p.amax)), L((int)e_->layers.size()), R(R_), B(p.B), fwd(p.amax_fwd), bwd(p.amax_bwd) {}
+    const probav_engine* e; unsigned* base; unsigned* wbase; unsigned* bbase; int L, R, B, fwd;
+    // wslots: where the weights' slots live -- the head of the workspace's amax region, or the weight cache's; S: the reverse pass's scratch (its slots live there)
+    AmaxSlots(const probav_engine* e_, const Plan& p, const float* W, int R_, unsigned* wslots = nullptr, float* S = nullptr)
+        : e(e_), base(reinterpret_cast<unsigned*>(const_cast<float*>(W) + p.amax)), wbase(wslots ? wslots : reinterpret_cast<unsigned*>(const_cast<float*>(W) + p.amax)),
+          bbase(S ? reinterpret_cast<unsigned*>(S + p.bamax) : nullptr), L((int)e_->layers.size()), R(R_), B(p.B), fwd(p.amax_fwd) {}
     unsigned* w(int li) const { return wbase + li; }                                   // whole weight tensor of layer li
     unsigned* b(int li) const { return wbase + L + li; }                               // its bias
     unsigned* wcol(int li) const { return wbase + 2 * L + e->layers[li].wn.n_off; }     // per output channel (Cout slots): columns of the forward matrices
@@ -297,7 +306,7 @@ struct AmaxSlots {
     unsigned* act(int i) const { return base + fwd + B * i; }                         // per-sample arrays (B slots each)
     unsigned* dec(int i) const { return base + fwd + B * (R + 1 + i); }
     unsigned* red(int k) const { return base + fwd + B * (2 * R + 1 + k); }
-    unsigned* back(int j) const { return base + bwd + B * j; }                        // j-th tensor produced by the backward pass
+    unsigned* back(int j) const { return bbase + B * j; }                             // j-th tensor produced by the backward pass
 };
 
 static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const float* x, const float* gate, const float* w,
@@ -642,7 +651,7 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
     if (!e || !params || !x || !y || !ws || B < 1) { set_error("probav_forward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const Plan p = make_plan(e, B, training);
-    if (ws_bytes < p.total * sizeof(float)) { set_error("probav_forward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
+    if (ws_bytes < p.fwd_total * sizeof(float)) { set_error("probav_forward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
     float* W = (float*)ws;
     const WcPlan wc = make_wc_plan(e);
     // where the parameter-derived tensors live: inside the workspace (recomputed by this call) or in the caller's weight cache
@@ -730,14 +739,18 @@ int probav_forward_wc(probav_engine* e, const float* params, const float* x, flo
     return forward_impl(e, params, x, y, ws, ws_bytes, B, training, (const float*)wcache, stream);
 }
 
-static int backward_impl(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes,
-                         int B, const float* WC, void* stream)
+// ws: the saved state of the matching forward pass (READ ONLY here); scratch: what the reverse pass writes on its way (gradient buffers, slabs, its amax
+// slots; contents meaningless before and after).  scratch == nullptr: the one-piece form, the scratch is the tail of `ws`.
+static int backward_impl(probav_engine* e, const float* params, const float* dy, float* grads, const void* ws, size_t ws_bytes,
+                         void* scratch, size_t scratch_bytes, int B, const float* WC, void* stream)
 {
     if (!e || !params || !dy || !grads || !ws || B < 1) { set_error("probav_backward: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const Plan p = make_plan(e, B, 1);
-    if (ws_bytes < p.total * sizeof(float)) { set_error("probav_backward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
-    float* W = (float*)ws;
+    if (ws_bytes < (scratch ? p.fwd_total : p.total) * sizeof(float)) { set_error("probav_backward: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
+    if (scratch && scratch_bytes < p.bwd_total * sizeof(float)) { set_error("probav_backward: scratch too small", hipSuccess); return PROBAV_ENOSPACE; }
+    const float* W = (const float*)ws;
+    float* S = scratch ? (float*)scratch : const_cast<float*>(W) + p.fwd_total;
     const WcPlan wc = make_wc_plan(e);
     const float* Wweff = WC ? WC + wc.weff : W + p.weff;
     const float* WweffT = WC ? WC + wc.weffT : W + p.weffT;
@@ -757,7 +770,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     };
     // amax slots of the gradient tensors, in launch order (the forward pass left those of the weights and activations)
     const bool h3 = e->impl >= 4;
-    const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
+    const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr, S);
     int nback = 0;
     auto new_slot = [&]() -> unsigned* { return h3 ? A.back(nback++) : nullptr; };
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wrow(li); m.y = ay; } return m; };   // backward-data: the matrix' columns are the layer's INPUT channels
@@ -770,35 +783,35 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         return PROBAV_EINVAL;
     }
     if (h3 && hipMemsetAsync(A.back(0), 0, (size_t)(p.n_amax - p.amax_bwd) * sizeof(unsigned), s) != hipSuccess) { set_error("probav_backward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
-    auto dweff = [&](int li) { return W + p.dweff + e->layers[li].wn.w_off; };
+    auto dweff = [&](int li) { return S + p.dweff2 + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     int npart = 0;
-    auto next_part = [&]() -> float* { const size_t k = (size_t)npart < p.part_off.size() ? (size_t)npart : p.part_off.size() - 1; ++npart; return W + p.partial + p.part_off[k]; };
+    auto next_part = [&]() -> float* { const size_t k = (size_t)npart < p.part_off.size() ? (size_t)npart : p.part_off.size() - 1; ++npart; return S + p.partial + p.part_off[k]; };
     SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s);
 
-    CK(tail_backward(dy, W + p.dtail, B, P, c.scale, c.std, s));
+    CK(tail_backward(dy, S + p.dtail, B, P, c.scale, c.std, s));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first
     {
         hipStream_t rs = reduce_fork(s);                 // beside the main chain: nothing below depends on it until the weight-norm backward
         const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g3, W + p.r2, W + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), next_part(), Amax(), rs));
-        CK(conv_fwd(e, bwd_data_geom(g3), W + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, W + p.dr2, Amax(), rs));
+        CK(conv_wgrad(e, g3, W + p.r2, S + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), next_part(), Amax(), rs));
+        CK(conv_fwd(e, bwd_data_geom(g3), S + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, S + p.dr2, Amax(), rs));
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-        CK(conv_wgrad(e, g2, W + p.r1, W + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), next_part(), Amax(), rs));
-        CK(conv_fwd(e, bwd_data_geom(g2), W + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, W + p.dr1, Amax(), rs));
+        CK(conv_wgrad(e, g2, W + p.r1, S + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), next_part(), Amax(), rs));
+        CK(conv_fwd(e, bwd_data_geom(g2), S + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, S + p.dr1, Amax(), rs));
         const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
-        CK(conv_wgrad(e, g1, W + p.mn, W + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), next_part(), Amax(), rs));
+        CK(conv_wgrad(e, g1, W + p.mn, S + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), next_part(), Amax(), rs));
     }
     // upscale + reducers (models/modelsTF.py:152-164)
     const int nred = (int)e->iRed.size();
-    float* cur = W + p.gA;
-    float* oth = W + p.gB;
+    float* cur = S + p.gA;
+    float* oth = S + p.gB;
     unsigned* acur = new_slot();                    // amax slot of the tensor `cur` holds
     {
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
-        CK(conv_wgrad(e, gu, W + p.red[nred - 1], W + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), next_part(), Amax(), reduce_fork(s)));   // (only the weight-norm backward reads it)
-        CK(conv_fwd(e, bwd_data_geom(gu), W + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
+        CK(conv_wgrad(e, gu, W + p.red[nred - 1], S + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), next_part(), Amax(), reduce_fork(s)));   // (only the weight-norm backward reads it)
+        CK(conv_fwd(e, bwd_data_geom(gu), S + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
     }
     for (int k = nred - 1; k >= 0; --k) {
         const probav_engine::RedSpec& rs = e->redSpec[k];
@@ -810,8 +823,8 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         // (each stage of the chain writes a buffer of its own)
         { Amax m; if (h3) { m.x = k ? A.red(k - 1) : A.act(R); m.w = acur; }
           CK(conv_wgrad(e, gr, xin, cur, W + p.red[k], dweff(e->iRed[k]), dbias(e->iRed[k]), next_part(), m, e->side_mode >= 2 ? reduce_fork(s) : s)); }
-        float* outA = W + p.gred[2 * k];
-        float* outB = W + p.gred[2 * k + 1];
+        float* outA = S + p.gred[2 * k];
+        float* outB = S + p.gred[2 * k + 1];
         unsigned* aoth = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gr), cur, W + p.red[k], weffT(e->iRed[k]), fragT(e->iRed[k]), nullptr, nullptr, outA, amx(acur, e->iRed[k], aoth), s));
         if (refl) {
@@ -827,15 +840,15 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
             acur = aoth;
         }
     }
-    oth = W + p.gB;                                 // (the unfused block path below ping-pongs between `cur` and this)
+    oth = S + p.gB;                                 // (the unfused block path below ping-pongs between `cur` and this)
     // residual blocks (models/modelsTF.py:177-189), last first.  cur = d loss / d act[i+1]
     const ConvGeom ge = make_geom(B, Hin, T, F, Hin, T, E, 1, 1, 1, 0, 0, 0, 1);
     const ConvGeom gd = make_geom(B, Hin, T, E, Hin, T, D, 1, 1, 1, 0, 0, 0, 0);
     const ConvGeom gn = make_geom(B, Hin, T, D, Hin, T, F, 3, 3, 3, 1, 1, 0, 0);
     for (int i = R - 1; i >= 0; --i) {
-        float* gDec = W + p.gDec;
-        float* Hbuf = W + p.H;
-        float* dH = W + p.dH;
+        float* gDec = S + p.gDec;
+        float* Hbuf = S + p.Hb;
+        float* dH = S + p.dH;
         const int le = e->iExp[i], ld = e->iDec[i], ln = e->iNorm[i];
         // normConv_i: d loss/d w, then d loss/d dec_i
         const bool fusedp = e->impl >= 1 && e->pw_mfma;
@@ -843,7 +856,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
           // (from the second block on, the last thing enqueued on s was the previous block's pointwise backward, whose slab sums forked right behind it)
           CK(conv_wgrad(e, gn, W + p.dec[i], cur, nullptr, dweff(ln), dbias(ln), next_part(), m,
                         (fusedp && e->side_mode >= 2) ? (i < R - 1 ? reduce_fork_adjacent(s) : reduce_fork(s)) : s)); }
-        if (fusedp) oth = W + p.gblk[i];                   // this block's dX goes to its own buffer: `cur` stays intact for the late backward-filter
+        if (fusedp) oth = S + p.gblk[i];                   // this block's dX goes to its own buffer: `cur` stays intact for the late backward-filter
         unsigned* agdec = new_slot();
         CK(conv_fwd(e, bwd_data_geom(gn), cur, nullptr, weffT(ln), fragT(ln), nullptr, nullptr, gDec, amx(acur, ln, agdec), s));
         if (e->impl >= 1 && e->pw_mfma) {
@@ -881,19 +894,34 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
                   dweff(e->iMain), dbias(e->iMain), next_part(), Amax(), s));
     CK(reduce_join(s));                                                       // every slab sum has landed in dweff / the bias gradients
-    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, W + p.dweff, Winvn, grads, s)); }
+    { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, S + p.dweff2, Winvn, grads, s)); }
     return PROBAV_OK;
 }
 
 int probav_backward(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes, int B, void* stream)
 {
-    return backward_impl(e, params, dy, grads, ws, ws_bytes, B, nullptr, stream);
+    return backward_impl(e, params, dy, grads, ws, ws_bytes, nullptr, 0, B, nullptr, stream);
+}
+int probav_backward_split(probav_engine* e, const float* params, const float* dy, float* grads, const void* saved, size_t saved_bytes,
+                          void* scratch, size_t scratch_bytes, int B, const void* wcache, size_t wcache_bytes, void* stream)
+{
+    if (!scratch) { set_error("probav_backward_split: null scratch", hipSuccess); return PROBAV_EINVAL; }
+    if (wcache && (!e || wcache_bytes < make_wc_plan(e).total * sizeof(float))) { set_error("probav_backward_split: weight cache too small", hipSuccess); return PROBAV_EINVAL; }
+    return backward_impl(e, params, dy, grads, saved, saved_bytes, scratch, scratch_bytes, B, (const float*)wcache, stream);
+}
+int probav_workspace_split(const probav_engine* e, int batch, size_t* saved_bytes, size_t* scratch_bytes)
+{
+    if (!e || batch < 1 || !saved_bytes || !scratch_bytes) { set_error("probav_workspace_split: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    const Plan p = make_plan(e, batch, 1);
+    *saved_bytes = p.fwd_total * sizeof(float);
+    *scratch_bytes = p.bwd_total * sizeof(float);
+    return PROBAV_OK;
 }
 int probav_backward_wc(probav_engine* e, const float* params, const float* dy, float* grads, void* ws, size_t ws_bytes, int B,
                        const void* wcache, size_t wcache_bytes, void* stream)
 {
     if (!e || !wcache || wcache_bytes < make_wc_plan(e).total * sizeof(float)) { set_error("probav_backward_wc: weight cache missing / too small", hipSuccess); return PROBAV_EINVAL; }
-    return backward_impl(e, params, dy, grads, ws, ws_bytes, B, (const float*)wcache, stream);
+    return backward_impl(e, params, dy, grads, ws, ws_bytes, nullptr, 0, B, (const float*)wcache, stream);
 }
 
 size_t probav_weight_cache_bytes(const probav_engine* e) { return e ? make_wc_plan(e).total * sizeof(float) : 0; }
@@ -954,13 +982,13 @@ int probav_workspace_view(const probav_engine* e, int batch, int training, int k
     return PROBAV_EINVAL;
 }
 
-int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t ws_bytes, int B, int block, float* hidden, const void* wcache, void* stream)
+int probav_debug_hidden(probav_engine* e, const float* params, const void* ws, size_t ws_bytes, int B, int block, float* hidden, float* dec_scratch, const void* wcache, void* stream)
 {
-    if (!e || !params || !ws || !hidden || B < 1 || block < 0 || block >= e->cfg.num_res_blocks) { set_error("probav_debug_hidden: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
+    if (!e || !params || !ws || !hidden || !dec_scratch || B < 1 || block < 0 || block >= e->cfg.num_res_blocks) { set_error("probav_debug_hidden: null/invalid argument", hipSuccess); return PROBAV_EINVAL; }
     if (e->impl < 3 || !e->pw_mfma) { set_error("probav_debug_hidden: only the split-operand kernel families (impl 3, 4) expose their hidden tile", hipSuccess); return PROBAV_EINVAL; }
     const Plan p = make_plan(e, B, 1);
-    if (ws_bytes < p.total * sizeof(float)) { set_error("probav_debug_hidden: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
-    float* W = (float*)ws;
+    if (ws_bytes < p.fwd_total * sizeof(float)) { set_error("probav_debug_hidden: workspace too small", hipSuccess); return PROBAV_ENOSPACE; }
+    const float* W = (const float*)ws;
     const probav_net_cfg& c = e->cfg;
     const int D = c.dec_channels, R = c.num_res_blocks, i = block;
     const long nvox = (long)B * e->Hin * e->Hin * c.num_img_lr;
@@ -968,13 +996,13 @@ int probav_debug_hidden(probav_engine* e, const float* params, void* ws, size_t 
     const float* WC = (const float*)wcache;                           // the forward pass ran from the weight cache: its fragments and weight slots live there
     const float* Wpack = WC ? WC + wc.wpack : W + p.wpack;
     const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
-    // the forward launch of block i again, into a scratch output (gDec is dead between passes), with the hidden tile written out;
+    // the forward launch of block i again, into the caller's scratch output (the saved state is only read), with the hidden tile written out;
     // no amax report (the slots of the saved tensors stay as the forward pass left them)
     PwAmax m;
     const bool h3 = e->impl >= 4;
     if (h3) { m.x = A.act(i); m.w1 = A.w(e->iExp[i]); m.w2 = A.w(e->iDec[i]); m.w2c = A.wcol(e->iDec[i]); m.b1 = A.b(e->iExp[i]); }
     return x6_pw_forward(W + p.act[i], Wpack + (h3 ? e->pkW1h[i] : e->pkW1x6[i]), Wpack + (h3 ? e->pkW2h[i] : e->pkW2x6[i]),
-                         params + e->layers[e->iExp[i]].wn.b_off, params + e->layers[e->iDec[i]].wn.b_off, W + p.gDec, nvox, nvox / B, D, h3 ? 2 : 1, m,
+                         params + e->layers[e->iExp[i]].wn.b_off, params + e->layers[e->iDec[i]].wn.b_off, dec_scratch, nvox, nvox / B, D, h3 ? 2 : 1, m,
                          (hipStream_t)stream, hidden);
 }
 

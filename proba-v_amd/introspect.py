@@ -28,9 +28,10 @@ def device_gates(m, flat_used, B, T=9):
     gates = {"mainConv1": (view(0, 0) > 0).cpu().numpy(), "residConv1": (view(3, 0) > 0).cpu().numpy()}
     nvox = B * hin * hin * T
     hid = torch.empty(nvox * m.numFilters * m.expRate, device=ws.device)
+    dec = torch.empty(nvox * 32, device=ws.device)                     # the launch's regular output (decConv), discarded
     for i in range(m.numResBlocks):
-        _lib.check(L.probav_debug_hidden(h, _lib.ptr(flat_used), _lib.ptr(ws), ws.numel() * 4, B, i, _lib.ptr(hid), _lib.ptr(wc), _lib.current_stream()),
-                   "probav_debug_hidden")
+        _lib.check(L.probav_debug_hidden(h, _lib.ptr(flat_used), _lib.ptr(ws), ws.numel() * 4, B, i, _lib.ptr(hid), _lib.ptr(dec), _lib.ptr(wc),
+                                         _lib.current_stream()), "probav_debug_hidden")
         gates["expConv_%d" % i] = (hid > 0).cpu().numpy()
     k = 0
     while True:

@@ -196,10 +196,13 @@ class WDSRModel(torch.nn.Module):
         """The workspace the LAST forward call of this (batch, training) shape produced (every call gets its own: an output of
         torch.ops.probav.wdsr_forward, held by the autograd graph until its backward has run)."""
         ws = self._ws.get((int(batch), bool(training), self.flat.device))
-        if isinstance(ws, weakref.ref):
-            ws = ws()
         if ws is None:
             raise RuntimeError("no forward pass of batch %d (training=%s) has run on this model" % (batch, training))
+        if isinstance(ws, weakref.ref):
+            ws = ws()
+            if ws is None:
+                raise RuntimeError("the workspace of the last forward pass of batch %d (training=%s) has already been released (its backward "
+                                   "has run, or nothing holds its output): set PROBAV_KEEP_WS=1 to keep it for inspection" % (batch, training))
         return ws
 
     def __del__(self):

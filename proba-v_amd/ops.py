@@ -38,11 +38,13 @@ def _dev(t, name):
 _WS_POOLS = {}
 
 
-def _ws_pool(device):
+def _ws_pool(device, kind="ws"):
     """A private, never-split allocator pool for the engine workspaces (torch.cuda.MemPool): a multi-GB block that returns to the general
     pool gets carved up by the next megabyte-sized request, and the following step then pays a hipMalloc of the full size (~80 ms,
-    device-synchronous).  In its own pool a freed workspace block can only be taken by the next workspace."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    device-synchronous).  In its own pool a freed workspace block can only be taken by the next workspace.  The reverse pass's scratch
+    blocks (kind "scratch") have a pool of their own: a freed 2 GB scratch block must not be handed to the next 2 GB workspace request
+    while the following scratch request then finds nothing."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), kind)
     pool = _WS_POOLS.get(key)
     if pool is None:
         try:
@@ -58,25 +60,33 @@ def release_workspaces(device=None):
     private pool for as long as the pool lives (a trainer alternating training batches, a partial last batch, validation batches and
     inference micro-batches holds one block each); call this between such phases of a long-lived process.  Blocks still referenced
     (an un-run backward) are freed when their tensors die."""
-    keys = list(_WS_POOLS) if device is None else [torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()]
-    for k in keys:
+    dev = None if device is None else (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+    for k in [k for k in _WS_POOLS if dev is None or k[0] == dev]:
         _WS_POOLS.pop(k, None)
     torch.cuda.empty_cache()
 
 
-def _scratch_alias(ws):
-    """A second tensor over the workspace's storage with a version counter of its own.  The reverse pass writes gradient buffers and
-    partial-sum slabs into regions of the workspace the forward pass left empty; the saved activations are only read.  Handing THIS
-    tensor to the mutating op keeps the saved workspace's counter still, so a second backward over the same graph (retain_graph, a
-    gradient check) is legal -- and right: it reads the same activations."""
-    return torch.empty(0, dtype=ws.dtype, device=ws.device).set_(ws.untyped_storage(), ws.storage_offset(), ws.shape, ws.stride())
-
-
 def _ws_floats(engine, batch, training):
-    nbytes = _lib.lib().probav_workspace_bytes(c_void_p(engine), int(batch), 1 if training else 0)
+    """Floats of the workspace wdsr_forward returns: in training mode the SAVED STATE of the pass only (probav_workspace_split) -- the reverse
+    pass brings its own scratch."""
+    import ctypes
+    L = _lib.lib()
+    if training:
+        saved, scratch = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(L.probav_workspace_split(c_void_p(engine), int(batch), ctypes.byref(saved), ctypes.byref(scratch)), "probav_workspace_split")
+        nbytes = saved.value
+    else:
+        nbytes = L.probav_workspace_bytes(c_void_p(engine), int(batch), 0)
     if nbytes == 0:
         raise RuntimeError("probav_workspace_bytes returned 0")
     return (nbytes + 3) // 4
+
+
+def _scratch_floats(engine, batch):
+    import ctypes
+    saved, scratch = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(_lib.lib().probav_workspace_split(c_void_p(engine), int(batch), ctypes.byref(saved), ctypes.byref(scratch)), "probav_workspace_split")
+    return (scratch.value + 3) // 4
 
 
 @torch.library.custom_op("probav::wdsr_forward", mutates_args=(), device_types="cuda")
@@ -106,19 +116,21 @@ def _(flat, x, engine, out_size, training, wcache=None):
     return (x.new_empty((B, out_size, out_size, 1), dtype=torch.float32), x.new_empty((_ws_floats(engine, int(B), training),), dtype=torch.float32))
 
 
-@torch.library.custom_op("probav::wdsr_backward", mutates_args=("ws",), device_types="cuda")
+@torch.library.custom_op("probav::wdsr_backward", mutates_args=(), device_types="cuda")
 def wdsr_backward(flat: Tensor, dy: Tensor, ws: Tensor, engine: int, wcache: Optional[Tensor] = None) -> Tensor:
-    """d loss / d flat from d loss / d y; `ws` = the workspace the matching forward returned (its gradient buffers are scratch: mutated);
-    wcache = the weight cache that forward ran from, if any."""
+    """d loss / d flat from d loss / d y; `ws` = the saved state the matching forward returned, only READ here (probav_backward_split): the
+    reverse pass's gradient buffers and partial-sum slabs live in a scratch block of this call's own, from the same private pool as the
+    workspaces.  The op is functional -- a second backward over the same graph (retain_graph, a gradient check) reads the same
+    activations, and AOT-autograd traces the formula of wdsr_forward without any storage aliasing.  wcache = the weight cache that
+    forward ran from, if any."""
     _dev(dy, "output gradient")
     grads = torch.empty_like(flat)
-    L = _lib.lib()
-    if wcache is None:
-        _lib.check(L.probav_backward(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
-                                     dy.shape[0], _lib.current_stream()), "probav_backward")
-    else:
-        _lib.check(L.probav_backward_wc(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
-                                        dy.shape[0], _lib.ptr(wcache), wcache.numel() * 4, _lib.current_stream()), "probav_backward_wc")
+    B = dy.shape[0]
+    with torch.cuda.use_mem_pool(_ws_pool(dy.device, "scratch"), device=dy.device):
+        scratch = torch.empty(_scratch_floats(engine, B), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().probav_backward_split(c_void_p(engine), _lib.ptr(flat), _lib.ptr(dy), _lib.ptr(grads), _lib.ptr(ws), ws.numel() * 4,
+                                                _lib.ptr(scratch), scratch.numel() * 4, B, _lib.ptr(wcache),
+                                                0 if wcache is None else wcache.numel() * 4, _lib.current_stream()), "probav_backward_split")
     return grads
 
 
@@ -145,7 +157,7 @@ def _wdsr_bwd(ctx, dy, dws):
         raise RuntimeError("backward through model(x, training=False): call the model with training=True "
                            "to keep the activations the reverse pass needs")
     flat, ws = ctx.saved_tensors
-    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), _scratch_alias(ws), ctx.engine, ctx.wcache)
+    g = torch.ops.probav.wdsr_backward(flat, dy.contiguous().float(), ws, ctx.engine, ctx.wcache)
     return g, None, None, None, None, None
 
 

@@ -22,7 +22,7 @@ def _model(dev, T=9):
 def test_ops_are_registered_with_schemas():
     import probav_amd.ops  # noqa: F401
     want = {"wdsr_forward": "(Tensor flat, Tensor x, SymInt engine, SymInt out_size, bool training, Tensor? wcache=None) -> (Tensor, Tensor)",
-            "wdsr_backward": "(Tensor flat, Tensor dy, Tensor(a2!) ws, SymInt engine, Tensor? wcache=None) -> Tensor",
+            "wdsr_backward": "(Tensor flat, Tensor dy, Tensor ws, SymInt engine, Tensor? wcache=None) -> Tensor",      # functional: the saved state is only read
             "nadam_step": None, "optimizer_wn_step": None, "shift_loss": None, "shift_loss_backward": None, "shift_metrics": None, "clip_round": None}
     for name, schema in want.items():
         op = getattr(torch.ops.probav, name).default
@@ -90,13 +90,46 @@ def test_ops_trace_under_torch_compile_fullgraph(dev):
     want.backward()
     gw = flat.grad.clone()
     flat.grad = None
-    try:
+    try:                                                       # ONLY a torch build without dynamo may skip; "aot_eager" needs no codegen toolchain
+        import importlib
+        importlib.import_module("torch._dynamo")               # (a plain `import torch._dynamo` here would make `torch` a local of this function)
         cstep = torch.compile(step, backend="aot_eager", fullgraph=True)
-        got = cstep(flat, x, hr, mk)
-    except Exception as exc:                                   # noqa: BLE001
-        pytest.skip("torch.compile unavailable on this box: %r" % (exc,))
-    got.backward()
+    except (ImportError, ModuleNotFoundError) as exc:
+        pytest.skip("torch.compile (dynamo) is not part of this torch build: %r" % (exc,))
+    got = cstep(flat, x, hr, mk)                               # a failure of the trace, of the call or of its backward FAILS the test
+    got.backward(retain_graph=True)
     assert float(got) == float(want) and torch.equal(flat.grad, gw)
+    flat.grad = None
+    got.backward()                                             # the saved state is only read: a second reverse pass over the same graph gives the same bits
+    assert torch.equal(flat.grad, gw)
+
+
+def test_backward_is_functional_the_saved_state_is_untouched(dev):
+    """probav::wdsr_backward reads the saved state of the forward pass and writes a scratch block of its own (probav_backward_split): the
+    workspace tensor is bitwise unchanged by a reverse pass, two reverse passes over one retained graph agree bit for bit, and the one-piece
+    C entry point (probav_backward on a workspace of probav_workspace_bytes) gives the same gradient."""
+    import ctypes
+    from probav_amd import _lib as L
+    m = _model(dev)
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in synth.synth_batch(2, seed=65))
+    eng = m._handle()
+    flat = m.flat.detach().clone().requires_grad_(True)
+    y, ws = torch.ops.probav.wdsr_forward(flat, x, int(eng.value), 48, True)
+    saved, scratch = ctypes.c_size_t(), ctypes.c_size_t()
+    L.check(L.lib().probav_workspace_split(eng, 2, ctypes.byref(saved), ctypes.byref(scratch)))
+    assert ws.numel() * 4 == saved.value and saved.value + scratch.value == L.lib().probav_workspace_bytes(eng, 2, 1)
+    before = ws.clone()
+    dy = torch.randn_like(y)
+    (g1,) = torch.autograd.grad(y, flat, dy, retain_graph=True)
+    assert torch.equal(ws.view(torch.int32), before.view(torch.int32))
+    (g2,) = torch.autograd.grad(y, flat, dy)
+    assert torch.equal(g1, g2)
+    whole = torch.empty((saved.value + scratch.value) // 4, device=dev)
+    y2, g3 = torch.empty_like(y), torch.empty_like(g1)
+    s = L.current_stream()
+    L.check(L.lib().probav_forward(eng, L.ptr(flat), L.ptr(x), L.ptr(y2), L.ptr(whole), whole.numel() * 4, 2, 1, s))
+    L.check(L.lib().probav_backward(eng, L.ptr(flat), L.ptr(dy), L.ptr(g3), L.ptr(whole), whole.numel() * 4, 2, s))
+    assert torch.equal(y2, y.detach()) and torch.equal(g3, g1)
 
 
 def test_fused_optimizer_weight_norm_step(dev):
@@ -212,3 +245,21 @@ def test_weight_cache_invalidation_after_writes_behind_the_version_counter(dev, 
     ops.release_workspaces()
     with torch.no_grad():
         assert torch.equal(m(x), y_ref)                                 # a released pool is simply rebuilt
+
+
+def test_default_workspace_reference_is_weak(dev, monkeypatch):
+    """Without PROBAV_KEEP_WS the model holds no strong reference to a pass's multi-GB workspace: it is alive while the autograd graph
+    needs it, gone after the backward, and asking for it then says so (not 'no forward pass has run')."""
+    import gc
+    monkeypatch.delenv("PROBAV_KEEP_WS", raising=False)
+    m = _model(dev)
+    x = torch.as_tensor(synth.synth_batch(2, seed=66)[0]).to(dev)
+    with pytest.raises(RuntimeError, match="no forward pass"):
+        m._workspace(2, True)
+    y = m(x, training=True)
+    assert m._workspace(2, True).numel() > 0                   # held by the graph of y
+    y.sum().backward()
+    del y
+    gc.collect()
+    with pytest.raises(RuntimeError, match="already been released"):
+        m._workspace(2, True)

@@ -15,9 +15,15 @@ from oracle import wdsr_numpy as on
 from oracle import wdsr_torch as ot
 from probav_amd import synth
 
-os.environ.setdefault("PROBAV_KEEP_WS", "1")     # the gate tests read a pass's workspace after its backward has run (modelsTF.WDSRModel.forward)
-
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _keep_workspaces(monkeypatch):
+    """The gate tests of THIS module read a pass's workspace after its backward has run (modelsTF.WDSRModel.forward keeps only a weak
+    reference by default).  Per test, so that every other GPU module runs with the product's default."""
+    monkeypatch.setenv("PROBAV_KEEP_WS", "1")
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 IMPLS = [0, 1, 2, 3, 4]   # 4 = H3 kernels (three products of scaled fp16 piece pairs), same tolerances; 3 = x6 kernels (fp32 products as six bf16-piece MFMA products), held to the SAME tolerances
 
