@@ -23,7 +23,7 @@ template <int SHAPE, int NV, int ROLE>
 __global__ __launch_bounds__(512) void co(float* out, Stamp* st, int iters, const f16x8* src)
 {
     const int wave = threadIdx.x >> 6;
-    const bool mf = ROLE == 0 || wave < 4;
+    const bool mf = ROLE == 0 || (ROLE != 4 && wave < 4);      // ROLE 4: fillers on both halves; ROLE 5: waves 0-3 [MFMA + NV fillers], waves 4-7 fillers only
     if ((ROLE == 1 && !mf) || (ROLE == 2 && mf)) return;
     f32x16 A0, A1, A2, A3;
     f32x4 B0, B1, B2, B3;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void co(float* out, Stamp* st, int iters, cons
                     if ((u & 3) == 2) { B2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, B2, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
                     if ((u & 3) == 3) { B3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, B3, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
                 }
-                if (ROLE == 0) {
+                if (ROLE == 0 || ROLE == 5) {
 #pragma unroll
                     for (int k = 0; k < NV; ++k) FILL(k & 7);
                 }
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void co(float* out, Stamp* st, int iters, cons
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
 #pragma unroll
-                for (int k = 0; k < NV; ++k) FILL(k & 7);
+                for (int k = 0; k < (ROLE == 5 ? 8 : NV); ++k) FILL(k & 7);
             }
         }
     }
@@ -102,7 +102,7 @@ template <int SHAPE, int NV, int ROLE> static Res run(float* out, Stamp* st, con
         for (int w = 0; w < threads / 64; ++w) {
             const Stamp& s = h[g * 8 + w];
             if (!s.cyc) continue;
-            const bool mf = ROLE == 0 || w < 4;
+            const bool mf = ROLE == 0 || (ROLE != 4 && w < 4);
             (mf ? cm : cv).push_back((double)s.cyc / (iters * 16.0));
             if (s.rt) clk.push_back((double)s.cyc / ((double)s.rt * 10.0) );      // cycles per ns: s_memrealtime ticks at 100 MHz
         }
@@ -127,6 +127,12 @@ template <int SHAPE> static void rowsB(float* out, Stamp* st, const f16x8* src)
            "filler wave %5.2f cycles per v_fma_f32 (%.2f GHz); kernel %.0f / %.0f / %.0f us\n",
            SHAPE == 0 ? "32x32x16" : "16x16x32", m.cyc_m, m.ghz, v.cyc_v / 8.0, v.ghz, both.cyc_m, both.cyc_v / 8.0, both.ghz, m.us, v.us, both.us);
 }
+template <int SHAPE, int NV> static void rowC(float* out, Stamp* st, const f16x8* src)
+{
+    const Res r = run<SHAPE, NV, 5>(out, st, src, 512);
+    printf("%-9s | waves 0-3: [MFMA + %d fillers], waves 4-7: fillers only | MFMA wave %6.2f cycles per MFMA (its %d fillers included), filler wave %5.2f cycles per v_fma_f32 = %.1f of its instructions per MFMA of the partner (%.2f GHz)\n",
+           SHAPE == 0 ? "32x32x16" : "16x16x32", NV, r.cyc_m, NV, r.cyc_v / 8.0, r.cyc_m / (r.cyc_v / 8.0), r.ghz);
+}
 int main()
 {
     float* out; f16x8* src; Stamp* st;
@@ -139,5 +145,12 @@ int main()
     rowA<1, 0>(out, st, src); rowA<1, 1>(out, st, src); rowA<1, 2>(out, st, src); rowA<1, 3>(out, st, src); rowA<1, 4>(out, st, src); rowA<1, 6>(out, st, src);
     printf("# experiment B: waves 0-3 MFMA only, waves 4-7 v_fma_f32 only (one of each per SIMD)\n");
     rowsB<0>(out, st, src); rowsB<1>(out, st, src);
+    {
+        const Res one = run<0, 8, 2>(out, st, src, 512), two = run<0, 8, 4>(out, st, src, 512);
+        printf("# v_fma_f32 only: one wave per SIMD %5.2f cycles per instruction (%.2f GHz); two waves per SIMD %5.2f cycles per instruction of EACH wave = %5.2f per instruction of the SIMD (%.2f GHz)\n",
+               one.cyc_v / 8.0, one.ghz, two.cyc_v / 8.0, two.cyc_v / 16.0, two.ghz);
+    }
+    printf("# experiment C: a matrix wave that carries its own fillers beside a pure vector wave\n");
+    rowC<0, 0>(out, st, src); rowC<0, 2>(out, st, src); rowC<0, 4>(out, st, src); rowC<0, 6>(out, st, src); rowC<1, 0>(out, st, src); rowC<1, 2>(out, st, src);
     return 0;
 }

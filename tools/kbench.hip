@@ -99,6 +99,9 @@ int main(int argc, char** argv)
 #else
     timeit("pw_fwd  (expConv+ReLU+decConv)", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, V, D, 2, pam, 0); });
     timeit("pw_bwd  (fused reverse)", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, V, D, 2, pam, 0); });
+#ifdef KB_ONLY_PW
+    continue;                                        // (ablation builds of the fused pointwise kernels: -DH3S_... ; only the two lines above)
+#endif
     { PwAmax q = pam; q.y = nullptr;
       timeit("pw_bwd  no amax report", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, V, D, 2, q, 0); });
       timeit("pw_fwd  no amax report", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, V, D, 2, q, 0); }); }
