@@ -1595,10 +1595,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             h3_cut4_scaled(gs[0], gs[1], gs[2], gs[3], qa0, qa1);
             h3_cut4_scaled(gs[4], gs[5], gs[6], gs[7], qb0, qb1);
             // dH' pieces to the wave's transpose image: (d) reads it transposed, (c) as stored
+#ifndef H3T_NODHSTORE
             *reinterpret_cast<uint2*>(Ti + (s0 ^ ((2 * kb) << 4))) = qa0;
             *reinterpret_cast<uint2*>(Ti + (s0 ^ ((2 * kb + 1) << 4))) = qb0;
             *reinterpret_cast<uint2*>(Ti + PS_IMG + (s0 ^ ((2 * kb) << 4))) = qa1;
             *reinterpret_cast<uint2*>(Ti + PS_IMG + (s0 ^ ((2 * kb + 1) << 4))) = qb1;
+#else
+            asm volatile("" :: "v"(qa0.x), "v"(qa0.y), "v"(qb0.x), "v"(qb0.y), "v"(qa1.x), "v"(qa1.y), "v"(qb1.x), "v"(qb1.y));
+#endif
         }
 #endif
     };
@@ -1614,7 +1618,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
 #endif
         // ================================ Y(k): 30 MFMAs, (d), (e), (c) of tile k-1, then (a), (b) of tile k ================================
         H = zero;
-        {
             const unsigned char* Xb = XA + b0 * PB_TILE;
             const unsigned char* Db = DA + b0 * PB_TILE;
             const unsigned char* Xp = XA + bprev * PB_TILE;
@@ -1625,14 +1628,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             const float sx = nB ? sxB : sxA, sd = nB ? sdB : sdA;
             unsigned char* sXd = XA + bnext * PB_TILE + rs;
             unsigned char* sDd = DA + bnext * PB_TILE;
-#ifdef T_STAGEX2
-            auto stageX2 = [&](float u, float v, int off) {
-                unsigned q[NP];
-                cut_pair<AR>(u, v, sx, q);
-                *reinterpret_cast<unsigned*>(sXd + off) = q[0];
-                *reinterpret_cast<unsigned*>(sXd + PB_IMG + off) = q[1];
-            };
-#endif
             auto stageX = [&]() {
                 uint2 q0, q1;
                 h3_cut4_scaled(nxv.x * sx, nxv.y * sx, nxv.z * sx, nxv.w * sx, q0, q1);
@@ -1647,9 +1642,17 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
                 rf[kk] += nd[kk];
             };
             // half B: dX of tile k-2 = dOut + its eight chunk partials, in the order of the chunks (partial jj is requested two gaps ahead)
-            const float* Tp = TbAll + (k & 1) * 8 * PS_TB + rs;
-            const int egs = t_inB(k - 2) ? scB.eg : scA.eg;
+#ifdef H3T_PURE
+            constexpr int SUMT = 1;                                        // X(k) sums tile k-1
+#else
+            constexpr int SUMT = 2;                                        // Y(k) sums tile k-2
+#endif
+            const float* Tp = TbAll + ((k - SUMT) & 1) * 8 * PS_TB + rs;
+            const int egs = t_inB(k - SUMT) ? scB.eg : scA.eg;
             float4 tq[3];                                                  // (three in flight)
+#ifdef H3T_PURE
+            float4 tq8[8];
+#endif
             float sa[4] = {0.f, 0.f, 0.f, 0.f};
             auto sums_read = [&](int jj) { tq[jj % 3] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); };
             auto sums_add = [&](int jj) { sa[0] += tq[jj % 3].x; sa[1] += tq[jj % 3].y; sa[2] += tq[jj % 3].z; sa[3] += tq[jj % 3].w; };
@@ -1657,7 +1660,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
                 const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) sa[kk] = ldexpf(sa[kk], rc[kk] - egs) + od[kk];         // (c) partials -> true values: W1's cin row (rc = minus its exponent) and the sample's dH scale
-                const __amdgpu_buffer_rsrc_t ry = tile_rsrc(dX, k - 2, 128);
+                const __amdgpu_buffer_rsrc_t ry = tile_rsrc(dX, k - SUMT, 128);
                 u32x4b q = {__float_as_uint(sa[0]), __float_as_uint(sa[1]), __float_as_uint(sa[2]), __float_as_uint(sa[3])};
                 __builtin_amdgcn_raw_buffer_store_b128(q, ry, ro, 0, 0);                               // (rows beyond the tile: dropped)
             };
@@ -1679,8 +1682,12 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             // (the store of group g must come behind the LAST transposed read of the previous tile's H' image: rd_de(1, 3) in gap 11 -- LDS
             // operations of a wave execute in order, and inside a gap the operand requests are issued first)
             auto hstore = [&](int g) {
+#ifndef H3T_NOHSTORE              /* (timing-only ablations: what do the LDS stores cost) */
                 *reinterpret_cast<uint2*>(Th + (s0 ^ (g << 4))) = hq0;
                 *reinterpret_cast<uint2*>(Th + PS_IMG + (s0 ^ (g << 4))) = hq1;
+#else
+                asm volatile("" :: "v"(hq0.x), "v"(hq0.y), "v"(hq1.x), "v"(hq1.y));
+#endif
             };
             // ---- operands, requested in the gaps ahead of their MFMAs ----
             Frag xf[2][NP], df[2][NP], gq[2][NP];
@@ -1704,14 +1711,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
                 if constexpr (S >= 8 && S <= 11) rd_de(1, S - 8);
                 if constexpr (S >= 12 && S <= 15) rd_gq((S - 12) >> 1, (S - 12) & 1);
                 if constexpr (S >= 19 && S <= 22) rd_df((S - 19) >> 1, (S - 19) & 1);
+#ifndef H3T_PURE
                 if constexpr (ROLE == 0) {
 #ifndef H3S_NOSTAGE
-#ifdef T_STAGEX2
-                    if constexpr (S == 0) stageX2(nxv.x, nxv.y, 0);
-                    if constexpr (S == 1) stageX2(nxv.z, nxv.w, 4);
-#else
                     if constexpr (S == 0) stageX();
-#endif
                     if constexpr (S >= 2 && S <= 5) stageD(S - 2);
 #endif
                 } else {
@@ -1722,7 +1725,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
                     if constexpr (S == 9) sums_max();
 #endif
                 }
-#ifndef H3S_NOGATE
+#endif
+#if !defined(H3S_NOGATE) && !defined(H3T_PURE)
                 constexpr int H0 = ROLE == 0 ? 8 : 11;                  // the first gap of the relu(H) work: per group of four registers bias+ReLU in one gap, cut + store two gaps on
                 if constexpr (S >= H0 - 2 && S < H0 + 14 && ((S - H0 + 2) & 3) == 0) bbq[(S - H0 + 2) >> 2] = *reinterpret_cast<const float4*>(sB + 8 * ((S - H0 + 2) >> 2));      // its biases, two gaps ahead
                 if constexpr (S >= H0 && S < H0 + 16) {
@@ -1736,7 +1740,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             };
 #define GAP(n) gap(std::integral_constant<int, n>())
-#ifdef PROBAV_STAMP_Y
+#if defined(PROBAV_STAMP_Y) && !defined(H3T_PURE)
 #define YS(q) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ys_acc[q] += t_ - ys_t; ys_t = t_; } while (0)
             unsigned long long ys_t = __builtin_amdgcn_s_memtime();
 #else
@@ -1746,7 +1750,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
-#ifndef H3S_NOSUMS
+#if !defined(H3S_NOSUMS) && !defined(H3T_PURE)
             if constexpr (ROLE == 1) { sums_read(0); sums_read(1); }
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -1791,7 +1795,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             {
                 unsigned char* Tb = reinterpret_cast<unsigned char*>(TbAll + (((k - 1) & 1) * 8 + wave) * PS_TB);
 #pragma unroll
+#ifndef H3T_NOTB
                 for (int G = 0; G < 4; ++G) *reinterpret_cast<float4*>(Tb + (w0 ^ (G << 5))) = make_float4(dx[4 * G], dx[4 * G + 1], dx[4 * G + 2], dx[4 * G + 3]);
+#else
+                for (int G = 0; G < 4; ++G) asm volatile("" :: "v"(dx[4 * G]), "v"(dx[4 * G + 1]), "v"(dx[4 * G + 2]), "v"(dx[4 * G + 3]), "v"(Tb));
+#endif
             }
             dH = MFMA16H(w2[1][1], df[1][0], dH); GAP(27);
             dH = MFMA16H(w2[1][0], df[1][1], dH); GAP(28);
@@ -1802,7 +1810,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
 #endif
 #undef GAP
 #undef YS
-        }
         XS_ACC(2);
 #ifndef H3S_NOPRIO
         __builtin_amdgcn_s_setprio(0);
@@ -1811,18 +1818,63 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
         XS_ACC(3);
         // ================================ X(k), first part: requested here, used one phase on ================================
         // the rows of tile k+2 (half A: staged in Y(k+1)) / dOut of tile k-1 (half B: summed in Y(k+1))
+#if defined(H3T_PURE) && defined(PROBAV_STAMP_Y)
+#define XSS(q) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ys_acc[q] += t_ - xs_tt; xs_tt = t_; } while (0)
+        unsigned long long xs_tt = __builtin_amdgcn_s_memtime();
+#else
+#define XSS(q) do { } while (0)
+#endif
+#ifdef H3T_PURE
+        // every piece of vector work of the iteration sits HERE, beside the other half's matrix phase (whose gaps hold operand requests only):
+        // bias / ReLU / cut of tile k's hidden tile, then the staging of tile k+1 (half A) / the dX sums of tile k-1 (half B); the gate follows at the loop top
+#ifndef H3S_NOGATE
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bbq[g] = *reinterpret_cast<const float4*>(sB + 8 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { relu2(g, 0); relu2(g, 2); hcut(g); hstore(g); }
+#endif
+        XSS(0);
+        if constexpr (ROLE == 0) {
+#ifndef H3S_NOSTAGE
+            stageX();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) stageD(kk);
+#endif
+            XSS(1);
+            stage_load(k + 2, nxv, nd);
+            XSS(2);
+        } else {
+#ifndef H3S_NOSUMS
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { tq8[jj] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { sa[0] += tq8[jj].x; sa[1] += tq8[jj].y; sa[2] += tq8[jj].z; sa[3] += tq8[jj].w; }
+            sums_out();
+            sums_max();
+#endif
+            XSS(1);
+            const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k, 128), ro, 0, 0);
+            rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+            XSS(2);
+        }
+#else
         if constexpr (ROLE == 0) stage_load(k + 2, nxv, nd);
         else {
             const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k - 1, 128), ro, 0, 0);
             rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
         }
+#endif
         b0 = bnext;
     };
     // ---- the run: k = 0 .. nt+1, per k the gate of tile k-1 (X(k-1), second part), then Y(k) and the loads of X(k).  ONE loop; it is left and
     // entered again where something happens once per sample ----
     const int kend = nt + 2;
     const int kE2 = hasB ? jb + 1 : kend;                         // between Y(jb) and the gate of tile jb: the running sums change scales
+#ifdef H3T_PURE
+    const int kE3 = kE2;                                           // X(jb) summed sample A's last tile, X(jb+1) sums sample B's first: sample A's largest |dX| is complete
+#else
     const int kE3 = hasB && jb + 2 < kend ? jb + 2 : kend;        // between Y(jb+1) (which summed sample A's last tile) and Y(jb+2): sample A's largest |dX|
+#endif
     int on = n0;                                                   // half B: the sample whose largest |dX| rf[0] is collecting
     if (hb) bar();                                                 // half B starts one segment late ...
     auto events = [&](int k) __attribute__((always_inline)) {
@@ -1844,19 +1896,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             on = n0 + 1; rf[0] = 0.f;
         }
     };
-#ifdef T_NEST
-    int k = 0;
-    while (true) {
-        const int stop = k < kE2 ? kE2 : (k < kE3 ? kE3 : kend);
-        if (hb) for (; k < stop; ++k) { gate(k - 1); XS_ACC(5); front(std::integral_constant<int, 1>(), k); }
-        else for (; k < stop; ++k) { gate(k - 1); XS_ACC(5); front(std::integral_constant<int, 0>(), k); }
-        if (k >= kend) break;
-        events(k);
-    }
-#else
     if (hb) for (int k = 0; k < kend; ++k) { if (__builtin_expect(k == kE2 || k == kE3, 0)) events(k); gate(k - 1); XS_ACC(5); front(std::integral_constant<int, 1>(), k); }
     else for (int k = 0; k < kend; ++k) { if (__builtin_expect(k == kE2 || k == kE3, 0)) events(k); gate(k - 1); XS_ACC(5); front(std::integral_constant<int, 0>(), k); }
-#endif
     if (!hb) bar();                                                // ... and half A waits for its last one
     __syncthreads();
     if (hb && nt > 0 && am.y) amax_commit(rf[0], am.y + on);

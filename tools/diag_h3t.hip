@@ -52,7 +52,7 @@ int main()
                acc[1] / iters, acc[2] / iters, acc[3] / iters, acc[5] / iters, (acc[1] + acc[2] + acc[3] + acc[5]) / iters, mn[2] / iters, mx[2] / iters, mn[5] / iters, mx[5] / iters);
     }
 #ifdef PROBAV_STAMP_Y
-    printf("inside Y (extra stamps, each a full lgkmcnt(0) wait: the phase is longer than in the build without them), cycles per iteration:\nwave | prologue + (a) | (d),(e) k-block 0 | (d),(e) k-block 1 | (c) | (b)\n");
+    printf("inside Y (extra stamps, each a full lgkmcnt(0) wait: the phase is longer than in the build without them), cycles per iteration:\nwave | prologue + (a) | (d),(e) k-block 0 | (d),(e) k-block 1 | (c) | (b)      [-DH3T_PURE: bias+ReLU+cut+store | staging / sums | loads | - | -]\n");
     for (int wave = 0; wave < 8; ++wave) {
         double acc[5] = {0};
         for (int b = 0; b < 256; ++b) for (int q = 0; q < 5; ++q) acc[q] += (double)st[4096 * 8 + (b * 8 + wave) * 8 + q];
