@@ -239,13 +239,19 @@ def run_rank(args):
     def stepper(model, data, opt=None):
         x, hr, mask = data
 
-        def step(full=False):
+        def step(full=False, comm_events=None):
             pred = model(x, training=True)
             loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
             model.flat.grad = None
             loss.backward()
             if dp:
+                if comm_events is not None:                # (diagnostic leg only: the headline region carries no events inside a step)
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record()
                 allreduce_mean_(model.flat.grad)
+                if comm_events is not None:
+                    eb.record()
+                    comm_events.append((ea, eb))
             if full:
                 opt.step()
                 losses.shiftCompensatedcPSNR(hr, mask, pred.detach())
@@ -295,6 +301,38 @@ def run_rank(args):
         hsh.update(loss.detach().cpu().numpy().tobytes())
         hsh.update(model.flat.grad.detach().cpu().numpy().tobytes())
         digest = hsh.hexdigest()
+    # Data-parallel self-diagnosis (N > 1, or --force-dp), behind the headline region: one run yields the curve's inputs AND what explains them --
+    # every rank's own median step, the gradient all-reduce's own time per step (HIP events around the collective on the launch stream: its
+    # wait for the slowest rank is inside), and a proof that the replicas hold the same bits: the all-reduced gradient and the parameters
+    # digest identically on every rank (reference semantics: debug/trainClassMultiGPU0.py:67-84,153,162-178 -- one replica per GPU, the
+    # gradients reduced once per step, the variables mirrored).
+    dp_diag = None
+    if dp:
+        comm = []
+        kd = min(10, args.steps)
+        _, ms_d, _ = timed(step, kd, False, comm)
+        torch.cuda.synchronize()
+        comm_ms = [a.elapsed_time(b) for a, b in comm]
+
+        def digest64(t):                                   # a position-weighted 64-bit fold of the bit patterns, computed on the device
+            v = t.detach().contiguous().view(torch.int32).to(torch.int64)
+            w = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64)
+            return int(((v * (w % 65521 + 1)).sum()).item())
+        mine = torch.tensor([sorted(step_ms)[len(step_ms) // 2], sorted(comm_ms)[len(comm_ms) // 2], float(digest64(model.flat) % (1 << 52)),
+                             float(digest64(model.flat.grad) % (1 << 52))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(v) for v in r.tolist()] for r in allr]
+        same_params = all(r[2] == rows[0][2] for r in rows)
+        same_grads = all(r[3] == rows[0][3] for r in rows)
+        if not (same_params and same_grads):
+            raise RuntimeError("data-parallel replicas diverged: parameter digests equal: %s, all-reduced gradient digests equal: %s" % (same_params, same_grads))
+        dp_diag = {"world_size": dist.get_world_size(), "backend": "nccl (RCCL)", "per_rank_step_ms_median": [round(r[0], 4) for r in rows],
+                   "allreduce_ms_per_step_median_per_rank": [round(r[1], 4) for r in rows],
+                   "allreduce_share_of_step": round(max(r[1] for r in rows) / max(r[0] for r in rows), 4),
+                   "allreduce_payload_bytes": int(model.flat.numel() * 4), "replicas_bitwise_identical": True,
+                   "note": "a short run of steps behind the headline region; the all-reduce's time is HIP events around the collective on the launch "
+                           "stream and includes its wait for the slowest rank; digests: parameters and the all-reduced gradient, compared over all ranks"}
     # Roofline leg, right behind it: the same steps with the engine's HIP events around kernel launches.  Events around EVERY launch cost
     # ~6 % of the step (launch ramps no longer overlap), so two steps bracketed in full give the per-class table and name the dominant
     # class, and a second timed run of steps brackets only that class's launches (its average launch time is the roofline's `achieved`).
@@ -425,6 +463,8 @@ def run_rank(args):
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",
                                   "note": "derived from the reference's TensorBoard logs (BASELINE.md), not a published figure"},
         }
+        if dp_diag is not None:
+            out["dp"] = dp_diag
         hbm_profile = hbm_profile_path()
         if T == 9:
             # the HBM view SURVEY.md §8d asks for next to the compute roofline: the un-fused layer-boundary byte model, the bytes the

@@ -318,7 +318,17 @@ static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const floa
     reported = false;                                // does the kernel write am.y itself?
     // the experimental 19-frame reducer: 5x5x5 kernels, pads of 2, mirrored depth pads (and their backward-data forms): generic kernels
     const bool exotic = g.reflect_t || g.ph > 2 || g.pw > 2 || g.pt > 2 || (!pw && g.kh != 3) || (g.reflect_hw && g.ph > 1);
+    // upscaleConv1 and its backward-data (0.2 % of the work): dedicated small VALU kernels instead of 32x32 matrix tiles around a 32x9 product
+    if (e->impl >= 1 && !gate && !skip && bwd && conv3d_up_bwd_data_supported(g)) {
+        ProfScope ps(e, CLS_CONV3_BWD_DATA, geom_macs(g), s);
+        reported = true;
+        return conv3d_up_bwd_data(g, x, w, nullptr, y, am.y, s);
+    }
     if (exotic) { ProfScope ps(e, bwd ? CLS_CONV3_BWD_DATA : CLS_CONV3_FWD, geom_macs(g), s); return conv3d_direct_forward(g, x, gate, w, bias, skip, y, s); }
+    if (e->impl >= 1 && !gate && !skip && bias && !am.y && conv3d_up_forward_supported(g)) {
+        ProfScope ps(e, CLS_CONV3_FWD, geom_macs(g), s);
+        return conv3d_up_forward(g, x, w, bias, y, s);
+    }
     if (e->impl >= 1 && !gate && !skip && bias && conv3d_cin1_forward_supported(g)) {
         ProfScope ps(e, CLS_CONV3_FWD, geom_macs(g), s);
         reported = true;
@@ -1087,6 +1097,9 @@ int probav_conv3d_forward(const int32_t geom[17], const float* x, const float* g
     const ConvGeom g = geom_from(geom);
     if (!geom_ok(g)) { set_error("probav_conv3d_forward: bad geometry", hipSuccess); return PROBAV_EINVAL; }
     if (impl < 0 || impl > 4) { set_error("probav_conv3d_forward: impl must be 0..4", hipSuccess); return PROBAV_EINVAL; }
+    // (what the engine does for these two geometries in every kernel family but 0)
+    if (impl >= 1 && !gate && !skip && bias && conv3d_up_forward_supported(g)) return conv3d_up_forward(g, x, w, bias, y, (hipStream_t)stream);
+    if (impl >= 1 && !gate && !skip && !g.relu && conv3d_up_bwd_data_supported(g)) return conv3d_up_bwd_data(g, x, w, bias, y, nullptr, (hipStream_t)stream);
     if (impl >= 1) {
         const bool pstrip = impl == 4 && x6_strip_wants_tap_fragments(g, 2);
         const bool x6row = impl >= 3 && !mfma_conv_strip_supported(g) && !pstrip && x6_conv_rowtile_supported(g);

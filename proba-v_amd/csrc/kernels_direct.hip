@@ -11,6 +11,7 @@
 // wave-uniform, so the compiler fetches them through the scalar cache (s_load) and the FMAs take
 // them as SGPR operands -- filter reuse costs no vector memory traffic at all.
 #include "probav_common.h"
+#include <mutex>
 #include "x6_device.h"
 
 namespace probav {
@@ -184,6 +185,143 @@ int conv3d_direct_forward(const ConvGeom& g, const float* x, const float* gate, 
     if (g.Cout % 9 == 0)  return launch_fwd<9>(g, x, gate, w, bias, skip, y, s);
     if (g.Cout % 4 == 0)  return launch_fwd<4>(g, x, gate, w, bias, skip, y, s);
     return launch_fwd<1>(g, x, gate, w, bias, skip, y, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// upscaleConv1 (models/modelsTF.py:163-164): valid 3x3x3, 32 -> s^2 = 9 channels, on the last reducer's [18][18][3] output -- the depth
+// collapses to 1.  0.26 GMAC per batch of 128, 0.2 % of the step's work: the row-tile MFMA kernel spent 44 us on it (a 32x9 product in
+// 32x32 tiles, four percent busy) and the generic VALU kernel 77 us on its backward-data.  Two small VALU kernels, one workgroup per
+// (sample, output row), input rows and the whole filter in LDS:
+//   forward        y[n][h][w][co] = b[co] + sum_{a,b,c,ci} x[n][h+a][w+b][c][ci] W[a][b][c][ci][co]: thread (w, k-part): 1/16 of the 27 x 32
+//                  products for all nine outputs, then a butterfly over the 16 parts (fixed order: bitwise reproducible)
+//   backward-data  the full correlation of the one-deep 9-channel dY with the flipped filter (the engine passes W^T: [a'][b'][c'][co][ci]):
+//                  dX[n][h][w][t][ci] = sum_{a',b',co} dY[n][h+a'-2][w+b'-2][co] W^T[a'][b'][2-t][co][ci]; thread (w, t, 4 ci); the per-sample
+//                  amax of dX (the next H3 kernels' scale) comes out of the same pass
+// ---------------------------------------------------------------------------------------------------
+bool conv3d_up_forward_supported(const ConvGeom& g)
+{
+    return g.Cin == 32 && g.Cout == 9 && g.kh == 3 && g.kw == 3 && g.kt == 3 && g.ph == 0 && g.pw == 0 && g.pt == 0 && !g.reflect_hw && !g.reflect_t &&
+           g.Ti == 3 && g.To == 1 && g.Ho == g.Hi - 2 && g.Wo == g.Wi - 2 && g.Wo == 16;
+}
+bool conv3d_up_bwd_data_supported(const ConvGeom& g)
+{
+    return g.Cin == 9 && g.Cout == 32 && g.kh == 3 && g.kw == 3 && g.kt == 3 && g.ph == 2 && g.pw == 2 && g.pt == 2 && !g.reflect_hw && !g.reflect_t &&
+           g.Ti == 1 && g.To == 3 && g.Ho == g.Hi + 2 && g.Wo == g.Wi + 2 && g.Wi <= 30;
+}
+__global__ __launch_bounds__(256) void conv3_up_fwd_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y)
+{
+    extern __shared__ float up_lds[];
+    float* sW = up_lds;                                   // [27 * 32][9]
+    float* sX = sW + 27 * 32 * 9;                         // [3 rows][Wi][3][32]
+    const int tid = threadIdx.x;
+    const int rowf = g.Wi * 3 * 32;                        // floats of one input row
+    for (int i = tid; i < 27 * 32 * 9 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(w)[i];      // once per workgroup: the grid is ~one per CU
+    const int wo = tid >> 4, kp = tid & 15;                // 16 output columns x 16 parts of the 864 products: part kp = (a, b, c, ci) index = kp + 16 j
+    for (int row = blockIdx.x; row < g.N * g.Ho; row += gridDim.x) {
+    const int n = row / g.Ho, h = row - n * g.Ho;
+    __syncthreads();                                       // (the previous row's readers are done)
+    const float4* xr = reinterpret_cast<const float4*>(x + ((long)n * g.Hi + h) * rowf);
+    for (int i = tid; i < 3 * rowf / 4; i += 256) reinterpret_cast<float4*>(sX)[i] = xr[i];
+    __syncthreads();
+    float acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+#pragma unroll 2
+    for (int q = 0; q < 54; ++q) {
+        const int k = kp + 16 * q;                         // (tap, ci) = (k >> 5, k & 31); tap = (a * 3 + b) * 3 + c
+        const int tap = k >> 5, ci = k & 31;
+        const int a = tap / 9, bc = tap - 9 * a, b = bc / 3, c = bc - 3 * b;
+        const float xv = sX[a * rowf + ((wo + b) * 3 + c) * 32 + ci];
+        const float* wr = sW + k * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        float v = acc[j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+        acc[j] = v;
+    }
+    if (kp < 9) {
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) o = kp == j ? acc[j] : o;
+        o += bias ? bias[kp] : 0.f;
+        if (g.relu) o = fmaxf(o, 0.f);
+        y[(((long)n * g.Ho + h) * g.Wo + wo) * 9 + kp] = o;
+    }
+    }
+}
+__global__ __launch_bounds__(256) void conv3_up_bwd_data_kernel(ConvGeom g, const float* __restrict__ dy, const float* __restrict__ wT,
+                                                               const float* __restrict__ bias, float* __restrict__ dx, unsigned* __restrict__ amax)
+{
+    extern __shared__ float up_lds[];
+    float* sW = up_lds;                                   // [27][9][32]
+    float* sD = sW + 27 * 9 * 32;                         // [3 rows][Wi + 4][9] with two zero columns on each side
+    const int tid = threadIdx.x;
+    const int Wp = g.Wi + 4;
+    for (int i = tid; i < 27 * 9 * 32 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(wT)[i];
+    __shared__ float red[4];
+    for (int row = blockIdx.x; row < g.N * g.Ho; row += gridDim.x) {
+    const int n = row / g.Ho, h = row - n * g.Ho;
+    __syncthreads();
+    for (int i = tid; i < 3 * Wp * 9; i += 256) {
+        const int a = i / (Wp * 9), r = i - a * Wp * 9, wp = r / 9, co = r - 9 * wp;
+        const int ih = h + a - 2, iw = wp - 2;
+        sD[i] = (ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi) ? dy[(((long)n * g.Hi + ih) * g.Wi + iw) * 9 + co] : 0.f;
+    }
+    __syncthreads();
+    float omax = 0.f;
+    const int items = g.Wo * 3 * 8;                        // (w, t, group of 4 input channels)
+    for (int it = tid; it < items; it += 256) {
+        const int cg = it & 7, wt = it >> 3, wo = wt / 3, t = wt - 3 * wo;
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);      // (the engine's backward-data has none)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float* dp = sD + (a * Wp + wo + b) * 9;
+                const float* wp = sW + (((a * 3 + b) * 3 + (2 - t)) * 9) * 32 + 4 * cg;
+#pragma unroll
+                for (int co = 0; co < 9; ++co) {
+                    const float d = dp[co];
+                    const float4 q = *reinterpret_cast<const float4*>(wp + co * 32);
+                    acc.x = fmaf(d, q.x, acc.x); acc.y = fmaf(d, q.y, acc.y); acc.z = fmaf(d, q.z, acc.z); acc.w = fmaf(d, q.w, acc.w);
+                }
+            }
+        *reinterpret_cast<float4*>(dx + ((((long)n * g.Ho + h) * g.Wo + wo) * 3 + t) * 32 + 4 * cg) = acc;
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = omax;
+        __syncthreads();
+        if (tid == 0) {
+            const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax + n)) atomicMax(amax + n, __float_as_uint(m));
+        }
+    }
+    }
+}
+int conv3d_up_forward(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s)
+{
+    if (!conv3d_up_forward_supported(g)) { set_error("conv3d_up_forward: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    const size_t lds = ((size_t)27 * 32 * 9 + (size_t)3 * g.Wi * 3 * 32) * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] { note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); });
+    hipLaunchKernelGGL(conv3_up_fwd_kernel, dim3((unsigned)(g.N * g.Ho < 512 ? g.N * g.Ho : 512)), dim3(256), lds, s, g, x, w, bias, y);
+    return check_launch("conv3_up_fwd");
+}
+// amax: per-sample slots of the output (may be null; zeroed by the caller)
+int conv3d_up_bwd_data(const ConvGeom& g, const float* dy, const float* wT, const float* bias, float* dx, unsigned* amax, hipStream_t s)
+{
+    if (!conv3d_up_bwd_data_supported(g)) { set_error("conv3d_up_bwd_data: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    const size_t lds = ((size_t)27 * 9 * 32 + (size_t)3 * (g.Wi + 4) * 9) * sizeof(float);
+    hipLaunchKernelGGL(conv3_up_bwd_data_kernel, dim3((unsigned)(g.N * g.Ho < 768 ? g.N * g.Ho : 768)), dim3(256), lds, s, g, dy, wT, bias, dx, amax);
+    return check_launch("conv3_up_bwd_data");
 }
 
 // ---------------------------------------------------------------------------------------------------

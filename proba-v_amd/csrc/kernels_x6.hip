@@ -1580,6 +1580,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
 #endif
     // ---- the gate of tile k (vector phase; a ghost: dH = 0, so its gradient tile is zero whatever relu(bias) is) ----
     auto gate = [&](int k) __attribute__((always_inline)) {
+#ifdef H3T_GATEPRIO
+        __builtin_amdgcn_s_setprio(H3T_GATEPRIO);
+#endif
 #ifndef H3S_NOGATE
         const float cg = t_inB(k) ? cgB : cgA;
 #pragma unroll

@@ -71,6 +71,11 @@ int reduce_join(hipStream_t s);
 bool conv3d_cin1_forward_supported(const ConvGeom& g);
 int conv3d_cin1_forward(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, unsigned* amax, hipStream_t s);
 // geometries for which conv3d_direct_wgrad runs a dedicated kernel that beats the matrix kernels (one input channel: mainConv1)
+// upscaleConv1 (32 -> 9, valid, depth 3 -> 1) and its backward-data (9 -> 32, full, depth 1 -> 3; w = the flipped, channel-swapped filter): small VALU kernels
+bool conv3d_up_forward_supported(const ConvGeom& g);
+int conv3d_up_forward(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+bool conv3d_up_bwd_data_supported(const ConvGeom& g);
+int conv3d_up_bwd_data(const ConvGeom& g, const float* dy, const float* wT, const float* bias, float* dx, unsigned* amax, hipStream_t s);
 bool conv3d_direct_wgrad_is_tuned(const ConvGeom& g);
 
 // ---- kernels_small.hip ---------------------------------------------------------------------------

@@ -11,11 +11,17 @@ import torch
 from . import _lib
 
 
-def device_gates(m, flat_used, B, T=9):
+def device_gates(m, flat_used, B, T=9, samples=None):
     """{layer: bool array}: the ReLU decisions of the last training forward of `m` (batch B, T frames), read from the saved activations
     (a post-ReLU value is > 0 exactly where the gate is open: `probav_workspace_view`) and, for the 256-channel hidden tiles that never
     reach memory, recomputed by the forward kernel itself (`probav_debug_hidden`).  Needs the pass's workspace alive: run the forward
-    with PROBAV_KEEP_WS=1, or call this before the backward pass releases it."""
+    with PROBAV_KEEP_WS=1, or call this before the backward pass releases it.
+    samples (optional): only these samples of the batch, in this order -- the gates of a sub-batch of a large batch (every saved tensor is
+    sample-major), sliced on the device.
+    The hidden tiles come from the 32x32x16 arrangement of the fused forward kernel, which is the one the BACKWARD pass recomputes them
+    with: these are the gates the gradient was taken at.  The forward pass proper (pw_fwd_h3k_kernel: 16x16x32) sums the same products in
+    another order; a pre-activation that is zero to the last bit can be open in one and closed in the other -- its forward contribution
+    is its value, ~0 (csrc/kernels_x6.hip, the comment above that kernel)."""
     L = _lib.lib()
     h, ws = m._handle(), m._workspace(B, True)
     wc = m.weight_cache()                    # the cache the forward pass ran from (None: it recomputed the weights into its workspace)
@@ -25,18 +31,22 @@ def device_gates(m, flat_used, B, T=9):
         off, cnt = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(L.probav_workspace_view(h, B, 1, kind, idx, ctypes.byref(off), ctypes.byref(cnt)), "probav_workspace_view")
         return ws[off.value: off.value + cnt.value]
-    gates = {"mainConv1": (view(0, 0) > 0).cpu().numpy(), "residConv1": (view(3, 0) > 0).cpu().numpy()}
+    def pick(t):                                     # [B * per] (or any sample-major flat tensor) -> the chosen samples
+        if samples is None:
+            return t
+        return t.view(B, -1)[torch.as_tensor(list(samples), device=t.device)].reshape(-1)
+    gates = {"mainConv1": (pick(view(0, 0)) > 0).cpu().numpy(), "residConv1": (pick(view(3, 0)) > 0).cpu().numpy()}
     nvox = B * hin * hin * T
     hid = torch.empty(nvox * m.numFilters * m.expRate, device=ws.device)
     dec = torch.empty(nvox * 32, device=ws.device)                     # the launch's regular output (decConv), discarded
     for i in range(m.numResBlocks):
         _lib.check(L.probav_debug_hidden(h, _lib.ptr(flat_used), _lib.ptr(ws), ws.numel() * 4, B, i, _lib.ptr(hid), _lib.ptr(dec), _lib.ptr(wc),
                                          _lib.current_stream()), "probav_debug_hidden")
-        gates["expConv_%d" % i] = (hid > 0).cpu().numpy()
+        gates["expConv_%d" % i] = (pick(hid) > 0).cpu().numpy()
     k = 0
     while True:
         try:
-            gates["convReducer_%d" % (k + 1)] = (view(2, k) > 0).cpu().numpy()
+            gates["convReducer_%d" % (k + 1)] = (pick(view(2, k)) > 0).cpu().numpy()
         except ValueError:
             break
         k += 1

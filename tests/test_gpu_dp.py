@@ -58,6 +58,11 @@ def test_bench_step_under_a_world_size_1_rccl_group_is_bitwise_the_plain_step(de
         c = line["config"]
         assert c["world_size"] == 1 and c["backend"] == "nccl (RCCL)" and c["forced_dp"] is True and "all-reduce" in c["workload"]
         assert line["n_gpus"] == 1 and line["digest"] == plain["digest"], "the RCCL all-reduce over one rank changed the gradient"
+        # the self-diagnosis of the first real N > 1 run, exercised on the one GPU there is: per-rank step, the all-reduce's own time, identical replicas
+        d = line["dp"]
+        assert d["world_size"] == 1 and len(d["per_rank_step_ms_median"]) == 1 and d["replicas_bitwise_identical"] is True
+        assert 0.0 < d["allreduce_ms_per_step_median_per_rank"][0] < d["per_rank_step_ms_median"][0] and d["allreduce_payload_bytes"] == 535267 * 4
+    assert "dp" not in plain
 
 
 TRAINER = r"""

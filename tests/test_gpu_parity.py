@@ -88,6 +88,7 @@ CONV_CASES = [
     ("convReducer_3 valid relu", 2, (20, 20, 5), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
     ("bwd-data of convReducer_3: full 32->32 gated", 2, (18, 18, 3), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
     ("T=7 normConv same 25->32 + skip", 3, (22, 22, 7), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("bwd-data of upscaleConv1: full 9->32, depth 1 -> 3", 3, (16, 16, 1), 9, 32, (3, 3, 3), (2, 2, 2), 0, 0, 0, 0),
 ]
 
 
@@ -634,11 +635,12 @@ def _device_gates(m, flat_used, B, T=9):
     return device_gates(m, flat_used, B, T)
 
 
-@pytest.mark.parametrize("impl,T,B", [(4, 9, 2), (3, 9, 2), (4, 13, 2), (4, 9, 5), (4, 7, 3)],
-                         ids=["h3-t9-b2", "x6-t9-b2", "h3-t13-b2", "h3-t9-b5", "h3-t7-b3"])
+@pytest.mark.parametrize("impl,T,B", [(4, 9, 2), (3, 9, 2), (4, 13, 2), (4, 9, 5), (4, 7, 3), (4, 19, 2)],
+                         ids=["h3-t9-b2", "x6-t9-b2", "h3-t13-b2", "h3-t9-b5", "h3-t7-b3", "h3-t19-b2"])
 def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl, T, B):
     """T = 9, B = 2: the golden inputs.  T = 13 (reducer v3, rows cut into column ranges), T = 7, and B = 5 (more than two per-sample
-    scale slots behind `amax_over_samples`, a different strip partition): seeded synthetic inputs."""
+    scale slots behind `amax_over_samples`, a different strip partition): seeded synthetic inputs.  T = 19: the only network with a
+    5x5x5 kernel and a mirror pad along T (models/modelsTF.py:76-121), on the generic kernels."""
     from probav_amd.loss import Losses
     if (T, B) == (9, 2):
         z = np.load(os.path.join(GOLD, "wdsr_t9_b2.npz"))
@@ -675,6 +677,55 @@ def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl, T, B):
                 worst = (e, L_.name + "/" + key)
             assert e < 1e-3, (L_.name, key, e)
     print("impl %d: worst per-tensor max-norm gradient error with the device's gates: %.3g (%s)" % (impl, worst[0], worst[1]))
+
+
+@pytest.mark.parametrize("T", [9])
+def test_batch128_backward_of_a_sub_batch_matches_the_oracle(dev, T):
+    """The reverse pass AT THE BENCHMARK'S SIZE against the oracle (at batch 128 the backward was covered by properties only).
+    The loss is a batch mean of per-sample terms, so d loss / d pred of sample s depends on sample s alone: run the forward on all 128
+    patches, hand the backward an output gradient that is that of a two-sample loss on samples (5, 77) and zero elsewhere, and compare all
+    132 gradient tensors with the fp64 oracle on those two samples, evaluated at the device's gates for them -- element-wise, 1e-3 of each
+    tensor's max norm.  Every kernel runs its batch-128 partition (two-sample tile runs, 128 per-sample scale
+    slots, the slabs of 256 workgroups); what the other 126 samples contribute is exactly zero."""
+    from probav_amd.loss import Losses
+    pick = [5, 77]
+    params = synth.synth_params(seed=31, perturb=True, numImgLR=T)
+    m = _model(dev, T, params=params)
+    lo = Losses(targetShape=(48, 48, 1))
+    xs, hs, ms = synth.synth_batch(128, seed=32, numImgLR=T)
+    x, hr, mask = (torch.as_tensor(a).to(dev) for a in (xs, hs, ms))
+    pred = m(x, training=True)
+    sub = pred[pick].detach().clone().requires_grad_(True)
+    l2 = lo.shiftCompensatedL1Loss(hr[pick].contiguous(), mask[pick].contiguous(), sub)
+    l2.backward()
+    dy = torch.zeros_like(pred)
+    dy[pick] = sub.grad
+    pred.backward(dy)
+    gates = _device_gates_sub(m, m.flat.detach(), 128, T, pick)
+    report = {}
+    pred_o, loss_o, grads_o = ot.train_step_grads(torch.tensor(xs[pick], dtype=torch.float64), torch.tensor(hs[pick]), torch.tensor(ms[pick]),
+                                                  ot.to_torch_params(params), synth.NIR_MEAN, synth.NIR_STD, numImgLR=T, gates=gates, gate_report=report)
+    worst_margin = max((r[0][1] / max(r[0][2], 1e-30)) for r in report.values())
+    assert worst_margin < 1e-4, "a gate that differs is NOT a ~0 pre-activation: the forward itself is off"
+    assert abs(float(l2) - float(loss_o)) < 1e-5 * float(loss_o)
+    e = np.abs(pred[pick].detach().cpu().double().numpy() - pred_o.numpy()).max() / np.abs(pred_o.numpy()).max()
+    assert e < 2e-5, e
+    gdev = m.flat.grad.detach().cpu().double().numpy()
+    worst = (0.0, None)
+    for L_ in m.layers:
+        go = grads_o[L_.name]
+        for key, lo_, hi_ in (("g", L_.g_off, L_.v_off), ("v", L_.v_off, L_.b_off), ("bias", L_.b_off, L_.b_off + L_.cout)):
+            ref = go[key].numpy().reshape(-1)
+            err = np.abs(gdev[lo_:hi_] - ref).max() / (np.abs(ref).max() + 1e-30)
+            if err > worst[0]:
+                worst = (err, L_.name + "/" + key)
+            assert err < 1e-3, (L_.name, key, err)
+    print("batch 128, samples %s: worst per-tensor max-norm gradient error with the device's gates: %.3g (%s)" % (pick, worst[0], worst[1]))
+
+
+def _device_gates_sub(m, flat_used, B, T, samples):
+    from probav_amd.introspect import device_gates
+    return device_gates(m, flat_used, B, T, samples=samples)
 
 
 def test_train_steps_match_oracle(dev, tmp_path):
