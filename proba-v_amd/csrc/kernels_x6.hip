@@ -1394,6 +1394,9 @@ __device__ __forceinline__ void h3_cut4_scaled(float a0, float a1, float b0, flo
     h3_second_pieces2(q0.x, a0, a1, q0.y, b0, b1, q1.x, q1.y);
 }
 
+#ifndef H3T_LOADGAP
+#define H3T_LOADGAP 12
+#endif
 __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
     const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
     const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
@@ -1714,6 +1717,18 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
                 if constexpr (S >= 8 && S <= 11) rd_de(1, S - 8);
                 if constexpr (S >= 12 && S <= 15) rd_gq((S - 12) >> 1, (S - 12) & 1);
                 if constexpr (S >= 19 && S <= 22) rd_df((S - 19) >> 1, (S - 19) & 1);
+#if !defined(H3T_PURE) && !defined(H3T_LOADS_IN_X)
+                // the global requests of the NEXT phases go out here, late in the matrix phase (scalar descriptor arithmetic and five vector-memory
+                // instructions cost a gap nothing), not at the head of X(k): the vector phase is then the gate alone -- it was the segment's
+                // critical path by the ~200 cycles its loads' bookkeeping took -- and the requests get a phase more of lead
+                if constexpr (S == H3T_LOADGAP) {
+                    if constexpr (ROLE == 0) stage_load(k + 2, nxv, nd);      // (nxv / nd were consumed in gaps 0-5)
+                    else {
+                        const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k - 1, 128), ro, 0, 0);      // (rdo was consumed in gap 8)
+                        rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+                    }
+                }
+#endif
 #ifndef H3T_PURE
                 if constexpr (ROLE == 0) {
 #ifndef H3S_NOSTAGE
@@ -1860,7 +1875,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
             rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
             XSS(2);
         }
-#else
+#elif defined(H3T_LOADS_IN_X)
         if constexpr (ROLE == 0) stage_load(k + 2, nxv, nd);
         else {
             const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k - 1, 128), ro, 0, 0);

@@ -197,7 +197,12 @@ class GradBucket:
     replica's mean loss and mean metric -- what debug/trainClassMultiGPU0.py:162-178 sends as a gradient all-reduce plus two
     `strategy.reduce(MEAN)` calls.  `reduce_` pre-scales by 1 / world, all-reduces (SUM) once, re-points every `p.grad` at its
     slice of the bucket (no copy back) and returns the two global means.  At 8 ranks a latency-bound RCCL call costs more than the
-    2 MB of wire time, so the pair rides with the gradient instead of taking a launch of its own."""
+    2 MB of wire time, so the pair rides with the gradient instead of taking a launch of its own.
+    A deliberate deviation from the reference's replica context: there `optimizer.apply_gradients` SUM-aggregates the gradients of
+    the per-replica MEAN losses (debug/trainClassMultiGPU0.py:153: `computeLoss` with the global batch size is defined and not used), so
+    its effective gradient is `world` times the global-batch mean; here the update is that of ONE batch of world x 128 patches, the
+    mean, so that the learning rate means the same at every world size.  With Nadam / Adam the factor only moves
+    the update through epsilon.  The two scalars pass through fp32 in the bucket's tail (they are logged, not trained on)."""
 
     def __init__(self):
         self.buf = None

@@ -30,11 +30,35 @@ def _tree(rel):
         return ast.parse(fh.read(), filename=rel)
 
 
+# What is lifted out of the reference is EXECUTED here, and the reference is untrusted content: every node is pinned to the sha256 of
+# its `ast.dump` as reviewed when this script was written.  A reference that has changed since (or another checkout) is refused, not run.
+# Manual tool: nothing in tests/ or the build invokes it; run it by hand in the build container (no network) to regenerate the fixture.
+PINS = {
+    "test.py::reconstruct_from_patches+resolveByBatch": "85d9ccfb6a750c7ffec44b481657403dc43f35226087af634a69a6b73cdc9e77",
+    "models/testClass.py::Enhancer.reconstruct": "00d8bbe12dbcc21b42fa4415127aa44d468e64db4f4f62f269e1cc1fbdb9674d",
+    "utils/dataGenerator.py::generatePatches+generatePatchesPerImgSet": "baac2cd268a0e1d9222e58a9b0b8420fd59dfc9d4ea938fd32ff5254532e4d7b",
+    "utils/dataGenerator.py:106-121": "b9bfbd9371eb844f7b90c1a191d796146a4ebb0439862384adb15d54d2d54556",
+}
+
+
+def _pinned(key, nodes):
+    import hashlib
+    import sys
+    digest = hashlib.sha256("\n".join(ast.dump(n, include_attributes=False) for n in nodes).encode()).hexdigest()
+    if "--print-pins" in sys.argv:
+        print('    "%s": "%s",' % (key, digest))
+        return
+    if PINS.get(key) != digest:
+        raise SystemExit("make_ref_fixtures: the reference code behind %r is not the reviewed one (sha256 %s, pinned %s): "
+                         "read it, then update PINS" % (key, digest, PINS.get(key)))
+
+
 def _functions(rel, names, namespace):
     """Compile the top-level functions `names` of a reference module into `namespace` (nothing else of the module runs)."""
     tree = _tree(rel)
     nodes = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
     assert sorted(n.name for n in nodes) == sorted(names), (rel, [n.name for n in nodes])
+    _pinned(rel + "::" + "+".join(sorted(names)), nodes)
     exec(compile(ast.Module(body=nodes, type_ignores=[]), os.path.join(REF, rel), "exec"), namespace)
     return {n.name: (n.lineno, n.end_lineno) for n in nodes}
 
@@ -43,6 +67,7 @@ def _method(rel, cls, name, namespace):
     tree = _tree(rel)
     (c,) = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls]
     (m,) = [n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    _pinned(rel + "::" + cls + "." + name, [m])
     exec(compile(ast.Module(body=[m], type_ignores=[]), os.path.join(REF, rel), "exec"), namespace)
     return (m.lineno, m.end_lineno)
 
@@ -62,6 +87,7 @@ def _statements(rel, first, last):
                     if isinstance(sub, list) and sub and isinstance(sub[0], ast.stmt):
                         walk(sub)
     walk(tree.body)
+    _pinned("%s:%d-%d" % (rel, first, last), out)
     return compile(ast.Module(body=out, type_ignores=[]), os.path.join(REF, rel), "exec"), [(n.lineno, n.end_lineno) for n in out]
 
 
