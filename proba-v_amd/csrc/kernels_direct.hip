@@ -524,6 +524,7 @@ static void wgrad_plan(const ConvGeom& g, int& ci_per, int& gy, int& gz, int& ch
 // zero-padded in LDS (3 KB), 16 voxel streams (8 waves x 2 half-waves) run over the row's voxels with lane = output channel, so
 // dY / mask loads are 128-byte rows and every x value is an LDS broadcast; 27 + 1 accumulators per thread, one slab per workgroup.
 // ---------------------------------------------------------------------------------------------------
+template <bool GATE>
 __global__ __launch_bounds__(512) void wgrad_cin1_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ gate, float* __restrict__ partial,
                                                         float* __restrict__ partial_b)
@@ -546,18 +547,31 @@ __global__ __launch_bounds__(512) void wgrad_cin1_kernel(ConvGeom g, const float
         }
         __syncthreads();
         const long ob = ((long)n * g.Ho + h) * nvr;
-        for (int vi = 2 * wave + half; vi < nvr; vi += 16) {
-            const int w = vi / g.To, t = vi - w * g.To;
-            float d = dy[(ob + vi) * 32 + co];
-            if (gate) d = gate[(ob + vi) * 32 + co] > 0.f ? d : 0.f;
-            bsum += d;
-            const float* px = sx + w * Tp + t;
+        // four voxels of a stream per round, all eight requests out before the first is used: one request per round left the kernel waiting
+        // for memory 68 times in a row (63 us for 142 MB); the clamped index of a slot beyond the row reads a valid voxel and counts as zero
+        for (int v0 = 2 * wave + half; v0 < nvr; v0 += 64) {
+            float d[4], m[4];
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
+            for (int u = 0; u < 4; ++u) {
+                const int vi = v0 + 16 * u < nvr ? v0 + 16 * u : v0;
+                d[u] = dy[(ob + vi) * 32 + co];
+                if constexpr (GATE) m[u] = gate[(ob + vi) * 32 + co]; else m[u] = 1.f;      // (a run-time test around a load makes hipcc branch and drain vmcnt per element)
+            }
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw)
+            for (int u = 0; u < 4; ++u) {
+                const bool live = v0 + 16 * u < nvr;                   // (predicated, not skipped: a branch here sinks the requests above into it)
+                const int vi = live ? v0 + 16 * u : v0;
+                const int w = vi / g.To, t = vi - w * g.To;
+                const float dd = (live && m[u] > 0.f) ? d[u] : 0.f;
+                bsum += dd;
+                const float* px = sx + w * Tp + t;
 #pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) acc[(dh * 3 + dw) * 3 + dt] = fmaf(px[dh * rowf + dw * Tp + dt], d, acc[(dh * 3 + dw) * 3 + dt]);
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+                        for (int dt = 0; dt < 3; ++dt) acc[(dh * 3 + dw) * 3 + dt] = fmaf(px[dh * rowf + dw * Tp + dt], dd, acc[(dh * 3 + dw) * 3 + dt]);
+            }
         }
     }
     // the 16 streams of an output channel meet in a fixed order: half-waves by shuffle, waves through LDS
@@ -608,7 +622,8 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
         const int slabs = cin1_grid(g);
         float* pb = partial + (size_t)slabs * 27 * 32;
         const size_t lds = (size_t)(3 * (g.Wi + 2) * (g.Ti + 2) + 8 * 28 * 32) * sizeof(float);
-        hipLaunchKernelGGL(wgrad_cin1_kernel, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
+        if (gate) hipLaunchKernelGGL(wgrad_cin1_kernel<true>, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
+        else hipLaunchKernelGGL(wgrad_cin1_kernel<false>, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
         int rc = check_launch("wgrad_cin1");
         if (rc) return rc;
         hipStream_t rs = reduce_fork(s);

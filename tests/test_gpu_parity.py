@@ -378,9 +378,12 @@ def test_end_to_end_against_golden(dev, T, impl):
         assert torch.equal(m(x, training=False), pred.detach())
 
 
-@pytest.mark.parametrize("nvox", [32, 1000, 4356 * 3])
-def test_fused_pointwise_forward_backward(dev, nvox):
-    """expConv + ReLU + decConv fused in accumulators (and its fused reverse pass) against fp64 numpy."""
+@pytest.mark.parametrize("nvox,vps", [(32, 0), (1000, 0), (4356 * 3, 0), (5 * 1640, 1640), (600 * 64, 64)],
+                         ids=["32", "1000", "13068", "5 samples of 1640 (partial last tiles, sample boundaries inside the runs)",
+                              "600 samples of 64 (runs longer than a sample: the general kernel)"])
+def test_fused_pointwise_forward_backward(dev, nvox, vps):
+    """expConv + ReLU + decConv fused in accumulators (and its fused reverse pass) against fp64 numpy.  vps = voxels per sample (0: one
+    sample): H3 scales, tiles and the reverse kernel's runs follow the samples."""
     L = _lib()
     D = 25
     rng = np.random.default_rng(nvox)
@@ -398,7 +401,7 @@ def test_fused_pointwise_forward_backward(dev, nvox):
     ref = Hh @ W2 + b2
     for impl in (2, 3, 4):                    # native fp32 MFMA, the six-product bf16 split and the three-product fp16 split: one tolerance
         dec = torch.full((nvox, D), float("nan"), device=dev)
-        L.check(L.lib().probav_pw_forward(L.ptr(xd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(dec), nvox, 0, D, impl,
+        L.check(L.lib().probav_pw_forward(L.ptr(xd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(b2d), L.ptr(dec), nvox, vps, D, impl,
                                           L.current_stream()))
         err = np.abs(dec.cpu().double().numpy() - ref).max() / np.abs(ref).max()
         print("pw_forward impl %d nvox %d: max err / max |ref| = %.3g" % (impl, nvox, err))
@@ -411,7 +414,7 @@ def test_fused_pointwise_forward_backward(dev, nvox):
         dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
         dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
         L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
-                                           L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, 0, D, impl, L.current_stream()))
+                                           L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, vps, D, impl, L.current_stream()))
         for name, got in (("dx", dx), ("dw1", dw1), ("db1", db1), ("dw2", dw2), ("db2", db2)):
             r = refs[name]
             err = np.abs(got.cpu().double().numpy() - r).max() / np.abs(r).max()
