@@ -236,22 +236,31 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
     float* sB1 = reinterpret_cast<float*>(sW2 + 8 * 2 * NP * 64);    // 256
     float* sB2 = sB1 + 256;                                      // 32
     int* sE2 = reinterpret_cast<int*>(sB2 + 32);                 // 32: H3 exponent of decConv's output column d
+    float* sBw = reinterpret_cast<float*>(sE2 + 32);             // [8 waves][256]: the expand biases at THIS WAVE's current sample's scale (2^(eh - 16)); private to the wave
     const int tid = threadIdx.x, lane = tid & 63, m16 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
     if (tid < 256) sB1[tid] = b1[tid];
     if (tid < 32) { sB2[tid] = tid < D ? b2[tid] : 0.f; sE2[tid] = tid < D ? h3_exp_w(am.w2c[tid]) : 0; }
     __syncthreads();
-    float sx = 1.f, sbias = 1.f, c1 = 1.f; int eh = 0;
+    // Bias + ReLU as ONE instruction: v_fma_f32 ... clamp computes min(max(H c + b, 0), 1), so the accumulator is brought to 2^-16 of the hidden tile's
+    // scale (where the tile's bound is < 1/2: the upper clamp never acts), and an exact multiplication by 2^16 follows.  The bits are those of
+    // max(fma(H, c1, b), 0) * 2^eh (powers of two commute with the fma's one rounding); what is gone is the v_max_f32 per element -- this kernel is bound by
+    // its vector instructions at their real prices (a hidden element costs fma 5.7 + max 5.6 + scale 6.2 + cvt 2.9 + mix 9.6 cycles of its SIMD).
+    float sx = 1.f, c1c = 1.f, sb2 = 1.f; int eh = 0;
     const unsigned aw1 = *am.w1, ab1 = *am.b1;
     const int ew1 = h3_exp_w(aw1);
     auto sample_scales = [&](int n) {
         const unsigned ax = am.x[n];
         const int ex = h3_exp(ax);
         eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1));
-        sx = pow2i(ex); sbias = pow2i(eh);
-        const int k1 = -(ex + ew1);
-        c1 = pow2i(k1 < -126 ? -126 : k1);
+        sx = pow2i(ex);
+        const int k1 = -(ex + ew1), k1c = k1 < -126 ? -126 : k1;
+        const int kc = k1c + eh - 16, kb = eh - 16;
+        c1c = pow2i(kc < -126 ? -126 : kc);                      // accumulator of the first product -> hidden values at 2^(eh - 16)
+        sb2 = pow2i(kb < -126 ? -126 : kb);                      // the biases likewise: rewritten once per sample of the wave's run (same wave writes and reads: program order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sBw[wave * 256 + lane + 64 * q] = sB1[lane + 64 * q] * sb2;
     };
     const int tps = (vps + 31) >> 5;
     const long ntiles = (nvox / vps) * tps;
@@ -314,15 +323,31 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
                     a2[o][p].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
             // bias + ReLU + cut: registers (s, i) of H[s][u] are k-slots 4 s + i
-            const float4 bq0 = *reinterpret_cast<const float4*>(sB1 + 32 * c + 4 * kq), bq1 = *reinterpret_cast<const float4*>(sB1 + 32 * c + 16 + 4 * kq);
+            const float4 bq0 = *reinterpret_cast<const float4*>(sBw + wave * 256 + 32 * c + 4 * kq), bq1 = *reinterpret_cast<const float4*>(sBw + wave * 256 + 32 * c + 16 + 4 * kq);
             const float bv[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
             Frag hb[2][NP];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float hs[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { hs[i] = fmaxf(fmaf(H[0][u][i], c1, bv[i]), 0.f); hs[4 + i] = fmaxf(fmaf(H[1][u][i], c1, bv[4 + i]), 0.f); }
-                cut8<AR>(hs, sbias, hb[u]);
+                for (int i = 0; i < 4; ++i) {
+#ifdef H3K_OLDRELU            /* (A/B builds of tools/kbench.hip: fma, max, scale -- the same bits) */
+                    hs[i] = fmaxf(fmaf(H[0][u][i], c1c, bv[i]), 0.f) * 65536.f; hs[4 + i] = fmaxf(fmaf(H[1][u][i], c1c, bv[4 + i]), 0.f) * 65536.f;
+#else
+                    // (med3(x, 0, 1) is the compiler's clamp pattern: it folds into the fma's clamp bit.  Not inline asm: the hazard recognizer does not
+                    // see an asm statement's read of an MFMA result and would not insert the wait states between them)
+                    const float t0 = __builtin_amdgcn_fmed3f(fmaf(H[0][u][i], c1c, bv[i]), 0.f, 1.f);
+                    const float t1 = __builtin_amdgcn_fmed3f(fmaf(H[1][u][i], c1c, bv[4 + i]), 0.f, 1.f);
+#ifdef H3K_MUL65536
+                    hs[i] = t0 * 65536.f; hs[4 + i] = t1 * 65536.f;
+#else
+                    // x 2^16 as an integer add on the exponent field (the compiler packs the multiplications into v_pk_mul_f32: 12.6 cycles apiece beside MFMAs,
+                    // tools/coissue_cycles.hip -DFK=4).  t is in [0, 1/2): no overflow; t = 0 or denormal becomes < 2^-110, both fp16 pieces of which are 0 -- as before
+                    hs[i] = __uint_as_float(__float_as_uint(t0) + (16u << 23)); hs[4 + i] = __uint_as_float(__float_as_uint(t1) + (16u << 23));
+#endif
+#endif
+                }
+                cut8_scaled<AR>(hs, hb[u]);
             }
             PWK(T[0][0], a2[0], 1, hb[0], 0); PWK(T[0][1], a2[0], 1, hb[1], 0); PWK(T[1][0], a2[1], 1, hb[0], 0); PWK(T[1][1], a2[1], 1, hb[1], 0);
             PWK(T[0][0], a2[0], 0, hb[0], 1); PWK(T[0][1], a2[0], 0, hb[1], 1); PWK(T[1][0], a2[1], 0, hb[0], 1); PWK(T[1][1], a2[1], 0, hb[1], 1);
@@ -376,7 +401,7 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_forward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2c || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
-        const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32) * sizeof(float);
+        const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32 + 8 * 256) * sizeof(float);      // (+ pw_fwd_h3k_kernel's per-wave bias tables; two workgroups per CU still fit)
         static const bool v1_env = getenv("PROBAV_PW_FWD_V1") != nullptr;      // A/B runs: the 32x32x16 kernel
         if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                                       b1, b2, dec, nvox, (int)vps, D, am, hdump);

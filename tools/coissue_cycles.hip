@@ -32,9 +32,28 @@ __global__ __launch_bounds__(512) void co(float* out, Stamp* st, int iters, cons
     const f16x8 a = src[threadIdx.x & 63], b = src[64 + (threadIdx.x & 63)];
     float v0 = threadIdx.x * 1e-3f, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f, v4 = v0 + 4.f, v5 = v0 + 5.f, v6 = v0 + 6.f, v7 = v0 + 7.f;
     const float c1 = 1.0001f, c2 = 1e-6f;
+    typedef float f32x2q __attribute__((ext_vector_type(2)));
+    f32x2q pp = {v0, v1}, pq = {c1, c1};
+#define FILL(k) do { if ((k) == 0) FINS(v0); if ((k) == 1) FINS(v1); if ((k) == 2) FINS(v2); if ((k) == 3) FINS(v3); if ((k) == 4) FINS(v4); if ((k) == 5) FINS(v5); if ((k) == 6) FINS(v6); if ((k) == 7) FINS(v7); } while (0)
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#define FILL(k) do { \
+#ifndef FK
+#define FK 0
+#endif
+#if FK == 1      /* v_fma_mixlo_f16: the second H3 piece */
+#define FINS(v) asm volatile("v_fma_mixlo_f16 %0, %0, -1.0, %1 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(v) : "v"(c1))
+#elif FK == 2    /* v_cvt_pk_f16_f32 */
+#define FINS(v) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v) : "v"(c1))
+#elif FK == 3    /* v_max_f32 */
+#define FINS(v) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v) : "v"(c2))
+#elif FK == 4    /* v_pk_mul_f32 on a register pair */
+#define FINS(v) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pp) : "v"(pq))
+#elif FK == 5    /* v_cmp + v_cndmask (a gate) */
+#define FINS(v) asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(v) : "v"(c1) : "vcc")
+#else
+#define FINS(v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(c1), "v"(c2))
+#endif
+#define FILL_OLD(k) do { \
         if ((k) == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v0) : "v"(c1), "v"(c2)); \
         if ((k) == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v1) : "v"(c1), "v"(c2)); \
         if ((k) == 2) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v2) : "v"(c1), "v"(c2)); \
@@ -76,8 +95,9 @@ __global__ __launch_bounds__(512) void co(float* out, Stamp* st, int iters, cons
         }
     }
 #undef FILL
+#undef FILL_OLD
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    float r = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+    float r = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + pp[0] + pp[1];
     for (int i = 0; i < 16; ++i) r += A0[i] + A1[i] + A2[i] + A3[i];
     for (int i = 0; i < 4; ++i) r += B0[i] + B1[i] + B2[i] + B3[i];
     out[blockIdx.x * 512 + threadIdx.x] = r;
