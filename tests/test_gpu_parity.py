@@ -25,6 +25,16 @@ def _keep_workspaces(monkeypatch):
     monkeypatch.setenv("PROBAV_KEEP_WS", "1")
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+# Un-gated golden gradients, relative L2 per tensor: twice the worst value measured over every tensor and implementation on MI355X
+# (round 4: T=9 2.7e-4 on the MFMA paths and 3.1e-3 on the scalar path, T=13 6.5e-4, T=7 2.7e-3, T=19 2.4e-3).  What is left in these
+# numbers is ReLU gates at ~0 that an fp32 and an fp64 evaluation set differently, which is why they move with T and with the summation
+# order and not with the arithmetic: the gate-masked tests further down hold the same gradients to 1e-5.
+def _grad_l2_tol(T, impl):
+    if T == 9:
+        return 6.2e-3 if impl == 0 else 6e-4
+    return {13: 1.3e-3, 7: 5.4e-3, 19: 5e-3}[T]
+
+
 IMPLS = [0, 1, 2, 3, 4]   # 4 = H3 kernels (three products of scaled fp16 piece pairs), same tolerances; 3 = x6 kernels (fp32 products as six bf16-piece MFMA products), held to the SAME tolerances
 
 
@@ -357,22 +367,31 @@ def test_end_to_end_against_golden(dev, T, impl):
         # test_gradients_match_oracle_with_the_devices_relu_masks removes exactly that effect and then holds 1e-3 in the max norm).
         gref = np.load(os.path.join(GOLD, "wdsr_t9_b2_grads.npz"))["grad_flat"].astype(np.float64)
         gdev = m.flat.grad.detach().cpu().double().numpy()
+        worst = {"g": (0.0, None), "v": (0.0, None), "bias": (0.0, None)}
         for L_ in m.layers:
             for key, lo, hi in (("g", L_.g_off, L_.v_off), ("v", L_.v_off, L_.b_off), ("bias", L_.b_off, L_.b_off + L_.cout)):
-                tol = 2e-2 if key == "g" else 5e-3
+                tol = _grad_l2_tol(9, impl)
                 err = np.sqrt(((gdev[lo:hi] - gref[lo:hi]) ** 2).sum()) / (np.sqrt((gref[lo:hi] ** 2).sum()) + 1e-30)
+                if err > worst[key][0]:
+                    worst[key] = (err, L_.name)
                 assert err < tol, (L_.name, key, err)
+        print("impl %d: worst un-gated relative-L2 gradient error per tensor kind: %s" % (impl, worst))
+    worst_sub = {"g": 0.0, "v": 0.0}
     for k, (n, g) in enumerate(zip(names, grads)):
         ref_norm, ref_max = z["grad_norms"][k]
         # Metric: relative L2 error per tensor.  Element-wise maxima are not meaningful for these gradients: one
         # ReLU gate whose pre-activation is ~0 can flip between an fp32 and an fp64 evaluation and moves the
         # affected filter-gradient entries by ~1/sqrt(#voxels) (each entry is a sum over all voxels with heavy
         # cancellation); the gradient of a weight-norm gain `g` is the ill-conditioned dot product <dw, v>/||v||.
-        tol = 2e-2 if n.endswith("/g") else 5e-3
+        tol = _grad_l2_tol(T, impl)
         assert abs(np.sqrt((g ** 2).sum()) - ref_norm) < tol * ref_norm + 1e-12, n
         key = "grad/" + n
         if key in z.files:
-            assert np.sqrt(((g - z[key]) ** 2).sum()) < tol * ref_norm + 1e-12, n
+            e2 = np.sqrt(((g - z[key]) ** 2).sum()) / (ref_norm + 1e-30)
+            wk = "g" if n.endswith("/g") else "v"
+            worst_sub[wk] = max(worst_sub[wk], e2)
+            assert e2 < tol, (n, e2)
+    print("impl %d T %d: worst un-gated relative-L2 error over the stored gradient tensors: %s" % (impl, T, worst_sub))
     # inference mode (ping-pong workspace) gives the same prediction bit for bit
     with torch.no_grad():
         assert torch.equal(m(x, training=False), pred.detach())
