@@ -2210,10 +2210,22 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     const int tbeg = (int)((long)blockIdx.x * a.total_tiles / gridDim.x), tend = (int)((long)(blockIdx.x + 1) * a.total_tiles / gridDim.x);
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     XS_DECL;
-    __syncthreads();                                       // ring zeroed
     if (tbeg < tend) {
-        int n, ws0, Wts, ho; decode(tbeg, n, ws0, Wts, ho); stage_three(n, ho, ws0, Wts);
-        if constexpr (DYI) { float4 d0[NDY]; dy_load(n, ho, ws0, Wts, d0); dy_store(Wts, d0); }
+        // the first tile's three rows and its dY row are requested together and BEFORE the barrier that ends the zeroing of the ring (a thread reads
+        // only its own entries of the staging table): one memory latency in the prologue instead of four in a row
+        int n, ws0, Wts, ho; decode(tbeg, n, ws0, Wts, ho);
+        float f3[3][NST][2];
+        int mt3[3][NST];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) stage_load(n, ho + rr, ws0, Wts, f3[rr], mt3[rr]);
+        float4 d0[NDY];
+        if constexpr (DYI) dy_load(n, ho, ws0, Wts, d0);
+        __syncthreads();                                   // ring zeroed
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) stage_store(ho + rr, f3[rr], mt3[rr]);
+        if constexpr (DYI) dy_store(Wts, d0);
+    } else {
+        __syncthreads();
     }
     XS_ACC(1);
 #pragma unroll 1
@@ -2433,6 +2445,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
     }
     __syncthreads();
     if (ksel == 0) {
+        // The slab is written through a buffer descriptor: a GEMM row that is no (tap, input channel) pair gets an offset beyond the slab and the
+        // store is dropped -- no branch per store.  Registers 4 q .. 4 q + 3 of a lane are four consecutive rows R0 .. R0 + 3 with R0 a multiple of 4,
+        // and RT is one too: they belong to ONE tap, so the row -> (tap, channel) division is done once per four stores.
+        unsigned plo = (unsigned)(unsigned long)pp, phi = (unsigned)((unsigned long)pp >> 32);
+        plo = __builtin_amdgcn_readfirstlane(plo); phi = __builtin_amdgcn_readfirstlane(phi);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((unsigned long)phi << 32) | plo), 0, 27 * CIN * 32 * 4, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int T = tg + 4 * j;
@@ -2444,10 +2462,15 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
                 if constexpr (AR::SCALED) v[r] = ldexpf(v[r], kun);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int R = 32 * T + rowmap(r, h);                                   // row of the GEMM -> (tap, input channel)
-                const int tap = R / RT, ci = R - tap * RT;
-                if (tap < 27 && ci < CIN) pp[((long)tap * CIN + ci) * 32 + col] = v[r];
+            for (int q = 0; q < 4; ++q) {
+                const int R0 = 32 * T + 8 * q + 4 * h;                                 // = 32 T + rowmap(4 q, h): row of the GEMM -> (tap, input channel)
+                const int tap = R0 / RT, ci0 = R0 - tap * RT;
+                const int base = tap < 27 ? ((tap * CIN + ci0) * 32 + col) * 4 : (int)0x80000000;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = ci0 + i < CIN ? base + i * 128 : (int)0x80000000;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[4 * q + i]), rs, off, 0, 0);
+                }
             }
         }
         if (tg == 0 && !DYI) {

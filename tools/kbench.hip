@@ -93,6 +93,10 @@ int main(int argc, char** argv)
     const double gv = (double)nvox * 2e-9;
     for (g_pass = 0; g_pass < 3; ++g_pass) {          // pass 0 warms the clocks up and is not printed
     if (g_pass) printf("-- pass %d\n", g_pass);
+#ifdef KB_ONLY_WG
+    timeit("wgrad<25> normConv backward-filter", iters, gv * 21600, [&] { x6_conv_wgrad(gf, x25, y32, nullptr, dw, db, part, 2, am, 0); });
+    continue;
+#endif
 #ifdef KB_OLD
     timeit("pw_fwd  (expConv+ReLU+decConv)", iters, gv * 14592, [&] { x6_pw_forward(x32, w, w + X6_PW_FRAG_WORDS, b1, b2, y25, nvox, D, 2, pam, 0); });
     timeit("pw_bwd  (fused reverse)", iters, gv * 29184, [&] { x6_pw_backward(x32, x25, y32, w, w + X6_PW_FRAG_WORDS, w + 2 * X6_PW_FRAG_WORDS, b1, z32, dW1, dW2, db1, db2, slabs, nvox, D, 2, pam, 0); });
