@@ -30,10 +30,10 @@
 extern "C" {
 #endif
 
-#define PROBAV_ABI_VERSION 5
+#define PROBAV_ABI_VERSION 6
 
 /* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
- * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale=True)   (models/modelsTF.py:8-17) */
+ * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale)   (models/modelsTF.py:8-17) */
 typedef struct probav_net_cfg {
     int32_t scale;            /* 3 */
     int32_t num_filters;      /* 32 */
@@ -44,6 +44,8 @@ typedef struct probav_net_cfg {
     int32_t patch_size_lr;    /* 16 */
     int32_t max_shift;        /* 6 */
     float mean, std;          /* per-band constants (train.py:47-52) */
+    int32_t in_channels;      /* 1: isGrayScale=True (every shipped cfg); 3: isGrayScale=False -- the input is [N,H,W,T,3], mainConv1 and
+                                 residConv1 take three channels, the output stays one channel (models/modelsTF.py:19-20, :23-27) */
 } probav_net_cfg;
 
 typedef struct probav_engine probav_engine;

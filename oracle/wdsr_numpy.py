@@ -41,13 +41,13 @@ def reducer_plan(numImgLR):
     raise ValueError("reference defines reducers only for numImgLR in {7, 9, 13, 19}; got %r" % numImgLR)
 
 
-def layer_specs(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImgLR=9, scale=3):
+def layer_specs(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImgLR=9, scale=3, inChannels=1):
     """[(keras_name, v_shape)] in Keras topological order = checkpoint order
     `model/layer_with_weights-K` (modelInfo/ckpt_p16t9c85r12/NIR/ckpt-124.index).
     Per layer the variables are g [Cout], v (= kernel), bias [Cout]  (TFA WeightNormalization)."""
     f = numFilters
     dec = int(f * decayRate)                                   # models/modelsTF.py:182
-    specs = [("mainConv1", (3, 3, 3, 1, f))]                    # :58
+    specs = [("mainConv1", (3, 3, 3, inChannels, f))]           # :58; Input(..., 1) or (..., 3): :19-20
     for i in range(numResBlocks):                               # :59-60, :177-189
         specs.append(("expConv_%d" % i, (1, 1, 1, f, f * expRate)))
         specs.append(("decConv_%d" % i, (1, 1, 1, f * expRate, dec)))
@@ -55,7 +55,7 @@ def layer_specs(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImg
     for i, (k, _, _) in enumerate(reducer_plan(numImgLR)):      # :159-160, :80
         specs.append(("convReducer_%d" % (i + 1), (k, k, k, f, f)))
     s2 = scale * scale
-    specs.append(("residConv1", (3, 3, 1, s2)))                 # :45-50 (depth-interleaved with main path)
+    specs.append(("residConv1", (3, 3, inChannels, s2)))        # :45-50 (depth-interleaved with main path)
     specs.append(("upscaleConv1", (3, 3, 3, f, s2)))            # :162-163
     specs.append(("residConv2", (3, 3, s2, s2)))
     specs.append(("residConv3", (3, 3, s2, s2)))

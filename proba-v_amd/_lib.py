@@ -18,7 +18,7 @@ class NetCfg(ctypes.Structure):
     """struct probav_net_cfg (include/probav_hip.h)."""
     _fields_ = [("scale", c_int32), ("num_filters", c_int32), ("num_res_blocks", c_int32), ("exp_rate", c_int32),
                 ("dec_channels", c_int32), ("num_img_lr", c_int32), ("patch_size_lr", c_int32),
-                ("max_shift", c_int32), ("mean", c_float), ("std", c_float)]
+                ("max_shift", c_int32), ("mean", c_float), ("std", c_float), ("in_channels", c_int32)]
 
 
 # every symbol include/probav_hip.h declares: name -> (restype, argtypes)
@@ -96,7 +96,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if L.probav_abi_version() != 5:
+        if L.probav_abi_version() != 6:
             raise RuntimeError("libprobav_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -30,17 +30,18 @@ def reducer_plan(numImgLR):
     return plans[numImgLR]
 
 
-def layer_table(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImgLR=9, scale=3):
-    """Ordered list of Layer records and the total parameter count."""
+def layer_table(numFilters=32, numResBlocks=12, expRate=8, decayRate=0.8, numImgLR=9, scale=3, inChannels=1):
+    """Ordered list of Layer records and the total parameter count.  inChannels: 1 (isGrayScale=True) or 3 -- the two input-facing
+    layers, mainConv1 and residConv1, are the only ones that see it (models/modelsTF.py:19-20, :23-27)."""
     f, s2 = numFilters, scale * scale
     dec = int(numFilters * decayRate)                      # models/modelsTF.py:182
-    shapes = [("mainConv1", (3, 3, 3, 1, f))]
+    shapes = [("mainConv1", (3, 3, 3, inChannels, f))]
     for i in range(numResBlocks):
         shapes += [("expConv_%d" % i, (1, 1, 1, f, f * expRate)),
                    ("decConv_%d" % i, (1, 1, 1, f * expRate, dec)),
                    ("normConv_%d" % i, (3, 3, 3, dec, f))]
     shapes += [("convReducer_%d" % (i + 1), (k, k, k, f, f)) for i, (k, _, _) in enumerate(reducer_plan(numImgLR))]
-    shapes += [("residConv1", (3, 3, 1, s2)), ("upscaleConv1", (3, 3, 3, f, s2)),
+    shapes += [("residConv1", (3, 3, inChannels, s2)), ("upscaleConv1", (3, 3, 3, f, s2)),
                ("residConv2", (3, 3, s2, s2)), ("residConv3", (3, 3, s2, s2))]
     layers, off = [], 0
     for name, vs in shapes:

@@ -199,7 +199,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
         p.amax = take((size_t)p.amax_bwd);
     }
     p.wpack = take(e->wpack_count);
-    p.xn = take(V); p.mn = take((size_t)B * Hin * Hin);
+    p.xn = take(V * c.in_channels); p.mn = take((size_t)B * Hin * Hin * c.in_channels);
     if (training) {
         for (int i = 0; i <= R; ++i) p.act.push_back(take(V * F));
         for (int i = 0; i < R; ++i) p.dec.push_back(take(V * D));
@@ -252,7 +252,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
             const int nred = (int)e->iRed.size();
             need.push_back(wgrad_need(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0)));           // residConv3, 2, 1
             need.push_back(wgrad_need(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0)));
-            need.push_back(wgrad_need(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1)));
+            need.push_back(wgrad_need(e, make_geom(B, Hin, 1, c.in_channels, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1)));
             need.push_back(wgrad_need(e, make_geom(B, p.redH[nred - 1], p.redT[nred - 1], F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0)));   // upscaleConv1
             for (int k = nred - 1; k >= 0; --k)
                 need.push_back(wgrad_need(e, red_geom(e, B, (size_t)k, k ? p.redH[k - 1] : Hin, k ? p.redT[k - 1] : T, F)));
@@ -263,7 +263,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
                 if (!unfused) need.push_back(mfma_pw_backward_slab_floats(D));
                 else { need.push_back(wgrad_need(e, gd)); need.push_back(wgrad_need(e, ge)); }
             }
-            need.push_back(wgrad_need(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1)));               // mainConv1
+            need.push_back(wgrad_need(e, make_geom(B, Hin, T, c.in_channels, Hin, T, F, 3, 3, 3, 1, 1, 0, 1)));               // mainConv1
             size_t acc = 0;
             for (size_t q : need) { p.part_off.push_back(acc); acc += (q + 63) & ~(size_t)63; }
             p.partial = take(acc);
@@ -411,7 +411,7 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
         return PROBAV_EINVAL;
     }
     if (cfg->num_filters < 1 || cfg->num_res_blocks < 0 || cfg->exp_rate < 1 || cfg->dec_channels < 1 ||
-        cfg->patch_size_lr < 1 || !(cfg->std > 0.f)) {
+        cfg->patch_size_lr < 1 || !(cfg->std > 0.f) || (cfg->in_channels != 1 && cfg->in_channels != 3)) {
         set_error("probav_engine_create: bad hyper-parameter", hipSuccess);
         return PROBAV_EINVAL;
     }
@@ -419,7 +419,8 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
     e->cfg = *cfg;
     e->Hin = cfg->patch_size_lr + cfg->max_shift;
     const int F = cfg->num_filters, E = F * cfg->exp_rate, D = cfg->dec_channels, s2 = cfg->scale * cfg->scale;
-    e->iMain = add_layer(e, "mainConv1", 3, 3, 3, 1, F);
+    const int Cx = cfg->in_channels;                                   // 1, or 3 for isGrayScale=False (models/modelsTF.py:19-20)
+    e->iMain = add_layer(e, "mainConv1", 3, 3, 3, Cx, F);
     for (int i = 0; i < cfg->num_res_blocks; ++i) {
         e->iExp.push_back(add_layer(e, "expConv_" + std::to_string(i), 1, 1, 1, F, E));
         e->iDec.push_back(add_layer(e, "decConv_" + std::to_string(i), 1, 1, 1, E, D));
@@ -435,7 +436,7 @@ int probav_engine_create(const probav_net_cfg* cfg, probav_engine** out)
                       RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}, RS{3, 0, 0, 0, 0}};
     for (size_t k = 0; k < e->redSpec.size(); ++k)
         e->iRed.push_back(add_layer(e, "convReducer_" + std::to_string(k + 1), e->redSpec[k].k, e->redSpec[k].k, e->redSpec[k].k, F, F));
-    e->iResid1 = add_layer(e, "residConv1", 3, 3, 1, 1, s2);
+    e->iResid1 = add_layer(e, "residConv1", 3, 3, 1, Cx, s2);
     e->iUp = add_layer(e, "upscaleConv1", 3, 3, 3, F, s2);
     e->iResid2 = add_layer(e, "residConv2", 3, 3, 1, s2, s2);
     e->iResid3 = add_layer(e, "residConv3", 3, 3, 1, s2, s2);
@@ -691,17 +692,17 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
         { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
         if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
     }
-    CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.mean, c.std, s));
+    CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.in_channels, c.mean, c.std, s));
     // the low-frequency residual path (three small 2-D convolutions on the temporal mean) meets the main path only in tail_forward: it runs
     // on the side stream, in the gaps of the chip-filling launches
     SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s);
     {
         hipStream_t rs = reduce_fork(s);
-        CK(conv_fwd(e, make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), rs));
+        CK(conv_fwd(e, make_geom(B, Hin, 1, c.in_channels, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), rs));
         CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, Amax(), rs));
         CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, Amax(), rs));
     }
-    CK(conv_fwd(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
+    CK(conv_fwd(e, make_geom(B, Hin, T, c.in_channels, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
     for (int i = 0; i < R; ++i) {
         if (e->impl >= 1 && e->pw_mfma) {
             // fused expConv + ReLU + decConv: the 256-channel tensor never leaves the accumulators
@@ -809,7 +810,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
         CK(conv_wgrad(e, g2, W + p.r1, S + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), next_part(), Amax(), rs));
         CK(conv_fwd(e, bwd_data_geom(g2), S + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, S + p.dr1, Amax(), rs));
-        const ConvGeom g1 = make_geom(B, Hin, 1, 1, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
+        const ConvGeom g1 = make_geom(B, Hin, 1, c.in_channels, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
         CK(conv_wgrad(e, g1, W + p.mn, S + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), next_part(), Amax(), rs));
     }
     // upscale + reducers (models/modelsTF.py:152-164)
@@ -901,7 +902,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         acur = aoth;
     }
     // mainConv1 (input-facing: no backward-data)
-    CK(conv_wgrad(e, make_geom(B, Hin, T, 1, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
+    CK(conv_wgrad(e, make_geom(B, Hin, T, c.in_channels, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
                   dweff(e->iMain), dbias(e->iMain), next_part(), Amax(), s));
     CK(reduce_join(s));                                                       // every slab sum has landed in dweff / the bias gradients
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, S + p.dweff2, Winvn, grads, s)); }

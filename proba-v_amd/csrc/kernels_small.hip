@@ -311,24 +311,26 @@ int wn_backward(const WnLayer* d_layers, int nlayers, int cout_total, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// head: x [N,H,W,T,1] -> xn = (x - mean)/std  [N,H,W,T] ,  mn = (mean_T(x) - mean)/std  [N,H,W]
+// head: x [N,H,W,T,C] -> xn = (x - mean)/std  [N,H,W,T,C] ,  mn = (mean_T(x) - mean)/std  [N,H,W,C]     (C = 1, or 3 for isGrayScale=False)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, float* __restrict__ xn,
-                                                  float* __restrict__ mn, int nhw, int T, float mean, float stdv)
+                                                  float* __restrict__ mn, int nhw, int T, int C, float mean, float stdv)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nhw) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (pixel, channel)
+    if (i >= nhw * C) return;
+    const int px = i / C, c = i - px * C;
     float s = 0.f;
     for (int t = 0; t < T; ++t) {
-        const float q = x[(long)i * T + t];
+        const long o = ((long)px * T + t) * C + c;
+        const float q = x[o];
         s += q;
-        xn[(long)i * T + t] = (q - mean) / stdv;
+        xn[o] = (q - mean) / stdv;
     }
     mn[i] = (s / (float)T - mean) / stdv;
 }
-int head_forward(const float* x, float* xn, float* mn, int nhw, int T, float mean, float stdv, hipStream_t s)
+int head_forward(const float* x, float* xn, float* mn, int nhw, int T, int C, float mean, float stdv, hipStream_t s)
 {
-    hipLaunchKernelGGL(head_kernel, dim3((nhw + 255) / 256), dim3(256), 0, s, x, xn, mn, nhw, T, mean, stdv);
+    hipLaunchKernelGGL(head_kernel, dim3((nhw * C + 255) / 256), dim3(256), 0, s, x, xn, mn, nhw, T, C, mean, stdv);
     return check_launch("head");
 }
 

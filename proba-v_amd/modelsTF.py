@@ -24,15 +24,16 @@ class WDSRModel(torch.nn.Module):
     """What ``WDSRConv3D.build`` returns (the Keras ``Model`` of models/modelsTF.py:43)."""
 
     def __init__(self, name, band, mean, std, maxShift, scale, numFilters, numResBlocks, expRate, decayRate,
-                 numImgLR, patchSizeLR, seed=None):
+                 numImgLR, patchSizeLR, seed=None, inChannels=1):
         super().__init__()
         self.name, self.band = name, band
         self.mean, self.std, self.maxShift = float(mean), float(std), int(maxShift)
         self.scale, self.numFilters, self.numResBlocks = int(scale), int(numFilters), int(numResBlocks)
         self.expRate, self.decayRate = int(expRate), float(decayRate)
         self.numImgLR, self.patchSizeLR = int(numImgLR), int(patchSizeLR)
+        self.inChannels = int(inChannels)                  # 1, or 3 for isGrayScale=False (models/modelsTF.py:19-20)
         self.arch = dict(numFilters=self.numFilters, numResBlocks=self.numResBlocks, expRate=self.expRate,
-                         decayRate=self.decayRate, numImgLR=self.numImgLR, scale=self.scale)
+                         decayRate=self.decayRate, numImgLR=self.numImgLR, scale=self.scale, inChannels=self.inChannels)
         self.layers, total = layer_table(**self.arch)
         # state after the reference's first call: v ~ glorot_uniform, g = ||v||, bias = 0
         # (tensorflow_addons WeightNormalization with data_init=False; SURVEY.md A.3)
@@ -103,9 +104,9 @@ class WDSRModel(torch.nn.Module):
     def forward(self, x, training=False):
         x = _lib.require_device(x, "model input")
         hin = self.patchSizeLR + self.maxShift
-        if x.dim() != 5 or tuple(x.shape[1:]) != (hin, hin, self.numImgLR, 1):
-            raise ValueError("model input must be [N, %d, %d, %d, 1] (models/modelsTF.py:19), got %s"
-                             % (hin, hin, self.numImgLR, tuple(x.shape)))
+        if x.dim() != 5 or tuple(x.shape[1:]) != (hin, hin, self.numImgLR, self.inChannels):
+            raise ValueError("model input must be [N, %d, %d, %d, %d] (models/modelsTF.py:19-20), got %s"
+                             % (hin, hin, self.numImgLR, self.inChannels, tuple(x.shape)))
         if self.flat.device != x.device:
             raise RuntimeError("model parameters are on %s but the input is on %s" % (self.flat.device, x.device))
         x = x.contiguous().float()
@@ -129,7 +130,7 @@ class WDSRModel(torch.nn.Module):
             L = _lib.lib()
             cfg = _lib.NetCfg(self.scale, self.numFilters, self.numResBlocks, self.expRate,
                               int(self.numFilters * self.decayRate), self.numImgLR, self.patchSizeLR,
-                              self.maxShift, self.mean, self.std)
+                              self.maxShift, self.mean, self.std, self.inChannels)
             h = c_void_p()
             _lib.check(L.probav_engine_create(byref(cfg), byref(h)), "probav_engine_create")
             if L.probav_param_count(h) != self.flat.numel():
@@ -225,15 +226,16 @@ class WDSRConv3D:
 
     def build(self, scale, numFilters, kernelSize, numResBlocks, expRate, decayRate, numImgLR, patchSizeLR,
               isGrayScale, seed=None):
-        """models/modelsTF.py:15-43.  kernelSize must be (3, 3, 3) and isGrayScale True: the only
-        configuration the reference's cfg files, checkpoints and train.py/test.py use."""
+        """models/modelsTF.py:15-43.  isGrayScale=False builds the reference's other input branch (:19-20): three input channels, seen by
+        mainConv1 and residConv1 only; the output stays one channel.  kernelSize must be (3, 3, 3): it is the only value for which the
+        reference's own graph closes -- its valid reducers take (k - 1) frames and pixels each, so with k = 5 the temporal axis of the
+        9-frame graph runs 9 -> 5 -> 1 -> negative and Keras refuses to build it, and the residual path (scale valid k x k convolutions
+        on a patch of P + maxShift, :45-53) only lands on P x P for k = 3."""
         ks = tuple(kernelSize) if not isinstance(kernelSize, int) else (kernelSize,) * 3
         if ks != (3, 3, 3):
-            raise ValueError("kernelSize %r: the HIP engine implements the reference's 3x3x3 configuration" % (ks,))
-        if not isGrayScale:
-            raise NotImplementedError("isGrayScale=False (3-channel input) is outside the PROBA-V hot path")
+            raise ValueError("kernelSize %r: the reference's graph (models/modelsTF.py:45-53, :152-164) only closes for 3x3x3" % (ks,))
         return WDSRModel(self.name, self.band, self.mean, self.std, self.maxShift, scale, numFilters,
-                         numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, seed=seed)
+                         numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, seed=seed, inChannels=1 if isGrayScale else 3)
 
     def normalize(self, x):
         return (x - self.mean) / self.std

@@ -54,11 +54,11 @@ def unflatten_params(flat, **arch):
 
 
 def synth_batch(batch, seed=1234, numImgLR=9, patchSizeLR=16, maxShift=6, scale=3,
-                mean=NIR_MEAN, std=NIR_STD):
-    """(x [B,P+s,P+s,T,1] f32, hr [B,3P,3P,1] f32, mask [B,3P,3P,1] bool)."""
+                mean=NIR_MEAN, std=NIR_STD, inChannels=1):
+    """(x [B,P+s,P+s,T,C] f32, hr [B,3P,3P,1] f32, mask [B,3P,3P,1] bool)."""
     rng = np.random.default_rng(seed)
     hin, hout = patchSizeLR + maxShift, scale * patchSizeLR
-    x = np.clip(rng.normal(mean, std, size=(batch, hin, hin, numImgLR, 1)), 0, 16383).astype(np.float32)
+    x = np.clip(rng.normal(mean, std, size=(batch, hin, hin, numImgLR, inChannels)), 0, 16383).astype(np.float32)
     hr = np.clip(rng.normal(mean, std, size=(batch, hout, hout, 1)), 0, 16383).astype(np.float32)
     mask = rng.random(size=(batch, hout, hout, 1)) < 0.9
     for b in range(batch):                                   # keep >= 85 % clear pixels per sample

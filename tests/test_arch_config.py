@@ -31,6 +31,26 @@ def test_variable_inventory_matches_reference_checkpoint():
     assert off == total
 
 
+def test_three_channel_branch_and_kernel_size():
+    """isGrayScale=False touches the two input-facing layers only (models/modelsTF.py:19-20); kernelSize != 3 is refused like the reference's
+    own graph refuses it (its valid reducers and residual path only close for 3: the docstring of WDSRConv3D.build)."""
+    from probav_amd.modelsTF import WDSRConv3D
+    layers, total = layer_table(inChannels=3)
+    assert total == 535267 + 27 * 2 * 32 + 9 * 2 * 9
+    assert layers[0].vshape == (3, 3, 3, 3, 32) and layers[40].vshape == (3, 3, 3, 9) and layers[1].vshape == (1, 1, 1, 32, 256)
+    b = WDSRConv3D("t", "NIR", 8075.2045, 3160.7272, 6)
+    m = b.build(3, 32, (3, 3, 3), 12, 8, 0.8, 9, 16, False, seed=0)
+    assert m.inChannels == 3 and m.flat.numel() == total and len(m.trainable_variables) == 132
+    assert b.build(3, 32, 3, 12, 8, 0.8, 9, 16, True, seed=0).inChannels == 1
+    with pytest.raises(ValueError):
+        b.build(3, 32, (5, 5, 5), 12, 8, 0.8, 9, 16, True)
+    # why: the reference's 9-frame graph with k = 5 -- depth 9 -> 5 -> 1 -> negative at the third valid reducer (models/modelsTF.py:152-164)
+    t = 9
+    for _ in range(3):
+        t -= 5 - 1
+    assert t < 1
+
+
 def test_reducer_plans():
     a, b = (3, 1, 0), (3, 0, 0)                              # (kernel, mirrored H/W pad, mirrored depth pad)
     assert reducer_plan(9) == (a, b, b)                      # models/modelsTF.py:152-164

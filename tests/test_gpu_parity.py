@@ -179,9 +179,9 @@ def test_conv3d_wgrad_matches_autograd(dev, case, impl):
     assert torch.equal(dw, dw2)
 
 
-def _model(dev, T=9, params=None, seed=0):
+def _model(dev, T=9, params=None, seed=0, gray=True):
     from probav_amd.modelsTF import WDSRConv3D
-    m = WDSRConv3D("t", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, True, seed=seed)
+    m = WDSRConv3D("t", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, 16, gray, seed=seed)
     if params is not None:
         m.load_variables(params)
     return m.to(dev)
@@ -663,13 +663,51 @@ def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl, T, B):
     """T = 9, B = 2: the golden inputs.  T = 13 (reducer v3, rows cut into column ranges), T = 7, and B = 5 (more than two per-sample
     scale slots behind `amax_over_samples`, a different strip partition): seeded synthetic inputs.  T = 19: the only network with a
     5x5x5 kernel and a mirror pad along T (models/modelsTF.py:76-121), on the generic kernels."""
+    _gate_masked_parity(dev, impl, T, B, 1)
+
+
+@pytest.mark.parametrize("impl", [3, 4])
+def test_three_channel_input_branch_matches_the_oracle(dev, impl):
+    """isGrayScale=False (models/modelsTF.py:19-20): input [N, 22, 22, 9, 3], mainConv1 and residConv1 on three channels, the temporal mean per
+    channel (:23), a one-channel output.  Forward against the fp64 numpy oracle, loss and all 132 gradients against the fp64 autograd oracle
+    at the device's gates (the split-operand families expose their hidden tiles: impl 3 and the default, 4)."""
+    _gate_masked_parity(dev, impl, 9, 2, 3)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+def test_three_channel_input_branch_on_the_fp32_families(dev, impl):
+    """The same branch on the generic kernels (impl 0) and the fp32-MFMA families (1, 2), which do not expose their gates: forward and loss
+    to the same bars, gradients in relative L2 per tensor against the un-gated fp64 oracle (the tolerance of the one-channel golden test)."""
     from probav_amd.loss import Losses
-    if (T, B) == (9, 2):
+    x, hr, mask = synth.synth_batch(2, seed=392, numImgLR=9, inChannels=3)
+    params = synth.synth_params(seed=101, perturb=True, inChannels=3)
+    m = _model(dev, 9, params, gray=False)
+    m.set_impl(impl)
+    pred = m(torch.as_tensor(x).to(dev), training=True)
+    loss = Losses(targetShape=(48, 48, 1)).shiftCompensatedL1Loss(torch.as_tensor(hr).to(dev), torch.as_tensor(mask).to(dev), pred)
+    loss.backward()
+    ref = on.wdsr_forward(x, params, synth.NIR_MEAN, synth.NIR_STD)
+    e = np.abs(pred.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max()
+    assert e < 2e-5, "output rel err %.3e (bar 1e-3)" % e
+    _, loss_o, grads_o = ot.train_step_grads(torch.tensor(x, dtype=torch.float64), torch.tensor(hr), torch.tensor(mask), ot.to_torch_params(params),
+                                             synth.NIR_MEAN, synth.NIR_STD, numImgLR=9)
+    assert abs(float(loss.detach()) - float(loss_o)) < 1e-5 * float(loss_o)
+    gdev = m.flat.grad.detach().cpu().double().numpy()
+    for L_ in m.layers:
+        for key, lo_, hi_ in (("g", L_.g_off, L_.v_off), ("v", L_.v_off, L_.b_off), ("bias", L_.b_off, L_.b_off + L_.cout)):
+            r = grads_o[L_.name][key].numpy().reshape(-1)
+            err = np.sqrt(((gdev[lo_:hi_] - r) ** 2).sum()) / (np.sqrt((r ** 2).sum()) + 1e-30)
+            assert err < _grad_l2_tol(9, 0), (L_.name, key, err)
+
+
+def _gate_masked_parity(dev, impl, T, B, C):
+    from probav_amd.loss import Losses
+    if (T, B, C) == (9, 2, 1):
         z = np.load(os.path.join(GOLD, "wdsr_t9_b2.npz"))
     else:
-        z = dict(zip(("x", "hr", "mask"), synth.synth_batch(B, seed=300 + 10 * T + B, numImgLR=T)))
-    params = synth.synth_params(seed=101, perturb=True, numImgLR=T)
-    m = _model(dev, T, params)
+        z = dict(zip(("x", "hr", "mask"), synth.synth_batch(B, seed=300 + 10 * T + B, numImgLR=T, inChannels=C)))
+    params = synth.synth_params(seed=101, perturb=True, numImgLR=T, inChannels=C)
+    m = _model(dev, T, params, gray=(C == 1))
     m.set_impl(impl)
     lo = Losses(targetShape=(48, 48, 1))
     x, hr, mask = (torch.as_tensor(z[k]).to(dev) for k in ("x", "hr", "mask"))
@@ -688,6 +726,11 @@ def test_gradients_match_oracle_with_the_devices_relu_masks(dev, impl, T, B):
           % (impl, nflip, ngate, worst_margin))
     assert worst_margin < 1e-4, "a gate that differs is NOT a ~0 pre-activation: the forward itself is off"
     assert abs(float(loss) - float(loss_o)) < 1e-5 * float(loss_o)
+    if C != 1:       # (the one-channel forward is held against the committed fixtures in test_end_to_end_against_golden)
+        assert tuple(pred.shape) == (B, 48, 48, 1)
+        ref = on.wdsr_forward(z["x"], params, synth.NIR_MEAN, synth.NIR_STD, numImgLR=T)
+        e = np.abs(pred.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max()
+        assert e < 2e-5, "output rel err %.3e (bar 1e-3)" % e
     gdev = m.flat.grad.detach().cpu().double().numpy()
     worst = (0.0, None)
     for L_ in m.layers:

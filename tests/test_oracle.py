@@ -29,6 +29,22 @@ def test_two_restatements_agree_fp64():
     np.testing.assert_allclose(on.shift_cpsnr(hr, m, y), ot.shift_cpsnr(torch.tensor(hr), torch.tensor(m), yt).numpy(), rtol=1e-12)
 
 
+def test_two_restatements_agree_on_the_three_channel_branch():
+    """isGrayScale=False (models/modelsTF.py:19-20): [N, 22, 22, 9, 3] in, the temporal mean taken per channel (:23), mainConv1 and residConv1
+    on three channels, one channel out."""
+    assert dict(on.layer_specs(inChannels=3))["mainConv1"] == (3, 3, 3, 3, 32) and dict(on.layer_specs(inChannels=3))["residConv1"] == (3, 3, 3, 9)
+    p = synth.synth_params(seed=3, perturb=True, inChannels=3)
+    x, hr, m = synth.synth_batch(1, seed=4, inChannels=3)
+    assert x.shape == (1, 22, 22, 9, 3)
+    y = on.wdsr_forward(x, p, synth.NIR_MEAN, synth.NIR_STD)
+    yt = ot.wdsr_forward(torch.tensor(x, dtype=torch.float64), ot.to_torch_params(p, requires_grad=False), synth.NIR_MEAN, synth.NIR_STD)
+    assert y.shape == (1, 48, 48, 1)
+    assert np.abs(y - yt.numpy()).max() <= 1e-9 * np.abs(y).max()
+    # the three channels are really used: another value in channel 2 of one frame moves the output
+    x2 = x.copy(); x2[0, 11, 11, 4, 2] += 500.0
+    assert np.abs(on.wdsr_forward(x2, p, synth.NIR_MEAN, synth.NIR_STD) - y).max() > 1e-3
+
+
 def test_loss_gradient_matches_autograd_and_finite_differences():
     rng = np.random.default_rng(0)
     _, hr, m = synth.synth_batch(3, seed=5)
