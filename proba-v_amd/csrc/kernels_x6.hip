@@ -239,6 +239,23 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
     float* sBw = reinterpret_cast<float*>(sE2 + 32);             // [8 waves][256]: the expand biases at THIS WAVE's current sample's scale (2^(eh - 16)); private to the wave
     const int tid = threadIdx.x, lane = tid & 63, m16 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the wave's run of tiles, and its first tile's rows requested before anything else: they are in flight while the weight images are copied
+    const int tps = (vps + 31) >> 5;
+    const long ntiles = (nvox / vps) * tps;
+    const long gw = (long)blockIdx.x * WAVES + wave, nw = (long)gridDim.x * WAVES;
+    const long tb = ntiles * gw / nw, te = ntiles * (gw + 1) / nw;
+    int n = (int)(tb / tps), j = (int)(tb - (long)n * tps);
+    float4 nx[2][2];                                             // [u][two float4]: cin 8 kq .. 8 kq + 7 of voxel 16 u + m16
+    auto load_x = [&](int nn, int jj) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int vl = 32 * jj + 16 * u + m16;
+            const long v = (long)nn * vps + (vl < vps ? vl : vps - 1);
+            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 8 * kq);
+            nx[u][0] = xp[0]; nx[u][1] = xp[1];
+        }
+    };
+    if (tb < te) load_x(n, j);
     for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
     if (tid < 256) sB1[tid] = b1[tid];
     if (tid < 32) { sB2[tid] = tid < D ? b2[tid] : 0.f; sE2[tid] = tid < D ? h3_exp_w(am.w2c[tid]) : 0; }
@@ -262,24 +279,8 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) sBw[wave * 256 + lane + 64 * q] = sB1[lane + 64 * q] * sb2;
     };
-    const int tps = (vps + 31) >> 5;
-    const long ntiles = (nvox / vps) * tps;
-    const long gw = (long)blockIdx.x * WAVES + wave, nw = (long)gridDim.x * WAVES;
-    const long tb = ntiles * gw / nw, te = ntiles * (gw + 1) / nw;
-    int n = (int)(tb / tps), j = (int)(tb - (long)n * tps);
     float omax = 0.f;
     if (tb < te) sample_scales(n);
-    float4 nx[2][2];                                             // [u][two float4]: cin 8 kq .. 8 kq + 7 of voxel 16 u + m16
-    auto load_x = [&](int nn, int jj) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int vl = 32 * jj + 16 * u + m16;
-            const long v = (long)nn * vps + (vl < vps ? vl : vps - 1);
-            const float4* xp = reinterpret_cast<const float4*>(x + v * 32 + 8 * kq);
-            nx[u][0] = xp[0]; nx[u][1] = xp[1];
-        }
-    };
-    if (tb < te) load_x(n, j);
     // lane parts of the operand addresses inside the weight images (bytes)
     const int a1l = ((kq >> 1) * NP * 64 + m16 + 32 * (kq & 1)) * 16;                 // + s * 256 + piece * 1024 + chunk * (2 NP 1024)
     const int a2l = (m16 + 32 * (kq & 1)) * 16 + 8 * (kq >> 1);                      // + o * 256 + piece * 1024 + kb * (NP 1024) + chunk * (2 NP 1024)
