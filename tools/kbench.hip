@@ -93,6 +93,11 @@ int main(int argc, char** argv)
     const double gv = (double)nvox * 2e-9;
     for (g_pass = 0; g_pass < 3; ++g_pass) {          // pass 0 warms the clocks up and is not printed
     if (g_pass) printf("-- pass %d\n", g_pass);
+#ifdef KB_ONLY_STRIP
+    timeit("pstrip<25> normConv forward + skip", iters, gv * 21600, [&] { x6_conv_strip_forward(gf, x25, nullptr, wf, bias, y32, z32, 2, am, 0); });
+    timeit("pstrip<32> normConv backward-data", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });
+    continue;
+#endif
 #ifdef KB_ONLY_WG
     timeit("wgrad<25> normConv backward-filter", iters, gv * 21600, [&] { x6_conv_wgrad(gf, x25, y32, nullptr, dw, db, part, 2, am, 0); });
     continue;
