@@ -93,6 +93,36 @@ int main(int argc, char** argv)
     const double gv = (double)nvox * 2e-9;
     for (g_pass = 0; g_pass < 3; ++g_pass) {          // pass 0 warms the clocks up and is not printed
     if (g_pass) printf("-- pass %d\n", g_pass);
+#ifdef KB_REDUCERS
+    {   // the reducer stages of the 9-frame network (32 -> 32 channels): forward, backward-data (with and without the ReLU mask), backward-filter
+        static float* wfr = nullptr; static float* partr = nullptr; static float *x32, *y32, *z32;          // (shadow the benchmark's buffers: the padded 24 x 24 x 9 tensor is larger)
+        if (!wfr) {
+            hipMalloc(&wfr, X6_CONV_FRAG_WORDS * 4); fill_frag(wfr, X6_CONV_FRAG_WORDS);
+            const size_t nb = (size_t)B * 24 * 24 * 9 * 32;
+            hipMalloc(&x32, nb * 4); hipMalloc(&y32, nb * 4); hipMalloc(&z32, nb * 4);
+            std::vector<float> hb(nb);
+            for (size_t i = 0; i < nb; ++i) hb[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
+            hipMemcpy(x32, hb.data(), nb * 4, hipMemcpyHostToDevice); hipMemcpy(y32, hb.data(), nb * 4, hipMemcpyHostToDevice); hipMemcpy(z32, hb.data(), nb * 4, hipMemcpyHostToDevice);
+        }
+        const int hs[4] = {24, 22, 20, 18}, ts[4] = {9, 7, 5, 3};           // extents: padded input of reducer 1, then the outputs of reducers 1..3
+        for (int k = 0; k < 3; ++k) {
+            ConvGeom f{B, hs[k], hs[k], ts[k], 32, hs[k + 1], hs[k + 1], ts[k + 1], 32, 3, 3, 3, 0, 0, 0, 0, 1, 0};             // valid, ReLU
+            ConvGeom bd{B, hs[k + 1], hs[k + 1], ts[k + 1], 32, hs[k], hs[k], ts[k], 32, 3, 3, 3, 2, 2, 2, 0, 0, 0};           // its backward-data ("full")
+            if (!partr) hipMalloc(&partr, x6_wgrad_partial_floats(ConvGeom{B, 24, 24, 9, 32, 22, 22, 7, 32, 3, 3, 3, 0, 0, 0, 0, 1, 0}) * 4);
+            char nm[96];
+            const double gfl = (double)B * hs[k + 1] * hs[k + 1] * ts[k + 1] * 27 * 32 * 32 * 2e-9;
+            snprintf(nm, sizeof(nm), "reducer %d forward  (%dx%dx%d out)", k + 1, hs[k + 1], hs[k + 1], ts[k + 1]);
+            timeit(nm, iters, gfl, [&] { x6_conv_strip_forward(f, x32, nullptr, wfr, bias, nullptr, y32, 2, am, 0); });
+            snprintf(nm, sizeof(nm), "reducer %d backward-data, gated", k + 1);
+            timeit(nm, iters, gfl, [&] { x6_conv_strip_forward(bd, y32, z32, wfr, nullptr, nullptr, x32, 2, am, 0); });
+            snprintf(nm, sizeof(nm), "reducer %d backward-data, no gate", k + 1);
+            timeit(nm, iters, gfl, [&] { x6_conv_strip_forward(bd, y32, nullptr, wfr, nullptr, nullptr, x32, 2, am, 0); });
+            snprintf(nm, sizeof(nm), "reducer %d backward-filter, gated", k + 1);
+            timeit(nm, iters, gfl, [&] { x6_conv_wgrad(f, x32, y32, z32, dw, db, partr, 2, am, 0); });
+        }
+    }
+    continue;
+#endif
 #ifdef KB_ONLY_STRIP
     timeit("pstrip<25> normConv forward + skip", iters, gv * 21600, [&] { x6_conv_strip_forward(gf, x25, nullptr, wf, bias, y32, z32, 2, am, 0); });
     timeit("pstrip<32> normConv backward-data", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });

@@ -62,5 +62,20 @@ def main():
         print("    %3d x %7.1f us  %-40s -> %s" % (n, t / 1e3, a, b))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 3 and sys.argv[3] == "dump"):
     main()
+
+
+def dump(path, si=None):
+    """every kernel of one step in start order: queue, start (us from the step's first launch), duration (us), name, grid"""
+    rows = list(csv.DictReader(open(path)))
+    ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["LDS_Block_Size"])) for r in rows), key=lambda k: k[0])
+    heads = [i for i, k in enumerate(ks) if k[3].startswith("head_kernel")]
+    si = len(heads) - 2 if si is None else si
+    step = ks[heads[si]:heads[si + 1]]
+    for s, e, q, n, g, lds in step:
+        print("q%d %9.1f %8.1f  %-46s grid %5d lds %6d" % (q, (s - step[0][0]) / 1e3, (e - s) / 1e3, n, g, lds))
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "dump":
+    dump(sys.argv[1], int(sys.argv[2]) if sys.argv[2] != "-" else None)
