@@ -1592,6 +1592,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
                                                          const uint4* __restrict__ wfrag, const float* __restrict__ bias,
                                                          const float* __restrict__ skip, float* __restrict__ y, Amax am)
 {
+    XS_ENTRY;
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
     using AR = H3;
     constexpr int NP = 2, REC = 128, PF = 3;

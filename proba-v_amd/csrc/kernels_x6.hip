@@ -227,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
                                                             const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ dec,
                                                             long nvox, int vps, int D, PwAmax am)
 {
+    XS_ENTRY;
     using AR = H3;
     constexpr int NP = 2, WAVES = 8;
     typedef float f32x4k __attribute__((ext_vector_type(4)));
@@ -242,8 +243,13 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
     // the wave's run of tiles, and its first tile's rows requested before anything else: they are in flight while the weight images are copied
     const int tps = (vps + 31) >> 5;
     const long ntiles = (nvox / vps) * tps;
-    const long gw = (long)blockIdx.x * WAVES + wave, nw = (long)gridDim.x * WAVES;
-    const long tb = ntiles * gw / nw, te = ntiles * (gw + 1) / nw;
+    // Partition: the workgroup's share first, then its four SIMD pairs (waves w and w + 4 sit on one SIMD and share its pipes: what must be even is
+    // the PAIR's count), then the pair's two waves -- a SIMD then carries 8 or 9 tiles of this workgroup instead of 8 to 10 (17 536 tiles / 4 096 waves = 4.28:
+    // dealt per wave, a SIMD's four waves of two workgroups held 16 to 19, and the launch waited for the 19s)
+    const long wb = ntiles * blockIdx.x / gridDim.x, we = ntiles * (blockIdx.x + 1) / gridDim.x;
+    const int pr = wave & 3, hf = wave >> 2;
+    const long pb = wb + (we - wb) * pr / 4, pe = wb + (we - wb) * (pr + 1) / 4;
+    const long tb = hf ? pb + (pe - pb + 1) / 2 : pb, te = hf ? pe : pb + (pe - pb + 1) / 2;
     int n = (int)(tb / tps), j = (int)(tb - (long)n * tps);
     float4 nx[2][2];                                             // [u][two float4]: cin 8 kq .. 8 kq + 7 of voxel 16 u + m16
     auto load_x = [&](int nn, int jj) {
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
     const int a2l = (m16 + 32 * (kq & 1)) * 16 + 8 * (kq >> 1);                      // + o * 256 + piece * 1024 + kb * (NP 1024) + chunk * (2 NP 1024)
     const unsigned char* w1b = reinterpret_cast<const unsigned char*>(sW1) + a1l;
     const unsigned char* w2b = reinterpret_cast<const unsigned char*>(sW2) + a2l;
+    XS_DECL;
     for (long tile = tb; tile < te; ++tile) {
         Frag xb[2][NP];
 #pragma unroll
@@ -386,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
         }
     }
     if (am.y && j != 0 && tb < te) amax_commit(omax, am.y + n);
+    XS_OUT;
 }
 
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
@@ -1428,6 +1436,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
     const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
     const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int vps, int D, PwAmax am)
 {
+    XS_ENTRY;
     using AR = H3;
     constexpr int NP = 2;
     constexpr int PB_TILE = NP * PB_IMG;                          // one staged tensor tile: NP piece images
@@ -2044,6 +2053,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_x6_kernel(WgArgs a, const 
                                                                const float* __restrict__ gate, float* __restrict__ partial,
                                                                float* __restrict__ partial_b, Amax am)
 {
+    XS_ENTRY;
     constexpr int NPC = AR::NP;                    // pieces per value
     constexpr int CB = CIN <= 28 ? 56 : 64;        // bytes of one piece of one voxel (channels padded to 28 / 32)
     constexpr int VS = NPC * CB;                   // bytes per voxel

@@ -22,16 +22,23 @@ namespace probav {
 #define XS2(k) do { } while (0)
 #endif
 #ifdef PROBAV_STAMP
+#define XS_ENTRY do { } while (0)
 #define XS_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[8] = {xs_t, 0, 0, 0, 0, 0, 0, 0}
 #define XS_ACC(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); xs_acc[k] += t_ - xs_t; xs_t = t_; } while (0)
 #define XS_OUT do { xs_acc[7] = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 8; ++k_) g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k_] = xs_acc[k_]; } while (0)
 #elif defined(PROBAV_STAMP_CLOCK)
 // clock-only build (tools/kbench.hip -DPROBAV_STAMP_CLOCK): two stamps per wave, none inside the loops; in-kernel clock = cycles / (100 MHz ticks) * 0.1 GHz
+// XS_ENTRY (first statement of a kernel): the wave's arrival, so that a launch can be taken apart -- dispatch ramp, prologue (entry -> XS_DECL), loop, tail.
+// Slots per wave: [0] cycles and [1] 100-MHz ticks between XS_DECL and XS_OUT, [2] entry, [3] XS_DECL, [4] XS_OUT (absolute 100-MHz ticks), [5] XCC_ID << 32 | HW_ID (where the wave ran)
+static constexpr unsigned long long xs_re = 0;            // (kernels without an XS_ENTRY: the local one shadows this)
+#define XS_ENTRY const unsigned long long xs_re = __builtin_amdgcn_s_memrealtime()
 #define XS_DECL const unsigned long long xs_c0 = __builtin_amdgcn_s_memtime(), xs_r0 = __builtin_amdgcn_s_memrealtime()
 #define XS_ACC(k) do { } while (0)
 #define XS_OUT do { const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime(); \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8] = c1_ - xs_c0; g_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 1] = r1_ - xs_r0; } } while (0)
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { unsigned long long* o_ = g_stamps + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8; o_[0] = c1_ - xs_c0; o_[1] = r1_ - xs_r0; o_[2] = xs_re; o_[3] = xs_r0; o_[4] = r1_; \
+        unsigned hw_, xc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xc_)); o_[5] = ((unsigned long long)(xc_ & 15) << 32) | hw_; } } while (0)
 #else
+#define XS_ENTRY do { } while (0)
 #define XS_DECL do { } while (0)
 #define XS_ACC(k) do { } while (0)
 #define XS_OUT do { } while (0)

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <map>
 using namespace probav;
 
 static int g_pass = 0;
@@ -34,6 +35,29 @@ template <class F> static float timeit(const char* name, int iters, double gflop
         for (size_t w = 0; w < 8192; ++w) if (st[w * 8 + 1] > 0) { clk.push_back((double)st[w * 8] / (double)st[w * 8 + 1] * 0.1); cyc.push_back((double)st[w * 8]); }
         if (!clk.empty()) { std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
             printf("   clock %.2f GHz (p10 %.2f, p90 %.2f), %.0f cycles between the stamps", clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10], cyc[cyc.size() / 2]); }
+        {   // anatomy of the LAST launch (100-MHz ticks -> us): arrival of the waves, prologue (entry -> first stamp), loop, how long the last wave runs beyond the median one
+            std::vector<double> en, pr, lp, ex;
+            double e0 = 1e30, x1 = 0;
+            for (size_t w = 0; w < 8192; ++w) if (st[w * 8 + 1] > 0 && st[w * 8 + 2] > 0) { en.push_back((double)st[w * 8 + 2]); pr.push_back((double)(st[w * 8 + 3] - st[w * 8 + 2])); lp.push_back((double)st[w * 8 + 1]); ex.push_back((double)st[w * 8 + 4]); e0 = std::min(e0, (double)st[w * 8 + 2]); x1 = std::max(x1, (double)st[w * 8 + 4]); }
+            if (!en.empty()) {
+                auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+                auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
+                printf("\n      launch anatomy: first entry -> last exit %.1f us | entry: median +%.1f, last +%.1f | prologue median %.1f (max %.1f) | loop median %.1f (max %.1f) | exit: median %.1f before the last",
+                       (x1 - e0) * 0.01, (med(en) - e0) * 0.01, (mx(en) - e0) * 0.01, med(pr) * 0.01, mx(pr) * 0.01, med(lp) * 0.01, mx(lp) * 0.01, (x1 - med(ex)) * 0.01);
+                // where the time is really lost: a SIMD is idle from the exit of ITS last wave to the exit of the launch's last wave (HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID)
+                std::map<unsigned long long, double> simd_last, cu_last, xcd_last;
+                for (size_t w = 0; w < 8192; ++w) if (st[w * 8 + 1] > 0 && st[w * 8 + 2] > 0) {
+                    const unsigned long long id = st[w * 8 + 5], ks = id & ~0xfull & 0xf0000ffffull, kc = ks & ~0x30ull, kx = id >> 32;
+                    const double x = (double)st[w * 8 + 4];
+                    simd_last[ks] = std::max(simd_last[ks], x); cu_last[kc] = std::max(cu_last[kc], x); xcd_last[kx] = std::max(xcd_last[kx], x);
+                }
+                double idle = 0; for (auto& kv : simd_last) idle += x1 - kv.second;
+                double idc = 0; for (auto& kv : cu_last) idc += x1 - kv.second;
+                printf("\n      %zu SIMDs on %zu CUs seen: a SIMD idles %.1f us on average behind its last wave (a CU %.1f us); last exit per XCD, us before the launch's:", simd_last.size(), cu_last.size(),
+                       idle / simd_last.size() * 0.01, idc / cu_last.size() * 0.01);
+                for (auto& kv : xcd_last) printf(" %.1f", (x1 - kv.second) * 0.01);
+            }
+        }
         std::fill(st.begin(), st.end(), 0ull);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), st.data(), st.size() * 8);
     }
