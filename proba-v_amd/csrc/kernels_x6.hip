@@ -262,9 +262,19 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
         }
     };
     if (tb < te) load_x(n, j);
-    for (int i = tid; i < 8 * 2 * NP * 64; i += 64 * WAVES) { sW1[i] = w1frag[i]; sW2[i] = w2frag[i]; }
-    if (tid < 256) sB1[tid] = b1[tid];
-    if (tid < 32) { sB2[tid] = tid < D ? b2[tid] : 0.f; sE2[tid] = tid < D ? h3_exp_w(am.w2c[tid]) : 0; }
+    {   // the two weight images: all eight 16-byte requests of a thread first, then the stores -- one round trip, not four in a row
+        constexpr int NI = 8 * 2 * NP * 64 / (64 * WAVES);       // = 4
+        uint4 q1[NI], q2[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) { q1[k] = w1frag[tid + 64 * WAVES * k]; q2[k] = w2frag[tid + 64 * WAVES * k]; }
+        const float bq = tid < 256 ? b1[tid] : 0.f;
+        float b2q = 0.f; int e2q = 0;
+        if (tid < 32) { b2q = tid < D ? b2[tid] : 0.f; e2q = tid < D ? h3_exp_w(am.w2c[tid]) : 0; }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) { sW1[tid + 64 * WAVES * k] = q1[k]; sW2[tid + 64 * WAVES * k] = q2[k]; }
+        if (tid < 256) sB1[tid] = bq;
+        if (tid < 32) { sB2[tid] = b2q; sE2[tid] = e2q; }
+    }
     __syncthreads();
     // Bias + ReLU as ONE instruction: v_fma_f32 ... clamp computes min(max(H c + b, 0), 1), so the accumulator is brought to 2^-16 of the hidden tile's
     // scale (where the tile's bound is < 1/2: the upper clamp never acts), and an exact multiplication by 2^16 follows.  The bits are those of
