@@ -56,6 +56,12 @@ template <class F> static float timeit(const char* name, int iters, double gflop
                 printf("\n      %zu SIMDs on %zu CUs seen: a SIMD idles %.1f us on average behind its last wave (a CU %.1f us); last exit per XCD, us before the launch's:", simd_last.size(), cu_last.size(),
                        idle / simd_last.size() * 0.01, idc / cu_last.size() * 0.01);
                 for (auto& kv : xcd_last) printf(" %.1f", (x1 - kv.second) * 0.01);
+                {   // per XCD: median loop time (us) and median in-kernel clock (GHz) of its waves
+                    std::map<unsigned long long, std::vector<double>> xl, xc;
+                    for (size_t w = 0; w < 8192; ++w) if (st[w * 8 + 1] > 0 && st[w * 8 + 2] > 0) { xl[st[w * 8 + 5] >> 32].push_back((double)st[w * 8 + 1] * 0.01); xc[st[w * 8 + 5] >> 32].push_back((double)st[w * 8] / (double)st[w * 8 + 1] * 0.1); }
+                    printf("\n      per XCD, median loop us @ GHz:");
+                    for (auto& kv : xl) printf(" %.1f@%.2f", med(kv.second), med(xc[kv.first]));
+                }
             }
         }
         std::fill(st.begin(), st.end(), 0ull);
