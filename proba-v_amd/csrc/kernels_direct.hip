@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void conv3_up_bwd_data_kernel(ConvGeom g, cons
         __syncthreads();
         if (tid == 0) {
             const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax + n)) atomicMax(amax + n, __float_as_uint(m));
+            atomicMax(amax + n, __float_as_uint(m));
         }
     }
     }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ xal
     __syncthreads();
     if (threadIdx.x == 0) {                                          // one atomic per workgroup, skipped when the slot already holds more
         m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, __float_as_uint(m));
+        atomicMax(slot, __float_as_uint(m));
     }
 }
 int amax_tensor(const float* x, size_t per_sample, int N, unsigned* slots, hipStream_t s)
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
         __syncthreads();
         if (threadIdx.x == 0) {
             m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-            if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(amax + n)) atomicMax(amax + n, __float_as_uint(m));
+            atomicMax(amax + n, __float_as_uint(m));
         }
     }
 }
@@ -486,9 +486,72 @@ int reduce_join(hipStream_t s)
     return PROBAV_OK;
 }
 
+// The same fold, one workgroup per output row (n, h): which padded rows fold onto it is a property of the workgroup (row h + 1, and row 0 / H + 1 behind
+// rows 1 / H - 2), the row's 16-byte elements are walked in order (every request of a wave is one contiguous run), one multiply-high finds the column.
+__global__ __launch_bounds__(256) void reflect_fold_rows_kernel(const float4* __restrict__ dpad, float4* __restrict__ dx, int H, int W, int TCv, unsigned mTCv,
+                                                               unsigned* __restrict__ amax)
+{
+    const int h = blockIdx.x, n = blockIdx.y;
+    const int rowv = (W + 2) * TCv;                                 // 16-byte elements of a padded row
+    const float4* r0 = dpad + ((long)n * (H + 2) + h + 1) * rowv;
+    const int extra = h == 1 ? -(h + 1) : (h == H - 2 ? 2 : 0);     // the second padded row that folds onto this one, relative to r0 (0: none)
+    const float4* r1 = r0 + (long)extra * rowv;
+    float4* dst = dx + ((long)n * H + h) * W * TCv;
+    float m = 0.f;
+    const int nel = W * TCv;
+    for (int i0 = threadIdx.x; i0 < nel; i0 += 256 * 4) {           // four elements per thread and round: their requests go out together
+        float4 a[4], b[4];
+        int c1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k < nel ? i0 + 256 * k : i0;
+            const int w = (int)__umulhi((unsigned)i, mTCv), e = i - w * TCv;
+            const int c0 = (w + 1) * TCv + e;
+            c1[k] = w == 1 ? e : (w == W - 2 ? (W + 1) * TCv + e : -1);          // the second padded column
+            a[k] = r0[c0];
+            b[k] = r1[c0];                                                          // (extra == 0: the same element again, unused)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            if (i >= nel) break;
+            float4 v = a[k];
+            if (extra) { v.x += b[k].x; v.y += b[k].y; v.z += b[k].z; v.w += b[k].w; }
+            if (c1[k] >= 0) {
+                float4 q = r0[c1[k]];
+                if (extra) { const float4 c = r1[c1[k]]; q.x += c.x; q.y += c.y; q.z += c.z; q.w += c.w; }
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            dst[i] = v;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __shared__ float wm[4];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+            atomicMax(amax + n, __float_as_uint(m));                   // (no guarding read of the slot: x6_device.h, amax_commit)
+        }
+    }
+}
+
 int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax, hipStream_t s)
 {
     if (H < 4 || W < 4) { set_error("reflect_fold: H, W must be >= 4", hipSuccess); return PROBAV_EINVAL; }
+    static const bool old_form = getenv("PROBAV_FOLD_V1") != nullptr;              // A/B runs: the flat-index kernel
+    if (!old_form && TC % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpad) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 && H <= 65535 && N <= 65535) {
+        const int TCv = TC / 4;
+        const unsigned mTCv = (unsigned)((0x100000000ull + (unsigned)TCv - 1) / (unsigned)TCv);     // floor(i / TCv) = umulhi(i, m) for i < 2^16 * ... (i < W * TCv here)
+        if ((long)W * TCv < (1l << 20) && TCv >= 2 && TCv < 4096) {
+            hipLaunchKernelGGL(reflect_fold_rows_kernel, dim3((unsigned)H, (unsigned)N), dim3(256), 0, s, reinterpret_cast<const float4*>(dpad),
+                               reinterpret_cast<float4*>(dx), H, W, TCv, mTCv, amax);
+            return check_launch("reflect_fold");
+        }
+    }
     const long per = (long)H * W * TC;
     long blocks = (per + 255) / 256;
     const long cap = N >= 4096 ? 1 : 4096 / N;

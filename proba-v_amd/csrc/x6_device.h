@@ -91,8 +91,9 @@ __device__ __forceinline__ void amax_commit(float m, unsigned* slot)
 {
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    // (a stale read only costs a redundant atomic: the slot never decreases while its tensor is being produced)
-    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, __float_as_uint(m));
+    // NO read of the slot first ("skip the atomic if the slot already holds more"): the per-sample slots of a tensor share a few cache lines, and a load of a
+    // line that thousands of atomics are queued on waits behind them -- measured on reflect_fold: 91 us with the guard, 27 without (tools/copybw.hip)
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
 }
 
 // ---- X6: the three truncation pieces of one value, as fp32 bit patterns whose low 16 bits are zero
