@@ -98,14 +98,13 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
     const WnLayer L = layers[li];
     float* v = params + L.v_off;
     const int lane = threadIdx.x;
-    float gain = params[L.g_off + co], bias_abs = fabsf(params[L.b_off + co]);
+    float gain = params[L.g_off + co];
     if constexpr (UPDATE) {
         {   // the gain g[co] and the bias[co]: every lane computes both (the values are needed below), lanes 0 and 1 store them
             const int ig = L.g_off + co, ib = L.b_off + co;
             float mg = om[ig], vg = ov[ig], mb = om[ib], vb = ov[ib];
             gain = opt_update(gain, grad[ig], mg, vg, oc);
             const float bnew = opt_update(params[ib], grad[ib], mb, vb, oc);
-            bias_abs = fabsf(bnew);
             if (lane == 0) { params[ig] = gain; om[ig] = mg; ov[ig] = vg; }
             if (lane == 1) { params[ib] = bnew; om[ib] = mb; ov[ib] = vb; }
         }
@@ -158,17 +157,16 @@ __global__ __launch_bounds__(64) void wn_forward_kernel(const WnLayer* __restric
     if (amax) {     // largest |effective weight| and |bias| of the layer (slots li and nl + li) and of this output column: operand scales of the H3 kernels
 #pragma unroll
         for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-        if (lane == 0) {
-            atomicMax(amax + li, __float_as_uint(wmax)); atomicMax(amax + nl + li, __float_as_uint(bias_abs));
-            amax[2 * nl + L.n_off + co] = __float_as_uint(wmax);
-        }
+        // (the layer's own two slots, li and nl + li, are filled by wn_rowmax_kernel from the per-column slots and the biases: 2 x 3 920 atomicMax calls on
+        // three cache lines queued for 24 us -- tools/atomic_probe.hip: 3 ns apiece, one after the other)
+        if (lane == 0) amax[2 * nl + L.n_off + co] = __float_as_uint(wmax);
     }
 }
 
 // largest |effective weight| per INPUT channel (the output columns of the backward-data matrices weffT, and the rows of W1 the fused
 // pointwise backward scales its dX by): one wave per (layer, input channel), after wn_forward_kernel on the same stream
 __global__ __launch_bounds__(64) void wn_rowmax_kernel(const WnLayer* __restrict__ layers, int nl, const float* __restrict__ weff,
-                                                      unsigned* __restrict__ arow)
+                                                      unsigned* __restrict__ arow, unsigned* __restrict__ amax, const float* __restrict__ params)
 {
     const int i = find_by_offset(layers, nl, (int)blockIdx.x, true);
     const WnLayer L = layers[i];
@@ -191,6 +189,14 @@ __global__ __launch_bounds__(64) void wn_rowmax_kernel(const WnLayer* __restrict
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) arow[blockIdx.x] = __float_as_uint(m);
+    if (ci == 0) {      // the layer's first wave also fills the layer's own slots: largest |effective weight| (= the largest of its per-column slots, written by
+                        // wn_forward_kernel before this launch) and largest |bias| (the parameters hold the updated biases by now)
+        unsigned wm = 0u; float bm = 0.f;
+        for (int c = lane; c < L.Cout; c += 64) { const unsigned q = amax[2 * nl + L.n_off + c]; wm = q > wm ? q : wm; bm = fmaxf(bm, fabsf(params[L.b_off + c])); }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const unsigned q = (unsigned)__shfl_xor((int)wm, o, 64); wm = q > wm ? q : wm; bm = fmaxf(bm, __shfl_xor(bm, o, 64)); }
+        if (lane == 0) { amax[i] = wm; amax[nl + i] = __float_as_uint(bm); }
+    }
 }
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ xall, size_t n, unsigned* __restrict__ slots)
@@ -289,7 +295,7 @@ int wn_forward(const WnLayer* d_layers, int nlayers, int cout_total, int cin_tot
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr, OptCoef());
     int rc = check_launch("wn_forward");
     if (rc || !amax) return rc;
-    hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total);
+    hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total, amax, params);
     return check_launch("wn_rowmax");
 }
 int optimizer_wn_step(const WnLayer* d_layers, int nlayers, int cout_total, int cin_total, float* params, const float* grad, float* m, float* v,
@@ -300,7 +306,7 @@ int optimizer_wn_step(const WnLayer* d_layers, int nlayers, int cout_total, int 
     hipLaunchKernelGGL(wn_forward_kernel<true>, dim3(cout_total), dim3(64), 0, s, d_layers, nlayers, params, weff, weffT, inv_norm, amax, grad, m, v, oc);
     int rc = check_launch("optimizer_wn_step");
     if (rc || !amax) return rc;
-    hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total);
+    hipLaunchKernelGGL(wn_rowmax_kernel, dim3(cin_total), dim3(64), 0, s, d_layers, nlayers, weff, amax + 2 * nlayers + cout_total, amax, params);
     return check_launch("wn_rowmax");
 }
 int wn_backward(const WnLayer* d_layers, int nlayers, int cout_total, const float* params,
