@@ -648,22 +648,46 @@ __global__ __launch_bounds__(256) void shift_loss_fwd_kernel(
     const float* P = pred + (long)b * S * S;
     for (int j = wave; j < ns; j += 4) {
         const int sft = i * ns + j;
+        // Both passes walk the crop four pixels per lane and round, requested together (one pixel per round was one memory round trip per
+        // pixel: 112 of them in a row per wave); the sums take the pixels in the same order as before, so the bits are the same.
+        constexpr int U = 4;
+        const int n = L * L;
         double cnt = 0.0, dsum = 0.0;
-        for (int k = lane; k < L * L; k += 64) {
-            const int r = k / L, c = k - r * L;
-            const float m = M[(i + r) * S + j + c] ? 1.f : 0.f;
-            cnt += (double)m;
-            dsum += (double)(H[(i + r) * S + j + c] - P[(border + r) * S + border + c] * m);
+        for (int k0 = lane; k0 < n; k0 += 64 * U) {
+            float m[U], h[U], q[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 64 * u < n ? k0 + 64 * u : k0;
+                const int r = k / L, c = k - r * L;
+                m[u] = M[(i + r) * S + j + c] ? 1.f : 0.f;
+                h[u] = H[(i + r) * S + j + c];
+                q[u] = P[(border + r) * S + border + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + 64 * u < n) { cnt += (double)m[u]; dsum += (double)(h[u] - q[u] * m[u]); }
         }
         cnt = wave_sum(cnt); dsum = wave_sum(dsum);
         const double bias = dsum / cnt;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = lane; k < L * L; k += 64) {
-            const int r = k / L, c = k - r * L;
-            const double m = M[(i + r) * S + j + c] ? 1.0 : 0.0;
-            const double e = (double)H[(i + r) * S + j + c] - ((double)P[(border + r) * S + border + c] + bias) * m;
-            s1 += fabs(e);
-            s2 += e * e;
+        for (int k0 = lane; k0 < n; k0 += 64 * U) {
+            float h[U], q[U]; bool mk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 64 * u < n ? k0 + 64 * u : k0;
+                const int r = k / L, c = k - r * L;
+                mk[u] = M[(i + r) * S + j + c] != 0;
+                h[u] = H[(i + r) * S + j + c];
+                q[u] = P[(border + r) * S + border + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + 64 * u < n) {
+                    const double m = mk[u] ? 1.0 : 0.0;
+                    const double e = (double)h[u] - ((double)q[u] + bias) * m;
+                    s1 += fabs(e);
+                    s2 += e * e;
+                }
         }
         s1 = wave_sum(s1) / cnt; s2 = wave_sum(s2) / cnt;
         if (lane == 0) { cand[((long)b * nshift + sft) * 2] = s1; cand[((long)b * nshift + sft) * 2 + 1] = s2; }
