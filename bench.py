@@ -72,9 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--side-stream-mode", type=int, default=2, choices=(0, 1, 2),
-                    help="probav_engine_side_stream: 2 (default) = slab sums, residual path AND the backward-filter kernels on the engine's low-priority "
-                         "side stream; 1 = backward-filter kernels on the launch stream (per-kernel profiles: rocprofv3 / PMC passes); 0 = no side stream")
+    ap.add_argument("--side-stream-mode", type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help="probav_engine_side_stream: 2 = slab sums, residual path AND the backward-filter kernels on the engine's low-priority "
+                         "side stream; 1 = backward-filter kernels on the launch stream (per-kernel profiles: rocprofv3 / PMC passes); 0 = no side stream; "
+                         "-1 (default) = WDSRModel.tune_side_stream picks 1 or 2 in a few untimed steps behind the warm-up (which is faster depends on the box)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--force-dp", action="store_true", help="with ONE rank: still initialise a world-size-1 RCCL process group and run the data-parallel "
@@ -279,10 +280,16 @@ def run_rank(args):
     opt = make_optimizer("nadam", model, 5e-4)
     step = stepper(model, data, opt)
     h = model._handle()
-    _lib.check(L.probav_engine_side_stream(h, args.side_stream_mode), "probav_engine_side_stream")
+    side_probe = None
+    if args.side_stream_mode >= 0:
+        _lib.check(L.probav_engine_side_stream(h, args.side_stream_mode), "probav_engine_side_stream")
     for _ in range(args.warmup):
         step()
     sync()
+    if args.side_stream_mode < 0:       # untimed, behind the W warm-up steps: the trainer does the same at the start of training (trainClass.ModelTrainer)
+        args.side_stream_mode, side_probe = model.tune_side_stream(step)
+        side_probe = {str(k): round(v, 4) for k, v in side_probe.items()}
+        sync()
     use_events = not args.no_kernel_events
     n = len(CLASSES)
 
@@ -405,6 +412,7 @@ def run_rank(args):
         del step, opt
         model._ws.clear()
         m13, d13 = make(13)
+        m13.set_side_stream_mode(args.side_stream_mode)
         s13 = stepper(m13, d13)
         for _ in range(3):
             s13()
@@ -458,7 +466,9 @@ def run_rank(args):
                                       "fp32 in, fp32 out, fp32 accumulate; every fp32 product is evaluated as six exact bf16-piece products on the "
                                       "bf16 MFMA pipe (x6 kernels, error of the order of fp32 rounding: see tests/test_gpu_parity.py)" if args.impl == 3
                                       else "native fp32 MFMA / VALU"),
-                       "loss": float(loss.detach()), "kernel_events": use_events},
+                       "loss": float(loss.detach()), "kernel_events": use_events,
+                       "side_stream_mode": args.side_stream_mode,
+                       "side_stream_probe_ms": side_probe},      # None: the mode was given; else {mode: median ms per step} of WDSRModel.tune_side_stream
             "algorithmic_tflops_whole_step": round(value * ALGO_GFLOP_PER_PATCH / 1e3, 3) if T == 9 else None,
             "reference_derived": {"value": 215, "unit": "patches/s", "hardware": "GTX 1080 Ti",
                                   "note": "derived from the reference's TensorBoard logs (BASELINE.md), not a published figure"},

@@ -628,10 +628,11 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
         else hipLaunchKernelGGL(wgrad_cin1_kernel<false>, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
         int rc = check_launch("wgrad_cin1");
         if (rc) return rc;
-        hipStream_t rs = reduce_fork(s);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((27 * 32 + 31) / 32)), dim3(256), 0, rs, partial, dw, (long)27 * 32, slabs);
-        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, rs, pb, db, (long)32, slabs);
-        return check_launch("reduce_partials");
+        return reduce_later(s, [=](hipStream_t rs) -> int {
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((27 * 32 + 31) / 32)), dim3(256), 0, rs, partial, dw, (long)27 * 32, slabs);
+            if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, rs, pb, db, (long)32, slabs);
+            return check_launch("reduce_partials");
+        });
     }
     {
         int halves; size_t lds;
@@ -643,10 +644,12 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
             int rc = check_launch("wgrad2d_small");
             if (rc) return rc;
             const long nw = K * g.Cout;
-            hipStream_t rs = reduce_fork(s);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, rs, partial, dw, nw, slabs);
-            if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), dim3(256), 0, rs, pb, db, (long)g.Cout, slabs);
-            return check_launch("reduce_partials");
+            const int cout = g.Cout;
+            return reduce_later(s, [=](hipStream_t rs) -> int {
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, rs, partial, dw, nw, slabs);
+                if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cout + 31) / 32)), dim3(256), 0, rs, pb, db, (long)cout, slabs);
+                return check_launch("reduce_partials");
+            });
         }
     }
     float* partial_b = partial + (size_t)chunks * K * g.Cout;
@@ -670,10 +673,12 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     int rc = check_launch("conv_direct_wgrad");
     if (rc) return rc;
     const long nw = K * g.Cout;
-    hipStream_t rs = reduce_fork(s);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), block, 0, rs, partial, dw, nw, chunks);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((g.Cout + 31) / 32)), block, 0, rs, partial_b, db, (long)g.Cout, chunks);
-    return check_launch("reduce_partials");
+    const int cout = g.Cout;
+    return reduce_later(s, [=](hipStream_t rs) -> int {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, rs, partial, dw, nw, chunks);
+        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cout + 31) / 32)), dim3(256), 0, rs, partial_b, db, (long)cout, chunks);
+        return check_launch("reduce_partials");
+    });
 }
 
 }  // namespace probav

@@ -2807,7 +2807,7 @@ __global__ __launch_bounds__(256) void reduce_slabs4_kernel(const float4* __rest
 
 int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, float* db, long nw, int Cout, int slabs, hipStream_t s0)
 {
-    hipStream_t s = reduce_fork(s0);                                         // (the engine's side stream during a backward pass)
+    return reduce_later(s0, [=](hipStream_t s) -> int {                       // (the engine's side stream during a backward pass, at its next flush)
     const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0;
     if ((nw & 3) == 0 && Cout <= 32 && al) {
         const int nbw = (int)((nw / 4 + 15) / 16);
@@ -2818,6 +2818,7 @@ int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, f
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, slabs);
     if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)Cout, slabs);
     return check_launch("reduce_slabs");
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3123,9 +3124,10 @@ static const int PW_BWD_GRID = 256;
 int mfma_pw_backward_reduce(const float* slabs, int D, float* dW1, float* dW2, float* db1, float* db2, hipStream_t s)
 {
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
-    hipLaunchKernelGGL(pw_bwd2_reduce_kernel, dim3((unsigned)((slab_floats + 31) / 32)), dim3(256), 0, reduce_fork(s), slabs, PW_BWD_GRID, D,
-                       dW1, dW2, db1, db2);
-    return check_launch("pw_bwd2_reduce");
+    return reduce_later(s, [=](hipStream_t rs) -> int {
+        hipLaunchKernelGGL(pw_bwd2_reduce_kernel, dim3((unsigned)((slab_floats + 31) / 32)), dim3(256), 0, rs, slabs, PW_BWD_GRID, D, dW1, dW2, db1, db2);
+        return check_launch("pw_bwd2_reduce");
+    });
 }
 int mfma_pw_backward_grid() { return PW_BWD_GRID; }
 
@@ -3141,9 +3143,9 @@ int mfma_pw_backward(const float* x, const float* dT, const float* dOut, const f
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
     hipLaunchKernelGGL(pw_bwd2_mfma_kernel, dim3(PW_BWD_GRID), dim3(64 * PW2_WAVES), lds, s, x, dT, dOut, (const float4*)w1kcin,
                        (const float4*)w2kout, (const float4*)w1khch, b1, dX, slabs, nvox, D);
-    hipLaunchKernelGGL(pw_bwd2_reduce_kernel, dim3((unsigned)((slab_floats + 31) / 32)), dim3(256), 0, reduce_fork(s), slabs, PW_BWD_GRID, D,
-                       dW1, dW2, db1, db2);
-    return check_launch("pw_bwd2_mfma");
+    int rc = check_launch("pw_bwd2_mfma");
+    if (rc) return rc;
+    return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
 }
 
 }  // namespace probav

@@ -8,6 +8,8 @@
 #include "probav_common.h"
 #include <cstdlib>
 #include <atomic>
+#include <vector>
+#include <functional>
 #include <stdio.h>
 #include <string.h>
 
@@ -476,12 +478,39 @@ hipStream_t reduce_fork_adjacent(hipStream_t s)
     ReduceSide* c = g_reduce_side;
     if (!c || !c->side || s == c->side) return s;
     static const bool always_record = getenv("PROBAV_FORK_EVENTS") != nullptr;     // A/B runs: an event at every fork
-    if (c->k == 0 || c->last != s || always_record) return reduce_fork(s);   // (nothing forked yet in this pass, or the last fork did not take: there is no earlier point)
+    if (c->k == 0 || c->last != s || always_record || c->defer) return reduce_fork(s);   // (deferred launches: the previous fork point is no longer adjacent)   // (nothing forked yet in this pass, or the last fork did not take: there is no earlier point)
     return c->side;
+}
+typedef std::vector<std::function<int(hipStream_t)>> PendingList;
+int reduce_later(hipStream_t s, std::function<int(hipStream_t)> fn)
+{
+    ReduceSide* c = g_reduce_side;
+    if (!c || !c->side || !c->defer || s == c->side) return fn(reduce_fork(s));
+    if (!c->pending) c->pending = new PendingList();
+    static_cast<PendingList*>(c->pending)->push_back(std::move(fn));
+    return PROBAV_OK;
+}
+int reduce_flush(hipStream_t s)
+{
+    ReduceSide* c = g_reduce_side;
+    if (!c || !c->pending) return PROBAV_OK;
+    PendingList* q = static_cast<PendingList*>(c->pending);
+    if (q->empty()) return PROBAV_OK;
+    hipStream_t rs = reduce_fork(s);
+    int rc = PROBAV_OK;
+    for (auto& fn : *q) { const int r = fn(rs); if (r && !rc) rc = r; }
+    q->clear();
+    return rc;
+}
+void reduce_drop_pending()
+{
+    ReduceSide* c = g_reduce_side;
+    if (c && c->pending) static_cast<PendingList*>(c->pending)->clear();
 }
 int reduce_join(hipStream_t s)
 {
     ReduceSide* c = g_reduce_side;
+    { const int rc = reduce_flush(s); if (rc) return rc; }
     if (!c || !c->side || c->k == 0) return PROBAV_OK;
     if (hipEventRecord(c->joined, c->side) != hipSuccess || hipStreamWaitEvent(s, c->joined, 0) != hipSuccess) {
         set_error("reduce_join: event record / wait", hipGetLastError());

@@ -4,6 +4,7 @@
 //   kernels      [kh][kw][kt][Cin][Cout]       (Keras layout; models/modelsTF.py:191-197)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -62,10 +63,16 @@ int mfma_probe(const void* seed, float* sink, int iters, int launches, hipStream
 // launches.  While a ReduceSide is active on the calling thread (the engine's backward pass), reduce_fork(s) records the point on s,
 // makes the engine's side stream wait for it and returns the side stream; the reducing kernels are launched there and run in the
 // gaps of the main chain.  reduce_join(s) makes s wait for everything forked.  Without an active context reduce_fork(s) is s.
-struct ReduceSide { hipStream_t side; hipEvent_t ev[8]; hipEvent_t joined; int k; hipStream_t last; };   // last: the stream of the latest SUCCESSFUL fork since the join (reduce_fork_adjacent)
+// Every fork is an event record between two kernels of the caller's stream, and that costs the stream about 6.5 us of bubble (30 of them in a backward
+// pass: 0.2 ms).  With `defer` set, reduce_later(s, fn) only QUEUES the launch fn(stream); reduce_flush(s) forks once and launches everything queued
+// (each of those launches reads slabs that nobody writes again before the pass ends, so it may run any time after its producer); reduce_join flushes first.
+struct ReduceSide { hipStream_t side; hipEvent_t ev[8]; hipEvent_t joined; int k; hipStream_t last; int defer; void* pending; };   // last: the stream of the latest SUCCESSFUL fork since the join (reduce_fork_adjacent); pending: the queued launches (kernels_small.hip)
 void reduce_side_activate(ReduceSide* ctx);                 // nullptr deactivates
 hipStream_t reduce_fork(hipStream_t s);
 hipStream_t reduce_fork_adjacent(hipStream_t s);           // the same point as the caller's previous reduce_fork(s) (nothing enqueued on s in between): no new event
+int reduce_later(hipStream_t s, std::function<int(hipStream_t)> fn);      // fn(reduce_fork(s)) now, or queued until the next reduce_flush (ReduceSide::defer)
+int reduce_flush(hipStream_t s);                            // one fork for everything queued
+void reduce_drop_pending();                                 // an aborted pass: forget the queue (its closures may point into a dead frame)
 int reduce_join(hipStream_t s);
 // mainConv1 forward (one input channel -> 32, 3x3x3, zero pads of 1): dedicated store-bound kernel; amax = per-sample slots of y or null
 bool conv3d_cin1_forward_supported(const ConvGeom& g);

@@ -157,6 +157,35 @@ class WDSRModel(torch.nn.Module):
         of two per sample / per filter column).  Every family computes a sample independently of its batch mates, bit for bit."""
         _lib.check(_lib.lib().probav_engine_set_impl(self._handle(), int(impl)), "probav_engine_set_impl")
 
+    def set_side_stream_mode(self, mode):
+        """probav_engine_side_stream: 0 = everything on the caller's stream; 1 = the slab sums, the residual path and the upscale layer's backward-filter on the
+        engine's low-priority side stream; 2 = also the blocks' backward-filter kernels (the engine's default)."""
+        _lib.check(_lib.lib().probav_engine_side_stream(self._handle(), int(mode)), "probav_engine_side_stream")
+
+    def tune_side_stream(self, step, steps=8, rounds=2, modes=(2, 1)):
+        """Which of the two side-stream modes is faster depends on the BOX: where the workgroups of a launch finish unevenly (the pool's slower boxes) the
+        backward-filter kernels fill the gaps from the side stream (mode 2: -1.1 % there), elsewhere they are better off in the chain (mode 1: -1.2 %).
+        Times `steps` calls of `step()` (one training step on the caller's current stream) per mode, `rounds` times alternating, keeps the faster mode and
+        returns (mode, {mode: median ms per step}).  Both modes compute the same bits."""
+        import statistics
+        ms = {m: [] for m in modes}
+        for _ in range(rounds):
+            for m in modes:
+                self.set_side_stream_mode(m)
+                step()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a.record()
+                for _ in range(steps):
+                    step()
+                b.record()
+                torch.cuda.synchronize()
+                ms[m].append(a.elapsed_time(b) / steps)
+        med = {m: statistics.median(v) for m, v in ms.items()}
+        best = min(med, key=med.get)
+        self.set_side_stream_mode(best)
+        return best, med
+
     # -- weight cache (SURVEY.md section 8f-2) -----------------------------------------------------------------
     def weight_cache_buffer(self):
         """The device buffer the fused optimizer step writes the next step's effective weights / operand fragments into."""

@@ -394,6 +394,41 @@ def make_optimizer(name, model, learning_rate):
     return HipSGD(params, lr=learning_rate, model=fused)
 
 
+class _SideStreamTuner:
+    """The first training steps pick the engine's side-stream mode (probav_amd/modelsTF.py: WDSRModel.tune_side_stream has the why): windows of 8 steps, modes 2, 1, 2, 1,
+    timed by events on the training stream; the faster mode stays.  The steps are ordinary training steps -- both modes compute the same bits."""
+    ORDER, WINDOW = (2, 1, 2, 1), 8
+
+    def __init__(self, model):
+        self.model, self.k, self.ms, self.ev, self.mode = model, 0, {1: [], 2: []}, None, 2
+        flat = getattr(model, "flat", None)
+        self.ok = hasattr(model, "set_side_stream_mode") and flat is not None and flat.is_cuda
+
+    def tick(self):
+        """Call at the top of every step; True once the choice is made."""
+        if not self.ok:
+            return True
+        w, pos = divmod(self.k, self.WINDOW + 1)                    # one untimed step at the head of every window
+        self.k += 1
+        if pos == 0:
+            if self.ev is not None:
+                self.ev[1].record()
+                self.ev[1].synchronize()
+                self.ms[self.mode].append(self.ev[0].elapsed_time(self.ev[1]) / self.WINDOW)
+                self.ev = None
+            if w == len(self.ORDER):
+                best = min(self.ms, key=lambda m: sorted(self.ms[m])[len(self.ms[m]) // 2])
+                self.model.set_side_stream_mode(best)
+                logger.info("[ INFO ] engine side-stream mode %d (ms per step by mode: %s)", best, {m: [round(v, 3) for v in vs] for m, vs in self.ms.items()})
+                return True
+            self.mode = self.ORDER[w]
+            self.model.set_side_stream_mode(self.mode)
+        elif pos == 1:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return False
+
+
 class ModelTrainer:
     """models/trainClass.py:17-143."""
 
@@ -575,7 +610,10 @@ class ModelTrainer:
             self._scalar("Train PSNR", vals[1], gs)
             self._scalar("Train loss", vals[0], gs)
         late = _LateScalars(emit, self._device())
+        tuner = _SideStreamTuner(self.model) if os.environ.get("PROBAV_SIDE_STREAM_TUNE", "1") != "0" else None
         for xb, hb, mb in batches:
+            if tuner is not None and tuner.tick():
+                tuner = None
             if (totalSteps - step) == 0:
                 epoch += 1
                 step = self.step % totalSteps
