@@ -262,14 +262,24 @@ def run_rank(args):
     def timed(step, k, *a):
         """Wall clock around exactly k steps, max over ranks; HIP events at every step boundary (torch's current stream IS the launch stream)."""
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
-        sync()
-        t0 = time.perf_counter()
-        evs[0].record()
-        for i in range(k):
-            loss = step(*a)
-            evs[i + 1].record()
-        sync()
-        dt = time.perf_counter() - t0
+        # the host runs one step ahead of the device at most (134 launches): a generation-2 sweep of the interpreter's collector in the timed region is a
+        # 10-20 ms hole in the launch stream (seen once: one 26-ms step in 100).  The trainer does the same around its loop (trainClass.fitTrainData).
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            sync()
+            t0 = time.perf_counter()
+            evs[0].record()
+            for i in range(k):
+                loss = step(*a)
+                evs[i + 1].record()
+            sync()
+            dt = time.perf_counter() - t0
+        finally:
+            if gc_was:
+                gc.enable()
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if dp:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -687,14 +687,15 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
     const bool h3 = e->impl >= 4;
     const AmaxSlots A(e, p, W, R, WC ? reinterpret_cast<unsigned*>(const_cast<float*>(WC + wc.amax)) : nullptr);
     auto amx = [&](const unsigned* ax, int li, unsigned* ay) { Amax m; if (h3) { m.x = ax; m.w = A.wcol(li); m.y = ay; } return m; };
-    if (h3 && hipMemsetAsync(A.base, 0, (size_t)p.amax_bwd * sizeof(unsigned), s) != hipSuccess) { set_error("probav_forward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    // (the per-sample amax slots -- the atomicMax targets -- are cleared by head_kernel below; the weight slots in front of them are plain stores of wn_forward_kernel /
+    // wn_rowmax_kernel, every one of them written before anything reads it)
     if (training) { e->fwd_amax = h3; e->fwd_unfused = !(e->impl >= 1 && e->pw_mfma); }
 
     if (!WC) {
         { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_forward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, (int)e->cin_total, params, W + p.weff, W + p.weffT, W + p.invn, h3 ? A.base : nullptr, s)); }
         if (e->impl >= 1) { ProfScope ps(e, CLS_WN, 0.0, s); CK(mfma_pack(e->d_jobs, (int)e->jobs.size(), W + p.weff, W + p.weffT, W + p.wpack, A.base, s)); }
     }
-    CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.in_channels, c.mean, c.std, s));
+    CK(head_forward(x, W + p.xn, W + p.mn, B * Hin * Hin, T, c.in_channels, c.mean, c.std, s, h3 ? A.base + p.amax_fwd : nullptr, h3 ? p.amax_bwd - p.amax_fwd : 0));
     // the low-frequency residual path (three small 2-D convolutions on the temporal mean) meets the main path only in tail_forward: it runs
     // on the side stream, in the gaps of the chip-filling launches
     SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s);
@@ -795,7 +796,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         set_error("probav_backward: the H3 kernels (impl 4) need the amax slots of a forward pass run with the same kernel family", hipSuccess);
         return PROBAV_EINVAL;
     }
-    if (h3 && hipMemsetAsync(A.back(0), 0, (size_t)(p.n_amax - p.amax_bwd) * sizeof(unsigned), s) != hipSuccess) { set_error("probav_backward: amax reset", hipGetLastError()); return PROBAV_EHIP; }
+    // (the reverse pass's per-sample amax slots are cleared by tail_bwd_kernel, its first launch)
     auto dweff = [&](int li) { return S + p.dweff2 + e->layers[li].wn.w_off; };
     auto dbias = [&](int li) { return grads + e->layers[li].wn.b_off; };
     int npart = 0;
@@ -805,7 +806,7 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     static const bool no_defer = getenv("PROBAV_NO_DEFER") != nullptr;              // A/B runs: a fork per launch, as before
     SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s, no_defer ? 0 : 1);
 
-    CK(tail_backward(dy, S + p.dtail, B, P, c.scale, c.std, s));
+    CK(tail_backward(dy, S + p.dtail, B, P, c.scale, c.std, s, h3 ? A.back(0) : nullptr, h3 ? p.n_amax - p.amax_bwd : 0));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first: beside the main chain, nothing below depends on it until the weight-norm
     // backward -- queued (its slab regions are taken now, in the plan's launch order) and launched at the first flush, when the launch stream has its next kernels
     {

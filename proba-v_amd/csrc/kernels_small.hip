@@ -322,9 +322,10 @@ int wn_backward(const WnLayer* d_layers, int nlayers, int cout_total, const floa
 // head: x [N,H,W,T,C] -> xn = (x - mean)/std  [N,H,W,T,C] ,  mn = (mean_T(x) - mean)/std  [N,H,W,C]     (C = 1, or 3 for isGrayScale=False)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, float* __restrict__ xn,
-                                                  float* __restrict__ mn, int nhw, int T, int C, float mean, float stdv)
+                                                  float* __restrict__ mn, int nhw, int T, int C, float mean, float stdv, unsigned* __restrict__ zero, int nzero)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;          // (pixel, channel)
+    for (int z = i; z < nzero; z += gridDim.x * 256) zero[z] = 0u;      // the forward pass's per-sample amax slots (a 6-us memset launch of their own before)
     if (i >= nhw * C) return;
     const int px = i / C, c = i - px * C;
     float s = 0.f;
@@ -336,9 +337,9 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
     }
     mn[i] = (s / (float)T - mean) / stdv;
 }
-int head_forward(const float* x, float* xn, float* mn, int nhw, int T, int C, float mean, float stdv, hipStream_t s)
+int head_forward(const float* x, float* xn, float* mn, int nhw, int T, int C, float mean, float stdv, hipStream_t s, unsigned* zero, int nzero)
 {
-    hipLaunchKernelGGL(head_kernel, dim3((nhw * C + 255) / 256), dim3(256), 0, s, x, xn, mn, nhw, T, C, mean, stdv);
+    hipLaunchKernelGGL(head_kernel, dim3((nhw * C + 255) / 256), dim3(256), 0, s, x, xn, mn, nhw, T, C, mean, stdv, zero, nzero);
     return check_launch("head");
 }
 
@@ -354,10 +355,11 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const float* __restrict__
     y[i] = (up[src] + r3[src]) * stdv + mean;
 }
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dtail,
-                                                      int N, int P, int sc, float stdv)
+                                                      int N, int P, int sc, float stdv, unsigned* __restrict__ zero, int nzero)
 {
     const int S = P * sc, C = sc * sc;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long z = i; z < nzero; z += (long)gridDim.x * 256) zero[z] = 0u;      // the backward pass's per-sample amax slots
     if (i >= (long)N * P * P * C) return;
     const int c = (int)(i % C);
     long r = i / C;
@@ -372,10 +374,10 @@ int tail_forward(const float* up, const float* r3, float* y, int N, int P, int s
     hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, up, r3, y, N, P, sc, mean, stdv);
     return check_launch("tail_fwd");
 }
-int tail_backward(const float* dy, float* dtail, int N, int P, int sc, float stdv, hipStream_t s)
+int tail_backward(const float* dy, float* dtail, int N, int P, int sc, float stdv, hipStream_t s, unsigned* zero, int nzero)
 {
     const long n = (long)N * P * P * sc * sc;
-    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, dtail, N, P, sc, stdv);
+    hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, dtail, N, P, sc, stdv, zero, nzero);
     return check_launch("tail_bwd");
 }
 
@@ -733,6 +735,39 @@ __global__ __launch_bounds__(64) void batch_mean_kernel(const float* __restrict_
 }
 
 // per-sample minima over the shifts (ascending shift order, strict <: the first minimum wins ties); one thread per sample
+// One workgroup of up to 1024 threads: the batch means (batch_mean_kernel's sums, in its order: a wave's lanes take the samples 64 apart, then the butterfly)
+// are taken in the same launch -- a 6-us launch less between the forward and the backward pass.
+__global__ __launch_bounds__(1024) void shift_select_mean_kernel(const double* __restrict__ cand, int B, int nshift, float max_val,
+                                                                float* __restrict__ l1_out, float* __restrict__ l2_out, float* __restrict__ cpsnr_out,
+                                                                int* __restrict__ arg_l1, int* __restrict__ arg_l2, float* __restrict__ ma, float* __restrict__ mb)
+{
+    __shared__ float sl1[1024], sl2[1024];
+    const int b = threadIdx.x;
+    if (b < B) {
+        const double2* c = reinterpret_cast<const double2*>(cand) + (long)b * nshift;
+        double best1 = 1e300, best2 = 1e300;
+        int a1 = 0, a2 = 0;
+#pragma unroll 7
+        for (int sft = 0; sft < nshift; ++sft) {
+            const double2 v = c[sft];
+            if (v.x < best1) { best1 = v.x; a1 = sft; }
+            if (v.y < best2) { best2 = v.y; a2 = sft; }
+        }
+        sl1[b] = l1_out[b] = (float)best1;
+        sl2[b] = l2_out[b] = (float)best2;
+        cpsnr_out[b] = (float)(10.0 * log10((double)max_val * (double)max_val / best2));
+        arg_l1[b] = a1;
+        arg_l2[b] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = threadIdx.x; i < B; i += 64) { s1 += (double)sl1[i]; s2 += (double)sl2[i]; }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (threadIdx.x == 0) { *ma = (float)(s1 / B); *mb = (float)(s2 / B); }
+    }
+}
+
 __global__ __launch_bounds__(64) void shift_select_kernel(const double* __restrict__ cand, int B, int nshift, float max_val,
                                                          float* __restrict__ l1_out, float* __restrict__ l2_out, float* __restrict__ cpsnr_out,
                                                          int* __restrict__ arg_l1, int* __restrict__ arg_l2)
@@ -773,6 +808,10 @@ int shift_loss_forward(const float* hr, const uint8_t* mask, const float* pred, 
         cand_n = need;
     }
     hipLaunchKernelGGL(shift_loss_fwd_kernel, dim3(B, ns), dim3(256), 0, s, hr, mask, pred, S, border, cand);
+    if (B <= 1024) {
+        hipLaunchKernelGGL(shift_select_mean_kernel, dim3(1), dim3((unsigned)((B + 63) / 64 * 64)), 0, s, cand, B, ns * ns, max_val, l1, l2, cpsnr, arg_l1, arg_l2, mean_l1, mean_l2);
+        return check_launch("shift_loss_forward");
+    }
     hipLaunchKernelGGL(shift_select_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, cand, B, ns * ns, max_val, l1, l2, cpsnr, arg_l1, arg_l2);
     hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, s, l1, l2, mean_l1, mean_l2, B);
     return check_launch("shift_loss_forward");

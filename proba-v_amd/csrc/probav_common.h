@@ -107,9 +107,9 @@ int optimizer_wn_step(const WnLayer* d_layers, int nlayers, int cout_total, int 
                       float* weff, float* weffT, float* inv_norm, unsigned* amax, hipStream_t s);
 int wn_backward(const WnLayer* d_layers, int nlayers, int max_cout_total, const float* params,
                 const float* dweff, const float* inv_norm, float* grads, hipStream_t s);
-int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, int C, float mean, float stdv, hipStream_t s);
+int head_forward(const float* x, float* xn, float* mn, int nvox_hw, int T, int C, float mean, float stdv, hipStream_t s, unsigned* zero = nullptr, int nzero = 0);   // zero[0 .. nzero): cleared in the same launch (the pass's per-sample amax slots)
 int tail_forward(const float* up, const float* r3, float* y, int N, int P, int scale, float mean, float stdv, hipStream_t s);
-int tail_backward(const float* dy, float* dtail, int N, int P, int scale, float stdv, hipStream_t s);
+int tail_backward(const float* dy, float* dtail, int N, int P, int scale, float stdv, hipStream_t s, unsigned* zero = nullptr, int nzero = 0);
 int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax /* optional: N slots, receive max |dx| per sample */, hipStream_t s);
 // general form: gradient of tf.pad(x, [ph, pw, pt] 'reflect') folded back onto x [N,H,W,T,C]; pads <= 2
 int reflect_fold3(const float* dpad, float* dx, int N, int H, int W, int T, int C, int ph, int pw, int pt, hipStream_t s);

@@ -611,7 +611,15 @@ class ModelTrainer:
             self._scalar("Train loss", vals[0], gs)
         late = _LateScalars(emit, self._device())
         tuner = _SideStreamTuner(self.model) if os.environ.get("PROBAV_SIDE_STREAM_TUNE", "1") != "0" else None
+        # The host is at most one step (134 launches) ahead of the device: a generation-2 sweep of the interpreter's collector is a 10-20 ms hole in the launch
+        # stream.  The loop allocates no reference cycles of its own; the collector runs at the evaluation points instead.
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc_every = 2000
         for xb, hb, mb in batches:
+            if gc_every and self.step % gc_every == gc_every - 1:
+                gc.collect(1)
             if tuner is not None and tuner.tick():
                 tuner = None
             if (totalSteps - step) == 0:
