@@ -418,6 +418,41 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(
     }
 }
 
+// Two sums in one launch (a filter gradient and its bias gradient): the first nb1 workgroups take the first, the others the second -- every launch less on the
+// side stream is 5 us less that the command processor may spend there while the launch stream's next kernel waits to be dispatched.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             long n, int chunks);
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __restrict__ p1, float* __restrict__ o1, long n1, int nb1,
+                                                              const float* __restrict__ p2, float* __restrict__ o2, long n2, int chunks)
+{
+    const bool second = (int)blockIdx.x >= nb1;
+    const float* partial = second ? p2 : p1;
+    float* out = second ? o2 : o1;
+    const long n = second ? n2 : n1;
+    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const long i = (long)(second ? blockIdx.x - nb1 : blockIdx.x) * 32 + e;
+    __shared__ double red[8][32];
+    double a0 = 0.0, a1 = 0.0;
+    if (i < n) {
+        int c = part;
+        for (; c + 8 < chunks; c += 16) { a0 += (double)partial[(long)c * n + i]; a1 += (double)partial[(long)(c + 8) * n + i]; }
+        if (c < chunks) a0 += (double)partial[(long)c * n + i];
+    }
+    red[part][e] = a0 + a1;
+    __syncthreads();
+    if (part != 0 || i >= n) return;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][e];
+    out[i] = (float)t;
+}
+static void launch_reduce_partials(const float* p1, float* o1, long n1, const float* p2, float* o2, long n2, int chunks, hipStream_t s)
+{
+    const int nb1 = (int)((n1 + 31) / 32);
+    if (o2) hipLaunchKernelGGL(reduce_partials2_kernel, dim3((unsigned)(nb1 + (int)((n2 + 31) / 32))), dim3(256), 0, s, p1, o1, n1, nb1, p2, o2, n2, chunks);
+    else hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)nb1), dim3(256), 0, s, p1, o1, n1, chunks);
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                              long n, int chunks)
 {
@@ -629,8 +664,7 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
         int rc = check_launch("wgrad_cin1");
         if (rc) return rc;
         return reduce_later(s, [=](hipStream_t rs) -> int {
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((27 * 32 + 31) / 32)), dim3(256), 0, rs, partial, dw, (long)27 * 32, slabs);
-            if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, rs, pb, db, (long)32, slabs);
+            launch_reduce_partials(partial, dw, (long)27 * 32, pb, db, 32, slabs, rs);
             return check_launch("reduce_partials");
         });
     }
@@ -646,8 +680,7 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
             const long nw = K * g.Cout;
             const int cout = g.Cout;
             return reduce_later(s, [=](hipStream_t rs) -> int {
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, rs, partial, dw, nw, slabs);
-                if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cout + 31) / 32)), dim3(256), 0, rs, pb, db, (long)cout, slabs);
+                launch_reduce_partials(partial, dw, nw, pb, db, cout, slabs, rs);
                 return check_launch("reduce_partials");
             });
         }
@@ -675,8 +708,7 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     const long nw = K * g.Cout;
     const int cout = g.Cout;
     return reduce_later(s, [=](hipStream_t rs) -> int {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), 0, rs, partial, dw, nw, chunks);
-        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cout + 31) / 32)), dim3(256), 0, rs, partial_b, db, (long)cout, chunks);
+        launch_reduce_partials(partial, dw, nw, partial_b, db, cout, chunks, rs);
         return check_launch("reduce_partials");
     });
 }
