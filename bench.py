@@ -240,11 +240,15 @@ def run_rank(args):
     def stepper(model, data, opt=None):
         x, hr, mask = data
 
+        seed = [None]
+
         def step(full=False, comm_events=None):
             pred = model(x, training=True)
             loss = losses.shiftCompensatedL1Loss(hr, mask, pred)
             model.flat.grad = None
-            loss.backward()
+            if seed[0] is None:
+                seed[0] = torch.ones_like(loss)                # d loss / d loss, as in trainClass.trainStep: one fill launch per step less
+            loss.backward(seed[0])
             if dp:
                 if comm_events is not None:                # (diagnostic leg only: the headline region carries no events inside a step)
                     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

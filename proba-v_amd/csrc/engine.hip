@@ -916,9 +916,17 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         float* tmp = cur; cur = oth; oth = tmp;
         acur = aoth;
     }
-    // mainConv1 (input-facing: no backward-data)
-    CK(conv_wgrad(e, make_geom(B, Hin, T, c.in_channels, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
-                  dweff(e->iMain), dbias(e->iMain), next_part(), Amax(), s));
+    // mainConv1 (input-facing: no backward-data).  What is still queued leaves first, and this layer's own slab sum stays on the launch stream: forked, the
+    // weight-norm backward would wait for an event record, a 10-us kernel on the side stream and the join's record -- 45 us of hole at the end of the pass.
+    CK(reduce_flush(s));
+    {
+        ReduceSide* const ctx = side_guard.c;
+        reduce_side_activate(nullptr);
+        const int rc = conv_wgrad(e, make_geom(B, Hin, T, c.in_channels, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, cur, W + p.act[0],
+                                  dweff(e->iMain), dbias(e->iMain), next_part(), Amax(), s);
+        reduce_side_activate(ctx);
+        if (rc) return rc;
+    }
     CK(reduce_join(s));                                                       // every slab sum has landed in dweff / the bias gradients
     { ProfScope ps(e, CLS_WN, 0.0, s); CK(wn_backward(e->d_layers, (int)e->layers.size(), (int)e->cout_total, params, S + p.dweff2, Winvn, grads, s)); }
     return PROBAV_OK;

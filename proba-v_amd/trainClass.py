@@ -667,7 +667,11 @@ class ModelTrainer:
         predPatchHR = self._model(patchLR, training=True)
         loss = self.loss(patchHR, maskHR, predPatchHR)             # Loss(patchHR, maskHR, predPatchHR)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()                                            # tape.gradient(loss, trainable_variables)
+        # tape.gradient(loss, trainable_variables).  The seed d loss / d loss = 1 is a cached tensor: `loss.backward()` launches a fill kernel for it every step
+        seed = getattr(self, "_grad_seed", None)
+        if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
+            seed = self._grad_seed = torch.ones_like(loss)
+        loss.backward(seed)
         metric = self.metric(patchHR, maskHR, predPatchHR.detach())  # (does not depend on the update: evaluated before the exchange)
         if self._dp():
             # C1 + C2 as ONE collective: the flat gradient with the replica's loss / metric means in its tail
