@@ -586,6 +586,7 @@ void probav_engine_destroy(probav_engine* e)
 {
     if (!e) return;
     for (auto ev : e->prof_ev) (void)hipEventDestroy(ev);
+    reduce_free_pending(&e->side);
     if (e->side.side) {
         (void)hipStreamSynchronize(e->side.side);
         for (auto ev : e->side.ev) (void)hipEventDestroy(ev);

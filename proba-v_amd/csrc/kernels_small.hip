@@ -504,6 +504,10 @@ int reduce_flush(hipStream_t s)
     q->clear();
     return rc;
 }
+void reduce_free_pending(ReduceSide* ctx)
+{
+    if (ctx && ctx->pending) { delete static_cast<PendingList*>(ctx->pending); ctx->pending = nullptr; }
+}
 void reduce_drop_pending()
 {
     ReduceSide* c = g_reduce_side;

@@ -72,6 +72,7 @@ hipStream_t reduce_fork(hipStream_t s);
 hipStream_t reduce_fork_adjacent(hipStream_t s);           // the same point as the caller's previous reduce_fork(s) (nothing enqueued on s in between): no new event
 int reduce_later(hipStream_t s, std::function<int(hipStream_t)> fn);      // fn(reduce_fork(s)) now, or queued until the next reduce_flush (ReduceSide::defer)
 int reduce_flush(hipStream_t s);                            // one fork for everything queued
+void reduce_free_pending(ReduceSide* ctx);                // the engine is going away: release the queue object
 void reduce_drop_pending();                                 // an aborted pass: forget the queue (its closures may point into a dead frame)
 int reduce_join(hipStream_t s);
 // mainConv1 forward (one input channel -> 32, 3x3x3, zero pads of 1): dedicated store-bound kernel; amax = per-sample slots of y or null

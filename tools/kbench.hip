@@ -138,7 +138,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 3; ++k) {
             ConvGeom f{B, hs[k], hs[k], ts[k], 32, hs[k + 1], hs[k + 1], ts[k + 1], 32, 3, 3, 3, 0, 0, 0, 0, 1, 0};             // valid, ReLU
             ConvGeom bd{B, hs[k + 1], hs[k + 1], ts[k + 1], 32, hs[k], hs[k], ts[k], 32, 3, 3, 3, 2, 2, 2, 0, 0, 0};           // its backward-data ("full")
-            if (!partr) hipMalloc(&partr, x6_wgrad_partial_floats(ConvGeom{B, 24, 24, 9, 32, 22, 22, 7, 32, 3, 3, 3, 0, 0, 0, 0, 1, 0}) * 4);
+            if (!partr) hipMalloc(&partr, 2 * x6_wgrad_partial_floats(ConvGeom{B, 24, 24, 9, 32, 22, 22, 7, 32, 3, 3, 3, 0, 0, 0, 0, 1, 0}) * 4);   // (short rows: twice the slabs)
             char nm[96];
             const double gfl = (double)B * hs[k + 1] * hs[k + 1] * ts[k + 1] * 27 * 32 * 32 * 2e-9;
             snprintf(nm, sizeof(nm), "reducer %d forward  (%dx%dx%d out)", k + 1, hs[k + 1], hs[k + 1], ts[k + 1]);
