@@ -153,7 +153,8 @@ def cpu_baseline(seconds=20.0):
 def percentiles(ms):
     s = sorted(ms)
     q = lambda f: s[min(len(s) - 1, max(0, int(round(f * (len(s) - 1)))))]
-    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(s[0], 4), "max": round(s[-1], 4), "n": len(s)}
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(s[0], 4), "max": round(s[-1], 4), "n": len(s),
+            "argmax": max(range(len(ms)), key=lambda i: ms[i])}       # which step of the timed region was the slowest (0 = the first)
 
 
 def dry_run(args, world, rank):
@@ -303,6 +304,8 @@ def run_rank(args):
     if args.side_stream_mode < 0:       # untimed, behind the W warm-up steps: the trainer does the same at the start of training (trainClass.ModelTrainer)
         args.side_stream_mode, side_probe = model.tune_side_stream(step)
         side_probe = {str(k): round(v, 4) for k, v in side_probe.items()}
+        for _ in range(3):              # the probe ends by switching modes: the first step in the kept mode (new fork / join pattern, slabs of the other
+            step()                      # mode's layout cold) is not a step of the steady state -- three untimed ones stand between it and the timed region
         sync()
     use_events = not args.no_kernel_events
     n = len(CLASSES)
@@ -441,8 +444,10 @@ def run_rank(args):
         rng = np.random.default_rng(7)
         frames = torch.as_tensor(np.clip(rng.normal(synth.NIR_MEAN, synth.NIR_STD, (32, 9, 128, 128)), 0, 16383).astype(np.float32)).to(dev)
         inf = {}
-        for name, mb, reps in (("batched_2048", 2048, 6), ("reference_micro_batch_16", 16, 3)):
-            run = lambda: testClass.resolve_images(model, testClass.unfold_frames(frames), micro_batch=mb)
+        # reference_micro_batch_16: the drop-in default for test.py:125's batch_size=16 -- the micro-batches are coalesced into launch sets (same
+        # pixels bit for bit: tests/test_gpu_parity.py::test_config4_*); launch_sets_of_16: every micro-batch launched on its own, as the reference's loop does
+        for name, mb, lb, reps in (("batched_2048", 2048, None, 6), ("reference_micro_batch_16", 16, None, 6), ("launch_sets_of_16", 16, 16, 3)):
+            run = lambda: testClass.resolve_images(model, testClass.unfold_frames(frames), micro_batch=mb, launch_batch=lb)
             for _ in range(2):                      # the first pass sizes the workspace pool for this batch, the second finds it warm
                 run()
             torch.cuda.synchronize()
@@ -453,7 +458,7 @@ def run_rank(args):
                 torch.cuda.synchronize()
                 each.append(time.perf_counter() - t0)
             d4 = sum(each) / reps
-            inf[name] = {"micro_batch": mb, "images_per_s": round(32 / d4, 2), "patches_per_s": round(32 * 64 / d4, 1), "ms_per_32_images": round(d4 * 1e3, 3),
+            inf[name] = {"micro_batch": mb, "launch_batch": lb if lb else max(mb, testClass.LAUNCH_BATCH), "images_per_s": round(32 / d4, 2), "patches_per_s": round(32 * 64 / d4, 1), "ms_per_32_images": round(d4 * 1e3, 3),
                          "ms_each": [round(e * 1e3, 2) for e in each]}
         assert img.shape == (32, 384, 384)
         other["config4_inference"] = {"workload": "32 image sets x 9 frames of 128x128 resident in HBM -> unfold to 2048 patches of [22,22,9,1] -> forward -> "
@@ -509,6 +514,8 @@ def run_rank(args):
             out["digest"] = digest
         if mfma_probe is not None:
             out["sustained_mfma"] = mfma_probe
+            # the pool's boxes differ by several percent in what their matrix pipe sustains: the headline per sustained TFLOP/s compares builds across boxes
+            out["normalised_value"] = {"value": round(value / world / mfma_probe["tflops"], 4), "unit": "patches/s per sustained fp16-MFMA TFLOP/s (32x32x16), per GPU"}
         if fp32_leg is not None:
             out["fp32_mfma_path"] = fp32_leg
             # the pool's boxes fall into two classes under fp16-MFMA load (~8 % apart on the H3 kernels, < 1 % apart on the fp32-MFMA path):

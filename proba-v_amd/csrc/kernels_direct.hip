@@ -218,7 +218,13 @@ __global__ __launch_bounds__(256) void conv3_up_fwd_kernel(ConvGeom g, const flo
     float* sX = sW + 27 * 32 * 9;                         // [3 rows][Wi][3][32]
     const int tid = threadIdx.x;
     const int rowf = g.Wi * 3 * 32;                        // floats of one input row
-    for (int i = tid; i < 27 * 32 * 9 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(w)[i];      // once per workgroup: the grid is ~one per CU
+    // once per workgroup (the grid is ~one per CU).  The engine's filters are packed tightly behind one another (weff + w_off: 4-byte aligned
+    // only -- upscaleConv1 sits behind residConv1's 81 floats), so the 16-byte copy is taken only when the pointer allows it
+    if ((reinterpret_cast<unsigned long>(w) & 15) == 0) {
+        for (int i = tid; i < 27 * 32 * 9 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(w)[i];
+    } else {
+        for (int i = tid; i < 27 * 32 * 9; i += 256) sW[i] = w[i];
+    }
     const int wo = tid >> 4, kp = tid & 15;                // 16 output columns x 16 parts of the 864 products: part kp = (a, b, c, ci) index = kp + 16 j
     for (int row = blockIdx.x; row < g.N * g.Ho; row += gridDim.x) {
     const int n = row / g.Ho, h = row - n * g.Ho;
@@ -264,7 +270,11 @@ __global__ __launch_bounds__(256) void conv3_up_bwd_data_kernel(ConvGeom g, cons
     float* sD = sW + 27 * 9 * 32;                         // [3 rows][Wi + 4][9] with two zero columns on each side
     const int tid = threadIdx.x;
     const int Wp = g.Wi + 4;
-    for (int i = tid; i < 27 * 9 * 32 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(wT)[i];
+    if ((reinterpret_cast<unsigned long>(wT) & 15) == 0) {        // (see conv3_up_fwd_kernel: weffT + w_off is 4-byte aligned only)
+        for (int i = tid; i < 27 * 9 * 32 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(wT)[i];
+    } else {
+        for (int i = tid; i < 27 * 9 * 32; i += 256) sW[i] = wT[i];
+    }
     __shared__ float red[4];
     for (int row = blockIdx.x; row < g.N * g.Ho; row += gridDim.x) {
     const int n = row / g.Ho, h = row - n * g.Ho;
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void conv3_up_bwd_data_kernel(ConvGeom g, cons
     const int items = g.Wo * 3 * 8;                        // (w, t, group of 4 input channels)
     for (int it = tid; it < items; it += 256) {
         const int cg = it & 7, wt = it >> 3, wo = wt / 3, t = wt - 3 * wo;
-        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);      // (the engine's backward-data has none)
+        float4 acc = bias ? make_float4(bias[4 * cg], bias[4 * cg + 1], bias[4 * cg + 2], bias[4 * cg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);      // (the engine's backward-data has none; scalar reads: the pointer is 4-byte aligned only)
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll

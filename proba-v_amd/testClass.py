@@ -32,13 +32,42 @@ def resolve(model, lr_batch):
     return resolve_device(model, lr_batch).cpu().numpy()
 
 
+LAUNCH_BATCH = 2048        # patches per launch set of the coalesced paths (5.0 GB of workspace at T = 9)
+
+
+def _is_engine_model(model):
+    return hasattr(model, "_handle") and hasattr(model, "flat")
+
+
 def resolveByBatch(model, lr_batch, batch_size=16):
-    """test.py:125-134: micro-batches of `batch_size` plus the remainder, concatenated."""
+    """test.py:125-134: micro-batches of `batch_size` plus the remainder, concatenated.
+
+    The reference slices because its GPU could not hold more; the slices are invisible in the result (they are concatenated in order, and the
+    network has no cross-sample term: models/modelsTF.py:15-43).  On the engine every kernel family is bitwise independent of the batch
+    (tests/test_gpu_h3_range.py::test_forward_is_bitwise_independent_of_the_batch, tests/test_gpu_parity.py::test_config4_*), so the
+    micro-batches are coalesced into launch sets of up to LAUNCH_BATCH patches and the result is the same array, bit for bit, at the
+    batched rate (a 16-patch launch set fills a sixteenth of the device).  Any other callable takes the reference's loop as written
+    (tests/test_ref_plumbing.py holds its call pattern to the reference's own function)."""
+    if _is_engine_model(model) and resolve is _RESOLVE:
+        return resolve_coalesced(model, lr_batch, batch_size).cpu().numpy()
     n, rem = divmod(lr_batch.shape[0], batch_size)
     cache = [resolve(model, lr_batch[batch_size * i: batch_size * (i + 1)]) for i in range(n)]
     if rem:
         cache.append(resolve(model, lr_batch[batch_size * n: batch_size * n + rem]))
     return np.concatenate(cache)
+
+
+_RESOLVE = resolve
+
+
+def resolve_coalesced(model, lr_batch, batch_size=16, launch_batch=None):
+    """`resolveByBatch` on the device: the reference's micro-batches of `batch_size` grouped into launch sets of whole micro-batches
+    (at most `launch_batch` patches, default LAUNCH_BATCH); returns the device tensor [n, 3P, 3P, 1]."""
+    launch_batch = LAUNCH_BATCH if launch_batch is None else launch_batch
+    per = max(1, launch_batch // max(1, batch_size)) * max(1, batch_size)          # whole micro-batches per launch set
+    n = lr_batch.shape[0]
+    outs = [resolve_device(model, lr_batch[i:i + per]) for i in range(0, n, per)]
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 def resolveBySampleAveraging(model, lr_batch, rng=None):
@@ -71,7 +100,10 @@ def reconstruct_from_patches(images):
 
 
 def evaluate(model, X_test_patches, batch_size=16):
-    """test.py:103-111: one stitched prediction per image set."""
+    """test.py:103-111: one stitched prediction per image set.  On the engine the image sets and their micro-batches are coalesced
+    (see `resolveByBatch`): same pixels, one copy back."""
+    if _is_engine_model(model) and resolve is _RESOLVE:
+        return evaluate_device(model, X_test_patches, micro_batch=batch_size)
     return [reconstruct_from_patches(resolveByBatch(model, X_test_patches[i], batch_size))
             for i in range(X_test_patches.shape[0])]
 
@@ -128,24 +160,30 @@ def stitch_device(sr, sets):
     return sr.reshape(sets, n, n, ps, ps).permute(0, 1, 3, 2, 4).reshape(sets, n * ps, n * ps)
 
 
-def resolve_images(model, patches, micro_batch=2048):
+def resolve_images(model, patches, micro_batch=2048, launch_batch=None):
     """All image sets at once: patches [sets, n*n, P+s, P+s, T, 1] -> uint16-range images [sets, 3nP, 3nP] (device tensor).
     Samples are independent in every kernel family (models/modelsTF.py:15-43 has no cross-sample term; the H3 kernels scale their
     operands per sample), so any micro-batch gives bit-identical pixels to the reference's batches of 16
-    (tests/test_gpu_h3_range.py::test_forward_is_bitwise_independent_of_the_batch)."""
+    (tests/test_gpu_h3_range.py::test_forward_is_bitwise_independent_of_the_batch).
+    `micro_batch` is the reference-visible slicing (test.py:125: 16); `launch_batch` is how many patches one launch set of the engine takes:
+    None (default) coalesces whole micro-batches up to max(micro_batch, LAUNCH_BATCH); `launch_batch=micro_batch` launches every micro-batch
+    on its own, as the reference's loop does (the parity tests compare the two bit for bit)."""
     dev = _device_of(model)
     p = torch.as_tensor(patches)
     sets = p.shape[0]
     flat = p.reshape((-1,) + tuple(p.shape[2:]))
+    if launch_batch is None:
+        launch_batch = max(micro_batch, LAUNCH_BATCH)
+    per = max(1, launch_batch // max(1, micro_batch)) * max(1, micro_batch)
     outs = []
-    for i in range(0, flat.shape[0], micro_batch):
-        outs.append(resolve_device(model, flat[i:i + micro_batch].to(dev)))
-    return stitch_device(torch.cat(outs), sets)
+    for i in range(0, flat.shape[0], per):
+        outs.append(resolve_device(model, flat[i:i + per].to(dev)))
+    return stitch_device(torch.cat(outs) if len(outs) > 1 else outs[0], sets)
 
 
-def evaluate_device(model, X_test_patches, micro_batch=2048):
+def evaluate_device(model, X_test_patches, micro_batch=2048, launch_batch=None):
     """test.py:103-111 through the device pipeline: every image set in micro-batches of `micro_batch` patches (16 = the reference's
-    resolveByBatch), clip / round and the 8 x 8 stitch on the device, ONE copy back.  Returns a list of [384, 384, 1] float64 arrays,
-    element for element what `evaluate` returns."""
-    imgs = resolve_images(model, X_test_patches, micro_batch=micro_batch).cpu().numpy().astype(np.float64)
+    resolveByBatch; coalesced into launch sets unless `launch_batch` says otherwise), clip / round and the 8 x 8 stitch on the device, ONE
+    copy back.  Returns a list of [384, 384, 1] float64 arrays, element for element what the reference's `evaluate` returns."""
+    imgs = resolve_images(model, X_test_patches, micro_batch=micro_batch, launch_batch=launch_batch).cpu().numpy().astype(np.float64)
     return [im[:, :, None] for im in imgs]

@@ -397,10 +397,11 @@ def make_optimizer(name, model, learning_rate):
 class _SideStreamTuner:
     """The first training steps pick the engine's side-stream mode (probav_amd/modelsTF.py: WDSRModel.tune_side_stream has the why): windows of 8 steps, modes 2, 1, 2, 1,
     timed by events on the training stream; the faster mode stays.  The steps are ordinary training steps -- both modes compute the same bits."""
-    ORDER, WINDOW = (2, 1, 2, 1), 8
+    ORDER, WINDOW, DEFAULT, NOISE = (2, 1, 2, 1), 8, 2, 0.004
 
     def __init__(self, model):
         self.model, self.k, self.ms, self.ev, self.mode = model, 0, {1: [], 2: []}, None, 2
+        self.voided = False
         flat = getattr(model, "flat", None)
         self.ok = hasattr(model, "set_side_stream_mode") and flat is not None and flat.is_cuda
 
@@ -414,10 +415,11 @@ class _SideStreamTuner:
             if self.ev is not None:
                 self.ev[1].record()
                 self.ev[1].synchronize()
-                self.ms[self.mode].append(self.ev[0].elapsed_time(self.ev[1]) / self.WINDOW)
-                self.ev = None
+                if not self.voided:
+                    self.ms[self.mode].append(self.ev[0].elapsed_time(self.ev[1]) / self.WINDOW)
+                self.ev, self.voided = None, False
             if w == len(self.ORDER):
-                best = min(self.ms, key=lambda m: sorted(self.ms[m])[len(self.ms[m]) // 2])
+                best = self.choose()
                 self.model.set_side_stream_mode(best)
                 logger.info("[ INFO ] engine side-stream mode %d (ms per step by mode: %s)", best, {m: [round(v, 3) for v in vs] for m, vs in self.ms.items()})
                 return True
@@ -427,6 +429,32 @@ class _SideStreamTuner:
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.ev[0].record()
         return False
+
+    def void(self):
+        """The current window contains something that is not a training step (evaluation, checkpoint): drop it."""
+        if self.ev is not None:
+            self.voided = True
+
+    def choose(self):
+        """The faster mode by the windows' medians; the default when a mode has no valid window or the two are within NOISE of each other.
+        Data parallel: every rank takes rank 0's choice (a rank's windows include its wait for the others in the all-reduce; ranks in
+        different modes would compute the same bits at different speeds)."""
+        med = {m: (sorted(v)[len(v) // 2] if v else None) for m, v in self.ms.items()}
+        best = self.DEFAULT
+        if all(v is not None for v in med.values()):
+            cand = min(med, key=med.get)
+            other = max(med, key=med.get)
+            if cand != self.DEFAULT and med[other] - med[cand] <= self.NOISE * med[other]:
+                logger.info("[ INFO ] side-stream modes within %.1f %% of each other: the default stays", 100 * self.NOISE)
+            else:
+                best = cand
+        active, world = dp_state()
+        if active and world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([best], dtype=torch.int32, device=self.model.flat.device)
+            dist.broadcast(t, src=0)
+            best = int(t.item())
+        return best
 
 
 class ModelTrainer:
@@ -612,14 +640,26 @@ class ModelTrainer:
         late = _LateScalars(emit, self._device())
         tuner = _SideStreamTuner(self.model) if os.environ.get("PROBAV_SIDE_STREAM_TUNE", "1") != "0" else None
         # The host is at most one step (134 launches) ahead of the device: a generation-2 sweep of the interpreter's collector is a 10-20 ms hole in the launch
-        # stream.  The loop allocates no reference cycles of its own; the collector runs at the evaluation points instead.
+        # stream.  The loop allocates no reference cycles of its own: the automatic collector is OFF inside it (as in bench.py's timed region) and runs by
+        # hand at the evaluation points and every 2000 steps; the caller's setting comes back in the `finally` below.
         import gc
         gc.collect()
-        gc.freeze()
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            self._fit_loop(batches, late, tuner, gc, step, epoch, epochs, globalStep, totalSteps, valData, globalBatchSize, bufferSize, vrng, valSteps, saveBestOnly)
+        finally:
+            if gc_was:
+                gc.enable()
+        late.flush()
+        if self._log is not None:
+            self._log.flush()
+
+    def _fit_loop(self, batches, late, tuner, gc, step, epoch, epochs, globalStep, totalSteps, valData, globalBatchSize, bufferSize, vrng, valSteps, saveBestOnly):
         gc_every = 2000
         for xb, hb, mb in batches:
             if gc_every and self.step % gc_every == gc_every - 1:
-                gc.collect(1)
+                gc.collect()
             if tuner is not None and tuner.tick():
                 tuner = None
             if (totalSteps - step) == 0:
@@ -637,6 +677,9 @@ class ModelTrainer:
 
             if step != 0 and (step % self.evalStep) == 0:
                 late.flush()
+                if tuner is not None:
+                    tuner.void()                        # an evaluation / checkpoint inside a timing window: the window does not count
+                gc.collect()
                 self.testLoss.reset_states()
                 self.testPSNR.reset_states()
                 for k, vidx in enumerate(shuffle_repeat_batch(len(valData[0]), 1, globalBatchSize, bufferSize, vrng, repeat=False)):
@@ -655,9 +698,6 @@ class ModelTrainer:
                 logger.info("[ SAVE ] Saving checkpoint...")
                 self.psnr = testPSNR
                 self.save()
-        late.flush()
-        if self._log is not None:
-            self._log.flush()
 
     # -- one step (models/trainClass.py:124-143) -----------------------------------------------------------
     def _dp(self):

@@ -33,8 +33,8 @@ def parser():
     p.add_argument("--totest", type=str, default="TEST")
     p.add_argument("--micro-batch", type=int, default=2048, help="patches per forward launch; 16 = the reference's resolveByBatch (test.py:125). "
                    "Samples are independent, so the images do not depend on it")
-    p.add_argument("--reference-loop", action="store_true", help="the reference's own host loop: per image set, micro-batches of 16, one "
-                   "device-to-host copy per micro-batch (4x slower; same pixels)")
+    p.add_argument("--reference-loop", action="store_true", help="launch every micro-batch of 16 patches on its own, as the reference's loop does "
+                   "(test.py:125-134; 3x slower, same pixels); by default the micro-batches are coalesced into launch sets")
     return p.parse_args()
 
 
@@ -53,7 +53,8 @@ def main(config, opt):
     ckptDir = os.path.join(config["model_out"], "ckpt_%s" % basename, opt.band)
     ModelTrainer(model, None, None, None, ckptDir, os.path.join(config["model_out"], "logs_%s" % basename, opt.band))   # restores the latest checkpoint
     logger.info("[ INFO ] Generating predictions...")
-    y_preds = evaluate(model, patchLR) if opt.reference_loop else evaluate_device(model, patchLR, micro_batch=opt.micro_batch)
+    y_preds = (evaluate_device(model, patchLR, micro_batch=16, launch_batch=16) if opt.reference_loop
+               else evaluate_device(model, patchLR, micro_batch=opt.micro_batch))
 
     band = opt.band.upper()
     toOmit = []

@@ -555,6 +555,9 @@ def test_trainer_and_inference_on_device(dev, tmp_path):
     imgs = testClass.evaluate(m, patches[None], batch_size=16)
     np.testing.assert_array_equal(imgs[0], img)
     np.testing.assert_array_equal(testClass.evaluate_device(m, patches[None], micro_batch=16)[0], img)      # the device pipeline test.py uses
+    np.testing.assert_array_equal(testClass.evaluate_device(m, patches[None], micro_batch=16, launch_batch=16)[0], img)      # ... one launch set per micro-batch
+    looped = np.concatenate([testClass.resolve(m, patches[16 * i:16 * i + 16]) for i in range(4)])       # the reference's loop as written (test.py:125-134)
+    np.testing.assert_array_equal(looped, sr)
     # test.py:137-146, resolveBySampleAveraging: mean of 20 clipped + rounded predictions over compounding frame permutations
     avg = testClass.resolveBySampleAveraging(m, patches[:4], rng=np.random.default_rng(3)).cpu().numpy()
     rng3, xp, acc = np.random.default_rng(3), patches[:4], 0.0
@@ -874,8 +877,14 @@ def test_config4_full_size_inference_is_deterministic_and_micro_batch_independen
     assert tuple(full.shape) == (32, 384, 384) and bool((full == full.round()).all()) and float(full.min()) >= 0 and float(full.max()) <= 65536
     again = testClass.resolve_images(m, patches, micro_batch=2048)
     assert torch.equal(full, again)
-    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=16))
-    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=384))
+    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=16, launch_batch=16))       # 128 launch sets of 16 patches, as the reference's loop
+    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=384, launch_batch=384))
+    assert torch.equal(full, testClass.resolve_images(m, patches, micro_batch=16))                        # the drop-in default: micro-batches coalesced
+    # the reference's own entry points (test.py:103-134), coalesced on the engine: the same pixels
+    imgs = testClass.evaluate(m, patches.cpu().numpy(), batch_size=16)
+    np.testing.assert_array_equal(np.stack(imgs)[..., 0], full.cpu().numpy().astype(np.float64))
+    one_set = testClass.resolveByBatch(m, patches[5].cpu().numpy(), batch_size=16)
+    np.testing.assert_array_equal(testClass.stitch_device(torch.as_tensor(one_set), 1)[0].numpy(), full[5].cpu().numpy())
     pt = ot.to_torch_params(params, requires_grad=False)
     for s in (0, 31):
         with torch.no_grad():
