@@ -1,0 +1,631 @@
+// Fused backward of expConv + ReLU + decConv (1x1x1), H3 arithmetic -- ONE WAVE PER SIMD, the whole 512-register file (round 5).
+// Reference semantics: tape.gradient through models/modelsTF.py:179-183 (ResConv3D: expConv_i -> ReLU -> decConv_i).
+//
+// What round 4 measured on pw_bwd_h3t_kernel: two waves per SIMD, 228 VGPRs each, every wave one 32-channel hidden chunk of a tile
+// shared by the eight waves of the workgroup; matrix pipe 41 % busy, the rest dependent chains through LDS hand-offs (both H' and dH' cross the LDS
+// for their transposes, the dX partials of the eight chunks meet there, the two halves of the workgroup alternate phases behind s_barrier).
+// This kernel removes the hand-offs instead of tuning them:
+//   * A WAVE OWNS A TILE.  Four waves per workgroup (one per SIMD), each with its own run of 32-voxel tiles of ONE sample and all eight hidden
+//     chunks of it: the dX contributions of the chunks add up in the MFMA accumulator (no partials in LDS), a wave stages its own rows (no
+//     staging hand-off), and the tile loop holds no s_barrier at all.
+//   * THE HIDDEN CHANNEL SITS ON THE LANE.  (a) and (b) are issued with the data as the A operand: H^T[voxel][hidden] = X W1c, dH^T = dT W2c^T.
+//     Bias, ReLU and gate are elementwise; the cut registers of H'^T and dH'^T ARE the B operands of (e) dW2c^T += dT^T H' and (d) dW1c += X^T dH'
+//     (both contract over the voxel = the accumulator's row index: cdna_hip_programming.md section 3, 'An accumulator tile as the next MFMA's
+//     operand'), and the bias is one value per lane.  Only dH' crosses the LDS, once, for (c) dX^T += W1c dH'^T.
+//   * 256 ACCUMULATOR REGISTERS: dW1c and dW2c^T of all eight chunks stay in a[0:255] for the whole run (asm MFMAs with "+a" operands); the
+//     tile-local accumulators (H, dH, dX) are VGPR-form builtins (this unit is compiled with -mllvm -amdgpu-mfma-vgpr-form: build flags
+//     in __graft_entry__.py), so the vector instructions read them without v_accvgpr moves.
+//   * ONE INSTRUCTION STREAM, software-pipelined by hand over the chunks: chunk c's vector work (bias/ReLU, gate, the two cuts) runs in the
+//     gaps of (b) of chunk c, (e), (d), (c) of chunk c-1 and (a) of chunk c+1.  One set of H / dH registers: (a) of the next chunk is issued
+//     when the cut of H' is done, (b) when the cut of dH' is.
+// Weights: the three fragment sets (96 KB) live in LDS for the whole launch, read per chunk.  Per wave: X and dT piece images of the current
+// tile (row reads for (a), (b); transposed reads for (d), (e)), one dH' image, the expand biases at the sample's hidden scale.
+// Products and their order inside a tile are those of pw_bwd_h3t_kernel (w1 x0 + w0 x1 + w0 x0 per k-block); what differs is the summation
+// order ACROSS tiles (a wave's run instead of a workgroup's) and across chunks for dX (one accumulator chain instead of eight partials).
+#include "kernels_x6.h"
+#include "x6_device.h"
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
+namespace probav {
+#ifdef PW4_DIAG                 // tools/pw4bench.hip includes this file as probav::diag (stamped / ablated builds beside the product's copy in the library)
+namespace diag {
+#endif
+#ifdef PW4_STAMP                // diagnostic build only: cycles per phase, summed over a wave's run -- [wave][slot]: 0 (b), 1 (e), 2 (d), 3 (c), 4 (a) of the chunk iterations, 5 / 6 / 7 thirds of the boundary, 8 whole run, 9 100-MHz ticks of the run
+__device__ unsigned long long g_pw4_stamps[1024 * 16];
+#define PW4_ST(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define PW4_ST(k) do { } while (0)
+#endif
+
+// timing-only ablations of the diagnostic build (tools/pw4diag.hip; every one of them computes wrong results): PW4_ABL_NOMFMA no matrix instruction,
+// PW4_ABL_NOVALU no bias / ReLU / gate / cut, PW4_ABL_NOLDS no LDS read inside the chunk iterations
+#ifdef PW4_ABL_NOMFMA
+#define PW4_MFMA_V(a, b, c) (c)
+#else
+#define PW4_MFMA_V(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a).h, (b).h, (c), 0, 0, 0)
+#endif
+// accumulator in the AGPR half of the file.  The A / B operands are never written by the instruction in front of the statement: they come out of
+// LDS reads (the compiler's s_waitcnt stands in front) or were cut one chunk earlier.
+// (hipcc pads nothing inside an asm statement: a VALU write of an operand needs two wait states in front of the MFMA that reads it.  In the tile loop the operands
+// are LDS reads or cuts of the chunk before; tools/pw4_audit.py -- run by tests/test_pw4_audit.py on every build -- holds the emitted code to it.  PW4_MFMA_AS carries
+// the wait states itself: the boundary in FRONT of a run takes zero fragments that the compiler materialises right where they are used.)
+#ifdef PW4_ABL_NOMFMA
+#define PW4_MFMA_A(acc, a, b) asm volatile("" : "+a"(acc) : "v"((a).h), "v"((b).h))
+#define PW4_MFMA_AS(acc, a, b) asm volatile("" : "+a"(acc) : "v"((a).h), "v"((b).h))
+#else
+#define PW4_MFMA_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"((a).h), "v"((b).h))
+#define PW4_MFMA_AS(acc, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"((a).h), "v"((b).h))
+#endif
+#define PW4_MFMA_B(acc, a, b) do { if constexpr (FIRST) PW4_MFMA_AS(acc, a, b); else PW4_MFMA_A(acc, a, b); } while (0)      // inside the boundary: FIRST = the one in front of a run
+
+constexpr int PW4_WSET = 8 * 2 * 2 * 64 * 16;                 // bytes of one fragment set [8 chunks][2 k-blocks][2 pieces][64 lanes][16 B]
+constexpr int PW4_XI = 0, PW4_DI = 2 * PB_IMG, PW4_GI = 4 * PB_IMG, PW4_SB = PW4_GI + 2 * PS_IMG, PW4_EX = PW4_SB + 1024, PW4_WAVE = PW4_EX + 128;
+constexpr int PW4_TBL = 3 * PW4_WSET + 4 * PW4_WAVE;          // 832 ushort: byte offset of staged dT element f inside a piece image
+constexpr int PW4_LDS = PW4_TBL + 832 * 2;
+
+__global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
+    const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
+    const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
+    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, int nsamp, int vps, int D, int wps, PwAmax am)
+{
+    typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const PW = lds + 3 * PW4_WSET + wave * PW4_WAVE;
+    unsigned char* const XI = PW + PW4_XI;                         // [2 pieces][32 voxels][80 B]
+    unsigned char* const DI = PW + PW4_DI;                         // same for dT (channels D..31 stay zero)
+    unsigned char* const GI = PW + PW4_GI;                         // [2 pieces][32 hidden][64 B] dH' of one chunk (swizzled)
+    float* const SB = reinterpret_cast<float*>(PW + PW4_SB);      // 256 expand biases at the sample's hidden-tile scale
+    int* const EX = reinterpret_cast<int*>(PW + PW4_EX);           // 32: exponent that brings (c)'s accumulator row cin back to true scale
+    unsigned short* const TBL = reinterpret_cast<unsigned short*>(lds + PW4_TBL);
+
+    // ---- this wave's run: tiles [tb, te) of sample n ----
+    const int gw = blockIdx.x * 4 + wave;
+    const int n = gw / wps, jw = gw - n * wps;
+    const bool active = n < nsamp;
+    const int tps = (vps + 31) >> 5;
+    const int tb = active ? (int)((long)tps * jw / wps) : 0, te = active ? (int)((long)tps * (jw + 1) / wps) : 0;
+    const unsigned aw1 = *am.w1, aw2 = *am.w2, ab1 = *am.b1;
+    const int ew1 = h3_exp_w(aw1), ew2 = h3_exp_w(aw2);
+    int ex = 0, ed = 0, eh = 0, eg = 0;
+    if (active) {
+        const unsigned ax = am.x[n], ad = am.dt[n];
+        ex = __builtin_amdgcn_readfirstlane(h3_exp(ax)); ed = __builtin_amdgcn_readfirstlane(h3_exp(ad));
+        eh = __builtin_amdgcn_readfirstlane(h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1)));
+        eg = __builtin_amdgcn_readfirstlane(h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2)));
+    }
+    auto clampexp = [](int k) { return k < -126 ? -126 : k; };
+    const float sx = pow2i(ex), sd = pow2i(ed), ch = pow2i(clampexp(eh - ex - ew1)), cg = pow2i(clampexp(eg - ew2 - ed));
+
+    // ---- prologue: weights, tables, zeroed images ----
+    for (int i = tid; i < 3 * PW4_WSET / 16; i += 256)
+        reinterpret_cast<uint4*>(lds)[i] = i < PW4_WSET / 16 ? w1f[i] : (i < 2 * PW4_WSET / 16 ? w2kf[i - PW4_WSET / 16] : w1cf[i - 2 * PW4_WSET / 16]);
+    for (int i = lane; i < PW4_SB / 16; i += 64) reinterpret_cast<uint4*>(PW)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int f = tid; f < 832; f += 256) { const int v = f / D, o = f - v * D; TBL[f] = (unsigned short)(f < 32 * D ? v * PB_ROW + o * 2 : D * 2); }   // (beyond the tile: voxel 0's zero pad; the value stored there is a zero)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) SB[lane + 64 * k] = b1[lane + 64 * k] * pow2i(eh);
+    if (lane < 32) EX[lane] = -(h3_exp_w(am.w1r[lane]) + eg);
+    __syncthreads();
+
+    // ---- per-lane addresses ----
+    const int li = lane & 15, gcol = (lane >> 4) & 1;
+    const int rowo = col * PB_ROW + half * 16;                                       // row reads of a piece image: + kb * 32 + p * PB_IMG
+    const int tro = (4 * half + (li >> 2)) * PB_ROW + (16 * gcol + 4 * (li & 3)) * 2;    // transposed reads (tr_frag<PB_ROW>): + 16 kb * PB_ROW (+ 8 * PB_ROW) + p * PB_IMG
+    const int s0 = col * 64 + ((half ^ ps_key(col)) << 3);                           // dH' image, stores: s0 ^ (G << 4)
+    int t0;
+    { const int r0 = 4 * half + (li >> 2); t0 = r0 * 64 + (((4 * gcol + (li & 3)) ^ r0) << 3); }
+    auto toff = [&](int kb, int q) { return (t0 ^ ((2 * kb + q) << 3)) + 1024 * kb + 512 * q; };
+    const int wfo = lane * 16;                                                       // a weight fragment: + ((c * 2 + kb) * 2 + p) * 1024
+
+    // ---- global rows through per-tile buffer descriptors (pw_bwd_h3t_kernel): rows beyond a tile load zeros / store nothing; a ghost tile has no rows ----
+    // rows of tile t: none in front of the run (the ghost whose dX rows the first boundary would store) and none beyond the sample; a tile behind the run's end that
+    // still belongs to the sample is the next wave's first one -- staging it into the last boundary is harmless (nothing consumes it) and keeps this branch-free
+    auto t_rows = [&](int t) { int r = vps - 32 * t; r = r < 32 ? r : 32; r = r < 0 ? 0 : r; return t < tb ? 0 : r; };
+    auto tile_rsrc = [&](const float* base, int t, int row_bytes) {
+        const int tc = t < 0 ? 0 : t;
+        const unsigned long p = reinterpret_cast<unsigned long>(base) + (unsigned long)(((long)n * vps + 32L * tc) * row_bytes);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((unsigned long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(t_rows(t) * row_bytes), 0x00020000);
+    };
+
+    // ---- state ----
+    f32x16 dW1[8], dW2t[8];                                        // a[0:255]
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dW1[c][r] = 0.f; dW2t[c][r] = 0.f; }
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    f32x16 H = zero, dH = zero, dx = zero;                         // VGPRs
+    Frag hp[2][2], gp[2][2];                                       // [k-block][piece]: cut H'^T / dH'^T of the chunk before the current one
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { hp[kb][p].u = make_uint4(0u, 0u, 0u, 0u); gp[kb][p].u = make_uint4(0u, 0u, 0u, 0u); }
+    Frag w2c[2][2], df[2][2];                                      // operands of (b) of the coming chunk
+    float bc = 0.f;                                                // its bias (this lane's hidden channel)
+    float bs1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // db1 partials: hidden 32 c + col, this lane's 16 voxel rows of every tile
+    float bs2 = 0.f;                                               // db2 partial: out channel col (rows of dT^T), this lane's voxel slots
+    float omax = 0.f;
+    u32x4b xr[4]; unsigned dr[13]; u32x4b dor[4];                  // raw rows in flight: X / dT of the next tile, dOut of the current one
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xr[k] = u32x4b{0u, 0u, 0u, 0u}; dor[k] = u32x4b{0u, 0u, 0u, 0u}; }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) dr[k] = 0u;
+
+#ifdef PW4_STAMP
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto SBAR = [] { __builtin_amdgcn_sched_barrier(0); };
+    // raw rows in flight, requested in pieces from the gaps of chunks 3 .. 5 (a gap takes two or three requests beside its vector work)
+    __amdgpu_buffer_rsrc_t rsx = tile_rsrc(x, tb, 128), rsd = tile_rsrc(dT, tb, 4 * D), rso = tile_rsrc(dOut, tb - 1, 128);
+    auto load_x = [&](int k) __attribute__((always_inline)) {         // X rows of the next tile: this lane's cin 16 kb + 8 half + (0..7) of voxel col, k = 2 kb + (0 | 1)
+        xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsx, col * 128 + half * 32, (k >> 1) * 64 + (k & 1) * 16, 0);
+    };
+    auto load_d = [&](int k) __attribute__((always_inline)) {         // dT of the next tile: element f = lane + 64 k of its [32][D] block
+        dr[k] = __builtin_amdgcn_raw_buffer_load_b32(rsd, 4 * lane, 256 * k, 0);
+    };
+    auto load_o = [&](int G) __attribute__((always_inline)) {         // dOut of the current tile: cin 8 G + 4 half + (0..3) of voxel col
+        dor[G] = __builtin_amdgcn_raw_buffer_load_b128(rso, col * 128 + half * 16, 32 * G, 0);
+    };
+    // LDS reads
+#ifdef PW4_ABL_NOLDS
+    auto undef = [](Frag& f) { asm volatile("" : "=v"(f.u.x), "=v"(f.u.y), "=v"(f.u.z), "=v"(f.u.w)); };
+    auto rd_w = [&](const unsigned char*, int, int, int, Frag& f) { undef(f); };
+    auto rd_row = [&](const unsigned char*, int, int, Frag& f) { undef(f); };
+    auto rd_tr = [&](const unsigned char*, int, int, Frag& f) { undef(f); };
+    auto rd_g = [&](int, int, Frag& f) { undef(f); };
+#else
+    auto rd_w = [&](const unsigned char* set, int c, int kb, int p, Frag& f) { f.u = *reinterpret_cast<const uint4*>(set + wfo + ((c * 2 + kb) * 2 + p) * 1024); };
+    auto rd_row = [&](const unsigned char* img, int kb, int p, Frag& f) { f.u = *reinterpret_cast<const uint4*>(img + rowo + kb * 32 + p * PB_IMG); };
+    auto rd_tr = [&](const unsigned char* img, int kb, int p, Frag& f) {
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+        const unsigned char* q = img + tro + 16 * kb * PB_ROW + p * PB_IMG;
+        f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q));
+        f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 8 * PB_ROW));
+    };
+    auto rd_g = [&](int kb, int p, Frag& f) { tr_frag_sw(GI + p * PS_IMG, toff(kb, 0), toff(kb, 1), f); };
+
+#endif
+    // ---- the vector work of one chunk, in pieces sized for the gaps between MFMAs.  One wave per SIMD issues one vector instruction per ~4.9 cycles (v_cvt_pk 8,
+    // v_fma_mix 8.8; MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): the stream is bound by what it ISSUES (~880 cycles of vector work per chunk beside 960 of
+    // matrix pipe), so every gap carries ~30 cycles of it and nothing that waits: no v_cmp -> v_cndmask pair (a write of VCC and two wait states: 21 cycles per element).
+    // The gate is arithmetic.  H holds relu(hv) >= +0, and a positive H is never subnormal (it is the rounded sum of two fp32 numbers of ordinary magnitude: zero, or
+    // at least 2^-24 of the larger one), so H * 2^127 is 0 or >= 2^3 > cg (cg <= 2^-17, see the bounds): min(H * 2^127, cg) = (H > 0 ? cg : 0) exactly, and dH' = dH * that.
+#ifdef PW4_ABL_NOVALU
+    auto relu1 = [&](int e) { asm volatile("" : "+v"(H[e])); };
+    auto gate1 = [&](int e) { asm volatile("" : "+v"(dH[e]) : "v"(H[e])); };
+    auto db1add = [&](int e, float& bs) { asm volatile("" : "+v"(bs) : "v"(dH[e])); };
+    auto cutHA = [&](int g, uint2& q0) { asm volatile("" : "=v"(q0.x), "=v"(q0.y) : "v"(H[4 * g]), "v"(H[4 * g + 3])); };
+    auto cutHB = [&](int g, const uint2& q0) { asm volatile("" : "+v"(hp[g >> 1][0].u.x), "+v"(hp[g >> 1][1].u.x) : "v"(q0.x), "v"(q0.y)); };
+    auto cutGA = [&](int g, uint2& q0) { asm volatile("" : "=v"(q0.x), "=v"(q0.y) : "v"(dH[4 * g]), "v"(dH[4 * g + 3])); };
+    auto cutGB = [&](int g, const uint2& q0) { asm volatile("" : "+v"(gp[g >> 1][0].u.x), "+v"(gp[g >> 1][1].u.x) : "v"(q0.x), "v"(q0.y)); };
+#else
+    const float big = __uint_as_float(0x7f000000u);               // 2^127
+    auto relu1 = [&](int e) { H[e] = fmaxf(fmaf(H[e], ch, bc), 0.f); };
+    auto gate1 = [&](int e) { dH[e] = dH[e] * fminf(H[e] * big, cg); };
+    auto db1add = [&](int e, float& bs) { bs += dH[e]; };
+    // the cut of registers 4g .. 4g+3 (voxel rows 8g + 4 half + (0..3)) in two parts: A = the first pieces (two v_cvt_pk), B = the second ones (four v_fma_mix) and their
+    // place in the fragments: dwords (g & 1) * 2, + 1 of k-block g >> 1
+    auto cutHA = [&](int g, uint2& q0) {
+        const f32x2 va = {H[4 * g], H[4 * g + 1]}, vb = {H[4 * g + 2], H[4 * g + 3]};
+        q0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, f16x2)); q0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, f16x2));
+    };
+    auto cutHB = [&](int g, const uint2& q0) {
+        uint2 q1;
+        h3_second_pieces2(q0.x, H[4 * g], H[4 * g + 1], q0.y, H[4 * g + 2], H[4 * g + 3], q1.x, q1.y);
+        if (g & 1) { hp[g >> 1][0].u.z = q0.x; hp[g >> 1][0].u.w = q0.y; hp[g >> 1][1].u.z = q1.x; hp[g >> 1][1].u.w = q1.y; }
+        else { hp[g >> 1][0].u.x = q0.x; hp[g >> 1][0].u.y = q0.y; hp[g >> 1][1].u.x = q1.x; hp[g >> 1][1].u.y = q1.y; }
+    };
+    auto cutGA = [&](int g, uint2& q0) {
+        const f32x2 va = {dH[4 * g], dH[4 * g + 1]}, vb = {dH[4 * g + 2], dH[4 * g + 3]};
+        q0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, f16x2)); q0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, f16x2));
+    };
+    auto cutGB = [&](int g, const uint2& q0) {
+        uint2 q1;
+        h3_second_pieces2(q0.x, dH[4 * g], dH[4 * g + 1], q0.y, dH[4 * g + 2], dH[4 * g + 3], q1.x, q1.y);
+        if (g & 1) { gp[g >> 1][0].u.z = q0.x; gp[g >> 1][0].u.w = q0.y; gp[g >> 1][1].u.z = q1.x; gp[g >> 1][1].u.w = q1.y; }
+        else { gp[g >> 1][0].u.x = q0.x; gp[g >> 1][0].u.y = q0.y; gp[g >> 1][1].u.x = q1.x; gp[g >> 1][1].u.y = q1.y; }
+        // the same dwords to the dH' image [hidden = col][voxel]: (c) reads it transposed
+        *reinterpret_cast<uint2*>(GI + (s0 ^ (g << 4))) = q0;
+        *reinterpret_cast<uint2*>(GI + PS_IMG + (s0 ^ (g << 4))) = q1;
+    };
+#endif
+
+    // ---- one chunk iteration: 30 gaps.  C: the chunk whose vector work runs here; PREV: (e), (d), (c) of chunk C-1 are issued; NEXT: (a) of chunk C+1 and the
+    //      operands of its (b).  Order of the matrix work: (b) C | (e) C-1 | (d) C-1 | (c) C-1 | (a) C+1.  Order of the vector work, and why it may stand where it does:
+    //        gaps  1-6   bias + ReLU of H (complete since the previous iteration's last gaps)
+    //        gaps  7-14  the gate, two elements per gap (dH is complete one MFMA behind gap 6)
+    //        gaps 15-22  the cut of H' (hp is free: (e) C-1 has been issued) and the db1 sums        -- H is dead behind gap 22: (a) C+1 starts in gap 25
+    //        gaps 23-30  the cut of dH' (gp and the image are free: (d) C-1 has been issued, the image's reads stand in front of these stores in the wave's LDS order)
+    //      LDS reads are requested four to six gaps ahead of the MFMA that takes them. ----
+    auto iter = [&](auto c_tag, auto prev_tag, auto next_tag, int t) __attribute__((always_inline)) {
+        constexpr int C = decltype(c_tag)::value;
+        constexpr bool PREV = decltype(prev_tag)::value, NEXT = decltype(next_tag)::value;
+        constexpr int P = C - 1, N = C + 1;
+        Frag ae[2][2], at[2][2], gq[2][2], w3[2][2], xf[2][2], w1n[2][2];
+        uint2 qa;
+        float& bs = bs1[C];
+        PW4_ST(4);
+        SBAR();
+        dH = PW4_MFMA_V(df[0][0], w2c[0][1], zero);                                    // gap 1
+        if constexpr (PREV) { rd_tr(DI, 0, 1, ae[0][1]); rd_tr(DI, 0, 0, ae[0][0]); }
+        relu1(0); relu1(1); relu1(2);
+        SBAR();
+        dH = PW4_MFMA_V(df[0][1], w2c[0][0], dH);                                      // 2
+        if constexpr (PREV) { rd_tr(DI, 1, 1, ae[1][1]); rd_tr(DI, 1, 0, ae[1][0]); }
+        relu1(3); relu1(4); relu1(5);
+        SBAR();
+        dH = PW4_MFMA_V(df[0][0], w2c[0][0], dH);                                      // 3
+        relu1(6); relu1(7); relu1(8);
+        SBAR();
+        dH = PW4_MFMA_V(df[1][0], w2c[1][1], dH);                                      // 4
+        if constexpr (PREV) { rd_tr(XI, 0, 1, at[0][1]); rd_tr(XI, 0, 0, at[0][0]); }
+        relu1(9); relu1(10); relu1(11);
+        SBAR();
+        dH = PW4_MFMA_V(df[1][1], w2c[1][0], dH);                                      // 5
+        if constexpr (PREV) { rd_tr(XI, 1, 1, at[1][1]); rd_tr(XI, 1, 0, at[1][0]); }
+        relu1(12); relu1(13);
+        SBAR();
+        dH = PW4_MFMA_V(df[1][0], w2c[1][0], dH);                                      // 6
+        relu1(14); relu1(15);
+        if constexpr (C == 2) { rsx = tile_rsrc(x, t + 1, 128); rsd = tile_rsrc(dT, t + 1, 4 * D); rso = tile_rsrc(dOut, t, 128); }      // (scalar work; xr / dr were consumed by the staging in front of chunk 0)
+        if constexpr (C == 3) { load_x(0); load_x(1); }
+        SBAR();
+        PW4_ST(0);
+        // (e) of chunk C-1: dW2c^T[out][hidden] += dT^T H'
+        if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][1], hp[0][0]);                   // 7
+        if constexpr (C == 3) { load_x(2); load_x(3); }
+        if constexpr (C == 4) { load_d(5); load_d(6); }
+        if constexpr (C == 5) { load_o(0); load_o(1); }
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][0], hp[0][1]);                   // 8
+        gate1(0); gate1(1);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][0], hp[0][0]);                   // 9
+        if constexpr (PREV) { rd_g(0, 1, gq[0][1]); rd_g(0, 0, gq[0][0]); }
+        gate1(2); gate1(3);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][1], hp[1][0]);                   // 10
+        if constexpr (PREV) { rd_g(1, 1, gq[1][1]); rd_g(1, 0, gq[1][0]); }
+        gate1(4); gate1(5);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][0], hp[1][1]);                   // 11
+        if constexpr (C == 3) { load_d(0); load_d(1); }
+        if constexpr (C == 4) { load_d(7); load_d(8); }
+        if constexpr (C == 5) { load_o(2); load_o(3); }
+        gate1(6); gate1(7);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][0], hp[1][0]);                   // 12
+        if constexpr (C == 3) { load_d(2); load_d(3); load_d(4); }
+        if constexpr (C == 4) { load_d(9); load_d(10); }
+        gate1(8); gate1(9);
+        SBAR();
+        PW4_ST(1);
+        // (d) of chunk C-1: dW1c[cin][hidden] += X^T dH'
+        if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][1], gp[0][0]);                    // 13
+        if constexpr (PREV) { rd_w(lds + 2 * PW4_WSET, P, 0, 1, w3[0][1]); rd_w(lds + 2 * PW4_WSET, P, 0, 0, w3[0][0]); }
+        gate1(10); gate1(11);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][1]);                    // 14
+        if constexpr (PREV) { rd_w(lds + 2 * PW4_WSET, P, 1, 1, w3[1][1]); rd_w(lds + 2 * PW4_WSET, P, 1, 0, w3[1][0]); }
+        gate1(12); gate1(13);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][0]);                    // 15
+        if constexpr (C == 4) { load_d(11); load_d(12); }
+        gate1(14); gate1(15);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][1], gp[1][0]);                    // 16
+        cutHA(0, qa); db1add(0, bs); db1add(1, bs); db1add(2, bs);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][0], gp[1][1]);                    // 17
+        cutHB(0, qa);
+        SBAR();
+        if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][0], gp[1][0]);                    // 18
+        cutHA(1, qa); db1add(3, bs); db1add(4, bs); db1add(5, bs);
+        SBAR();
+        PW4_ST(2);
+        // (c) of chunk C-1: dX^T[cin][voxel] += W1c dH'^T (B: the dH' image of chunk C-1)
+        if constexpr (PREV) { if constexpr (P == 0) dx = PW4_MFMA_V(w3[0][1], gq[0][0], zero); else dx = PW4_MFMA_V(w3[0][1], gq[0][0], dx); }      // 19
+        if constexpr (NEXT) { rd_row(XI, 0, 0, xf[0][0]); rd_w(lds, N, 0, 1, w1n[0][1]); }
+        cutHB(1, qa);
+        SBAR();
+        if constexpr (PREV) dx = PW4_MFMA_V(w3[0][0], gq[0][1], dx);                   // 20
+        if constexpr (NEXT) { rd_row(XI, 0, 1, xf[0][1]); rd_w(lds, N, 0, 0, w1n[0][0]); }
+        cutHA(2, qa); db1add(6, bs); db1add(7, bs); db1add(8, bs);
+        SBAR();
+        if constexpr (PREV) dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                   // 21
+        if constexpr (NEXT) { rd_row(XI, 1, 0, xf[1][0]); rd_w(lds, N, 1, 1, w1n[1][1]); }
+        cutHB(2, qa);
+        SBAR();
+        if constexpr (PREV) dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                   // 22
+        if constexpr (NEXT) { rd_row(XI, 1, 1, xf[1][1]); rd_w(lds, N, 1, 0, w1n[1][0]); }
+        cutHA(3, qa); db1add(9, bs); db1add(10, bs); db1add(11, bs);
+        SBAR();
+        if constexpr (PREV) dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                   // 23
+        cutHB(3, qa);
+        SBAR();
+        if constexpr (PREV) dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                   // 24
+        cutGA(0, qa); db1add(12, bs); db1add(13, bs); db1add(14, bs); db1add(15, bs);
+        SBAR();
+        PW4_ST(3);
+        // (a) of chunk C+1: H^T[voxel][hidden] = X W1c (H is free: its cut is done)
+        if constexpr (NEXT) H = PW4_MFMA_V(xf[0][0], w1n[0][1], zero);                 // 25
+        if constexpr (NEXT) { rd_row(DI, 0, 0, df[0][0]); rd_w(lds + PW4_WSET, N, 0, 1, w2c[0][1]); }
+        cutGB(0, qa);
+        SBAR();
+        if constexpr (NEXT) H = PW4_MFMA_V(xf[0][1], w1n[0][0], H);                    // 26
+        if constexpr (NEXT) { rd_row(DI, 0, 1, df[0][1]); rd_w(lds + PW4_WSET, N, 0, 0, w2c[0][0]); }
+        cutGA(1, qa);
+        SBAR();
+        if constexpr (NEXT) H = PW4_MFMA_V(xf[0][0], w1n[0][0], H);                    // 27
+        if constexpr (NEXT) { rd_row(DI, 1, 0, df[1][0]); rd_w(lds + PW4_WSET, N, 1, 1, w2c[1][1]); }
+        cutGB(1, qa);
+        SBAR();
+        if constexpr (NEXT) H = PW4_MFMA_V(xf[1][0], w1n[1][1], H);                    // 28
+        if constexpr (NEXT) { rd_row(DI, 1, 1, df[1][1]); rd_w(lds + PW4_WSET, N, 1, 0, w2c[1][0]); }
+        cutGA(2, qa);
+        SBAR();
+        if constexpr (NEXT) H = PW4_MFMA_V(xf[1][1], w1n[1][0], H);                    // 29
+        if constexpr (NEXT) bc = SB[32 * N + col];
+        cutGB(2, qa); cutGA(3, qa);
+        SBAR();
+        if constexpr (NEXT) H = PW4_MFMA_V(xf[1][0], w1n[1][0], H);                    // 30
+        cutGB(3, qa);
+        SBAR();
+    };
+
+    // ---- between two tiles (24 gaps): (e), (d), (c) of the last chunk of tile t, its dX rows, the staging of tile t+1, (a) of that tile's chunk 0 and the operands of its
+    //      (b).  The images' last reads for tile t are requested first: they stand in front of the staging stores in the wave's LDS order. ----
+    auto boundary = [&](auto first_tag, int t) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        Frag ae[2][2], at[2][2], gq[2][2], w3[2][2], xf[2][2], w1n[2][2];
+        float xs[8];
+        uint2 q0, q1, r0, r1;
+        // this lane's X values: cut into its fragment of the row image (cin 16 kb + 8 half + (0..7) of voxel col)
+        auto xmul = [&](int kb) {
+            const u32x4b a = xr[2 * kb], b = xr[2 * kb + 1];
+            xs[0] = __uint_as_float(a.x) * sx; xs[1] = __uint_as_float(a.y) * sx; xs[2] = __uint_as_float(a.z) * sx; xs[3] = __uint_as_float(a.w) * sx;
+            xs[4] = __uint_as_float(b.x) * sx; xs[5] = __uint_as_float(b.y) * sx; xs[6] = __uint_as_float(b.z) * sx; xs[7] = __uint_as_float(b.w) * sx;
+        };
+        auto xput = [&](int kb) {
+            *reinterpret_cast<uint4*>(XI + rowo + kb * 32) = make_uint4(q0.x, q0.y, r0.x, r0.y);
+            *reinterpret_cast<uint4*>(XI + PB_IMG + rowo + kb * 32) = make_uint4(q1.x, q1.y, r1.x, r1.y);
+        };
+        // element f = lane + 64 k of the next tile's dT block: both pieces to its place in the image (the place comes from a table: f / D and f % D per element
+        // would be a dozen vector instructions)
+        auto dput = [&](int k) {
+            const float v = __uint_as_float(dr[k]) * sd;
+            const _Float16 h0 = (_Float16)v;
+            const unsigned h0b = (unsigned)__builtin_bit_cast(unsigned short, h0);
+            unsigned h1b;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(h1b) : "v"(h0b), "v"(v));
+            const int o = TBL[lane + 64 * k];
+            *reinterpret_cast<unsigned short*>(DI + o) = (unsigned short)h0b;
+            *reinterpret_cast<unsigned short*>(DI + PB_IMG + o) = (unsigned short)h1b;
+        };
+        const unsigned ones = 0x3c003c00u;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        // db2[out] = sum over the voxels of dT: the rows of dT^T are on the lanes (out = col), eight voxel slots per lane and k-block: pieces summed by v_dot2 (fp32 accumulate)
+        auto dsum = [&](const Frag& f) {
+            bs2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f.u.x), __builtin_bit_cast(h2, ones), bs2, false);
+            bs2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f.u.y), __builtin_bit_cast(h2, ones), bs2, false);
+            bs2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f.u.z), __builtin_bit_cast(h2, ones), bs2, false);
+            bs2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f.u.w), __builtin_bit_cast(h2, ones), bs2, false);
+        };
+        const __amdgpu_buffer_rsrc_t ry = tile_rsrc(dX, t, 128);
+        // the dX rows of tile t = dOut + the accumulator at true scale (registers 4G .. 4G+3 = cin 8G + 4 half + (0..3) of voxel col)
+        auto xout = [&](int G) {
+            const int4 e4 = *reinterpret_cast<const int4*>(EX + 8 * G + 4 * half);
+            float o[4];
+            o[0] = ldexpf(dx[4 * G], e4.x) + __uint_as_float(dor[G].x); o[1] = ldexpf(dx[4 * G + 1], e4.y) + __uint_as_float(dor[G].y);
+            o[2] = ldexpf(dx[4 * G + 2], e4.z) + __uint_as_float(dor[G].z); o[3] = ldexpf(dx[4 * G + 3], e4.w) + __uint_as_float(dor[G].w);
+            omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));      // (rows beyond the tile: zeros -- their X, dT and dOut rows were)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4b{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])}, ry, col * 128 + half * 16, 32 * G, 0);
+        };
+        PW4_ST(4);
+        SBAR();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { rd_tr(DI, kb, 1 - p, ae[kb][1 - p]); rd_tr(XI, kb, 1 - p, at[kb][1 - p]); }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { rd_g(kb, 1 - p, gq[kb][1 - p]); rd_w(lds + 2 * PW4_WSET, 7, kb, 1 - p, w3[kb][1 - p]); }
+        xmul(0);
+        SBAR();
+        PW4_MFMA_B(dW2t[7], ae[0][1], hp[0][0]);                                     // gap 1
+        h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
+        SBAR();
+        PW4_MFMA_B(dW2t[7], ae[0][0], hp[0][1]);                                     // 2
+        h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
+        SBAR();
+        PW4_MFMA_B(dW2t[7], ae[0][0], hp[0][0]);                                     // 3
+        xput(0); xmul(1);
+        SBAR();
+        PW4_MFMA_B(dW2t[7], ae[1][1], hp[1][0]);                                     // 4
+        h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
+        SBAR();
+        PW4_MFMA_B(dW2t[7], ae[1][0], hp[1][1]);                                     // 5
+        h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
+        SBAR();
+        PW4_MFMA_B(dW2t[7], ae[1][0], hp[1][0]);                                     // 6
+        xput(1); dsum(ae[0][0]);
+        SBAR();
+        PW4_ST(5);
+        PW4_MFMA_B(dW1[7], at[0][1], gp[0][0]);                                     // 7
+        dsum(ae[0][1]); dput(0);
+        SBAR();
+        PW4_MFMA_B(dW1[7], at[0][0], gp[0][1]);                                     // 8
+        dsum(ae[1][0]); dput(1);
+        SBAR();
+        PW4_MFMA_B(dW1[7], at[0][0], gp[0][0]);                                     // 9
+        dsum(ae[1][1]); dput(2);
+        SBAR();
+        PW4_MFMA_B(dW1[7], at[1][1], gp[1][0]);                                     // 10
+        dput(3); dput(4);
+        SBAR();
+        PW4_MFMA_B(dW1[7], at[1][0], gp[1][1]);                                     // 11
+        dput(5); dput(6);
+        SBAR();
+        PW4_MFMA_B(dW1[7], at[1][0], gp[1][0]);                                     // 12
+        dput(7); dput(8);
+        SBAR();
+        dx = PW4_MFMA_V(w3[0][1], gq[0][0], dx);                                        // 13
+        dput(9); dput(10);
+        SBAR();
+        dx = PW4_MFMA_V(w3[0][0], gq[0][1], dx);                                        // 14
+        rd_row(XI, 0, 0, xf[0][0]); rd_w(lds, 0, 0, 1, w1n[0][1]);
+        dput(11); dput(12);
+        SBAR();
+        dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                                        // 15
+        rd_row(XI, 0, 1, xf[0][1]); rd_w(lds, 0, 0, 0, w1n[0][0]);
+        SBAR();
+        dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                                        // 16
+        rd_row(XI, 1, 0, xf[1][0]); rd_w(lds, 0, 1, 1, w1n[1][1]);
+        SBAR();
+        dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                                        // 17
+        rd_row(XI, 1, 1, xf[1][1]); rd_w(lds, 0, 1, 0, w1n[1][0]);
+        SBAR();
+        dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                                        // 18
+        rd_row(DI, 0, 0, df[0][0]); rd_w(lds + PW4_WSET, 0, 0, 1, w2c[0][1]);
+        SBAR();
+        PW4_ST(6);
+        // (a) of chunk 0 of tile t+1
+        H = PW4_MFMA_V(xf[0][0], w1n[0][1], zero);                                      // 19
+        rd_row(DI, 0, 1, df[0][1]); rd_w(lds + PW4_WSET, 0, 0, 0, w2c[0][0]);
+        SBAR();
+        H = PW4_MFMA_V(xf[0][1], w1n[0][0], H);                                         // 20
+        rd_row(DI, 1, 0, df[1][0]); rd_w(lds + PW4_WSET, 0, 1, 1, w2c[1][1]);
+        xout(0);
+        SBAR();
+        H = PW4_MFMA_V(xf[0][0], w1n[0][0], H);                                         // 21
+        rd_row(DI, 1, 1, df[1][1]); rd_w(lds + PW4_WSET, 0, 1, 0, w2c[1][0]);
+        xout(1);
+        SBAR();
+        H = PW4_MFMA_V(xf[1][0], w1n[1][1], H);                                         // 22
+        bc = SB[col];
+        xout(2);
+        SBAR();
+        H = PW4_MFMA_V(xf[1][1], w1n[1][0], H);                                         // 23
+        xout(3);
+        SBAR();
+        H = PW4_MFMA_V(xf[1][0], w1n[1][0], H);                                         // 24
+        SBAR();
+        PW4_ST(7);
+    };
+
+    // ---- the run ----
+    if (te > tb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_x(k);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) load_d(k);
+        boundary(std::true_type(), tb - 1);                                          // (a ghost in front: zero pieces, zero image, no rows to store)
+        for (int t = tb; t < te; ++t) {
+            iter(std::integral_constant<int, 0>(), std::false_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 1>(), std::true_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 2>(), std::true_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 3>(), std::true_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 4>(), std::true_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 5>(), std::true_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 6>(), std::true_type(), std::true_type(), t);
+            iter(std::integral_constant<int, 7>(), std::true_type(), std::false_type(), t);
+            boundary(std::false_type(), t);
+        }
+        if (am.y) amax_commit(omax, am.y + n);
+    }
+#ifdef PW4_STAMP
+    st_acc[8] = __builtin_amdgcn_s_memtime() - st_c0; st_acc[9] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    if (lane == 0 && gw < 1024) for (int k = 0; k < 10; ++k) g_pw4_stamps[gw * 16 + k] = st_acc[k];
+#endif
+
+    // ---- the four waves' sums at true scale meet in LDS (fixed order), one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D] ----
+    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
+    float* sl = slabs + (long)blockIdx.x * slab_floats;
+    float* R = reinterpret_cast<float*>(lds);                      // [4 waves][8 chunks][16 registers][64 lanes]
+    __syncthreads();                                               // every wave is out of its loop: the weights and images are dead
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane] = ldexpf(dW1[c][r], -(ex + eg));
+    __syncthreads();
+    for (int e = tid; e < 8192; e += 256) {
+        const float v = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
+        const int l = e & 63, r = (e >> 6) & 15, c = e >> 10;
+        sl[(long)rowmap(r, l >> 5) * 256 + 32 * c + (l & 31)] = v;                              // [cin][hidden]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane] = ldexpf(dW2t[c][r], -(ed + eh));
+    float* R1 = R + 4 * 8192;                                      // [4 waves][8 chunks][64 lanes] db1 partials, then [4 waves][64 lanes] db2 partials
+#pragma unroll
+    for (int c = 0; c < 8; ++c) R1[(wave * 8 + c) * 64 + lane] = ldexpf(bs1[c], -eg);
+    R1[4 * 8 * 64 + wave * 64 + lane] = ldexpf(bs2, -ed);
+    __syncthreads();
+    for (int e = tid; e < 8192; e += 256) {
+        const float v = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
+        const int l = e & 63, r = (e >> 6) & 15, c = e >> 10;
+        const int rw = rowmap(r, l >> 5);
+        if (rw < D) sl[8192 + (long)(32 * c + (l & 31)) * D + rw] = v;                          // [hidden][out]
+    }
+    {
+        const int c = tid >> 5, hcol = tid & 31;                   // db1[hidden 32 c + hcol]: both lane halves of the four waves
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += R1[(w * 8 + c) * 64 + hcol] + R1[(w * 8 + c) * 64 + 32 + hcol];
+        sl[8192 + 256 * (long)D + tid] = v;
+        if (tid < D) {
+            float u = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) u += R1[4 * 8 * 64 + w * 64 + tid] + R1[4 * 8 * 64 + w * 64 + 32 + tid];
+            sl[8192 + 256 * (long)D + 256 + tid] = u;
+        }
+    }
+}
+
+static int g_pw4_enabled = -1;
+bool pw4_enabled()
+{
+    if (g_pw4_enabled < 0) g_pw4_enabled = getenv("PROBAV_PW_BWD_H3T") == nullptr;
+    return g_pw4_enabled != 0;
+}
+void pw4_set_enabled(int on) { g_pw4_enabled = on ? 1 : 0; }
+
+bool pw4_backward_supported(long nvox, long vps, int D)
+{
+    if (vps <= 0 || nvox % vps || D > 32 || D < 1 || 32 * D > 832) return false;
+    const long nsamp = nvox / vps;
+    return nsamp >= 1 && nsamp <= 4L * mfma_pw_backward_grid() && vps < (1L << 26);
+}
+
+int pw4_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
+                 const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
+                 const PwAmax& am, hipStream_t s)
+{
+    static std::once_flag once;
+    std::call_once(once, [] { note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    if (!pw4_backward_supported(nvox, vps, D)) { set_error("pw4_backward: unsupported shape", hipSuccess); return PROBAV_EINVAL; }
+    if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("pw4_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+    const int grid = mfma_pw_backward_grid(), nsamp = (int)(nvox / vps);
+    const int wps = 4 * grid / nsamp;                              // waves per sample (>= 1)
+    hipLaunchKernelGGL(pw_bwd_w4_kernel, dim3(grid), dim3(256), PW4_LDS, s, x, dT, dOut, (const uint4*)w1f, (const uint4*)w2kf, (const uint4*)w1cf,
+                       b1, dX, slabs, nsamp, (int)vps, D, wps, am);
+    int rc = check_launch("pw_bwd_w4");
+    if (rc) return rc;
+    return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
+}
+
+#ifdef PW4_DIAG
+}  // namespace diag
+#endif
+}  // namespace probav

@@ -23,6 +23,16 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
                    const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
                    int arith, const PwAmax& am, hipStream_t s);
 
+// the same reverse pass as ONE-WAVE-PER-SIMD kernel (kernels_pw4.hip; H3 arithmetic only): four independent waves per workgroup, each with a run of
+// tiles of one sample and all eight hidden chunks, dW1 / dW2 of the run in 256 accumulator registers.  x6_pw_backward dispatches to it when
+// pw4_backward_supported(); pw4_set_enabled(0) (or PROBAV_PW_BWD_H3T=1 in the environment) keeps round 4's kernel
+bool pw4_backward_supported(long nvox, long vps, int D);
+bool pw4_enabled();
+void pw4_set_enabled(int on);
+int pw4_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
+                 const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
+                 const PwAmax& am, hipStream_t s);
+
 // backward-filter of a 3x3x3 convolution with Cin = 25 or 32 and Cout = 32 (normConv, reducers; pads 0/1, reflect, ReLU gate);
 // partial: x6_wgrad_partial_floats(g) floats
 bool x6_wgrad_supported(const ConvGeom& g);

@@ -451,23 +451,6 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
 // 60 bf16 MFMAs per tile and chunk.  (A first x6 version produced the hidden tile in both orientations instead of
 // transposing -- 84 MFMAs and three cuts per tile; it was bound by the vector issue port: 6.9 VALU instructions per MFMA.)
 // ---------------------------------------------------------------------------------------------------
-constexpr int PB_ROW = 80;                  // bytes per voxel row of a piece image: 32 bf16 + 16 (row reads conflict-free)
-constexpr int PB_IMG = 32 * PB_ROW;
-constexpr int PB_TB = 32 * 33;              // floats of one dX partial
-
-constexpr int PT_ROW = 72;                  // row bytes of a wave's transpose image (only 8-byte accesses)
-constexpr int PT_IMG = 32 * PT_ROW;
-
-template <int ROW>
-__device__ __forceinline__ void tr_frag(const unsigned char* img, int lane, int kb, Frag& f)
-{
-    // operand [row|col = channel lane&31][k-slot j of half h <-> voxel 16kb + 8(j>>2) + 4h + (j&3)] of a [voxel][channel] image
-    const int li = lane & 15, gcol = (lane >> 4) & 1, h = lane >> 5;
-    const unsigned char* p = img + (16 * kb + 4 * h + (li >> 2)) * ROW + (16 * gcol + 4 * (li & 3)) * 2;
-    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-    f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
-    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 8 * ROW));
-}
 // the transpose image of an accumulator tile whose rows (registers) are channels and whose columns (lanes) are voxels: lane
 // (voxel col, half h) owns channels 8G + 4h + (0..3) in registers 4G..4G+3, i.e. the dwords of its cut fragments in order
 template <int NP>
@@ -908,16 +891,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 // 8-byte chunk c of voxel row r of an image at chunk c ^ key(r), key(r) = (r ^ (r >> 3)) & 7; 16-byte chunk q of row r of a partial at
 // chunk q ^ (r & 7) -- conflict-free for the stores, the transposed reads and the 16-byte reads of the sums alike.
 // ---------------------------------------------------------------------------------------------------
-constexpr int PS_IMG = 32 * 64;                     // bytes of one transpose image [32 voxels][32 fp16]
-constexpr int PS_TB = 32 * 32;                      // floats of one dX partial [32 voxels][32 cin]
-__device__ __forceinline__ int ps_key(int row) { return (row ^ (row >> 3)) & 7; }
-__device__ __forceinline__ void tr_frag_sw(const unsigned char* img, int o0, int o1, Frag& f)
-{
-    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-    f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + o0));
-    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + o1));
-}
-
 __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
     const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
     const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
@@ -1421,23 +1394,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
 //  * The second H3 pieces of two pairs are cut by one four-instruction block (lo, lo, hi, hi): the partial-register writes no longer
 //    need an s_nop between them.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void h3_second_pieces2(unsigned h0a, float a0, float a1, unsigned h0b, float b0, float b1, unsigned& ra, unsigned& rb)
-{
-    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(ra), "=&v"(rb) : "v"(h0a), "v"(h0b), "v"(a0), "v"(a1), "v"(b0), "v"(b1));
-}
-// both pieces of four values that already carry their tensor's scale: q0 = {pair a, pair b} first pieces, q1 = second pieces
-__device__ __forceinline__ void h3_cut4_scaled(float a0, float a1, float b0, float b1, uint2& q0, uint2& q1)
-{
-    const f32x2 va = {a0, a1}, vb = {b0, b1};
-    q0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, f16x2));
-    q0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, f16x2));
-    h3_second_pieces2(q0.x, a0, a1, q0.y, b0, b1, q1.x, q1.y);
-}
-
 #ifndef H3T_LOADGAP
 #define H3T_LOADGAP 12
 #endif
@@ -2000,6 +1956,9 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_backward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
+        // round 5: one wave per SIMD, 512 registers, no barrier in the tile loop (kernels_pw4.hip); PROBAV_PW_BWD_H3T=1 / pw4_set_enabled(0): round 4's kernel (A/B runs)
+        if (pw4_enabled() && pw4_backward_supported(nvox, vps, D))
+            return pw4_backward(x, dT, dOut, w1f, w2kf, w1cf, b1, dX, dW1, dW2, db1, db2, slabs, nvox, vps, D, am, s);
         static const bool v1_env = getenv("PROBAV_PW_BWD_V1") != nullptr;      // diagnostic / A-B runs: the one-program form (same bits)
         const bool same_program = v1_env || nvox * 32 >= (1L << 31);            // (the alternating-halves kernel keeps voxel indices in 32-bit scalars)
         if (!same_program) {

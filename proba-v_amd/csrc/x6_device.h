@@ -218,4 +218,53 @@ __device__ __forceinline__ f32x16 mac(const Frag (&a)[AR::NP], const Frag (&b)[A
 __device__ __forceinline__ void split8(const float (&x)[8], Frag (&f)[3]) { cut8<X6>(x, 1.f, f); }
 __device__ __forceinline__ f32x16 mac6(const Frag (&a)[3], const Frag (&b)[3], f32x16 acc) { return mac<X6>(a, b, acc); }
 
+
+// ---- LDS images of the fused pointwise kernels (kernels_x6.hip, kernels_pw4.hip) ----
+constexpr int PB_ROW = 80;                  // bytes per voxel row of a piece image: 32 bf16 + 16 (row reads conflict-free)
+constexpr int PB_IMG = 32 * PB_ROW;
+constexpr int PB_TB = 32 * 33;              // floats of one dX partial
+
+constexpr int PT_ROW = 72;                  // row bytes of a wave's transpose image (only 8-byte accesses)
+constexpr int PT_IMG = 32 * PT_ROW;
+
+template <int ROW>
+__device__ __forceinline__ void tr_frag(const unsigned char* img, int lane, int kb, Frag& f)
+{
+    // operand [row|col = channel lane&31][k-slot j of half h <-> voxel 16kb + 8(j>>2) + 4h + (j&3)] of a [voxel][channel] image
+    const int li = lane & 15, gcol = (lane >> 4) & 1, h = lane >> 5;
+    const unsigned char* p = img + (16 * kb + 4 * h + (li >> 2)) * ROW + (16 * gcol + 4 * (li & 3)) * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 8 * ROW));
+}
+
+constexpr int PS_IMG = 32 * 64;                     // bytes of one transpose image [32 voxels][32 fp16]
+constexpr int PS_TB = 32 * 32;                      // floats of one dX partial [32 voxels][32 cin]
+__device__ __forceinline__ int ps_key(int row) { return (row ^ (row >> 3)) & 7; }
+__device__ __forceinline__ void tr_frag_sw(const unsigned char* img, int o0, int o1, Frag& f)
+{
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + o0));
+    f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + o1));
+}
+
+
+__device__ __forceinline__ void h3_second_pieces2(unsigned h0a, float a0, float a1, unsigned h0b, float b0, float b1, unsigned& ra, unsigned& rb)
+{
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(ra), "=&v"(rb) : "v"(h0a), "v"(h0b), "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+// both pieces of four values that already carry their tensor's scale: q0 = {pair a, pair b} first pieces, q1 = second pieces
+__device__ __forceinline__ void h3_cut4_scaled(float a0, float a1, float b0, float b1, uint2& q0, uint2& q1)
+{
+    const f32x2 va = {a0, a1}, vb = {b0, b1};
+    q0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, f16x2));
+    q0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, f16x2));
+    h3_second_pieces2(q0.x, a0, a1, q0.y, b0, b1, q1.x, q1.y);
+}
+
+
 }  // namespace probav
