@@ -62,14 +62,17 @@ __device__ unsigned long long g_pw4_stamps[1024 * 16];
 
 constexpr int PW4_WSET = 8 * 2 * 2 * 64 * 16;                 // bytes of one fragment set [8 chunks][2 k-blocks][2 pieces][64 lanes][16 B]
 constexpr int PW4_XI = 0, PW4_DI = 2 * PB_IMG, PW4_GI = 4 * PB_IMG, PW4_SB = PW4_GI + 2 * PS_IMG, PW4_EX = PW4_SB + 1024, PW4_WAVE = PW4_EX + 128;
-constexpr int PW4_TBL = 3 * PW4_WSET + 4 * PW4_WAVE;          // 832 ushort: byte offset of staged dT element f inside a piece image
-constexpr int PW4_LDS = PW4_TBL + 832 * 2;
+constexpr int PW4_TBL = 3 * PW4_WSET + 4 * PW4_WAVE;          // [7][64] dwords: byte offsets of the staged dT elements f = lane + 64 (2j), lane + 64 (2j + 1) inside a piece image (low / high half)
+constexpr int PW4_LDS = PW4_TBL + 7 * 64 * 4;
 
 __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
     const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
     const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, int nsamp, int vps, int D, int wps, PwAmax am)
 {
+#ifdef PW4_STAMP
+    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     unsigned char* const GI = PW + PW4_GI;                         // [2 pieces][32 hidden][64 B] dH' of one chunk (swizzled)
     float* const SB = reinterpret_cast<float*>(PW + PW4_SB);      // 256 expand biases at the sample's hidden-tile scale
     int* const EX = reinterpret_cast<int*>(PW + PW4_EX);           // 32: exponent that brings (c)'s accumulator row cin back to true scale
-    unsigned short* const TBL = reinterpret_cast<unsigned short*>(lds + PW4_TBL);
+    unsigned* const TBL = reinterpret_cast<unsigned*>(lds + PW4_TBL);
 
     // ---- this wave's run: tiles [tb, te) of sample n ----
     const int gw = blockIdx.x * 4 + wave;
@@ -101,10 +104,21 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     const float sx = pow2i(ex), sd = pow2i(ed), ch = pow2i(clampexp(eh - ex - ew1)), cg = pow2i(clampexp(eg - ew2 - ed));
 
     // ---- prologue: weights, tables, zeroed images ----
-    for (int i = tid; i < 3 * PW4_WSET / 16; i += 256)
-        reinterpret_cast<uint4*>(lds)[i] = i < PW4_WSET / 16 ? w1f[i] : (i < 2 * PW4_WSET / 16 ? w2kf[i - PW4_WSET / 16] : w1cf[i - 2 * PW4_WSET / 16]);
+    {   // the three fragment sets, 96 KB: all of a thread's 24 requests first, then its stores -- one round trip (a copy loop waits for every request in turn: 9.6 us of prologue)
+        uint4 wq[24];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { wq[k] = w1f[tid + 256 * k]; wq[8 + k] = w2kf[tid + 256 * k]; wq[16 + k] = w1cf[tid + 256 * k]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) reinterpret_cast<uint4*>(lds)[(k >> 3) * (PW4_WSET / 16) + tid + 256 * (k & 7)] = wq[k];
+    }
     for (int i = lane; i < PW4_SB / 16; i += 64) reinterpret_cast<uint4*>(PW)[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int f = tid; f < 832; f += 256) { const int v = f / D, o = f - v * D; TBL[f] = (unsigned short)(f < 32 * D ? v * PB_ROW + o * 2 : D * 2); }   // (beyond the tile: voxel 0's zero pad; the value stored there is a zero)
+    for (int i = tid; i < 7 * 64; i += 256) {                      // (an element beyond the tile's 32 D: voxel 0's zero pad; the value stored there is a zero)
+        const int j = i >> 6, l = i & 63, f0 = l + 128 * j, f1 = f0 + 64;
+        const int v0 = f0 / D, v1 = f1 / D;
+        const unsigned o0 = f0 < 32 * D ? v0 * PB_ROW + (f0 - v0 * D) * 2 : D * 2, o1 = f1 < 32 * D ? v1 * PB_ROW + (f1 - v1 * D) * 2 : D * 2;
+        TBL[i] = o0 | (o1 << 16);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) SB[lane + 64 * k] = b1[lane + 64 * k] * pow2i(eh);
     if (lane < 32) EX[lane] = -(h3_exp_w(am.w1r[lane]) + eg);
@@ -147,7 +161,13 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int p = 0; p < 2; ++p) { hp[kb][p].u = make_uint4(0u, 0u, 0u, 0u); gp[kb][p].u = make_uint4(0u, 0u, 0u, 0u); }
-    Frag w2c[2][2], df[2][2];                                      // operands of (b) of the coming chunk
+    Frag w2c[2][2];                                                // W2 fragments of (b) of the coming chunk
+    Frag xf[2][2], df[2][2];                                       // this lane's rows of the tile's X and dT images (A operands of (a) and (b)): read once per tile, in the boundary
+    Frag at[2][2], ae[2][2];                                       // the same images transposed (A operands of (d) and (e)): likewise
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { at[kb][p].u = make_uint4(0u, 0u, 0u, 0u); ae[kb][p].u = make_uint4(0u, 0u, 0u, 0u); }
     float bc = 0.f;                                                // its bias (this lane's hidden channel)
     float bs1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // db1 partials: hidden 32 c + col, this lane's 16 voxel rows of every tile
     float bs2 = 0.f;                                               // db2 partial: out channel col (rows of dT^T), this lane's voxel slots
@@ -171,27 +191,52 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     auto load_d = [&](int k) __attribute__((always_inline)) {         // dT of the next tile: element f = lane + 64 k of its [32][D] block
         dr[k] = __builtin_amdgcn_raw_buffer_load_b32(rsd, 4 * lane, 256 * k, 0);
     };
+    // The rows are REQUESTED late (chunk 7: their registers are those of the tile's X / dT fragments, dead by then) and TOUCHED early (chunk 2: one byte of every
+    // 128-byte line of the three row blocks, so that the requests of chunk 7 find them in the L2 instead of waiting for HBM in front of the boundary)
+    unsigned touched[3] = {0u, 0u, 0u};                             // (their destinations: read by nobody but an empty asm statement at the boundary -- a use right behind the loads would wait for them)
+    auto touch_next = [&]() __attribute__((always_inline)) {
+        touched[0] = __builtin_amdgcn_raw_buffer_load_b32(rsx, lane * 64, 0, 0);
+        touched[1] = __builtin_amdgcn_raw_buffer_load_b32(rsd, lane * 64, 0, 0);
+        touched[2] = __builtin_amdgcn_raw_buffer_load_b32(rso, lane * 64, 0, 0);
+    };
     auto load_o = [&](int G) __attribute__((always_inline)) {         // dOut of the current tile: cin 8 G + 4 half + (0..3) of voxel col
         dor[G] = __builtin_amdgcn_raw_buffer_load_b128(rso, col * 128 + half * 16, 32 * G, 0);
     };
     // LDS reads
-#ifdef PW4_ABL_NOLDS
+#if defined(PW4_ABL_NOLDS) || defined(PW4_ABL_NOLDS_W) || defined(PW4_ABL_NOLDS_R) || defined(PW4_ABL_NOLDS_T) || defined(PW4_ABL_NOLDS_G)
     auto undef = [](Frag& f) { asm volatile("" : "=v"(f.u.x), "=v"(f.u.y), "=v"(f.u.z), "=v"(f.u.w)); };
+#endif
+#ifdef PW4_ABL_NOLDS
     auto rd_w = [&](const unsigned char*, int, int, int, Frag& f) { undef(f); };
     auto rd_row = [&](const unsigned char*, int, int, Frag& f) { undef(f); };
     auto rd_tr = [&](const unsigned char*, int, int, Frag& f) { undef(f); };
     auto rd_g = [&](int, int, Frag& f) { undef(f); };
 #else
+#ifdef PW4_ABL_NOLDS_W
+    auto rd_w = [&](const unsigned char*, int, int, int, Frag& f) { undef(f); };
+#else
     auto rd_w = [&](const unsigned char* set, int c, int kb, int p, Frag& f) { f.u = *reinterpret_cast<const uint4*>(set + wfo + ((c * 2 + kb) * 2 + p) * 1024); };
+#endif
+#ifdef PW4_ABL_NOLDS_R
+    auto rd_row = [&](const unsigned char*, int, int, Frag& f) { undef(f); };
+#else
     auto rd_row = [&](const unsigned char* img, int kb, int p, Frag& f) { f.u = *reinterpret_cast<const uint4*>(img + rowo + kb * 32 + p * PB_IMG); };
+#endif
+#ifdef PW4_ABL_NOLDS_T
+    auto rd_tr = [&](const unsigned char*, int, int, Frag& f) { undef(f); };
+#else
     auto rd_tr = [&](const unsigned char* img, int kb, int p, Frag& f) {
         typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
         const unsigned char* q = img + tro + 16 * kb * PB_ROW + p * PB_IMG;
         f.hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q));
         f.hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 8 * PB_ROW));
     };
+#endif
+#ifdef PW4_ABL_NOLDS_G
+    auto rd_g = [&](int, int, Frag& f) { undef(f); };
+#else
     auto rd_g = [&](int kb, int p, Frag& f) { tr_frag_sw(GI + p * PS_IMG, toff(kb, 0), toff(kb, 1), f); };
-
+#endif
 #endif
     // ---- the vector work of one chunk, in pieces sized for the gaps between MFMAs.  One wave per SIMD issues one vector instruction per ~4.9 cycles (v_cvt_pk 8,
     // v_fma_mix 8.8; MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): the stream is bound by what it ISSUES (~880 cycles of vector work per chunk beside 960 of
@@ -249,82 +294,80 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         constexpr int C = decltype(c_tag)::value;
         constexpr bool PREV = decltype(prev_tag)::value, NEXT = decltype(next_tag)::value;
         constexpr int P = C - 1, N = C + 1;
-        Frag ae[2][2], at[2][2], gq[2][2], w3[2][2], xf[2][2], w1n[2][2];
+        Frag gq[2][2], w3[2][2], w1n[2][2];
         uint2 qa;
         float& bs = bs1[C];
         PW4_ST(4);
         SBAR();
         dH = PW4_MFMA_V(df[0][0], w2c[0][1], zero);                                    // gap 1
-        if constexpr (PREV) { rd_tr(DI, 0, 1, ae[0][1]); rd_tr(DI, 0, 0, ae[0][0]); }
         relu1(0); relu1(1); relu1(2);
         SBAR();
         dH = PW4_MFMA_V(df[0][1], w2c[0][0], dH);                                      // 2
-        if constexpr (PREV) { rd_tr(DI, 1, 1, ae[1][1]); rd_tr(DI, 1, 0, ae[1][0]); }
         relu1(3); relu1(4); relu1(5);
         SBAR();
         dH = PW4_MFMA_V(df[0][0], w2c[0][0], dH);                                      // 3
         relu1(6); relu1(7); relu1(8);
         SBAR();
         dH = PW4_MFMA_V(df[1][0], w2c[1][1], dH);                                      // 4
-        if constexpr (PREV) { rd_tr(XI, 0, 1, at[0][1]); rd_tr(XI, 0, 0, at[0][0]); }
         relu1(9); relu1(10); relu1(11);
         SBAR();
         dH = PW4_MFMA_V(df[1][1], w2c[1][0], dH);                                      // 5
-        if constexpr (PREV) { rd_tr(XI, 1, 1, at[1][1]); rd_tr(XI, 1, 0, at[1][0]); }
         relu1(12); relu1(13);
         SBAR();
         dH = PW4_MFMA_V(df[1][0], w2c[1][0], dH);                                      // 6
         relu1(14); relu1(15);
         if constexpr (C == 2) { rsx = tile_rsrc(x, t + 1, 128); rsd = tile_rsrc(dT, t + 1, 4 * D); rso = tile_rsrc(dOut, t, 128); }      // (scalar work; xr / dr were consumed by the staging in front of chunk 0)
-        if constexpr (C == 3) { load_x(0); load_x(1); }
+        if constexpr (C == 2) touch_next();
         SBAR();
         PW4_ST(0);
         // (e) of chunk C-1: dW2c^T[out][hidden] += dT^T H'
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][1], hp[0][0]);                   // 7
-        if constexpr (C == 3) { load_x(2); load_x(3); }
-        if constexpr (C == 4) { load_d(5); load_d(6); }
-        if constexpr (C == 5) { load_o(0); load_o(1); }
+        if constexpr (C == 7) { load_x(0); load_x(1); }
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][0], hp[0][1]);                   // 8
+        if constexpr (C == 7) { load_x(2); load_x(3); }
         gate1(0); gate1(1);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][0], hp[0][0]);                   // 9
         if constexpr (PREV) { rd_g(0, 1, gq[0][1]); rd_g(0, 0, gq[0][0]); }
+        if constexpr (C == 7) { load_d(0); load_d(1); load_d(2); }
         gate1(2); gate1(3);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][1], hp[1][0]);                   // 10
         if constexpr (PREV) { rd_g(1, 1, gq[1][1]); rd_g(1, 0, gq[1][0]); }
+        if constexpr (C == 7) { load_d(3); load_d(4); load_d(5); }
         gate1(4); gate1(5);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][0], hp[1][1]);                   // 11
-        if constexpr (C == 3) { load_d(0); load_d(1); }
-        if constexpr (C == 4) { load_d(7); load_d(8); }
-        if constexpr (C == 5) { load_o(2); load_o(3); }
+        if constexpr (C == 7) { load_d(6); load_d(7); load_d(8); }
         gate1(6); gate1(7);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][0], hp[1][0]);                   // 12
-        if constexpr (C == 3) { load_d(2); load_d(3); load_d(4); }
-        if constexpr (C == 4) { load_d(9); load_d(10); }
+        if constexpr (C == 7) { load_d(9); load_d(10); }
         gate1(8); gate1(9);
         SBAR();
         PW4_ST(1);
         // (d) of chunk C-1: dW1c[cin][hidden] += X^T dH'
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][1], gp[0][0]);                    // 13
+        if constexpr (C == 7) { load_o(0); load_o(1); }
         if constexpr (PREV) { rd_w(lds + 2 * PW4_WSET, P, 0, 1, w3[0][1]); rd_w(lds + 2 * PW4_WSET, P, 0, 0, w3[0][0]); }
         gate1(10); gate1(11);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][1]);                    // 14
+        if constexpr (C == 7) { load_o(2); load_o(3); }
         if constexpr (PREV) { rd_w(lds + 2 * PW4_WSET, P, 1, 1, w3[1][1]); rd_w(lds + 2 * PW4_WSET, P, 1, 0, w3[1][0]); }
         gate1(12); gate1(13);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][0]);                    // 15
-        if constexpr (C == 4) { load_d(11); load_d(12); }
+        if constexpr (NEXT) { rd_w(lds, N, 0, 1, w1n[0][1]); rd_w(lds, N, 0, 0, w1n[0][0]); }
+        if constexpr (C == 7) { load_d(11); load_d(12); }
         gate1(14); gate1(15);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][1], gp[1][0]);                    // 16
         cutHA(0, qa); db1add(0, bs); db1add(1, bs); db1add(2, bs);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][0], gp[1][1]);                    // 17
+        if constexpr (NEXT) { rd_w(lds, N, 1, 1, w1n[1][1]); rd_w(lds, N, 1, 0, w1n[1][0]); }
         cutHB(0, qa);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][0], gp[1][0]);                    // 18
@@ -333,47 +376,41 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         PW4_ST(2);
         // (c) of chunk C-1: dX^T[cin][voxel] += W1c dH'^T (B: the dH' image of chunk C-1)
         if constexpr (PREV) { if constexpr (P == 0) dx = PW4_MFMA_V(w3[0][1], gq[0][0], zero); else dx = PW4_MFMA_V(w3[0][1], gq[0][0], dx); }      // 19
-        if constexpr (NEXT) { rd_row(XI, 0, 0, xf[0][0]); rd_w(lds, N, 0, 1, w1n[0][1]); }
         cutHB(1, qa);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[0][0], gq[0][1], dx);                   // 20
-        if constexpr (NEXT) { rd_row(XI, 0, 1, xf[0][1]); rd_w(lds, N, 0, 0, w1n[0][0]); }
+        if constexpr (NEXT) { rd_w(lds + PW4_WSET, N, 0, 1, w2c[0][1]); rd_w(lds + PW4_WSET, N, 0, 0, w2c[0][0]); }
         cutHA(2, qa); db1add(6, bs); db1add(7, bs); db1add(8, bs);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                   // 21
-        if constexpr (NEXT) { rd_row(XI, 1, 0, xf[1][0]); rd_w(lds, N, 1, 1, w1n[1][1]); }
         cutHB(2, qa);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                   // 22
-        if constexpr (NEXT) { rd_row(XI, 1, 1, xf[1][1]); rd_w(lds, N, 1, 0, w1n[1][0]); }
+        if constexpr (NEXT) { rd_w(lds + PW4_WSET, N, 1, 1, w2c[1][1]); rd_w(lds + PW4_WSET, N, 1, 0, w2c[1][0]); }
         cutHA(3, qa); db1add(9, bs); db1add(10, bs); db1add(11, bs);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                   // 23
         cutHB(3, qa);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                   // 24
+        if constexpr (NEXT) bc = SB[32 * N + col];
         cutGA(0, qa); db1add(12, bs); db1add(13, bs); db1add(14, bs); db1add(15, bs);
         SBAR();
         PW4_ST(3);
         // (a) of chunk C+1: H^T[voxel][hidden] = X W1c (H is free: its cut is done)
         if constexpr (NEXT) H = PW4_MFMA_V(xf[0][0], w1n[0][1], zero);                 // 25
-        if constexpr (NEXT) { rd_row(DI, 0, 0, df[0][0]); rd_w(lds + PW4_WSET, N, 0, 1, w2c[0][1]); }
         cutGB(0, qa);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[0][1], w1n[0][0], H);                    // 26
-        if constexpr (NEXT) { rd_row(DI, 0, 1, df[0][1]); rd_w(lds + PW4_WSET, N, 0, 0, w2c[0][0]); }
         cutGA(1, qa);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[0][0], w1n[0][0], H);                    // 27
-        if constexpr (NEXT) { rd_row(DI, 1, 0, df[1][0]); rd_w(lds + PW4_WSET, N, 1, 1, w2c[1][1]); }
         cutGB(1, qa);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[1][0], w1n[1][1], H);                    // 28
-        if constexpr (NEXT) { rd_row(DI, 1, 1, df[1][1]); rd_w(lds + PW4_WSET, N, 1, 0, w2c[1][0]); }
         cutGA(2, qa);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[1][1], w1n[1][0], H);                    // 29
-        if constexpr (NEXT) bc = SB[32 * N + col];
         cutGB(2, qa); cutGA(3, qa);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[1][0], w1n[1][0], H);                    // 30
@@ -385,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     //      (b).  The images' last reads for tile t are requested first: they stand in front of the staging stores in the wave's LDS order. ----
     auto boundary = [&](auto first_tag, int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        Frag ae[2][2], at[2][2], gq[2][2], w3[2][2], xf[2][2], w1n[2][2];
+        Frag gq[2][2], w3[2][2], w1n[2][2];
         float xs[8];
         uint2 q0, q1, r0, r1;
         // this lane's X values: cut into its fragment of the row image (cin 16 kb + 8 half + (0..7) of voxel col)
@@ -400,13 +437,14 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         };
         // element f = lane + 64 k of the next tile's dT block: both pieces to its place in the image (the place comes from a table: f / D and f % D per element
         // would be a dozen vector instructions)
+        unsigned tb2[7];
         auto dput = [&](int k) {
             const float v = __uint_as_float(dr[k]) * sd;
             const _Float16 h0 = (_Float16)v;
             const unsigned h0b = (unsigned)__builtin_bit_cast(unsigned short, h0);
             unsigned h1b;
             asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(h1b) : "v"(h0b), "v"(v));
-            const int o = TBL[lane + 64 * k];
+            const int o = (k & 1) ? (int)(tb2[k >> 1] >> 16) : (int)(tb2[k >> 1] & 0xffffu);
             *reinterpret_cast<unsigned short*>(DI + o) = (unsigned short)h0b;
             *reinterpret_cast<unsigned short*>(DI + PB_IMG + o) = (unsigned short)h1b;
         };
@@ -421,8 +459,9 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         };
         const __amdgpu_buffer_rsrc_t ry = tile_rsrc(dX, t, 128);
         // the dX rows of tile t = dOut + the accumulator at true scale (registers 4G .. 4G+3 = cin 8G + 4 half + (0..3) of voxel col)
+        int4 ex4[4];                                                   // (requested in gap 16, used from gap 20 on: a read right in front of its use waits out the LDS latency)
         auto xout = [&](int G) {
-            const int4 e4 = *reinterpret_cast<const int4*>(EX + 8 * G + 4 * half);
+            const int4 e4 = ex4[G];
             float o[4];
             o[0] = ldexpf(dx[4 * G], e4.x) + __uint_as_float(dor[G].x); o[1] = ldexpf(dx[4 * G + 1], e4.y) + __uint_as_float(dor[G].y);
             o[2] = ldexpf(dx[4 * G + 2], e4.z) + __uint_as_float(dor[G].z); o[3] = ldexpf(dx[4 * G + 3], e4.w) + __uint_as_float(dor[G].w);
@@ -430,15 +469,14 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
             __builtin_amdgcn_raw_buffer_store_b128(u32x4b{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])}, ry, col * 128 + half * 16, 32 * G, 0);
         };
         PW4_ST(4);
+        asm volatile("" :: "v"(touched[0]), "v"(touched[1]), "v"(touched[2]));      // (the touch loads have destinations: this is their only reader)
         SBAR();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) { rd_tr(DI, kb, 1 - p, ae[kb][1 - p]); rd_tr(XI, kb, 1 - p, at[kb][1 - p]); }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
             for (int p = 0; p < 2; ++p) { rd_g(kb, 1 - p, gq[kb][1 - p]); rd_w(lds + 2 * PW4_WSET, 7, kb, 1 - p, w3[kb][1 - p]); }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) tb2[j] = TBL[lane + 64 * j];
         xmul(0);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[0][1], hp[0][0]);                                     // gap 1
@@ -487,15 +525,21 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         SBAR();
         dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                                        // 15
         rd_row(XI, 0, 1, xf[0][1]); rd_w(lds, 0, 0, 0, w1n[0][0]);
+        rd_tr(XI, 0, 1, at[0][1]); rd_tr(XI, 0, 0, at[0][0]);
         SBAR();
         dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                                        // 16
         rd_row(XI, 1, 0, xf[1][0]); rd_w(lds, 0, 1, 1, w1n[1][1]);
+        rd_tr(XI, 1, 1, at[1][1]); rd_tr(XI, 1, 0, at[1][0]);
+#pragma unroll
+        for (int G = 0; G < 4; ++G) ex4[G] = *reinterpret_cast<const int4*>(EX + 8 * G + 4 * half);
         SBAR();
         dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                                        // 17
         rd_row(XI, 1, 1, xf[1][1]); rd_w(lds, 0, 1, 0, w1n[1][0]);
+        rd_tr(DI, 0, 1, ae[0][1]); rd_tr(DI, 0, 0, ae[0][0]);
         SBAR();
         dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                                        // 18
         rd_row(DI, 0, 0, df[0][0]); rd_w(lds + PW4_WSET, 0, 0, 1, w2c[0][1]);
+        rd_tr(DI, 1, 1, ae[1][1]); rd_tr(DI, 1, 0, ae[1][0]);
         SBAR();
         PW4_ST(6);
         // (a) of chunk 0 of tile t+1
@@ -544,20 +588,25 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     }
 #ifdef PW4_STAMP
     st_acc[8] = __builtin_amdgcn_s_memtime() - st_c0; st_acc[9] = __builtin_amdgcn_s_memrealtime() - st_r0;
-    if (lane == 0 && gw < 1024) for (int k = 0; k < 10; ++k) g_pw4_stamps[gw * 16 + k] = st_acc[k];
+    if (lane == 0 && gw < 1024) { for (int k = 0; k < 10; ++k) g_pw4_stamps[gw * 16 + k] = st_acc[k]; g_pw4_stamps[gw * 16 + 10] = st_r0 - st_entry; g_pw4_stamps[gw * 16 + 11] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
     // ---- the four waves' sums at true scale meet in LDS (fixed order), one slab per workgroup: [dW1 32x256 | dW2 256xD | db1 256 | db2 D] ----
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
     float* sl = slabs + (long)blockIdx.x * slab_floats;
+    // (the lane / thread index is taken afresh: a value kept across the tile loop for this epilogue would cost the loop a register -- or a spill)
+    const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), tid2 = wave * 64 + lane2;
     float* R = reinterpret_cast<float*>(lds);                      // [4 waves][8 chunks][16 registers][64 lanes]
     __syncthreads();                                               // every wave is out of its loop: the weights and images are dead
+#ifdef PW4_STAMP
+    if (lane2 == 0 && gw < 1024) g_pw4_stamps[gw * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane] = ldexpf(dW1[c][r], -(ex + eg));
+        for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane2] = ldexpf(dW1[c][r], -(ex + eg));
     __syncthreads();
-    for (int e = tid; e < 8192; e += 256) {
+    for (int e = tid2; e < 8192; e += 256) {
         const float v = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
         const int l = e & 63, r = (e >> 6) & 15, c = e >> 10;
         sl[(long)rowmap(r, l >> 5) * 256 + 32 * c + (l & 31)] = v;                              // [cin][hidden]
@@ -566,31 +615,34 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane] = ldexpf(dW2t[c][r], -(ed + eh));
+        for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane2] = ldexpf(dW2t[c][r], -(ed + eh));
     float* R1 = R + 4 * 8192;                                      // [4 waves][8 chunks][64 lanes] db1 partials, then [4 waves][64 lanes] db2 partials
 #pragma unroll
-    for (int c = 0; c < 8; ++c) R1[(wave * 8 + c) * 64 + lane] = ldexpf(bs1[c], -eg);
-    R1[4 * 8 * 64 + wave * 64 + lane] = ldexpf(bs2, -ed);
+    for (int c = 0; c < 8; ++c) R1[(wave * 8 + c) * 64 + lane2] = ldexpf(bs1[c], -eg);
+    R1[4 * 8 * 64 + wave * 64 + lane2] = ldexpf(bs2, -ed);
     __syncthreads();
-    for (int e = tid; e < 8192; e += 256) {
+    for (int e = tid2; e < 8192; e += 256) {
         const float v = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
         const int l = e & 63, r = (e >> 6) & 15, c = e >> 10;
         const int rw = rowmap(r, l >> 5);
         if (rw < D) sl[8192 + (long)(32 * c + (l & 31)) * D + rw] = v;                          // [hidden][out]
     }
     {
-        const int c = tid >> 5, hcol = tid & 31;                   // db1[hidden 32 c + hcol]: both lane halves of the four waves
+        const int c = tid2 >> 5, hcol = tid2 & 31;                   // db1[hidden 32 c + hcol]: both lane halves of the four waves
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += R1[(w * 8 + c) * 64 + hcol] + R1[(w * 8 + c) * 64 + 32 + hcol];
-        sl[8192 + 256 * (long)D + tid] = v;
-        if (tid < D) {
+        sl[8192 + 256 * (long)D + tid2] = v;
+        if (tid2 < D) {
             float u = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) u += R1[4 * 8 * 64 + w * 64 + tid] + R1[4 * 8 * 64 + w * 64 + 32 + tid];
-            sl[8192 + 256 * (long)D + 256 + tid] = u;
+            for (int w = 0; w < 4; ++w) u += R1[4 * 8 * 64 + w * 64 + tid2] + R1[4 * 8 * 64 + w * 64 + 32 + tid2];
+            sl[8192 + 256 * (long)D + 256 + tid2] = u;
         }
     }
+#ifdef PW4_STAMP
+    if (lane2 == 0 && gw < 1024) g_pw4_stamps[gw * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 static int g_pw4_enabled = -1;

@@ -43,8 +43,9 @@ int main(int argc, char** argv)
         for (int i = 0; i < iters; ++i) run();
         hipEventRecord(eb, 0); hipEventSynchronize(eb);
         float ms = 0; hipEventElapsedTime(&ms, ea, eb);
-        printf("pass %d: %.1f us per launch (stamped build, incl. the slab sum)\n", pass, ms * 1e3 / iters);
+        printf("pass %d: %.1f us per launch (incl. the slab sum)\n", pass, ms * 1e3 / iters);
     }
+#ifdef PW4_STAMP
     std::vector<unsigned long long> st(1024 * 16);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(diag::g_pw4_stamps), st.size() * 8);
     const char* nm[10] = {"(b) + relu", "(e) + gate", "(d) + gate, cut H'", "(c) + cut dH'", "(a) + cut dH', next operands", "boundary: (e), (d), staging", "boundary: (c), reads", "boundary: (a), dX rows", "whole run (cycles)", "whole run (100 MHz ticks)"};
@@ -52,5 +53,15 @@ int main(int argc, char** argv)
     const double tiles = 137.0 / 8.0;
     for (int k = 0; k < 10; ++k) printf("  slot %d  %-34s median %10.0f   per tile %8.0f   per chunk iteration %7.0f\n", k, nm[k], med(k), med(k) / tiles, med(k) / tiles / 8);
     printf("  in-kernel clock %.2f GHz; run %.1f us\n", med(8) / med(9) * 0.1, med(9) * 0.01);
+    {   // outside the loop (100-MHz ticks -> us): prologue (entry -> first barrier passed), wait at the barrier behind the loop, the LDS sums and slab stores
+        std::vector<double> pro, bw, epi, runs;
+        for (int wv = 0; wv < 1024; ++wv) if (st[wv * 16 + 8]) { pro.push_back(st[wv * 16 + 10] * 0.01); bw.push_back((double)(st[wv * 16 + 12] - st[wv * 16 + 11]) * 0.01); epi.push_back((double)(st[wv * 16 + 13] - st[wv * 16 + 12]) * 0.01); runs.push_back(st[wv * 16 + 9] * 0.01); }
+        auto md = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
+        auto mn = [](const std::vector<double>& v) { return *std::min_element(v.begin(), v.end()); };
+        printf("  prologue median %.1f us (max %.1f) | run min %.1f median %.1f max %.1f | wait at the barrier behind the loop median %.1f (max %.1f) | sums + slab stores median %.1f (max %.1f)\n",
+               md(pro), mx(pro), mn(runs), md(runs), mx(runs), md(bw), mx(bw), md(epi), mx(epi));
+    }
+#endif
     return 0;
 }
