@@ -62,8 +62,7 @@ __device__ unsigned long long g_pw4_stamps[1024 * 16];
 
 constexpr int PW4_WSET = 8 * 2 * 2 * 64 * 16;                 // bytes of one fragment set [8 chunks][2 k-blocks][2 pieces][64 lanes][16 B]
 constexpr int PW4_XI = 0, PW4_DI = 2 * PB_IMG, PW4_GI = 4 * PB_IMG, PW4_SB = PW4_GI + 2 * PS_IMG, PW4_EX = PW4_SB + 1024, PW4_WAVE = PW4_EX + 128;
-constexpr int PW4_TBL = 3 * PW4_WSET + 4 * PW4_WAVE;          // [7][64] dwords: byte offsets of the staged dT elements f = lane + 64 (2j), lane + 64 (2j + 1) inside a piece image (low / high half)
-constexpr int PW4_LDS = PW4_TBL + 7 * 64 * 4;
+constexpr int PW4_LDS = 3 * PW4_WSET + 4 * PW4_WAVE;
 
 __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
@@ -83,7 +82,6 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     unsigned char* const GI = PW + PW4_GI;                         // [2 pieces][32 hidden][64 B] dH' of one chunk (swizzled)
     float* const SB = reinterpret_cast<float*>(PW + PW4_SB);      // 256 expand biases at the sample's hidden-tile scale
     int* const EX = reinterpret_cast<int*>(PW + PW4_EX);           // 32: exponent that brings (c)'s accumulator row cin back to true scale
-    unsigned* const TBL = reinterpret_cast<unsigned*>(lds + PW4_TBL);
 
     // ---- this wave's run: tiles [tb, te) of sample n ----
     const int gw = blockIdx.x * 4 + wave;
@@ -113,12 +111,6 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         for (int k = 0; k < 24; ++k) reinterpret_cast<uint4*>(lds)[(k >> 3) * (PW4_WSET / 16) + tid + 256 * (k & 7)] = wq[k];
     }
     for (int i = lane; i < PW4_SB / 16; i += 64) reinterpret_cast<uint4*>(PW)[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < 7 * 64; i += 256) {                      // (an element beyond the tile's 32 D: voxel 0's zero pad; the value stored there is a zero)
-        const int j = i >> 6, l = i & 63, f0 = l + 128 * j, f1 = f0 + 64;
-        const int v0 = f0 / D, v1 = f1 / D;
-        const unsigned o0 = f0 < 32 * D ? v0 * PB_ROW + (f0 - v0 * D) * 2 : D * 2, o1 = f1 < 32 * D ? v1 * PB_ROW + (f1 - v1 * D) * 2 : D * 2;
-        TBL[i] = o0 | (o1 << 16);
-    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) SB[lane + 64 * k] = b1[lane + 64 * k] * pow2i(eh);
     if (lane < 32) EX[lane] = -(h3_exp_w(am.w1r[lane]) + eg);
@@ -172,11 +164,11 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     float bs1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // db1 partials: hidden 32 c + col, this lane's 16 voxel rows of every tile
     float bs2 = 0.f;                                               // db2 partial: out channel col (rows of dT^T), this lane's voxel slots
     float omax = 0.f;
-    u32x4b xr[4]; unsigned dr[13]; u32x4b dor[4];                  // raw rows in flight: X / dT of the next tile, dOut of the current one
+    u32x4b xr[4]; unsigned dr[16]; u32x4b dor[4];                  // raw rows in flight: X / dT of the next tile, dOut of the current one
 #pragma unroll
     for (int k = 0; k < 4; ++k) { xr[k] = u32x4b{0u, 0u, 0u, 0u}; dor[k] = u32x4b{0u, 0u, 0u, 0u}; }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) dr[k] = 0u;
+    for (int k = 0; k < 16; ++k) dr[k] = 0u;
 
 #ifdef PW4_STAMP
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
@@ -188,8 +180,10 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     auto load_x = [&](int k) __attribute__((always_inline)) {         // X rows of the next tile: this lane's cin 16 kb + 8 half + (0..7) of voxel col, k = 2 kb + (0 | 1)
         xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsx, col * 128 + half * 32, (k >> 1) * 64 + (k & 1) * 16, 0);
     };
-    auto load_d = [&](int k) __attribute__((always_inline)) {         // dT of the next tile: element f = lane + 64 k of its [32][D] block
-        dr[k] = __builtin_amdgcn_raw_buffer_load_b32(rsd, 4 * lane, 256 * k, 0);
+    // dT rows of the next tile: like X, this lane's out channels 16 kb + 8 half + (0..7) of voxel col, k = 8 kb + (0..7) -- single dwords (a row is 4 D bytes: no wider
+    // alignment).  Channels >= D of the last slice are the NEXT row's first values: they are multiplied by zero when the slice is cut (sdz)
+    auto load_d = [&](int k) __attribute__((always_inline)) {
+        dr[k] = __builtin_amdgcn_raw_buffer_load_b32(rsd, col * 4 * D + half * 32, (k >> 3) * 64 + (k & 7) * 4, 0);
     };
     // The rows are REQUESTED late (chunk 7: their registers are those of the tile's X / dT fragments, dead by then) and TOUCHED early (chunk 2: one byte of every
     // 128-byte line of the three row blocks, so that the requests of chunk 7 find them in the L2 instead of waiting for HBM in front of the boundary)
@@ -359,8 +353,9 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         gate1(12); gate1(13);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][0]);                    // 15
+        if constexpr (C == 7) { load_d(14); load_d(15); }
         if constexpr (NEXT) { rd_w(lds, N, 0, 1, w1n[0][1]); rd_w(lds, N, 0, 0, w1n[0][0]); }
-        if constexpr (C == 7) { load_d(11); load_d(12); }
+        if constexpr (C == 7) { load_d(11); load_d(12); load_d(13); }
         gate1(14); gate1(15);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][1], gp[1][0]);                    // 16
@@ -437,16 +432,16 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         };
         // element f = lane + 64 k of the next tile's dT block: both pieces to its place in the image (the place comes from a table: f / D and f % D per element
         // would be a dozen vector instructions)
-        unsigned tb2[7];
-        auto dput = [&](int k) {
-            const float v = __uint_as_float(dr[k]) * sd;
-            const _Float16 h0 = (_Float16)v;
-            const unsigned h0b = (unsigned)__builtin_bit_cast(unsigned short, h0);
-            unsigned h1b;
-            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(h1b) : "v"(h0b), "v"(v));
-            const int o = (k & 1) ? (int)(tb2[k >> 1] >> 16) : (int)(tb2[k >> 1] & 0xffffu);
-            *reinterpret_cast<unsigned short*>(DI + o) = (unsigned short)h0b;
-            *reinterpret_cast<unsigned short*>(DI + PB_IMG + o) = (unsigned short)h1b;
+        // this lane's dT values: the same, into the dT image (channels 16 kb + 8 half + (0..7) of voxel col; those >= D are zeros: the last slice of the upper lane half
+        // holds channel 24 and seven values of the next row, which its scale sdz = 0 removes)
+        const float sdz = half ? 0.f : sd;                             // (D = 25: slice kb = 1 of the upper half holds channel 24, then the next row)
+        auto dmul = [&](int kb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[j] = __uint_as_float(dr[8 * kb + j]) * ((kb == 0 || j == 0) ? sd : sdz);
+        };
+        auto dputv = [&](int kb) {
+            *reinterpret_cast<uint4*>(DI + rowo + kb * 32) = make_uint4(q0.x, q0.y, r0.x, r0.y);
+            *reinterpret_cast<uint4*>(DI + PB_IMG + rowo + kb * 32) = make_uint4(q1.x, q1.y, r1.x, r1.y);
         };
         const unsigned ones = 0x3c003c00u;
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -475,8 +470,6 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int p = 0; p < 2; ++p) { rd_g(kb, 1 - p, gq[kb][1 - p]); rd_w(lds + 2 * PW4_WSET, 7, kb, 1 - p, w3[kb][1 - p]); }
-#pragma unroll
-        for (int j = 0; j < 7; ++j) tb2[j] = TBL[lane + 64 * j];
         xmul(0);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[0][1], hp[0][0]);                                     // gap 1
@@ -486,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[0][0], hp[0][0]);                                     // 3
-        xput(0); xmul(1);
+        xput(0); xf[0][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); xf[0][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y); xmul(1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[1][1], hp[1][0]);                                     // 4
         h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
@@ -495,63 +488,62 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[1][0], hp[1][0]);                                     // 6
-        xput(1); dsum(ae[0][0]);
+        xput(1); xf[1][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); xf[1][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y); dsum(ae[0][0]);
         SBAR();
         PW4_ST(5);
         PW4_MFMA_B(dW1[7], at[0][1], gp[0][0]);                                     // 7
-        dsum(ae[0][1]); dput(0);
+        dsum(ae[0][1]); dmul(0);
         SBAR();
         PW4_MFMA_B(dW1[7], at[0][0], gp[0][1]);                                     // 8
-        dsum(ae[1][0]); dput(1);
+        dsum(ae[1][0]); h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[0][0], gp[0][0]);                                     // 9
-        dsum(ae[1][1]); dput(2);
+        dsum(ae[1][1]); h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[1][1], gp[1][0]);                                     // 10
-        dput(3); dput(4);
+        dputv(0); df[0][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); df[0][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y); dmul(1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[1][0], gp[1][1]);                                     // 11
-        dput(5); dput(6);
+        h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[1][0], gp[1][0]);                                     // 12
-        dput(7); dput(8);
+        h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         dx = PW4_MFMA_V(w3[0][1], gq[0][0], dx);                                        // 13
-        dput(9); dput(10);
+        dputv(1); df[1][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); df[1][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y);
+        rd_w(lds, 0, 0, 1, w1n[0][1]);
         SBAR();
         dx = PW4_MFMA_V(w3[0][0], gq[0][1], dx);                                        // 14
-        rd_row(XI, 0, 0, xf[0][0]); rd_w(lds, 0, 0, 1, w1n[0][1]);
-        dput(11); dput(12);
         SBAR();
         dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                                        // 15
-        rd_row(XI, 0, 1, xf[0][1]); rd_w(lds, 0, 0, 0, w1n[0][0]);
+        rd_w(lds, 0, 0, 0, w1n[0][0]);
         rd_tr(XI, 0, 1, at[0][1]); rd_tr(XI, 0, 0, at[0][0]);
         SBAR();
         dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                                        // 16
-        rd_row(XI, 1, 0, xf[1][0]); rd_w(lds, 0, 1, 1, w1n[1][1]);
+        rd_w(lds, 0, 1, 1, w1n[1][1]);
         rd_tr(XI, 1, 1, at[1][1]); rd_tr(XI, 1, 0, at[1][0]);
 #pragma unroll
         for (int G = 0; G < 4; ++G) ex4[G] = *reinterpret_cast<const int4*>(EX + 8 * G + 4 * half);
         SBAR();
         dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                                        // 17
-        rd_row(XI, 1, 1, xf[1][1]); rd_w(lds, 0, 1, 0, w1n[1][0]);
+        rd_w(lds, 0, 1, 0, w1n[1][0]);
         rd_tr(DI, 0, 1, ae[0][1]); rd_tr(DI, 0, 0, ae[0][0]);
         SBAR();
         dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                                        // 18
-        rd_row(DI, 0, 0, df[0][0]); rd_w(lds + PW4_WSET, 0, 0, 1, w2c[0][1]);
+        rd_w(lds + PW4_WSET, 0, 0, 1, w2c[0][1]);
         rd_tr(DI, 1, 1, ae[1][1]); rd_tr(DI, 1, 0, ae[1][0]);
         SBAR();
         PW4_ST(6);
         // (a) of chunk 0 of tile t+1
         H = PW4_MFMA_V(xf[0][0], w1n[0][1], zero);                                      // 19
-        rd_row(DI, 0, 1, df[0][1]); rd_w(lds + PW4_WSET, 0, 0, 0, w2c[0][0]);
+        rd_w(lds + PW4_WSET, 0, 0, 0, w2c[0][0]);
         SBAR();
         H = PW4_MFMA_V(xf[0][1], w1n[0][0], H);                                         // 20
-        rd_row(DI, 1, 0, df[1][0]); rd_w(lds + PW4_WSET, 0, 1, 1, w2c[1][1]);
+        rd_w(lds + PW4_WSET, 0, 1, 1, w2c[1][1]);
         xout(0);
         SBAR();
         H = PW4_MFMA_V(xf[0][0], w1n[0][0], H);                                         // 21
-        rd_row(DI, 1, 1, df[1][1]); rd_w(lds + PW4_WSET, 0, 1, 0, w2c[1][0]);
+        rd_w(lds + PW4_WSET, 0, 1, 0, w2c[1][0]);
         xout(1);
         SBAR();
         H = PW4_MFMA_V(xf[1][0], w1n[1][1], H);                                         // 22
@@ -571,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_x(k);
 #pragma unroll
-        for (int k = 0; k < 13; ++k) load_d(k);
+        for (int k = 0; k < 16; ++k) load_d(k);
         boundary(std::true_type(), tb - 1);                                          // (a ghost in front: zero pieces, zero image, no rows to store)
         for (int t = tb; t < te; ++t) {
             iter(std::integral_constant<int, 0>(), std::false_type(), std::true_type(), t);
@@ -655,7 +647,7 @@ void pw4_set_enabled(int on) { g_pw4_enabled = on ? 1 : 0; }
 
 bool pw4_backward_supported(long nvox, long vps, int D)
 {
-    if (vps <= 0 || nvox % vps || D > 32 || D < 1 || 32 * D > 832) return false;
+    if (vps <= 0 || nvox % vps || D != 25) return false;        // (the dT staging knows where channel D - 1 sits in a lane's slices; every network of the reference has D = int(32 * 0.8) = 25)
     const long nsamp = nvox / vps;
     return nsamp >= 1 && nsamp <= 4L * mfma_pw_backward_grid() && vps < (1L << 26);
 }
