@@ -241,10 +241,10 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     auto relu1 = [&](int e) { asm volatile("" : "+v"(H[e])); };
     auto gate1 = [&](int e) { asm volatile("" : "+v"(dH[e]) : "v"(H[e])); };
     auto db1add = [&](int e, float& bs) { asm volatile("" : "+v"(bs) : "v"(dH[e])); };
-    auto cutHA = [&](int g, uint2& q0) { asm volatile("" : "=v"(q0.x), "=v"(q0.y) : "v"(H[4 * g]), "v"(H[4 * g + 3])); };
-    auto cutHB = [&](int g, const uint2& q0) { asm volatile("" : "+v"(hp[g >> 1][0].u.x), "+v"(hp[g >> 1][1].u.x) : "v"(q0.x), "v"(q0.y)); };
-    auto cutGA = [&](int g, uint2& q0) { asm volatile("" : "=v"(q0.x), "=v"(q0.y) : "v"(dH[4 * g]), "v"(dH[4 * g + 3])); };
-    auto cutGB = [&](int g, const uint2& q0) { asm volatile("" : "+v"(gp[g >> 1][0].u.x), "+v"(gp[g >> 1][1].u.x) : "v"(q0.x), "v"(q0.y)); };
+    auto cutHA = [&](int g, uint2& q0, uint2& q1) { asm volatile("" : "=v"(q0.x), "=v"(q0.y), "=v"(q1.x), "=v"(q1.y) : "v"(H[4 * g]), "v"(H[4 * g + 3])); };
+    auto cutHB = [&](int g, const uint2& q0, uint2& q1) { asm volatile("" : "+v"(hp[g >> 1][0].u.x), "+v"(hp[g >> 1][1].u.x) : "v"(q0.x), "v"(q0.y), "v"(q1.x)); };
+    auto cutGA = [&](int g, uint2& q0, uint2& q1) { asm volatile("" : "=v"(q0.x), "=v"(q0.y), "=v"(q1.x), "=v"(q1.y) : "v"(dH[4 * g]), "v"(dH[4 * g + 3])); };
+    auto cutGB = [&](int g, const uint2& q0, uint2& q1) { asm volatile("" : "+v"(gp[g >> 1][0].u.x), "+v"(gp[g >> 1][1].u.x) : "v"(q0.x), "v"(q0.y), "v"(q1.x)); };
 #else
     const float big = __uint_as_float(0x7f000000u);               // 2^127
     auto relu1 = [&](int e) { H[e] = fmaxf(fmaf(H[e], ch, bc), 0.f); };
@@ -252,23 +252,32 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     auto db1add = [&](int e, float& bs) { bs += dH[e]; };
     // the cut of registers 4g .. 4g+3 (voxel rows 8g + 4 half + (0..3)) in two parts: A = the first pieces (two v_cvt_pk), B = the second ones (four v_fma_mix) and their
     // place in the fragments: dwords (g & 1) * 2, + 1 of k-block g >> 1
-    auto cutHA = [&](int g, uint2& q0) {
+    // the second pieces of a group in two halves (two v_fma_mix each; the partial writes of one register stay one instruction apart, as in h3_second_pieces2)
+    auto mixlo2 = [](unsigned h0a, float a0, unsigned h0b, float b0, unsigned& ra, unsigned& rb) {
+        asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(ra), "=&v"(rb) : "v"(h0a), "v"(h0b), "v"(a0), "v"(b0));
+    };
+    auto mixhi2 = [](unsigned h0a, float a1, unsigned h0b, float b1, unsigned& ra, unsigned& rb) {
+        asm("v_fma_mixhi_f16 %0, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ra), "+v"(rb) : "v"(h0a), "v"(h0b), "v"(a1), "v"(b1));
+    };
+    auto cutHA = [&](int g, uint2& q0, uint2& q1) {                // first pieces + the low halves of the second ones
         const f32x2 va = {H[4 * g], H[4 * g + 1]}, vb = {H[4 * g + 2], H[4 * g + 3]};
         q0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, f16x2)); q0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, f16x2));
+        mixlo2(q0.x, H[4 * g], q0.y, H[4 * g + 2], q1.x, q1.y);
     };
-    auto cutHB = [&](int g, const uint2& q0) {
-        uint2 q1;
-        h3_second_pieces2(q0.x, H[4 * g], H[4 * g + 1], q0.y, H[4 * g + 2], H[4 * g + 3], q1.x, q1.y);
+    auto cutHB = [&](int g, const uint2& q0, uint2& q1) {          // the high halves, and the group's place in the fragments
+        mixhi2(q0.x, H[4 * g + 1], q0.y, H[4 * g + 3], q1.x, q1.y);
         if (g & 1) { hp[g >> 1][0].u.z = q0.x; hp[g >> 1][0].u.w = q0.y; hp[g >> 1][1].u.z = q1.x; hp[g >> 1][1].u.w = q1.y; }
         else { hp[g >> 1][0].u.x = q0.x; hp[g >> 1][0].u.y = q0.y; hp[g >> 1][1].u.x = q1.x; hp[g >> 1][1].u.y = q1.y; }
     };
-    auto cutGA = [&](int g, uint2& q0) {
+    auto cutGA = [&](int g, uint2& q0, uint2& q1) {
         const f32x2 va = {dH[4 * g], dH[4 * g + 1]}, vb = {dH[4 * g + 2], dH[4 * g + 3]};
         q0.x = __builtin_bit_cast(unsigned, __builtin_convertvector(va, f16x2)); q0.y = __builtin_bit_cast(unsigned, __builtin_convertvector(vb, f16x2));
+        mixlo2(q0.x, dH[4 * g], q0.y, dH[4 * g + 2], q1.x, q1.y);
     };
-    auto cutGB = [&](int g, const uint2& q0) {
-        uint2 q1;
-        h3_second_pieces2(q0.x, dH[4 * g], dH[4 * g + 1], q0.y, dH[4 * g + 2], dH[4 * g + 3], q1.x, q1.y);
+    auto cutGB = [&](int g, const uint2& q0, uint2& q1) {
+        mixhi2(q0.x, dH[4 * g + 1], q0.y, dH[4 * g + 3], q1.x, q1.y);
         if (g & 1) { gp[g >> 1][0].u.z = q0.x; gp[g >> 1][0].u.w = q0.y; gp[g >> 1][1].u.z = q1.x; gp[g >> 1][1].u.w = q1.y; }
         else { gp[g >> 1][0].u.x = q0.x; gp[g >> 1][0].u.y = q0.y; gp[g >> 1][1].u.x = q1.x; gp[g >> 1][1].u.y = q1.y; }
         // the same dwords to the dH' image [hidden = col][voxel]: (c) reads it transposed
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
 
     // ---- one chunk iteration: 30 gaps.  C: the chunk whose vector work runs here; PREV: (e), (d), (c) of chunk C-1 are issued; NEXT: (a) of chunk C+1 and the
     //      operands of its (b).  Order of the matrix work: (b) C | (e) C-1 | (d) C-1 | (c) C-1 | (a) C+1.  Order of the vector work, and why it may stand where it does:
-    //        gaps  1-6   bias + ReLU of H (complete since the previous iteration's last gaps)
-    //        gaps  7-14  the gate, two elements per gap (dH is complete one MFMA behind gap 6)
+    //        gaps  2-7   bias + ReLU of H (gap 1 stays empty: H is complete two MFMAs behind the previous iteration's last one, and a read before that is padded with s_nop)
+    //        gaps  8-14  the gate, two or three elements per gap (dH is complete one MFMA behind gap 6)
     //        gaps 15-22  the cut of H' (hp is free: (e) C-1 has been issued) and the db1 sums        -- H is dead behind gap 22: (a) C+1 starts in gap 25
     //        gaps 23-30  the cut of dH' (gp and the image are free: (d) C-1 has been issued, the image's reads stand in front of these stores in the wave's LDS order)
     //      LDS reads are requested four to six gaps ahead of the MFMA that takes them. ----
@@ -289,127 +298,155 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         constexpr bool PREV = decltype(prev_tag)::value, NEXT = decltype(next_tag)::value;
         constexpr int P = C - 1, N = C + 1;
         Frag gq[2][2], w3[2][2], w1n[2][2];
-        uint2 qa;
+        uint2 qa, qb;
         float& bs = bs1[C];
         PW4_ST(4);
         SBAR();
         dH = PW4_MFMA_V(df[0][0], w2c[0][1], zero);                                    // gap 1
-        relu1(0); relu1(1); relu1(2);
+        SBAR();
         SBAR();
         dH = PW4_MFMA_V(df[0][1], w2c[0][0], dH);                                      // 2
-        relu1(3); relu1(4); relu1(5);
+        SBAR();
+        relu1(0); relu1(1); relu1(2);
         SBAR();
         dH = PW4_MFMA_V(df[0][0], w2c[0][0], dH);                                      // 3
-        relu1(6); relu1(7); relu1(8);
+        SBAR();
+        relu1(3); relu1(4); relu1(5);
         SBAR();
         dH = PW4_MFMA_V(df[1][0], w2c[1][1], dH);                                      // 4
-        relu1(9); relu1(10); relu1(11);
+        SBAR();
+        relu1(6); relu1(7); relu1(8);
         SBAR();
         dH = PW4_MFMA_V(df[1][1], w2c[1][0], dH);                                      // 5
-        relu1(12); relu1(13);
+        SBAR();
+        relu1(9); relu1(10); relu1(11);
         SBAR();
         dH = PW4_MFMA_V(df[1][0], w2c[1][0], dH);                                      // 6
-        relu1(14); relu1(15);
+        SBAR();
+        relu1(12); relu1(13);
         if constexpr (C == 2) { rsx = tile_rsrc(x, t + 1, 128); rsd = tile_rsrc(dT, t + 1, 4 * D); rso = tile_rsrc(dOut, t, 128); }      // (scalar work; xr / dr were consumed by the staging in front of chunk 0)
         if constexpr (C == 2) touch_next();
         SBAR();
         PW4_ST(0);
         // (e) of chunk C-1: dW2c^T[out][hidden] += dT^T H'
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][1], hp[0][0]);                   // 7
+        SBAR();
+        relu1(14); relu1(15);
         if constexpr (C == 7) { load_x(0); load_x(1); }
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][0], hp[0][1]);                   // 8
+        SBAR();
         if constexpr (C == 7) { load_x(2); load_x(3); }
-        gate1(0); gate1(1);
+        gate1(0); gate1(1); gate1(2);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[0][0], hp[0][0]);                   // 9
+        SBAR();
         if constexpr (PREV) { rd_g(0, 1, gq[0][1]); rd_g(0, 0, gq[0][0]); }
         if constexpr (C == 7) { load_d(0); load_d(1); load_d(2); }
-        gate1(2); gate1(3);
+        gate1(3); gate1(4);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][1], hp[1][0]);                   // 10
+        SBAR();
         if constexpr (PREV) { rd_g(1, 1, gq[1][1]); rd_g(1, 0, gq[1][0]); }
         if constexpr (C == 7) { load_d(3); load_d(4); load_d(5); }
-        gate1(4); gate1(5);
+        gate1(5); gate1(6);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][0], hp[1][1]);                   // 11
+        SBAR();
         if constexpr (C == 7) { load_d(6); load_d(7); load_d(8); }
-        gate1(6); gate1(7);
+        gate1(7); gate1(8);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW2t[P], ae[1][0], hp[1][0]);                   // 12
-        if constexpr (C == 7) { load_d(9); load_d(10); }
-        gate1(8); gate1(9);
+        SBAR();
+        if constexpr (C == 7) { load_d(9); load_d(10); load_d(11); }
+        gate1(9); gate1(10);
         SBAR();
         PW4_ST(1);
         // (d) of chunk C-1: dW1c[cin][hidden] += X^T dH'
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][1], gp[0][0]);                    // 13
-        if constexpr (C == 7) { load_o(0); load_o(1); }
+        SBAR();
+        if constexpr (C == 7) { load_d(12); load_d(13); load_d(14); load_d(15); }
         if constexpr (PREV) { rd_w(lds + 2 * PW4_WSET, P, 0, 1, w3[0][1]); rd_w(lds + 2 * PW4_WSET, P, 0, 0, w3[0][0]); }
-        gate1(10); gate1(11);
+        gate1(11); gate1(12);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][1]);                    // 14
-        if constexpr (C == 7) { load_o(2); load_o(3); }
+        SBAR();
+        if constexpr (C == 7) { load_o(0); load_o(1); load_o(2); load_o(3); }
         if constexpr (PREV) { rd_w(lds + 2 * PW4_WSET, P, 1, 1, w3[1][1]); rd_w(lds + 2 * PW4_WSET, P, 1, 0, w3[1][0]); }
-        gate1(12); gate1(13);
+        gate1(13); gate1(14); gate1(15);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[0][0], gp[0][0]);                    // 15
-        if constexpr (C == 7) { load_d(14); load_d(15); }
+        SBAR();
         if constexpr (NEXT) { rd_w(lds, N, 0, 1, w1n[0][1]); rd_w(lds, N, 0, 0, w1n[0][0]); }
-        if constexpr (C == 7) { load_d(11); load_d(12); load_d(13); }
-        gate1(14); gate1(15);
+        cutHA(0, qa, qb);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][1], gp[1][0]);                    // 16
-        cutHA(0, qa); db1add(0, bs); db1add(1, bs); db1add(2, bs);
+        SBAR();
+        cutHB(0, qa, qb); db1add(0, bs); db1add(1, bs); db1add(2, bs); db1add(3, bs);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][0], gp[1][1]);                    // 17
+        SBAR();
         if constexpr (NEXT) { rd_w(lds, N, 1, 1, w1n[1][1]); rd_w(lds, N, 1, 0, w1n[1][0]); }
-        cutHB(0, qa);
+        cutHA(1, qa, qb);
         SBAR();
         if constexpr (PREV) PW4_MFMA_A(dW1[P], at[1][0], gp[1][0]);                    // 18
-        cutHA(1, qa); db1add(3, bs); db1add(4, bs); db1add(5, bs);
+        SBAR();
+        cutHB(1, qa, qb); db1add(4, bs); db1add(5, bs); db1add(6, bs); db1add(7, bs);
         SBAR();
         PW4_ST(2);
         // (c) of chunk C-1: dX^T[cin][voxel] += W1c dH'^T (B: the dH' image of chunk C-1)
         if constexpr (PREV) { if constexpr (P == 0) dx = PW4_MFMA_V(w3[0][1], gq[0][0], zero); else dx = PW4_MFMA_V(w3[0][1], gq[0][0], dx); }      // 19
-        cutHB(1, qa);
+        SBAR();
+        cutHA(2, qa, qb);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[0][0], gq[0][1], dx);                   // 20
+        SBAR();
         if constexpr (NEXT) { rd_w(lds + PW4_WSET, N, 0, 1, w2c[0][1]); rd_w(lds + PW4_WSET, N, 0, 0, w2c[0][0]); }
-        cutHA(2, qa); db1add(6, bs); db1add(7, bs); db1add(8, bs);
+        cutHB(2, qa, qb); db1add(8, bs); db1add(9, bs); db1add(10, bs); db1add(11, bs);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                   // 21
-        cutHB(2, qa);
+        SBAR();
+        cutHA(3, qa, qb);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                   // 22
+        SBAR();
         if constexpr (NEXT) { rd_w(lds + PW4_WSET, N, 1, 1, w2c[1][1]); rd_w(lds + PW4_WSET, N, 1, 0, w2c[1][0]); }
-        cutHA(3, qa); db1add(9, bs); db1add(10, bs); db1add(11, bs);
+        cutHB(3, qa, qb); db1add(12, bs); db1add(13, bs); db1add(14, bs); db1add(15, bs);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                   // 23
-        cutHB(3, qa);
+        SBAR();
+        cutGA(0, qa, qb);
         SBAR();
         if constexpr (PREV) dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                   // 24
+        SBAR();
         if constexpr (NEXT) bc = SB[32 * N + col];
-        cutGA(0, qa); db1add(12, bs); db1add(13, bs); db1add(14, bs); db1add(15, bs);
+        cutGB(0, qa, qb);
         SBAR();
         PW4_ST(3);
         // (a) of chunk C+1: H^T[voxel][hidden] = X W1c (H is free: its cut is done)
         if constexpr (NEXT) H = PW4_MFMA_V(xf[0][0], w1n[0][1], zero);                 // 25
-        cutGB(0, qa);
+        SBAR();
+        cutGA(1, qa, qb);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[0][1], w1n[0][0], H);                    // 26
-        cutGA(1, qa);
+        SBAR();
+        cutGB(1, qa, qb);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[0][0], w1n[0][0], H);                    // 27
-        cutGB(1, qa);
+        SBAR();
+        cutGA(2, qa, qb);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[1][0], w1n[1][1], H);                    // 28
-        cutGA(2, qa);
+        SBAR();
+        cutGB(2, qa, qb);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[1][1], w1n[1][0], H);                    // 29
-        cutGB(2, qa); cutGA(3, qa);
+        SBAR();
+        cutGA(3, qa, qb);
         SBAR();
         if constexpr (NEXT) H = PW4_MFMA_V(xf[1][0], w1n[1][0], H);                    // 30
-        cutGB(3, qa);
+        SBAR();
+        cutGB(3, qa, qb);
         SBAR();
     };
 
@@ -473,87 +510,111 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
         xmul(0);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[0][1], hp[0][0]);                                     // gap 1
+        SBAR();
         h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[0][0], hp[0][1]);                                     // 2
+        SBAR();
         h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[0][0], hp[0][0]);                                     // 3
+        SBAR();
         xput(0); xf[0][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); xf[0][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y); xmul(1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[1][1], hp[1][0]);                                     // 4
+        SBAR();
         h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[1][0], hp[1][1]);                                     // 5
+        SBAR();
         h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         PW4_MFMA_B(dW2t[7], ae[1][0], hp[1][0]);                                     // 6
+        SBAR();
         xput(1); xf[1][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); xf[1][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y); dsum(ae[0][0]);
         SBAR();
         PW4_ST(5);
         PW4_MFMA_B(dW1[7], at[0][1], gp[0][0]);                                     // 7
+        SBAR();
         dsum(ae[0][1]); dmul(0);
         SBAR();
         PW4_MFMA_B(dW1[7], at[0][0], gp[0][1]);                                     // 8
+        SBAR();
         dsum(ae[1][0]); h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[0][0], gp[0][0]);                                     // 9
+        SBAR();
         dsum(ae[1][1]); h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[1][1], gp[1][0]);                                     // 10
+        SBAR();
         dputv(0); df[0][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); df[0][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y); dmul(1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[1][0], gp[1][1]);                                     // 11
+        SBAR();
         h3_cut4_scaled(xs[0], xs[1], xs[2], xs[3], q0, q1);
         SBAR();
         PW4_MFMA_B(dW1[7], at[1][0], gp[1][0]);                                     // 12
+        SBAR();
         h3_cut4_scaled(xs[4], xs[5], xs[6], xs[7], r0, r1);
         SBAR();
         dx = PW4_MFMA_V(w3[0][1], gq[0][0], dx);                                        // 13
+        SBAR();
         dputv(1); df[1][0].u = make_uint4(q0.x, q0.y, r0.x, r0.y); df[1][1].u = make_uint4(q1.x, q1.y, r1.x, r1.y);
         rd_w(lds, 0, 0, 1, w1n[0][1]);
         SBAR();
         dx = PW4_MFMA_V(w3[0][0], gq[0][1], dx);                                        // 14
         SBAR();
+        SBAR();
         dx = PW4_MFMA_V(w3[0][0], gq[0][0], dx);                                        // 15
+        SBAR();
         rd_w(lds, 0, 0, 0, w1n[0][0]);
         rd_tr(XI, 0, 1, at[0][1]); rd_tr(XI, 0, 0, at[0][0]);
         SBAR();
         dx = PW4_MFMA_V(w3[1][1], gq[1][0], dx);                                        // 16
+        SBAR();
         rd_w(lds, 0, 1, 1, w1n[1][1]);
         rd_tr(XI, 1, 1, at[1][1]); rd_tr(XI, 1, 0, at[1][0]);
 #pragma unroll
         for (int G = 0; G < 4; ++G) ex4[G] = *reinterpret_cast<const int4*>(EX + 8 * G + 4 * half);
         SBAR();
         dx = PW4_MFMA_V(w3[1][0], gq[1][1], dx);                                        // 17
+        SBAR();
         rd_w(lds, 0, 1, 0, w1n[1][0]);
         rd_tr(DI, 0, 1, ae[0][1]); rd_tr(DI, 0, 0, ae[0][0]);
         SBAR();
         dx = PW4_MFMA_V(w3[1][0], gq[1][0], dx);                                        // 18
+        SBAR();
         rd_w(lds + PW4_WSET, 0, 0, 1, w2c[0][1]);
         rd_tr(DI, 1, 1, ae[1][1]); rd_tr(DI, 1, 0, ae[1][0]);
         SBAR();
         PW4_ST(6);
         // (a) of chunk 0 of tile t+1
         H = PW4_MFMA_V(xf[0][0], w1n[0][1], zero);                                      // 19
+        SBAR();
         rd_w(lds + PW4_WSET, 0, 0, 0, w2c[0][0]);
         SBAR();
         H = PW4_MFMA_V(xf[0][1], w1n[0][0], H);                                         // 20
+        SBAR();
         rd_w(lds + PW4_WSET, 0, 1, 1, w2c[1][1]);
         xout(0);
         SBAR();
         H = PW4_MFMA_V(xf[0][0], w1n[0][0], H);                                         // 21
+        SBAR();
         rd_w(lds + PW4_WSET, 0, 1, 0, w2c[1][0]);
         xout(1);
         SBAR();
         H = PW4_MFMA_V(xf[1][0], w1n[1][1], H);                                         // 22
+        SBAR();
         bc = SB[col];
         xout(2);
         SBAR();
         H = PW4_MFMA_V(xf[1][1], w1n[1][0], H);                                         // 23
+        SBAR();
         xout(3);
         SBAR();
         H = PW4_MFMA_V(xf[1][0], w1n[1][0], H);                                         // 24
+        SBAR();
         SBAR();
         PW4_ST(7);
     };
