@@ -674,11 +674,10 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     for (int c = 0; c < 8; ++c) R1[(wave * 8 + c) * 64 + lane2] = ldexpf(bs1[c], -eg);
     R1[4 * 8 * 64 + wave * 64 + lane2] = ldexpf(bs2, -ed);
     __syncthreads();
-    for (int e = tid2; e < 8192; e += 256) {
-        const float v = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
-        const int l = e & 63, r = (e >> 6) & 15, c = e >> 10;
-        const int rw = rowmap(r, l >> 5);
-        if (rw < D) sl[8192 + (long)(32 * c + (l & 31)) * D + rw] = v;                          // [hidden][out]
+    for (int o = tid2; o < 256 * D; o += 256) {                    // [hidden][out], walked in the slab's own order: consecutive threads store consecutive floats
+        const int hid = o / D, out = o - hid * D;
+        const int e = (((hid >> 5) * 16 + (out & 3) + 4 * (out >> 3)) * 64) + (hid & 31) + 32 * ((out >> 2) & 1);      // register r, lane half with rowmap(r, half) = out
+        sl[8192 + o] = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
     }
     {
         const int c = tid2 >> 5, hcol = tid2 & 31;                   // db1[hidden 32 c + hcol]: both lane halves of the four waves
