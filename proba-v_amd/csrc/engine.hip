@@ -334,7 +334,7 @@ static int conv_fwd_launch(const probav_engine* e, const ConvGeom& g, const floa
         reported = true;
         return conv3d_cin1_forward(g, x, w, bias, y, am.y, s);
     }
-    static const bool no_strip = getenv("PROBAV_NO_STRIP") != nullptr;            // diagnostic: route strip-eligible layers to the row-tile kernel
+    const bool no_strip = false;
     const bool h3 = e->impl >= 4 && wf.h3 && am.x && am.w;
     const float* wsplit = h3 ? wf.h3 : wf.x6;
     const int arith = h3 ? 2 : 1;
@@ -804,23 +804,28 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
     auto next_part = [&]() -> float* { const size_t k = (size_t)npart < p.part_off.size() ? (size_t)npart : p.part_off.size() - 1; ++npart; return S + p.partial + p.part_off[k]; };
     // (defer: the slab sums and the small launches that only the weight-norm backward waits for are queued and leave in a few flushes -- one event record
     // on the launch stream per flush instead of one per launch, probav_common.h)
-    static const bool no_defer = getenv("PROBAV_NO_DEFER") != nullptr;              // A/B runs: a fork per launch, as before
-    SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s, no_defer ? 0 : 1);
+    SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s, 1);
 
     CK(tail_backward(dy, S + p.dtail, B, P, c.scale, c.std, s, h3 ? A.back(0) : nullptr, h3 ? p.n_amax - p.amax_bwd : 0));
     // low-frequency residual path (models/modelsTF.py:45-53), last layer first: beside the main chain, nothing below depends on it until the weight-norm
     // backward -- queued (its slab regions are taken now, in the plan's launch order) and launched at the first flush, when the launch stream has its next kernels
     {
         float* const rp0 = next_part(); float* const rp1 = next_part(); float* const rp2 = next_part();
-        CK(reduce_later(s, [&, rp0, rp1, rp2](hipStream_t rs) -> int {
+        // (the queued launch runs later, from reduce_flush: everything it needs is captured BY VALUE -- pointers and extents, nothing of this frame)
+        const float *r2 = W + p.r2, *r1 = W + p.r1, *mn = W + p.mn, *wT3 = weffT(e->iResid3), *wT2 = weffT(e->iResid2);
+        const Frags fT3 = fragT(e->iResid3), fT2 = fragT(e->iResid2);
+        float *dtail = S + p.dtail, *dr2 = S + p.dr2, *dr1 = S + p.dr1;
+        float *dw3 = dweff(e->iResid3), *db3 = dbias(e->iResid3), *dw2 = dweff(e->iResid2), *db2 = dbias(e->iResid2), *dw1 = dweff(e->iResid1), *db1 = dbias(e->iResid1);
+        const int inch = c.in_channels;
+        CK(reduce_later(s, [=](hipStream_t rs) -> int {
             const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-            CK(conv_wgrad(e, g3, W + p.r2, S + p.dtail, nullptr, dweff(e->iResid3), dbias(e->iResid3), rp0, Amax(), rs));
-            CK(conv_fwd(e, bwd_data_geom(g3), S + p.dtail, nullptr, weffT(e->iResid3), fragT(e->iResid3), nullptr, nullptr, S + p.dr2, Amax(), rs));
+            CK(conv_wgrad(e, g3, r2, dtail, nullptr, dw3, db3, rp0, Amax(), rs));
+            CK(conv_fwd(e, bwd_data_geom(g3), dtail, nullptr, wT3, fT3, nullptr, nullptr, dr2, Amax(), rs));
             const ConvGeom g2 = make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0);
-            CK(conv_wgrad(e, g2, W + p.r1, S + p.dr2, nullptr, dweff(e->iResid2), dbias(e->iResid2), rp1, Amax(), rs));
-            CK(conv_fwd(e, bwd_data_geom(g2), S + p.dr2, nullptr, weffT(e->iResid2), fragT(e->iResid2), nullptr, nullptr, S + p.dr1, Amax(), rs));
-            const ConvGeom g1 = make_geom(B, Hin, 1, c.in_channels, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
-            CK(conv_wgrad(e, g1, W + p.mn, S + p.dr1, W + p.r1, dweff(e->iResid1), dbias(e->iResid1), rp2, Amax(), rs));
+            CK(conv_wgrad(e, g2, r1, dr2, nullptr, dw2, db2, rp1, Amax(), rs));
+            CK(conv_fwd(e, bwd_data_geom(g2), dr2, nullptr, wT2, fT2, nullptr, nullptr, dr1, Amax(), rs));
+            const ConvGeom g1 = make_geom(B, Hin, 1, inch, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1);
+            CK(conv_wgrad(e, g1, mn, dr1, r1, dw1, db1, rp2, Amax(), rs));
             return PROBAV_OK;
         }));
     }
@@ -833,8 +838,10 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         const int h = p.redH[nred - 1], t = p.redT[nred - 1];
         const ConvGeom gu = make_geom(B, h, t, F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0);
         float* const up_part = next_part();
-        CK(reduce_later(s, [&, gu, up_part](hipStream_t rs) -> int {       // (only the weight-norm backward reads it)
-            return conv_wgrad(e, gu, W + p.red[nred - 1], S + p.dtail, nullptr, dweff(e->iUp), dbias(e->iUp), up_part, Amax(), rs); }));
+        const float* const upx = W + p.red[nred - 1];
+        float *const updy = S + p.dtail, *const updw = dweff(e->iUp), *const updb = dbias(e->iUp);
+        CK(reduce_later(s, [=](hipStream_t rs) -> int {       // (only the weight-norm backward reads it; captured by value: it runs from a later flush)
+            return conv_wgrad(e, gu, upx, updy, nullptr, updw, updb, up_part, Amax(), rs); }));
         CK(conv_fwd(e, bwd_data_geom(gu), S + p.dtail, nullptr, weffT(e->iUp), fragT(e->iUp), nullptr, nullptr, cur, amx(nullptr, e->iUp, acur), s));
     }
     for (int k = nred - 1; k >= 0; --k) {

@@ -2477,7 +2477,6 @@ static StripPlan strip_plan(const ConvGeom& g)
     return p;
 }
 
-static bool pp_disabled() { static const bool v = getenv("PROBAV_NO_PP") != nullptr; return v; }   // diagnostic: the same-program form (conv3_pstrip_kernel) instead
 bool mfma_conv_strip_supported(const ConvGeom& g) { return strip_plan(g).ok; }
 // does x6_conv_strip_forward(g, ..., arith) read per-tap fragments (PACK_*_CONV) even for 25 input channels?  (the H3 piece-ring kernel does;
 // the other 25-channel split kernels read the K-concatenated PACK_*_CONVK form)
@@ -2485,10 +2484,9 @@ bool x6_strip_wants_tap_fragments(const ConvGeom& g, int arith)
 {
     StripPlan pp;
     int rvp;
-    return arith == 2 && (pstrip_plan(g, pp) || (!pp_disabled() && pp_plan(g, pp, rvp)));   // (the alternating-halves form also takes rows shorter than 128 voxels: the later reducers)
+    return arith == 2 && (pstrip_plan(g, pp) || pp_plan(g, pp, rvp));   // (the alternating-halves form also takes rows shorter than 128 voxels: the later reducers)
 }
 
-int g_pp_k16 = -1;     // 1: 32 input channels through the 32x32x16 form (PROBAV_PP_K16; diagnostics flip it between launches)
 
 static int strip_launch(const ConvGeom& g, const float* x, const float* gate, const float* wfrag, const float* bias,
                         const float* skip, float* y, int arith, const Amax& am, hipStream_t s)
@@ -2497,41 +2495,27 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
     if (arith == 2 && x6_strip_wants_tap_fragments(g, arith)) {               // H3: the piece-ring kernel (filters: PACK_H3_CONV)
         StripPlan pp;
         int rvp = 2;
-        if (!pp_disabled() && pp_plan(g, pp, rvp)) {
+        if (pp_plan(g, pp, rvp)) {
             static std::once_flag onceq;
             std::call_once(onceq, [] {
-                allow_big_lds(conv3_pp_kernel<25, false, 2>); allow_big_lds(conv3_pp_kernel<25, true, 2>);
-                allow_big_lds(conv3_pp_kernel<32, false, 2>); allow_big_lds(conv3_pp_kernel<32, true, 2>);
-                allow_big_lds(conv3_pp_kernel<25, false, 3>); allow_big_lds(conv3_pp_kernel<25, true, 3>);
-                allow_big_lds(conv3_pp_kernel<32, false, 3>); allow_big_lds(conv3_pp_kernel<32, true, 3>);
+                allow_big_lds(conv3_pp_kernel<32, true, 3>);
                 allow_big_lds(conv3_pp_kernel<32, false, 2, true>); allow_big_lds(conv3_pp_kernel<32, true, 2, true>);
                 allow_big_lds(conv3_pp_kernel<32, false, 3, true>);
                 allow_big_lds(conv3_pp_kernel<25, false, 2, true>); allow_big_lds(conv3_pp_kernel<25, false, 3, true>); });
-            // 32 input channels: the 16x16x32 MFMA form (one k-block per tap) unless PROBAV_PP_K16 asks for the 32x32x16 one (A/B runs; bit-identical sums are not
-            // expected between the two: the order of the k-partial sums inside the matrix pipe differs)
-            if (g_pp_k16 < 0) g_pp_k16 = getenv("PROBAV_PP_K16") != nullptr ? 1 : 0;
-            const bool k16_env = g_pp_k16 == 1;
-#define PROBAV_PP(C, G, R) hipLaunchKernelGGL((conv3_pp_kernel<C, G, R>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
-#define PROBAV_PP_R(C, G) do { if (rvp == 2) PROBAV_PP(C, G, 2); else PROBAV_PP(C, G, 3); } while (0)
-            static const bool old25_env = getenv("PROBAV_PP_OLD25") != nullptr;          // A/B runs: the 25-channel layers (the forward pass) on the one-wave-per-tile form
-            if (g.Cin == 25 && (old25_env || gate)) { if (gate) PROBAV_PP_R(25, true); else PROBAV_PP_R(25, false); }    // (a gated 25-channel layer does not occur in this network: the old form, whose gated instance has the registers)
-            else if (g.Cin == 25) {
-#define PROBAV_PPN(R) hipLaunchKernelGGL((conv3_pp_kernel<25, false, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
-                if (rvp == 2) PROBAV_PPN(2); else PROBAV_PPN(3);
-#undef PROBAV_PPN
-            }
-            else if (k16_env) { if (gate) PROBAV_PP_R(32, true); else PROBAV_PP_R(32, false); }
-            else {
-#define PROBAV_PPK(G, R) hipLaunchKernelGGL((conv3_pp_kernel<32, G, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
-                if (gate) { if (rvp == 2) PROBAV_PPK(true, 2); else PROBAV_PP(32, true, 3); }    // (gated with three items per thread -- reducers at T = 13: the new form's instance would spill 42 registers; the one-wave-per-tile form has them, same step time)
-                else      { if (rvp == 2) PROBAV_PPK(false, 2); else PROBAV_PPK(false, 3); }
+            // the instances that ship: 25 input channels (the forward pass of the residual blocks) in the pair-split form; 32 input channels (backward-data, reducers) in
+            // the 16x16x32 MFMA form -- except the gated layer with three staging items per thread (reducers at T = 13), whose new-form instance would spill 42
+            // registers: it keeps the one-wave-per-tile 32x32x16 form.  (Rounds 3 / 4 carried the superseded forms behind PROBAV_PP_K16 / PROBAV_PP_OLD25 for A/B runs.)
+            if (g.Cin == 25 && gate) { set_error("x6_conv_strip_forward: a gated 25-channel layer has no piece-ring instance (none occurs in the reference's networks)", hipSuccess); return PROBAV_EINVAL; }
+#define PROBAV_PPK(C, G, R) hipLaunchKernelGGL((conv3_pp_kernel<C, G, R, true>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am)
+            if (g.Cin == 25) { if (rvp == 2) PROBAV_PPK(25, false, 2); else PROBAV_PPK(25, false, 3); }
+            else if (gate) {
+                if (rvp == 2) PROBAV_PPK(32, true, 2);
+                else hipLaunchKernelGGL((conv3_pp_kernel<32, true, 3>), dim3(pp.grid), dim3(512), pp.lds_bytes, s, pp.a, x, gate, (const uint4*)wfrag, bias, skip, y, am);
+            } else { if (rvp == 2) PROBAV_PPK(32, false, 2); else PROBAV_PPK(32, false, 3); }
 #undef PROBAV_PPK
-            }
-#undef PROBAV_PP_R
-#undef PROBAV_PP
             return check_launch("conv3_pp");
         }
-        if (!pstrip_plan(g, pp)) { set_error("x6_conv_strip_forward: no piece-ring plan for this geometry (PROBAV_NO_PP set?)", hipSuccess); return PROBAV_EINVAL; }
+        if (!pstrip_plan(g, pp)) { set_error("x6_conv_strip_forward: no piece-ring plan for this geometry", hipSuccess); return PROBAV_EINVAL; }
         static std::once_flag oncep;
         std::call_once(oncep, [] {
             allow_big_lds(conv3_pstrip_kernel<25, false>); allow_big_lds(conv3_pstrip_kernel<25, true>);

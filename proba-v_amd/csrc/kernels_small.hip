@@ -479,8 +479,7 @@ hipStream_t reduce_fork_adjacent(hipStream_t s)
 {
     ReduceSide* c = g_reduce_side;
     if (!c || !c->side || s == c->side) return s;
-    static const bool always_record = getenv("PROBAV_FORK_EVENTS") != nullptr;     // A/B runs: an event at every fork
-    if (c->k == 0 || c->last != s || always_record || c->defer) return reduce_fork(s);   // (deferred launches: the previous fork point is no longer adjacent)   // (nothing forked yet in this pass, or the last fork did not take: there is no earlier point)
+    if (c->k == 0 || c->last != s || c->defer) return reduce_fork(s);   // (deferred launches: the previous fork point is no longer adjacent)   // (nothing forked yet in this pass, or the last fork did not take: there is no earlier point)
     return c->side;
 }
 typedef std::vector<std::function<int(hipStream_t)>> PendingList;
@@ -500,7 +499,7 @@ int reduce_flush(hipStream_t s)
     if (q->empty()) return PROBAV_OK;
     hipStream_t rs = reduce_fork(s);
     int rc = PROBAV_OK;
-    for (auto& fn : *q) { const int r = fn(rs); if (r && !rc) rc = r; }
+    for (auto& fn : *q) { rc = fn(rs); if (rc) break; }      // (a failed launch ends the flush: the launches behind it belong to a pass that is being abandoned)
     q->clear();
     return rc;
 }
@@ -583,8 +582,7 @@ __global__ __launch_bounds__(256) void reflect_fold_rows_kernel(const float4* __
 int reflect_fold(const float* dpad, float* dx, int N, int H, int W, int TC, unsigned* amax, hipStream_t s)
 {
     if (H < 4 || W < 4) { set_error("reflect_fold: H, W must be >= 4", hipSuccess); return PROBAV_EINVAL; }
-    static const bool old_form = getenv("PROBAV_FOLD_V1") != nullptr;              // A/B runs: the flat-index kernel
-    if (!old_form && TC % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpad) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 && H <= 65535 && N <= 65535) {
+    if (TC % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpad) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 && H <= 65535 && N <= 65535) {
         const int TCv = TC / 4;
         const unsigned mTCv = (unsigned)((0x100000000ull + (unsigned)TCv - 1) / (unsigned)TCv);     // floor(i / TCv) = umulhi(i, m) for i < 2^16 * ... (i < W * TCv here)
         if ((long)W * TCv < (1l << 20) && TCv >= 2 && TCv < 4096) {

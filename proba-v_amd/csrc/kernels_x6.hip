@@ -412,7 +412,6 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
     static std::once_flag once;
     std::call_once(once, [] {
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_h3k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
@@ -421,12 +420,9 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2c || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
         const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32 + 8 * 256) * sizeof(float);      // (+ pw_fwd_h3k_kernel's per-wave bias tables; two workgroups per CU still fit)
-        static const bool v1_env = getenv("PROBAV_PW_FWD_V1") != nullptr;      // A/B runs: the 32x32x16 kernel
         if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                                       b1, b2, dec, nvox, (int)vps, D, am, hdump);
-        else if (!v1_env) hipLaunchKernelGGL(pw_fwd_h3k_kernel, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am);
-        else hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, false>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
-                                b1, b2, dec, nvox, (int)vps, D, am, hdump);
+        else hipLaunchKernelGGL(pw_fwd_h3k_kernel, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am);      // (the 32x32x16 form pw_fwd_x6_kernel<H3> stays for the hidden-tile dump of the parity tests)
     } else {
         const size_t lds = (size_t)2 * 8 * 2 * X6::NP * 64 * 16 + (256 + 32 + 32) * sizeof(float);
         if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<X6, true>), dim3(256 * PwfShape<X6>::WGS), dim3(64 * PwfShape<X6>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
@@ -870,1077 +866,6 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_x6_kernel(
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Alternating-halves form of the fused pointwise backward (H3 arithmetic): the same products in the same order as pw_bwd_x6_kernel<H3>
-// (its results are bit for bit those of that kernel), on another schedule.  There, all eight waves run one program behind one barrier
-// per tile: the two waves of a SIMD reach their MFMA phases together (one matrix pipe: each phase takes twice its length) and their
-// gate / cut phases together (the stamps: the younger wave's 170 vector instructions take 1 640 cycles, the older one's 780), and the
-// matrix pipe idles through every vector phase -- 6 400 cycles per tile around 2 x 960 cycles of MFMA.  Here the halves of the workgroup
-// (waves 0-3 / 4-7: one wave of each on every SIMD) TAKE TURNS, half B one segment behind half A:
-//      segment:   2i              2i+1            2i+2             2i+3
-//      half A:    Y(i)            X(i)            Y(i+1)           X(i+1)
-//      half B:    X(i-1)          Y(i)            X(i)             Y(i+1)
-//   Y(i) = the matrix phase: (c), (d), (e) of tile i-1 (from the pieces the wave cut in X(i-1): registers and its transpose images),
-//          the dX partial of tile i-1 to LDS, then (a), (b) of tile i: 30 MFMAs;
-//   X(i) = the vector phase: bias / ReLU / gate / cut of tile i's hidden tile and its gradient, pieces to the transpose images; half A
-//          also cuts and stages tile i+1 (its rows were requested at the start of Y(i)), half B sums the eight dX partials of tile i-1
-//          (+ dOut, requested at the start of Y(i)) and stores dX.
-// One barrier per segment, waiting for LDS traffic only.  A staged tile is read over four segments (A's and B's (a),(b), then their
-// (d),(e)): three staging buffers; the partials of tile i are complete after segment 2i+3, summed in 2i+4 and overwritten in 2i+6: two
-// parities.  To make room (160 KB exactly) the transpose images and the partials lose their padding columns and are swizzled instead:
-// 8-byte chunk c of voxel row r of an image at chunk c ^ key(r), key(r) = (r ^ (r >> 3)) & 7; 16-byte chunk q of row r of a partial at
-// chunk q ^ (r & 7) -- conflict-free for the stores, the transposed reads and the 16-byte reads of the sums alike.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void pw_bwd_h3s_kernel(
-    const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
-    const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
-    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int vps, int D, PwAmax am)
-{
-    using AR = H3;
-    constexpr int NP = 2;
-    constexpr int PB_TILE = NP * PB_IMG;                          // one staged tensor tile: NP piece images
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned char* XA = lds_raw;                                  // [3 buffers][NP pieces][32 voxels][80 B]
-    unsigned char* DA = XA + 3 * PB_TILE;                         // same for dT (channels D..31 stay zero)
-    float* TbAll = reinterpret_cast<float*>(DA + 3 * PB_TILE);   // [2 parities][8 waves][32][32] dX partials (swizzled)
-    float* sB1 = TbAll + 16 * PS_TB;                              // [2 sample parities][256] expand biases at the hidden tile's scale
-    unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 512);       // [8 waves][dH' | H'][NP pieces][32 voxels][64 B] (swizzled)
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hb = wave >> 2;                                     // 0: half A (stages), 1: half B (one segment behind; sums the partials)
-    const int c = wave;                                           // this wave's hidden chunk
-    const unsigned aw1 = *am.w1, aw2 = *am.w2, ab1 = *am.b1;
-    const int ew1 = h3_exp_w(aw1), ew2 = h3_exp_w(aw2);
-    // a tile: sample, tile inside it, and the sample's four exponents (X, dT, hidden tile, its gradient; each in [-113, 60]) packed into one
-    // scalar register -- three tiles are in flight (being staged / computed / summed) and scalar registers are scarce
-    struct Cur {
-        int n, j, e4, v0;                                           // v0: the tile's first voxel (nvox < 2^31: checked by the launcher)
-        __device__ __forceinline__ int ex() const { return (int)(signed char)(e4 & 0xff); }
-        __device__ __forceinline__ int ed() const { return (int)(signed char)((e4 >> 8) & 0xff); }
-        __device__ __forceinline__ int eh() const { return (int)(signed char)((e4 >> 16) & 0xff); }
-        __device__ __forceinline__ int eg() const { return e4 >> 24; }
-    };
-    auto load_scales = [&](Cur& q) {
-        const unsigned ax = am.x[q.n], ad = am.dt[q.n];
-        const int ex = h3_exp(ax), ed = h3_exp(ad);
-        const int eh = h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1));
-        const int eg = h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2));
-        q.e4 = __builtin_amdgcn_readfirstlane((ex & 0xff) | ((ed & 0xff) << 8) | ((eh & 0xff) << 16) | (eg << 24));
-    };
-    const int tps = (vps + 31) >> 5;                              // tiles per sample
-    auto advance = [&](Cur& q) { if (++q.j == tps) { q.j = 0; ++q.n; q.v0 = q.n * vps; load_scales(q); } else q.v0 += 32; };
-
-    Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            w1[kb][p].u = w1f[((c * 2 + kb) * NP + p) * 64 + lane];
-            w2[kb][p].u = w2kf[((c * 2 + kb) * NP + p) * 64 + lane];
-            w3[kb][p].u = w1cf[((c * 2 + kb) * NP + p) * 64 + lane];
-        }
-    unsigned char* Ti = TiAll + wave * 2 * NP * PS_IMG;           // dH' pieces
-    unsigned char* Th = Ti + NP * PS_IMG;                          // H' pieces
-    // Per-lane addresses inside a swizzled image / partial: ONE register each, the variants by an xor with a constant (registers are what
-    // this kernel is short of).  Transposed read q of k-block kb: row r = 16 kb + 8 q + r0, r0 = 4 half + (li >> 2) < 8, so key(r) = r0 ^ (2 kb + q)
-    // and the byte offset is (t0 ^ ((2 kb + q) << 3)) + 1024 kb + 512 q.  Store G of a lane's row (voxel col): chunk (half + 2 G) ^ key(col)
-    // = s0 ^ (G << 4) in bytes; its 16-byte chunk of the dX partial: w0 ^ (G << 5).
-    int t0, s0, w0;
-    {
-        const int li = lane & 15, gcol = (lane >> 4) & 1, r0 = 4 * half + (li >> 2);
-        t0 = r0 * 64 + (((4 * gcol + (li & 3)) ^ r0) << 3);
-        s0 = col * 64 + ((half ^ ps_key(col)) << 3);                              // (the key's bits 1, 2 meet G's: (half + 2 G) ^ key = (half ^ key) ^ (2 G))
-        w0 = col * 128 + ((half ^ (col & 7)) << 4);
-    }
-    auto toff = [&](int kb, int q) { return (t0 ^ ((2 * kb + q) << 3)) + 1024 * kb + 512 * q; };
-    f32x16 dW1, dW2t;
-    float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
-    const int ntiles = (int)(nvox / vps) * tps;
-    const int tbeg = (int)((long)ntiles * blockIdx.x / gridDim.x), tend = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);   // this workgroup's run of tiles
-    const int nt = tend - tbeg;
-    // ---- per-thread state of the two roles, in the SAME registers (the role is wave-uniform, and registers are what this kernel is short of):
-    //   half A (stages): rc[k] = byte offset of its dT element f = t + 256 k inside a piece image ([voxel][80 B]); rf[k] = running sum of that
-    //                    element (db2); ro = byte offset of its float4 of the X tile in memory, rs = in the piece image
-    //   half B (sums):   rc[k] = exponent of W1's cin row 4 rq + k (W1 as the operand of (c) is cut per cin row: its dX column);
-    //                    rf[0] = largest |dX| so far; ro = byte offset of its (voxel row, 4 cin) of a dX / dOut tile, rs = float offset in a partial
-    const int t8 = tid & 255, rrow = t8 >> 3, rq = t8 & 7;
-    int rc[4]; float rf[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int f = t8 + 256 * k, dv = f / D;
-        rc[k] = hb ? h3_exp_w(am.w1r[4 * rq + k]) : (f < 32 * D ? dv * PB_ROW + (f - dv * D) * 2 : D * 2);      // (an unused slot: voxel 0's zero pad, D < 32 there)
-    }
-    const unsigned ro = rrow * 128u + rq * 16u;                        // (both roles: row t8 >> 3, 16-byte column t8 & 7 of a [32][32] fp32 tile)
-    const int rs = hb ? rrow * 32 + ((rq ^ (rrow & 7)) << 2) : rrow * PB_ROW + rq * 8;
-    // staging: raw, clamped, unconditional loads (zeroing happens at the store); scalar base + 32-bit lane offset.  A dT element slot
-    // beyond 32 D (the last of the four when D < 32) is branch-free: it writes a zero into the zero pad of voxel 0 (rc[] points there).
-    const bool dvalid3 = t8 + 768 < 32 * D;
-    auto stage_load = [&](const Cur& q, float4& xv, float (&d)[4]) {
-        const int nrem = vps - 32 * q.j < 32 ? vps - 32 * q.j : 32;
-        const char* xb = reinterpret_cast<const char*>(x) + ((unsigned long)(unsigned)q.v0 << 7);
-        xv = *reinterpret_cast<const float4*>(xb + (rrow < nrem ? ro : rq * 16u));
-        const char* db = reinterpret_cast<const char*>(dT) + ((unsigned long)(unsigned)(q.v0 * D) << 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned f = t8 + 256 * k;
-            d[k] = *reinterpret_cast<const float*>(db + ((int)f < nrem * D ? 4u * f : 0u));
-        }
-    };
-    auto stage_store = [&](int buf, const Cur& q, const float4& xv, const float (&d)[4]) {         // (the prologue's; the loop stages in the gaps of its MFMAs)
-        const int nrem = vps - 32 * q.j < 32 ? vps - 32 * q.j : 32;
-        const float sx = pow2i(q.ex()), sd = pow2i(q.ed());
-        {
-            const bool xl = rrow < nrem;
-            unsigned a[NP], b[NP];
-            cut_pair<AR>(xl ? xv.x : 0.f, xl ? xv.y : 0.f, sx, a);
-            cut_pair<AR>(xl ? xv.z : 0.f, xl ? xv.w : 0.f, sx, b);
-            unsigned char* dst = XA + buf * PB_TILE + rs;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(dst + p * PB_IMG) = make_uint2(a[p], b[p]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool live = (k < 3 ? (D >= 24 || t8 + 256 * k < 32 * D) : dvalid3) && t8 + 256 * k < nrem * D;
-            const float dv = live ? d[k] : 0.f;
-            unsigned short qq[NP];
-            cut_one<AR>(dv, sd, qq);
-            unsigned char* dst = DA + buf * PB_TILE + rc[k];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<unsigned short*>(dst + p * PB_IMG) = qq[p];
-            rf[k] += dv;
-        }
-    };
-    // ---- the workgroup's slab: [dW1 32x256 | dW2 256xD | db1 256 | db2 D]; (d), (e) and the db1 sums are added to it at true scale when a
-    // jump of the scales is too large to carry the sums along, and at the end; the first flush stores ----
-    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
-    float* sl = slabs + (long)blockIdx.x * slab_floats;
-    bool flushed = false;                                             // wave-uniform
-    auto flush = [&](const Cur& q) __attribute__((always_inline)) {
-        asm volatile("" ::: "memory");                                // a rare path: nothing of it may be speculated into the tile loop
-        float a1[16], a2[16], a3[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            a1[r] = ldexpf(dW1[r], -(q.ex() + q.eg())); a2[r] = ldexpf(dW2t[r], -(q.ed() + q.eh()));
-            float v = bs1v[r];                                        // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-            a3[r] = ldexpf(v, -q.eg());
-            dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f;
-        }
-        if (flushed) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rw = rowmap(r, half);
-                a1[r] += sl[(long)rw * 256 + 32 * c + col];
-                if (rw < D) a2[r] += sl[8192 + (long)(32 * c + col) * D + rw];
-                if (col == 0) a3[r] += sl[8192 + 256 * (long)D + 32 * c + rw];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rw = rowmap(r, half);
-            sl[(long)rw * 256 + 32 * c + col] = a1[r];                                        // [cin][hidden]
-            if (rw < D) sl[8192 + (long)(32 * c + col) * D + rw] = a2[r];                     // [hidden][out]
-            if (col == 0) sl[8192 + 256 * (long)D + 32 * c + rw] = a3[r];
-        }
-        flushed = true;
-    };
-    int on = -1;                                                       // half B: the sample whose largest |dX| rf[0] is collecting
-
-    // tiles i-2 (its partials get summed), i-1 ((c), (d), (e)), i ((a), (b), gate), i+1 (staged), i+2 (requested)
-    // ONE program for every iteration i = 0 .. nt+1 of the run: tiles outside 0 .. nt-1 are GHOSTS.  A ghost in front of the run finds
-    // zeros in the staging buffers, the transpose images and the partials (all of LDS is cleared first): (d), (e), (c) add zeros, its sums
-    // are not stored.  A ghost behind the run is staged as zeros: dT = 0 makes its gradient tile, its db1 / dW terms and its partial
-    // vanish whatever relu(bias) is.  So no iteration needs a program of its own (a separate cold instance spilled 200 registers and
-    // took 1.7x a hot iteration: a tenth of the kernel).  A ghost's cursor is a copy of the nearest real tile's.
-    Cur c2p = {0, 0, 0, 0}, cprev = c2p, ccur = c2p, cnext = c2p, cnn = c2p;
-    if (nt > 0) {
-        ccur.n = tbeg / tps; ccur.j = tbeg - ccur.n * tps; ccur.v0 = ccur.n * vps + 32 * ccur.j; load_scales(ccur);
-        cnext = ccur; if (nt > 1) advance(cnext);
-        cnn = cnext; if (nt > 2) advance(cnn);
-        c2p = cprev = ccur;
-    }
-    for (int k = tid; k < 160 * 1024 / 16; k += 512) reinterpret_cast<uint4*>(lds_raw)[k] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};      // half A: the raw rows of the tile staged next
-    float4 rdo = make_float4(0.f, 0.f, 0.f, 0.f);                                          // half B: dOut of the tile summed next
-    if (nt > 0 && hb == 0) {
-        stage_load(ccur, nxv, nd);
-        stage_store(0, ccur, nxv, nd);
-        stage_load(cnext, nxv, nd);                                                        // (nt == 1: tile 0 again; staged as a ghost = zeros)
-    }
-    if (hb == 0) sB1[(ccur.n & 1) * 256 + t8] = b1[t8] * pow2i(ccur.eh());
-    // LDS only: requested rows and dX stores stay in flight; nothing (an MFMA least of all) may be scheduled across a segment boundary
-    auto bar = [] { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
-    int b0 = 0;                                                    // staging buffer of tile i (i mod 3)
-    f32x16 zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    f32x16 H = zero;                                               // accumulator of (a), then IN PLACE relu(H) of tile i at the hidden tile's scale: from Y(i) to X(i)
-    f32x16 dH = zero;                                              // its gradient (accumulator of (b)), likewise
-
-    XS_DECL;
-#ifdef PROBAV_STAMP
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // One iteration = the wave's Y(i) and X(i); ROLE = 0 / 1: the instance of half A / B (straight-line code: one scheduling region per
-    // phase, so that the vector work can be dealt out between the MFMAs).
-    auto iter = [&](auto role_tag, int i) __attribute__((always_inline)) {
-        constexpr int ROLE = decltype(role_tag)::value;
-        const bool real_p2 = i >= 2, real_p = i >= 1 && i <= nt, real_c = i < nt, real_n = i + 1 < nt, real_nn = i + 2 < nt;      // which of the five tiles exist
-        const int bprev = b0 == 0 ? 2 : b0 - 1, bnext = b0 == 2 ? 0 : b0 + 1;
-        bar();
-        XS_ACC(1);
-        // the matrix phase at priority 1: its MFMAs and the work in their gaps go ahead of the partner wave's vector phase in the SIMD's
-        // arbitration (measured: -3...5 % of the kernel; the phases of the two waves of a SIMD do not overlap on gfx950 -- tools/coissue.hip --
-        // so what the arbitration decides is who idles, and an idle matrix pipe is the expensive kind)
-#ifndef H3S_NOPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        // ================================ Y(i) ================================
-        H = zero;
-        {
-            // The matrix phase, scheduled by hand: 30 MFMAs in the order (a), (d)/(e) k-block 0, k-block 1, (c), (b); behind each MFMA a "gap"
-            // with a small piece of the phase's other work -- LDS reads of operands a few MFMAs ahead, and vector work that runs while that
-            // MFMA executes.  Every gap is fenced by sched_barrier(0), the only form every scheduling pass respects: what is written in a
-            // gap stays in it.  None of the vector work depends on (d), (e), (c), (b); relu(H) needs (a): its pieces start a few gaps behind
-            // (a)'s last MFMA.
-            const unsigned char* Xb = XA + b0 * PB_TILE;
-            const unsigned char* Db = DA + b0 * PB_TILE;
-            const unsigned char* Xp = XA + bprev * PB_TILE;
-            const unsigned char* Dp = DA + bprev * PB_TILE;
-            // ---- pieces of vector work ----
-            // half A: cut and stage tile i+1 (X float4: two pair cuts; four dT elements); a ghost is staged as zeros
-            const float sx = pow2i(cnext.ex()), sd = pow2i(cnext.ed());
-            const int nnrem = real_n ? (vps - 32 * cnext.j < 32 ? vps - 32 * cnext.j : 32) : 0;
-            const int nlim = __builtin_amdgcn_readfirstlane(nnrem * D);
-            unsigned char* sXd = XA + bnext * PB_TILE + rs;
-            unsigned char* sDd = DA + bnext * PB_TILE;
-            auto stageX = [&](float u, float v, int off) {
-                const bool xl = rrow < nnrem;
-                unsigned q[NP];
-                cut_pair<AR>(xl ? u : 0.f, xl ? v : 0.f, sx, q);
-                *reinterpret_cast<unsigned*>(sXd + off) = q[0];
-                *reinterpret_cast<unsigned*>(sXd + PB_IMG + off) = q[1];
-            };
-            auto stageD = [&](int k) {
-                const float dv = t8 + 256 * k < nlim ? nd[k] : 0.f;           // (nlim <= 32 D: a slot beyond the tile's elements stores a zero)
-                unsigned short qq[NP];
-                cut_one<AR>(dv, sd, qq);
-                *reinterpret_cast<unsigned short*>(sDd + rc[k]) = qq[0];
-                *reinterpret_cast<unsigned short*>(sDd + PB_IMG + rc[k]) = qq[1];
-                rf[k] += dv;
-            };
-            // half B: dX of tile i-2 = dOut + its eight chunk partials, in the order of the chunks (partial jj is requested two gaps ahead)
-            const float* Tp = TbAll + (i & 1) * 8 * PS_TB + rs;
-            const int snrem = real_p2 ? (vps - 32 * c2p.j < 32 ? vps - 32 * c2p.j : 32) : 0;
-            float4 tq[3];                                                  // (three in flight)
-            float sa[4] = {0.f, 0.f, 0.f, 0.f};
-            auto sums_read = [&](int jj) { tq[jj % 3] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); };
-            auto sums_add = [&](int jj) { sa[0] += tq[jj % 3].x; sa[1] += tq[jj % 3].y; sa[2] += tq[jj % 3].z; sa[3] += tq[jj % 3].w; };
-            auto sums_out = [&]() {
-                const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sa[k] = ldexpf(sa[k], -(rc[k] + c2p.eg())) + od[k];      // (c) partials -> true values: W1's cin row and the sample's dH scale
-                if (rrow < snrem) *reinterpret_cast<float4*>(reinterpret_cast<char*>(dX) + ((unsigned long)(unsigned)c2p.v0 << 7) + ro) = make_float4(sa[0], sa[1], sa[2], sa[3]);
-            };
-            auto sums_max = [&]() {
-                const float m = fmaxf(fmaxf(fabsf(sa[0]), fabsf(sa[1])), fmaxf(fabsf(sa[2]), fabsf(sa[3])));
-                rf[0] = fmaxf(rf[0], rrow < snrem ? m : 0.f);
-            };
-            // both: bias, ReLU and cut of the hidden tile, four registers (one 8-byte chunk of the lane's H' image row, both pieces) at a time
-            const int kh = ccur.eh() - ccur.ex() - ew1;                            // (<= -17 always, see the bounds)
-            const float ch = pow2i(kh < -126 ? -126 : kh);
-            const float* sB = sB1 + (ccur.n & 1) * 256 + 32 * c + 4 * half;
-            float4 bbq[4];
-            auto relu2 = [&](int g, int e0) {                          // registers 4g + e0, 4g + e0 + 1
-                const float bv[4] = {bbq[g].x, bbq[g].y, bbq[g].z, bbq[g].w};
-                H[4 * g + e0] = fmaxf(fmaf(H[4 * g + e0], ch, bv[e0]), 0.f);
-                H[4 * g + e0 + 1] = fmaxf(fmaf(H[4 * g + e0 + 1], ch, bv[e0 + 1]), 0.f);
-            };
-            unsigned hq[2][NP];
-            auto hcut = [&](int g, int pr) { cut_pair_scaled<AR>(H[4 * g + 2 * pr], H[4 * g + 2 * pr + 1], hq[pr]); };
-            auto hstore = [&](int g) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(Th + p * PS_IMG + (s0 ^ (g << 4))) = make_uint2(hq[0][p], hq[1][p]);
-            };
-            // ---- operands, requested in the gaps ahead of their MFMAs ----
-            Frag xf[2][NP], df[2][NP], gq[2][NP];
-            Frag at[2][NP], bt[2][NP], ae[2][NP], be[2][NP];          // [k-block][piece]
-            uint2 glo[2][NP], ghi[2][NP];
-            auto rd_de = [&](int kb, int which) {                      // two fragments = four transposed reads
-                if (which == 0) { tr_frag<PB_ROW>(Xp, lane, kb, at[kb][0]); tr_frag_sw(Ti, toff(kb, 0), toff(kb, 1), bt[kb][0]); }
-                if (which == 1) { tr_frag<PB_ROW>(Xp + PB_IMG, lane, kb, at[kb][1]); tr_frag_sw(Ti + PS_IMG, toff(kb, 0), toff(kb, 1), bt[kb][1]); }
-                if (which == 2) { tr_frag<PB_ROW>(Dp, lane, kb, ae[kb][0]); tr_frag_sw(Th, toff(kb, 0), toff(kb, 1), be[kb][0]); }
-                if (which == 3) { tr_frag<PB_ROW>(Dp + PB_IMG, lane, kb, ae[kb][1]); tr_frag_sw(Th + PS_IMG, toff(kb, 0), toff(kb, 1), be[kb][1]); }
-            };
-            auto rd_gq = [&](int kb, int p) {
-                glo[kb][p] = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4)));
-                ghi[kb][p] = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4)));
-            };
-            auto rd_df = [&](int kb, int p) { df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16); };
-            // gap `S` of the schedule
-            auto gap = [&](auto slot_tag) {
-                constexpr int S = decltype(slot_tag)::value;
-                __builtin_amdgcn_sched_barrier(0);
-                // operand requests
-                if constexpr (S >= 0 && S <= 3) rd_de(0, S);
-                if constexpr (S >= 8 && S <= 11) rd_de(1, S - 8);
-                if constexpr (S >= 12 && S <= 15) rd_gq((S - 12) >> 1, (S - 12) & 1);
-                if constexpr (S >= 19 && S <= 22) rd_df((S - 19) >> 1, (S - 19) & 1);
-                if constexpr (ROLE == 0) {
-#ifndef H3S_NOSTAGE
-                    if constexpr (S == 0) stageX(nxv.x, nxv.y, 0);
-                    if constexpr (S == 1) stageX(nxv.z, nxv.w, 4);
-                    if constexpr (S >= 2 && S <= 5) stageD(S - 2);
-#endif
-                } else {
-#ifndef H3S_NOSUMS
-                    if constexpr (S + 2 <= 7) sums_read(S + 2);
-                    if constexpr (S <= 7) sums_add(S);
-                    if constexpr (S == 8) sums_out();
-                    if constexpr (S == 9) sums_max();
-#endif
-                }
-#ifndef H3S_NOGATE
-                constexpr int H0 = ROLE == 0 ? 8 : 11;                  // the first gap of the relu(H) work (four gaps per group of four registers)
-                if constexpr (S >= H0 - 2 && S < H0 + 14 && ((S - H0 + 2) & 3) == 0) bbq[(S - H0 + 2) >> 2] = *reinterpret_cast<const float4*>(sB + 8 * ((S - H0 + 2) >> 2));      // its biases, two gaps ahead
-                if constexpr (S >= H0 && S < H0 + 16) {
-                    constexpr int g = (S - H0) >> 2, c4 = (S - H0) & 3;
-                    if constexpr (c4 == 0) relu2(g, 0);
-                    if constexpr (c4 == 1) { relu2(g, 2); hcut(g, 0); }
-                    if constexpr (c4 == 2) hcut(g, 1);
-                    if constexpr (c4 == 3) hstore(g);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            };
-#define GAP(n) gap(std::integral_constant<int, n>())
-            // ahead of the first MFMA: (a)'s operands, the biases, half B's first two partials
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
-#ifndef H3S_NOSUMS
-            if constexpr (ROLE == 1) { sums_read(0); sums_read(1); }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef H3S_NOY
-            // (a)
-            H = MFMA16H(w1[0][1], xf[0][0], H); GAP(0);
-            H = MFMA16H(w1[0][0], xf[0][1], H); GAP(1);
-            H = MFMA16H(w1[0][0], xf[0][0], H); GAP(2);
-            H = MFMA16H(w1[1][1], xf[1][0], H); GAP(3);
-            H = MFMA16H(w1[1][0], xf[1][1], H); GAP(4);
-            H = MFMA16H(w1[1][0], xf[1][0], H); GAP(5);
-            // (d), (e): dW1c[cin][hidden] += X^T dH', dW2c^T[out][hidden] += dT^T H'
-            dW1 = MFMA16H(at[0][1], bt[0][0], dW1); GAP(6);
-            dW2t = MFMA16H(ae[0][1], be[0][0], dW2t); GAP(7);
-            dW1 = MFMA16H(at[0][0], bt[0][1], dW1); GAP(8);
-            dW2t = MFMA16H(ae[0][0], be[0][1], dW2t); GAP(9);
-            dW1 = MFMA16H(at[0][0], bt[0][0], dW1); GAP(10);
-            dW2t = MFMA16H(ae[0][0], be[0][0], dW2t); GAP(11);
-            dW1 = MFMA16H(at[1][1], bt[1][0], dW1); GAP(12);
-            dW2t = MFMA16H(ae[1][1], be[1][0], dW2t); GAP(13);
-            dW1 = MFMA16H(at[1][0], bt[1][1], dW1); GAP(14);
-            dW2t = MFMA16H(ae[1][0], be[1][1], dW2t); GAP(15);
-            dW1 = MFMA16H(at[1][0], bt[1][0], dW1); GAP(16);
-            dW2t = MFMA16H(ae[1][0], be[1][0], dW2t); GAP(17);
-            // (c): its B operand is the cut gradient tile as this lane stored it, read back instead of held in 16 registers across the segments
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) gq[kb][p].u = make_uint4(glo[kb][p].x, glo[kb][p].y, ghi[kb][p].x, ghi[kb][p].y);
-            f32x16 dx = zero;
-            dx = MFMA16H(w3[0][1], gq[0][0], dx); GAP(18);
-            dx = MFMA16H(w3[0][0], gq[0][1], dx); GAP(19);
-            dx = MFMA16H(w3[0][0], gq[0][0], dx); GAP(20);
-            dx = MFMA16H(w3[1][1], gq[1][0], dx); GAP(21);
-            dx = MFMA16H(w3[1][0], gq[1][1], dx); GAP(22);
-            dx = MFMA16H(w3[1][0], gq[1][0], dx); GAP(23);
-            // (b)
-            dH = zero;
-            dH = MFMA16H(w2[0][1], df[0][0], dH); GAP(24);
-            dH = MFMA16H(w2[0][0], df[0][1], dH); GAP(25);
-            dH = MFMA16H(w2[0][0], df[0][0], dH); GAP(26);
-            {
-                unsigned char* Tb = reinterpret_cast<unsigned char*>(TbAll + (((i - 1) & 1) * 8 + wave) * PS_TB);
-#pragma unroll
-                for (int G = 0; G < 4; ++G) *reinterpret_cast<float4*>(Tb + (w0 ^ (G << 5))) = make_float4(dx[4 * G], dx[4 * G + 1], dx[4 * G + 2], dx[4 * G + 3]);
-            }
-            dH = MFMA16H(w2[1][1], df[1][0], dH); GAP(27);
-            dH = MFMA16H(w2[1][0], df[1][1], dH); GAP(28);
-            dH = MFMA16H(w2[1][0], df[1][0], dH); GAP(29);
-#else
-            GAP(0); GAP(1); GAP(2); GAP(3); GAP(4); GAP(5); GAP(6); GAP(7); GAP(8); GAP(9); GAP(10); GAP(11); GAP(12); GAP(13); GAP(14); GAP(15); GAP(16); GAP(17);
-            GAP(18); GAP(19); GAP(20); GAP(21); GAP(22); GAP(23); GAP(24); GAP(25); GAP(26);
-#endif
-#undef GAP
-        }
-        XS_ACC(2);
-#ifndef H3S_NOPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        bar();
-        XS_ACC(3);
-        // ================================ X(i) ================================
-        // requested here, used one phase on: the rows of tile i+2 (half A) / dOut of tile i-1, summed in Y(i+1) (half B); a ghost's
-        // request goes to the nearest real tile (its cursor) and is not used
-        if constexpr (ROLE == 0) stage_load(cnn, nxv, nd);
-        else {
-            const int pnrem = vps - 32 * cprev.j < 32 ? vps - 32 * cprev.j : 32;
-            rdo = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dOut) + ((unsigned long)(unsigned)cprev.v0 << 7) + (rrow < pnrem ? ro : rq * 16u));
-        }
-        // ---- once per sample (scalar branches, rarely taken) ----
-        if (real_p && real_c && ccur.n != cprev.n) {
-            // (d), (e) and the db1 sums of tile i run at another sample's scales.  The running sums (tiles <= i-1, all three) move to the new
-            // scales by an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright one -- banks them
-            // in the slab instead and starts over.
-            const int d1 = (ccur.ex() + ccur.eg()) - (cprev.ex() + cprev.eg()), d2 = (ccur.ed() + ccur.eh()) - (cprev.ed() + cprev.eh()), d3 = ccur.eg() - cprev.eg();
-            const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
-#ifndef H3S_NOFLUSH              /* (instruction-count builds only: tools/isa_budget.py) */
-            if (big > 40) flush(cprev);
-            else
-#endif
-            if (big != 0) {
-                const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
-            }
-        }
-        if constexpr (ROLE == 0) {
-            // the biases at the next sample's hidden scale, in that sample's parity (first read in Y(i+1); the last reader of what this
-            // overwrites -- the sample before the current one -- was a Y phase before this segment)
-            if (real_n && cnext.n != ccur.n) sB1[(cnext.n & 1) * 256 + t8] = b1[t8] * pow2i(cnext.eh());
-        } else {
-            // Y(i+1) sums tile i-1: when that enters another sample, the finished one's largest |dX| is committed here
-            if (real_p && on != cprev.n) {
-                if (on >= 0 && am.y) amax_commit(rf[0], am.y + on);
-                on = cprev.n; rf[0] = 0.f;
-            }
-        }
-#ifndef H3S_NOGATE
-        {
-            // gate of tile i (a ghost: dH = 0, so its gradient tile is zero whatever relu(bias) is)
-            const int kg = ccur.eg() - ew2 - ccur.ed();
-            const float cg = pow2i(kg < -126 ? -126 : kg);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                Frag gf[NP];
-                float gs[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r = 8 * kb + e;
-                    gs[e] = H[r] > 0.f ? dH[r] * cg : 0.f;             // (H holds relu(hv) by now: > 0 exactly where hv > 0)
-                    bs1v[r] += gs[e];
-                }
-                cut8_scaled<AR>(gs, gf);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {                         // dH' pieces to the wave's transpose image: (d) reads it transposed, (c) as stored
-                    *reinterpret_cast<uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4))) = make_uint2(gf[p].u.x, gf[p].u.y);
-                    *reinterpret_cast<uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4))) = make_uint2(gf[p].u.z, gf[p].u.w);
-                }
-            }
-        }
-#endif
-        XS_ACC(5);
-        c2p = cprev; cprev = ccur; ccur = cnext; cnext = cnn;
-        if (i + 3 < nt) advance(cnn);
-        b0 = bnext;
-    };
-    if (hb) bar();                                                 // half B starts one segment late ...
-    if (hb) for (int i = 0; i < nt + 2; ++i) iter(std::integral_constant<int, 1>(), i);
-    else for (int i = 0; i < nt + 2; ++i) iter(std::integral_constant<int, 0>(), i);
-    if (!hb) bar();                                                // ... and half A waits for its last one
-    __syncthreads();
-    if (hb && on >= 0 && am.y) amax_commit(rf[0], am.y + on);
-    flush(cprev);                                          // the sums of the run's last sample(s), at that sample's scales
-    // db2[out] = sum of the staged dT values: thread t < 256 always staged out (t % D), ((t + 256) % D), ...; fixed-order sum
-    float* R = TbAll;                                                 // R[f] = column sum of staged element f (f < 1024)
-    if (hb == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) R[tid + 256 * k] = (tid + 256 * k < 32 * D) ? rf[k] : 0.f;
-    }
-    __syncthreads();
-    if (tid < D) {
-        float t = 0.f;
-        for (int jj = tid; jj < 1024; jj += D) t += R[jj];
-        sl[8192 + 256 * (long)D + 256 + tid] = t;
-    }
-#ifdef PROBAV_STAMP
-    xs_acc[6] = __builtin_amdgcn_s_memrealtime() - rt0;      // (100 MHz ticks of the wave's life: life in cycles / this = clock / 100 MHz)
-#endif
-    XS_OUT;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// pw_bwd_h3t_kernel: the alternating-halves kernel above with everything that is not arithmetic taken out of the tile loop (round 4).
-// What the ablations said (tools/h3s_ablate.sh: cycles between the stamps, in-kernel clock): the skeleton of pw_bwd_h3s_kernel -- barriers,
-// cursors, rare-path tests, address selection; no MFMA, no cut, no gate -- is 62 000 of its 330 000 cycles; its vector phases alone
-// 276 000, its matrix phases alone 184 000, and in cycles the matrix pipe and the vector instructions of a SIMD's two waves DO run side
-// by side (tools/coissue_cycles.hip): a tile costs what its waves ISSUE, and a third of what they issued was bookkeeping.  Same
-// products in the same order (bit for bit pw_bwd_x6_kernel<H3>), same LDS layout and phase structure as pw_bwd_h3s_kernel; different:
-//  * A run of tiles touches at most TWO samples (the launcher checks tiles-per-run <= tiles-per-sample and falls back otherwise):
-//    sample A's and sample B's scales are run constants, a tile's sample is one scalar compare (t >= jb), its first voxel one
-//    multiply-add.  The five tile cursors that were shifted through scalar registers every iteration are gone.
-//  * Partial tiles, ghost tiles and the lanes beyond a tile's elements are handled by the buffer unit: every global access of the loop
-//    goes through a per-tile buffer descriptor whose num_records ends at the tile's last valid row (0 for a ghost), so out-of-range
-//    lanes load zeros and their stores are dropped -- no address clamps, no zero selects, no predicated store.
-//  * Once-per-sample work (rescaling the running sums, committing a sample's largest |dX|) sits BETWEEN two executions of the one tile
-//    loop, not inside it: the loop is rotated (gate of tile k-1, then Y(k) and the loads of X(k)) so that the points where that work
-//    belongs are loop boundaries; the biases of both samples are in LDS from the prologue on.
-//  * The second H3 pieces of two pairs are cut by one four-instruction block (lo, lo, hi, hi): the partial-register writes no longer
-//    need an s_nop between them.
-// ---------------------------------------------------------------------------------------------------
-#ifndef H3T_LOADGAP
-#define H3T_LOADGAP 12
-#endif
-__global__ __launch_bounds__(512, 2) void pw_bwd_h3t_kernel(
-    const float* __restrict__ x, const float* __restrict__ dT, const float* __restrict__ dOut,
-    const uint4* __restrict__ w1f, const uint4* __restrict__ w2kf, const uint4* __restrict__ w1cf,
-    const float* __restrict__ b1, float* __restrict__ dX, float* __restrict__ slabs, long nvox, int vps, int D, PwAmax am)
-{
-    XS_ENTRY;
-    using AR = H3;
-    constexpr int NP = 2;
-    constexpr int PB_TILE = NP * PB_IMG;                          // one staged tensor tile: NP piece images
-    typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned char* XA = lds_raw;                                  // [3 buffers][NP pieces][32 voxels][80 B]
-    unsigned char* DA = XA + 3 * PB_TILE;                         // same for dT (channels D..31 stay zero)
-    float* TbAll = reinterpret_cast<float*>(DA + 3 * PB_TILE);   // [2 parities][8 waves][32][32] dX partials (swizzled)
-    float* sB1 = TbAll + 16 * PS_TB;                              // [sample A | sample B][256] expand biases at the sample's hidden-tile scale
-    unsigned char* TiAll = reinterpret_cast<unsigned char*>(sB1 + 512);       // [8 waves][dH' | H'][NP pieces][32 voxels][64 B] (swizzled)
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hb = wave >> 2;                                     // 0: half A (stages), 1: half B (one segment behind; sums the partials)
-    const int c = wave;                                           // this wave's hidden chunk
-    const unsigned aw1 = *am.w1, aw2 = *am.w2, ab1 = *am.b1;
-    const int ew1 = h3_exp_w(aw1), ew2 = h3_exp_w(aw2);
-    // ---- the run: tiles t = 0 .. nt-1 of this workgroup; t < jb belong to sample n0 (A), the others to n0 + 1 (B) ----
-    const int tps = (vps + 31) >> 5;                              // tiles per sample
-    const int ntiles = (int)(nvox / vps) * tps;
-    const int tbeg = (int)((long)ntiles * blockIdx.x / gridDim.x), tend = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
-    const int nt = tend - tbeg;                                   // (<= tps: the launcher's condition)
-    const int n0 = nt > 0 ? tbeg / tps : 0, j0 = nt > 0 ? tbeg - n0 * tps : 0;
-    const int jb = tps - j0;                                      // >= 1
-    const bool hasB = jb < nt;
-    const int rlast = vps - 32 * (tps - 1);                       // rows of a sample's last tile
-    const int vA0 = n0 * vps + 32 * j0, vBB = (n0 + 1) * vps - 32 * jb;      // first voxel of tile t: 32 t + (t < jb ? vA0 : vBB)
-    struct Sc { int ex, ed, eh, eg; };
-    auto load_scales = [&](int n) -> Sc {
-        const unsigned ax = am.x[n], ad = am.dt[n];
-        Sc q;
-        q.ex = __builtin_amdgcn_readfirstlane(h3_exp(ax)); q.ed = __builtin_amdgcn_readfirstlane(h3_exp(ad));
-        q.eh = __builtin_amdgcn_readfirstlane(h3_exp(32.f * __uint_as_float(ax) * __uint_as_float(aw1) + __uint_as_float(ab1)));
-        q.eg = __builtin_amdgcn_readfirstlane(h3_exp((float)D * __uint_as_float(ad) * __uint_as_float(aw2)));
-        return q;
-    };
-    Sc scA = {0, 0, 0, 0}, scB = scA;
-    if (nt > 0) { scA = load_scales(n0); scB = hasB ? load_scales(n0 + 1) : scA; }
-    auto clampexp = [](int k) { return k < -126 ? -126 : k; };
-    // what the loop needs of a sample: 2^ex, 2^ed (staging), the factor that brings (a)'s accumulator to the hidden tile's scale, the one that
-    // brings (b)'s to its gradient's, and eg (the dX partials' way back)
-    const float sxA = pow2i(scA.ex), sdA = pow2i(scA.ed), chA = pow2i(clampexp(scA.eh - scA.ex - ew1)), cgA = pow2i(clampexp(scA.eg - ew2 - scA.ed));
-    const float sxB = pow2i(scB.ex), sdB = pow2i(scB.ed), chB = pow2i(clampexp(scB.eh - scB.ex - ew1)), cgB = pow2i(clampexp(scB.eg - ew2 - scB.ed));
-    // tile t (any integer; outside 0 .. nt-1 a ghost)
-    auto t_real = [&](int t) { return t >= 0 && t < nt; };
-    auto t_inB = [&](int t) { return (t < nt ? t : nt - 1) >= jb; };                      // a ghost behind the run: the last real tile's sample
-    auto t_v0 = [&](int t) { return 32 * t + (t >= jb ? vBB : vA0); };
-    auto t_rows = [&](int t) { return t_real(t) ? (t == jb - 1 ? rlast : 32) : 0; };     // valid voxel rows (a ghost: none)
-
-    Frag w1[2][NP], w2[2][NP], w3[2][NP];                         // chunk-resident weight pieces
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            w1[kb][p].u = w1f[((c * 2 + kb) * NP + p) * 64 + lane];
-            w2[kb][p].u = w2kf[((c * 2 + kb) * NP + p) * 64 + lane];
-            w3[kb][p].u = w1cf[((c * 2 + kb) * NP + p) * 64 + lane];
-        }
-    unsigned char* Ti = TiAll + wave * 2 * NP * PS_IMG;           // dH' pieces
-    unsigned char* Th = Ti + NP * PS_IMG;                          // H' pieces
-    int t0, s0, w0;                                               // per-lane addresses inside a swizzled image / partial (pw_bwd_h3s_kernel)
-    {
-        const int li = lane & 15, gcol = (lane >> 4) & 1, r0 = 4 * half + (li >> 2);
-        t0 = r0 * 64 + (((4 * gcol + (li & 3)) ^ r0) << 3);
-        s0 = col * 64 + ((half ^ ps_key(col)) << 3);
-        w0 = col * 128 + ((half ^ (col & 7)) << 4);
-    }
-    auto toff = [&](int kb, int q) { return (t0 ^ ((2 * kb + q) << 3)) + 1024 * kb + 512 * q; };
-    f32x16 dW1, dW2t;
-    float bs1v[16];                                               // db1 partial of (hidden rowmap(r, half), this lane's voxels)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f; }
-    // ---- per-thread state of the two roles, in the SAME registers (pw_bwd_h3s_kernel): half A: rc[k] = byte offset of its dT element
-    // f = t + 256 k inside a piece image, rf[k] = running sum of that element (db2); half B: rc[k] = MINUS the exponent of W1's cin row 4 rq + k,
-    // rf[0] = largest |dX| so far.  ro: byte offset of the thread's 16 bytes inside a [32][32] fp32 tile (both roles) ----
-    const int t8 = tid & 255, rrow = t8 >> 3, rq = t8 & 7;
-    int rc[4]; float rf[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int f = t8 + 256 * k, dv = f / D;
-        rc[k] = hb ? -h3_exp_w(am.w1r[4 * rq + k]) : (f < 32 * D ? dv * PB_ROW + (f - dv * D) * 2 : D * 2);     // (an unused slot: voxel 0's zero pad, D < 32 there)
-    }
-    const int ro = rrow * 128 + rq * 16;
-    const int rs = hb ? rrow * 32 + ((rq ^ (rrow & 7)) << 2) : rrow * PB_ROW + rq * 8;
-    // a tile's rows through a buffer descriptor of its own: base = the tile's first row, num_records = its valid rows -- a lane beyond them
-    // (a partial tile's missing rows, every lane of a ghost, a dT slot beyond the tile's 32 D elements) loads zeros / stores nothing
-    // (every component is wave-uniform; said explicitly, because a descriptor the compiler cannot PROVE uniform is applied through a waterfall loop)
-    auto tile_rsrc = [&](const float* base, int t, int row_bytes) {
-        const unsigned long p = reinterpret_cast<unsigned long>(base) + (unsigned long)((long)t_v0(t) * row_bytes);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((unsigned long)hi << 32) | lo), 0,
-                                                 __builtin_amdgcn_readfirstlane(t_rows(t) * row_bytes), 0x00020000);
-    };
-    auto stage_load = [&](int t, float4& xv, float (&d)[4]) {
-        const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x, t, 128), rd = tile_rsrc(dT, t, 4 * D);
-        const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(rx, ro, 0, 0);
-        xv = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, 4 * (t8 + 256 * k), 0, 0));
-    };
-    // cut and store one staged tile (rows the loads found out of range are zeros already)
-    auto stage_store = [&](unsigned char* sXd, unsigned char* sDd, float sx, float sd, const float4& xv, const float (&d)[4]) {
-        uint2 q0, q1;
-        h3_cut4_scaled(xv.x * sx, xv.y * sx, xv.z * sx, xv.w * sx, q0, q1);
-        *reinterpret_cast<uint2*>(sXd) = q0;
-        *reinterpret_cast<uint2*>(sXd + PB_IMG) = q1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            unsigned short qq[NP];
-            cut_one<AR>(d[k], sd, qq);
-            *reinterpret_cast<unsigned short*>(sDd + rc[k]) = qq[0];
-            *reinterpret_cast<unsigned short*>(sDd + PB_IMG + rc[k]) = qq[1];
-            rf[k] += d[k];
-        }
-    };
-    // ---- the workgroup's slab: [dW1 32x256 | dW2 256xD | db1 256 | db2 D] (pw_bwd_h3s_kernel) ----
-    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
-    float* sl = slabs + (long)blockIdx.x * slab_floats;
-    bool flushed = false;                                             // wave-uniform
-    auto flush = [&](const Sc& q) __attribute__((always_inline)) {
-        asm volatile("" ::: "memory");
-        // a rare path: its 48 per-lane slab addresses must not be hoisted out of it (they are loop invariants: hoisted, they sat in scratch memory
-        // beside a tile loop that is short of registers) -- they hang on a value the optimiser cannot see through
-        int colq = col, halfq = half;
-        asm volatile("" : "+v"(colq), "+v"(halfq));
-        float a1[16], a2[16], a3[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            a1[r] = ldexpf(dW1[r], -(q.ex + q.eg)); a2[r] = ldexpf(dW2t[r], -(q.ed + q.eh));
-            float v = bs1v[r];                                        // db1[hidden] = sum over the voxel lanes: butterfly inside each 32-lane half (fixed order)
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-            a3[r] = ldexpf(v, -q.eg);
-            dW1[r] = 0.f; dW2t[r] = 0.f; bs1v[r] = 0.f;
-        }
-        if (flushed) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rw = rowmap(r, halfq);
-                a1[r] += sl[(long)rw * 256 + 32 * c + colq];
-                if (rw < D) a2[r] += sl[8192 + (long)(32 * c + colq) * D + rw];
-                if (colq == 0) a3[r] += sl[8192 + 256 * (long)D + 32 * c + rw];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rw = rowmap(r, halfq);
-            sl[(long)rw * 256 + 32 * c + colq] = a1[r];                                        // [cin][hidden]
-            if (rw < D) sl[8192 + (long)(32 * c + colq) * D + rw] = a2[r];                     // [hidden][out]
-            if (colq == 0) sl[8192 + 256 * (long)D + 32 * c + rw] = a3[r];
-        }
-        flushed = true;
-    };
-
-    for (int k = tid; k < 160 * 1024 / 16; k += 512) reinterpret_cast<uint4*>(lds_raw)[k] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f); float nd[4] = {0.f, 0.f, 0.f, 0.f};      // half A: the raw rows of the tile staged next
-    float4 rdo = make_float4(0.f, 0.f, 0.f, 0.f);                                          // half B: dOut of the tile summed next
-    if (hb == 0) {
-        stage_load(0, nxv, nd);                                                            // (nt == 0: a ghost, zeros)
-        stage_store(XA + rs, DA, sxA, sdA, nxv, nd);                                        // tile 0 is always sample A's
-        stage_load(1, nxv, nd);
-        sB1[t8] = b1[t8] * pow2i(scA.eh);
-        sB1[256 + t8] = b1[t8] * pow2i(scB.eh);
-    }
-    // LDS only: requested rows and dX stores stay in flight; nothing (an MFMA least of all) may be scheduled across a segment boundary
-    auto bar = [] { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
-    f32x16 zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    f32x16 H = zero;                                               // accumulator of (a), then IN PLACE relu(H) of tile k at the hidden tile's scale: from Y(k) to the gate
-    f32x16 dH = zero;                                              // its gradient (accumulator of (b)), likewise
-
-    XS_DECL;
-#ifdef PROBAV_STAMP_Y
-    unsigned long long ys_acc[5] = {0, 0, 0, 0, 0};
-#endif
-#ifdef PROBAV_STAMP
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- the gate of tile k (vector phase; a ghost: dH = 0, so its gradient tile is zero whatever relu(bias) is) ----
-    auto gate = [&](int k) __attribute__((always_inline)) {
-#ifdef H3T_GATEPRIO
-        __builtin_amdgcn_s_setprio(H3T_GATEPRIO);
-#endif
-#ifndef H3S_NOGATE
-        const float cg = t_inB(k) ? cgB : cgA;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float gs[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int r = 8 * kb + e;
-                gs[e] = H[r] > 0.f ? dH[r] * cg : 0.f;             // (H holds relu(hv) by now: > 0 exactly where hv > 0)
-                bs1v[r] += gs[e];
-            }
-            uint2 qa0, qa1, qb0, qb1;
-            h3_cut4_scaled(gs[0], gs[1], gs[2], gs[3], qa0, qa1);
-            h3_cut4_scaled(gs[4], gs[5], gs[6], gs[7], qb0, qb1);
-            // dH' pieces to the wave's transpose image: (d) reads it transposed, (c) as stored
-#ifndef H3T_NODHSTORE
-            *reinterpret_cast<uint2*>(Ti + (s0 ^ ((2 * kb) << 4))) = qa0;
-            *reinterpret_cast<uint2*>(Ti + (s0 ^ ((2 * kb + 1) << 4))) = qb0;
-            *reinterpret_cast<uint2*>(Ti + PS_IMG + (s0 ^ ((2 * kb) << 4))) = qa1;
-            *reinterpret_cast<uint2*>(Ti + PS_IMG + (s0 ^ ((2 * kb + 1) << 4))) = qb1;
-#else
-            asm volatile("" :: "v"(qa0.x), "v"(qa0.y), "v"(qb0.x), "v"(qb0.y), "v"(qa1.x), "v"(qa1.y), "v"(qb1.x), "v"(qb1.y));
-#endif
-        }
-#endif
-    };
-    // ---- Y(k) and the loads of X(k); ROLE = 0 / 1: the instance of half A / B ----
-    int b0 = 0;                                                    // staging buffer of tile k
-    auto front = [&](auto role_tag, int k) __attribute__((always_inline)) {
-        constexpr int ROLE = decltype(role_tag)::value;
-        const int bprev = b0 == 0 ? 2 : b0 - 1, bnext = b0 == 2 ? 0 : b0 + 1;                       // staging buffers of tiles k-1, k+1 (b0: tile k's, k mod 3)
-        bar();
-        XS_ACC(1);
-#ifndef H3S_NOPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        // ================================ Y(k): 30 MFMAs, (d), (e), (c) of tile k-1, then (a), (b) of tile k ================================
-        H = zero;
-            const unsigned char* Xb = XA + b0 * PB_TILE;
-            const unsigned char* Db = DA + b0 * PB_TILE;
-            const unsigned char* Xp = XA + bprev * PB_TILE;
-            const unsigned char* Dp = DA + bprev * PB_TILE;
-            // ---- pieces of vector work (their gaps: pw_bwd_h3s_kernel) ----
-            // half A: cut and stage tile k+1 (requested in X(k-1))
-            const bool nB = t_inB(k + 1);
-            const float sx = nB ? sxB : sxA, sd = nB ? sdB : sdA;
-            unsigned char* sXd = XA + bnext * PB_TILE + rs;
-            unsigned char* sDd = DA + bnext * PB_TILE;
-            auto stageX = [&]() {
-                uint2 q0, q1;
-                h3_cut4_scaled(nxv.x * sx, nxv.y * sx, nxv.z * sx, nxv.w * sx, q0, q1);
-                *reinterpret_cast<uint2*>(sXd) = q0;
-                *reinterpret_cast<uint2*>(sXd + PB_IMG) = q1;
-            };
-            auto stageD = [&](int kk) {
-                unsigned short qq[NP];
-                cut_one<AR>(nd[kk], sd, qq);
-                *reinterpret_cast<unsigned short*>(sDd + rc[kk]) = qq[0];
-                *reinterpret_cast<unsigned short*>(sDd + PB_IMG + rc[kk]) = qq[1];
-                rf[kk] += nd[kk];
-            };
-            // half B: dX of tile k-2 = dOut + its eight chunk partials, in the order of the chunks (partial jj is requested two gaps ahead)
-#ifdef H3T_PURE
-            constexpr int SUMT = 1;                                        // X(k) sums tile k-1
-#else
-            constexpr int SUMT = 2;                                        // Y(k) sums tile k-2
-#endif
-            const float* Tp = TbAll + ((k - SUMT) & 1) * 8 * PS_TB + rs;
-            const int egs = t_inB(k - SUMT) ? scB.eg : scA.eg;
-            float4 tq[3];                                                  // (three in flight)
-#ifdef H3T_PURE
-            float4 tq8[8];
-#endif
-            float sa[4] = {0.f, 0.f, 0.f, 0.f};
-            auto sums_read = [&](int jj) { tq[jj % 3] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); };
-            auto sums_add = [&](int jj) { sa[0] += tq[jj % 3].x; sa[1] += tq[jj % 3].y; sa[2] += tq[jj % 3].z; sa[3] += tq[jj % 3].w; };
-            auto sums_out = [&]() {
-                const float od[4] = {rdo.x, rdo.y, rdo.z, rdo.w};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) sa[kk] = ldexpf(sa[kk], rc[kk] - egs) + od[kk];         // (c) partials -> true values: W1's cin row (rc = minus its exponent) and the sample's dH scale
-                const __amdgpu_buffer_rsrc_t ry = tile_rsrc(dX, k - SUMT, 128);
-                u32x4b q = {__float_as_uint(sa[0]), __float_as_uint(sa[1]), __float_as_uint(sa[2]), __float_as_uint(sa[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(q, ry, ro, 0, 0);                               // (rows beyond the tile: dropped)
-            };
-            auto sums_max = [&]() {      // (a row beyond the tile holds zeros: its X and dT rows were staged as zeros and its dOut was out of range)
-                rf[0] = fmaxf(rf[0], fmaxf(fmaxf(fabsf(sa[0]), fabsf(sa[1])), fmaxf(fabsf(sa[2]), fabsf(sa[3]))));
-            };
-            // both: bias, ReLU and cut of the hidden tile, four registers (one 8-byte chunk of the lane's H' image row, both pieces) at a time
-            const bool cB = t_inB(k);
-            const float ch = cB ? chB : chA;
-            const float* sB = sB1 + (cB ? 256 : 0) + 32 * c + 4 * half;
-            float4 bbq[4];
-            auto relu2 = [&](int g, int e0) {                          // registers 4g + e0, 4g + e0 + 1
-                const float bv[4] = {bbq[g].x, bbq[g].y, bbq[g].z, bbq[g].w};
-                H[4 * g + e0] = fmaxf(fmaf(H[4 * g + e0], ch, bv[e0]), 0.f);
-                H[4 * g + e0 + 1] = fmaxf(fmaf(H[4 * g + e0 + 1], ch, bv[e0 + 1]), 0.f);
-            };
-            uint2 hq0, hq1;
-            auto hcut = [&](int g) { h3_cut4_scaled(H[4 * g], H[4 * g + 1], H[4 * g + 2], H[4 * g + 3], hq0, hq1); };
-            // (the store of group g must come behind the LAST transposed read of the previous tile's H' image: rd_de(1, 3) in gap 11 -- LDS
-            // operations of a wave execute in order, and inside a gap the operand requests are issued first)
-            auto hstore = [&](int g) {
-#ifndef H3T_NOHSTORE              /* (timing-only ablations: what do the LDS stores cost) */
-                *reinterpret_cast<uint2*>(Th + (s0 ^ (g << 4))) = hq0;
-                *reinterpret_cast<uint2*>(Th + PS_IMG + (s0 ^ (g << 4))) = hq1;
-#else
-                asm volatile("" :: "v"(hq0.x), "v"(hq0.y), "v"(hq1.x), "v"(hq1.y));
-#endif
-            };
-            // ---- operands, requested in the gaps ahead of their MFMAs ----
-            Frag xf[2][NP], df[2][NP], gq[2][NP];
-            Frag at[2][NP], bt[2][NP], ae[2][NP], be[2][NP];          // [k-block][piece]
-            uint2 glo[2][NP], ghi[2][NP];
-            auto rd_de = [&](int kb, int which) {                      // two fragments = four transposed reads
-                if (which == 0) { tr_frag<PB_ROW>(Xp, lane, kb, at[kb][0]); tr_frag_sw(Ti, toff(kb, 0), toff(kb, 1), bt[kb][0]); }
-                if (which == 1) { tr_frag<PB_ROW>(Xp + PB_IMG, lane, kb, at[kb][1]); tr_frag_sw(Ti + PS_IMG, toff(kb, 0), toff(kb, 1), bt[kb][1]); }
-                if (which == 2) { tr_frag<PB_ROW>(Dp, lane, kb, ae[kb][0]); tr_frag_sw(Th, toff(kb, 0), toff(kb, 1), be[kb][0]); }
-                if (which == 3) { tr_frag<PB_ROW>(Dp + PB_IMG, lane, kb, ae[kb][1]); tr_frag_sw(Th + PS_IMG, toff(kb, 0), toff(kb, 1), be[kb][1]); }
-            };
-            auto rd_gq = [&](int kb, int p) {
-                glo[kb][p] = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb) << 4)));
-                ghi[kb][p] = *reinterpret_cast<const uint2*>(Ti + p * PS_IMG + (s0 ^ ((2 * kb + 1) << 4)));
-            };
-            auto rd_df = [&](int kb, int p) { df[kb][p].u = *reinterpret_cast<const uint4*>(Db + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16); };
-            auto gap = [&](auto slot_tag) {
-                constexpr int S = decltype(slot_tag)::value;
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (S >= 0 && S <= 3) rd_de(0, S);
-                if constexpr (S >= 8 && S <= 11) rd_de(1, S - 8);
-                if constexpr (S >= 12 && S <= 15) rd_gq((S - 12) >> 1, (S - 12) & 1);
-                if constexpr (S >= 19 && S <= 22) rd_df((S - 19) >> 1, (S - 19) & 1);
-#if !defined(H3T_PURE) && !defined(H3T_LOADS_IN_X)
-                // the global requests of the NEXT phases go out here, late in the matrix phase (scalar descriptor arithmetic and five vector-memory
-                // instructions cost a gap nothing), not at the head of X(k): the vector phase is then the gate alone -- it was the segment's
-                // critical path by the ~200 cycles its loads' bookkeeping took -- and the requests get a phase more of lead
-                if constexpr (S == H3T_LOADGAP) {
-                    if constexpr (ROLE == 0) stage_load(k + 2, nxv, nd);      // (nxv / nd were consumed in gaps 0-5)
-                    else {
-                        const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k - 1, 128), ro, 0, 0);      // (rdo was consumed in gap 8)
-                        rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-                    }
-                }
-#endif
-#ifndef H3T_PURE
-                if constexpr (ROLE == 0) {
-#ifndef H3S_NOSTAGE
-                    if constexpr (S == 0) stageX();
-                    if constexpr (S >= 2 && S <= 5) stageD(S - 2);
-#endif
-                } else {
-#ifndef H3S_NOSUMS
-                    if constexpr (S + 2 <= 7) sums_read(S + 2);
-                    if constexpr (S <= 7) sums_add(S);
-                    if constexpr (S == 8) sums_out();
-                    if constexpr (S == 9) sums_max();
-#endif
-                }
-#endif
-#if !defined(H3S_NOGATE) && !defined(H3T_PURE)
-                constexpr int H0 = ROLE == 0 ? 8 : 11;                  // the first gap of the relu(H) work: per group of four registers bias+ReLU in one gap, cut + store two gaps on
-                if constexpr (S >= H0 - 2 && S < H0 + 14 && ((S - H0 + 2) & 3) == 0) bbq[(S - H0 + 2) >> 2] = *reinterpret_cast<const float4*>(sB + 8 * ((S - H0 + 2) >> 2));      // its biases, two gaps ahead
-                if constexpr (S >= H0 && S < H0 + 16) {
-                    constexpr int g = (S - H0) >> 2, c4 = (S - H0) & 3;
-                    if constexpr (c4 == 0) relu2(g, 0);
-                    if constexpr (c4 == 1) relu2(g, 2);
-                    if constexpr (c4 == 2) hcut(g);
-                    if constexpr (c4 == 3) hstore(g);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            };
-#define GAP(n) gap(std::integral_constant<int, n>())
-#if defined(PROBAV_STAMP_Y) && !defined(H3T_PURE)
-#define YS(q) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ys_acc[q] += t_ - ys_t; ys_t = t_; } while (0)
-            unsigned long long ys_t = __builtin_amdgcn_s_memtime();
-#else
-#define YS(q) do { } while (0)
-#endif
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) xf[kb][p].u = *reinterpret_cast<const uint4*>(Xb + p * PB_IMG + col * PB_ROW + kb * 32 + half * 16);
-#if !defined(H3S_NOSUMS) && !defined(H3T_PURE)
-            if constexpr (ROLE == 1) { sums_read(0); sums_read(1); }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef H3S_NOY
-            // (a)
-            H = MFMA16H(w1[0][1], xf[0][0], H); GAP(0);
-            H = MFMA16H(w1[0][0], xf[0][1], H); GAP(1);
-            H = MFMA16H(w1[0][0], xf[0][0], H); GAP(2);
-            H = MFMA16H(w1[1][1], xf[1][0], H); GAP(3);
-            H = MFMA16H(w1[1][0], xf[1][1], H); GAP(4);
-            H = MFMA16H(w1[1][0], xf[1][0], H); GAP(5); YS(0);
-            // (d), (e): dW1c[cin][hidden] += X^T dH', dW2c^T[out][hidden] += dT^T H'
-            dW1 = MFMA16H(at[0][1], bt[0][0], dW1); GAP(6);
-            dW2t = MFMA16H(ae[0][1], be[0][0], dW2t); GAP(7);
-            dW1 = MFMA16H(at[0][0], bt[0][1], dW1); GAP(8);
-            dW2t = MFMA16H(ae[0][0], be[0][1], dW2t); GAP(9);
-            dW1 = MFMA16H(at[0][0], bt[0][0], dW1); GAP(10);
-            dW2t = MFMA16H(ae[0][0], be[0][0], dW2t); GAP(11); YS(1);
-            dW1 = MFMA16H(at[1][1], bt[1][0], dW1); GAP(12);
-            dW2t = MFMA16H(ae[1][1], be[1][0], dW2t); GAP(13);
-            dW1 = MFMA16H(at[1][0], bt[1][1], dW1); GAP(14);
-            dW2t = MFMA16H(ae[1][0], be[1][1], dW2t); GAP(15);
-            dW1 = MFMA16H(at[1][0], bt[1][0], dW1); GAP(16);
-            dW2t = MFMA16H(ae[1][0], be[1][0], dW2t); GAP(17); YS(2);
-            // (c): its B operand is the cut gradient tile as this lane stored it, read back instead of held in 16 registers across the segments
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) gq[kb][p].u = make_uint4(glo[kb][p].x, glo[kb][p].y, ghi[kb][p].x, ghi[kb][p].y);
-            f32x16 dx = zero;
-            dx = MFMA16H(w3[0][1], gq[0][0], dx); GAP(18);
-            dx = MFMA16H(w3[0][0], gq[0][1], dx); GAP(19);
-            dx = MFMA16H(w3[0][0], gq[0][0], dx); GAP(20);
-            dx = MFMA16H(w3[1][1], gq[1][0], dx); GAP(21);
-            dx = MFMA16H(w3[1][0], gq[1][1], dx); GAP(22);
-            dx = MFMA16H(w3[1][0], gq[1][0], dx); GAP(23); YS(3);
-            // (b)
-            dH = zero;
-            dH = MFMA16H(w2[0][1], df[0][0], dH); GAP(24);
-            dH = MFMA16H(w2[0][0], df[0][1], dH); GAP(25);
-            dH = MFMA16H(w2[0][0], df[0][0], dH); GAP(26);
-            {
-                unsigned char* Tb = reinterpret_cast<unsigned char*>(TbAll + (((k - 1) & 1) * 8 + wave) * PS_TB);
-#pragma unroll
-#ifndef H3T_NOTB
-                for (int G = 0; G < 4; ++G) *reinterpret_cast<float4*>(Tb + (w0 ^ (G << 5))) = make_float4(dx[4 * G], dx[4 * G + 1], dx[4 * G + 2], dx[4 * G + 3]);
-#else
-                for (int G = 0; G < 4; ++G) asm volatile("" :: "v"(dx[4 * G]), "v"(dx[4 * G + 1]), "v"(dx[4 * G + 2]), "v"(dx[4 * G + 3]), "v"(Tb));
-#endif
-            }
-            dH = MFMA16H(w2[1][1], df[1][0], dH); GAP(27);
-            dH = MFMA16H(w2[1][0], df[1][1], dH); GAP(28);
-            dH = MFMA16H(w2[1][0], df[1][0], dH); GAP(29); YS(4);
-#else
-            GAP(0); GAP(1); GAP(2); GAP(3); GAP(4); GAP(5); GAP(6); GAP(7); GAP(8); GAP(9); GAP(10); GAP(11); GAP(12); GAP(13); GAP(14); GAP(15); GAP(16); GAP(17);
-            GAP(18); GAP(19); GAP(20); GAP(21); GAP(22); GAP(23); GAP(24); GAP(25); GAP(26);
-#endif
-#undef GAP
-#undef YS
-        XS_ACC(2);
-#ifndef H3S_NOPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        bar();
-        XS_ACC(3);
-        // ================================ X(k), first part: requested here, used one phase on ================================
-        // the rows of tile k+2 (half A: staged in Y(k+1)) / dOut of tile k-1 (half B: summed in Y(k+1))
-#if defined(H3T_PURE) && defined(PROBAV_STAMP_Y)
-#define XSS(q) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ys_acc[q] += t_ - xs_tt; xs_tt = t_; } while (0)
-        unsigned long long xs_tt = __builtin_amdgcn_s_memtime();
-#else
-#define XSS(q) do { } while (0)
-#endif
-#ifdef H3T_PURE
-        // every piece of vector work of the iteration sits HERE, beside the other half's matrix phase (whose gaps hold operand requests only):
-        // bias / ReLU / cut of tile k's hidden tile, then the staging of tile k+1 (half A) / the dX sums of tile k-1 (half B); the gate follows at the loop top
-#ifndef H3S_NOGATE
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bbq[g] = *reinterpret_cast<const float4*>(sB + 8 * g);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { relu2(g, 0); relu2(g, 2); hcut(g); hstore(g); }
-#endif
-        XSS(0);
-        if constexpr (ROLE == 0) {
-#ifndef H3S_NOSTAGE
-            stageX();
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) stageD(kk);
-#endif
-            XSS(1);
-            stage_load(k + 2, nxv, nd);
-            XSS(2);
-        } else {
-#ifndef H3S_NOSUMS
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) { tq8[jj] = *reinterpret_cast<const float4*>(Tp + jj * PS_TB); }
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) { sa[0] += tq8[jj].x; sa[1] += tq8[jj].y; sa[2] += tq8[jj].z; sa[3] += tq8[jj].w; }
-            sums_out();
-            sums_max();
-#endif
-            XSS(1);
-            const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k, 128), ro, 0, 0);
-            rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-            XSS(2);
-        }
-#elif defined(H3T_LOADS_IN_X)
-        if constexpr (ROLE == 0) stage_load(k + 2, nxv, nd);
-        else {
-            const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(dOut, k - 1, 128), ro, 0, 0);
-            rdo = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-        }
-#endif
-        b0 = bnext;
-    };
-    // ---- the run: k = 0 .. nt+1, per k the gate of tile k-1 (X(k-1), second part), then Y(k) and the loads of X(k).  ONE loop; it is left and
-    // entered again where something happens once per sample ----
-    const int kend = nt + 2;
-    const int kE2 = hasB ? jb + 1 : kend;                         // between Y(jb) and the gate of tile jb: the running sums change scales
-#ifdef H3T_PURE
-    const int kE3 = kE2;                                           // X(jb) summed sample A's last tile, X(jb+1) sums sample B's first: sample A's largest |dX| is complete
-#else
-    const int kE3 = hasB && jb + 2 < kend ? jb + 2 : kend;        // between Y(jb+1) (which summed sample A's last tile) and Y(jb+2): sample A's largest |dX|
-#endif
-    int on = n0;                                                   // half B: the sample whose largest |dX| rf[0] is collecting
-    if (hb) bar();                                                 // half B starts one segment late ...
-    auto events = [&](int k) __attribute__((always_inline)) {
-        if (k == kE2) {
-            // (d), (e) and the db1 sums of tile jb run at sample B's scales.  The running sums (tiles < jb, all three) move to the new scales by
-            // an exact multiplication with a power of two; a jump beyond 2^+-40 -- a dead sample next to a bright one -- banks them in the slab
-            // instead and starts over.
-            const int d1 = (scB.ex + scB.eg) - (scA.ex + scA.eg), d2 = (scB.ed + scB.eh) - (scA.ed + scA.eh), d3 = scB.eg - scA.eg;
-            const int big = max(max(d1 < 0 ? -d1 : d1, d2 < 0 ? -d2 : d2), d3 < 0 ? -d3 : d3);
-            if (big > 40) flush(scA);
-            else if (big != 0) {
-                const float f1 = pow2i(d1), f2 = pow2i(d2), f3 = pow2i(d3);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { dW1[r] *= f1; dW2t[r] *= f2; bs1v[r] *= f3; }
-            }
-        }
-        if (k == kE3 && hb) {
-            if (am.y) amax_commit(rf[0], am.y + n0);
-            on = n0 + 1; rf[0] = 0.f;
-        }
-    };
-    if (hb) for (int k = 0; k < kend; ++k) { if (__builtin_expect(k == kE2 || k == kE3, 0)) events(k); gate(k - 1); XS_ACC(5); front(std::integral_constant<int, 1>(), k); }
-    else for (int k = 0; k < kend; ++k) { if (__builtin_expect(k == kE2 || k == kE3, 0)) events(k); gate(k - 1); XS_ACC(5); front(std::integral_constant<int, 0>(), k); }
-    if (!hb) bar();                                                // ... and half A waits for its last one
-    __syncthreads();
-    if (hb && nt > 0 && am.y) amax_commit(rf[0], am.y + on);
-    flush(t_inB(nt - 1) ? scB : scA);                              // the sums of the run's last sample, at that sample's scales
-    // db2[out] = sum of the staged dT values: thread t < 256 always staged out (t % D), ((t + 256) % D), ...; fixed-order sum
-    float* R = TbAll;                                                 // R[f] = column sum of staged element f (f < 1024)
-    if (hb == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) R[tid + 256 * kk] = (tid + 256 * kk < 32 * D) ? rf[kk] : 0.f;
-    }
-    __syncthreads();
-    if (tid < D) {
-        float t = 0.f;
-        for (int jj = tid; jj < 1024; jj += D) t += R[jj];
-        sl[8192 + 256 * (long)D + 256 + tid] = t;
-    }
-#ifdef PROBAV_STAMP
-    xs_acc[6] = __builtin_amdgcn_s_memrealtime() - rt0;
-#endif
-    XS_OUT;
-#ifdef PROBAV_STAMP_Y
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) for (int q = 0; q < 5; ++q) g_stamps[4096 * 8 + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + q] = ys_acc[q];
-#endif
-}
 
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,
                    const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
@@ -1949,36 +874,15 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     static std::once_flag once;
     std::call_once(once, [] {
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_h3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_h3t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_bwd_x6_kernel<H3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     if (vps <= 0 || vps > nvox) vps = nvox;
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_backward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
-        // round 5: one wave per SIMD, 512 registers, no barrier in the tile loop (kernels_pw4.hip); PROBAV_PW_BWD_H3T=1 / pw4_set_enabled(0): round 4's kernel (A/B runs)
+        // round 5: one wave per SIMD, 512 registers, no barrier in the tile loop (kernels_pw4.hip).  pw_bwd_x6_kernel<H3> below is the general form: any
+        // batch, any D <= 32 (and PROBAV_PW_BWD_GEN1=1 / pw4_set_enabled(0) for A/B runs); rounds 3 and 4's schedules of it (pw_bwd_h3s / h3t) left with round 5
         if (pw4_enabled() && pw4_backward_supported(nvox, vps, D))
             return pw4_backward(x, dT, dOut, w1f, w2kf, w1cf, b1, dX, dW1, dW2, db1, db2, slabs, nvox, vps, D, am, s);
-        static const bool v1_env = getenv("PROBAV_PW_BWD_V1") != nullptr;      // diagnostic / A-B runs: the one-program form (same bits)
-        const bool same_program = v1_env || nvox * 32 >= (1L << 31);            // (the alternating-halves kernel keeps voxel indices in 32-bit scalars)
-        if (!same_program) {
-            const size_t lds = (size_t)6 * H3::NP * PB_IMG + ((size_t)16 * PS_TB + 512) * sizeof(float) + (size_t)8 * 2 * H3::NP * PS_IMG;       // = 160 KB
-            // round 4's form needs every workgroup's run of tiles inside two samples: tiles per run <= tiles per sample (batch <= grid at the benchmark's shapes)
-            static const bool h3s_env = getenv("PROBAV_PW_BWD_H3S") != nullptr;     // A/B runs: round 3's alternating-halves kernel (same bits)
-            const long tps = (vps + 31) / 32, ntl = (nvox / vps) * tps, grid = mfma_pw_backward_grid();
-            if (!h3s_env && (ntl + grid - 1) / grid <= tps) {
-                hipLaunchKernelGGL(pw_bwd_h3t_kernel, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
-                                   (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);
-                int rc = check_launch("pw_bwd_h3t");
-                if (rc) return rc;
-                return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
-            }
-            hipLaunchKernelGGL(pw_bwd_h3s_kernel, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
-                               (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);
-            int rc = check_launch("pw_bwd_h3s");
-            if (rc) return rc;
-            return mfma_pw_backward_reduce(slabs, D, dW1, dW2, db1, db2, s);
-        }
         const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 2 * H3::NP * PT_IMG;   // (two transpose images per wave)
         hipLaunchKernelGGL(pw_bwd_x6_kernel<H3>, dim3(mfma_pw_backward_grid()), dim3(512), lds, s, x, dT, dOut, (const uint4*)w1f,
                            (const uint4*)w2kf, (const uint4*)w1cf, b1, dX, slabs, nvox, (int)vps, D, am);

@@ -638,7 +638,7 @@ class ModelTrainer:
             self._scalar("Train PSNR", vals[1], gs)
             self._scalar("Train loss", vals[0], gs)
         late = _LateScalars(emit, self._device())
-        tuner = _SideStreamTuner(self.model) if os.environ.get("PROBAV_SIDE_STREAM_TUNE", "1") != "0" else None
+        tuner = _SideStreamTuner(self.model) if getattr(self, "tune_side_stream", True) else None       # (set trainer.tune_side_stream = False to keep the engine's mode)
         # The host is at most one step (134 launches) ahead of the device: a generation-2 sweep of the interpreter's collector is a 10-20 ms hole in the launch
         # stream.  The loop allocates no reference cycles of its own: the automatic collector is OFF inside it (as in bench.py's timed region) and runs by
         # hand at the evaluation points and every 2000 steps; the caller's setting comes back in the `finally` below.

@@ -101,48 +101,15 @@ def test_training_step_replays_from_a_captured_graph():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
-def test_one_wave_per_simd_pointwise_backward_agrees_with_round_4s_kernel(B, T, tmp_path):
+def test_one_wave_per_simd_pointwise_backward_agrees_with_the_general_form(B, T, tmp_path):
     """The fused pointwise backward of round 5 (pw_bwd_w4_kernel: one wave per SIMD, a wave owns a tile and all eight hidden chunks) evaluates the products
-    of round 4's kernel (pw_bwd_h3t_kernel, PROBAV_PW_BWD_H3T=1) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
+    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_PW_BWD_GEN1=1) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
     the order of the fp32 additions across chunks (dX: one accumulator chain instead of eight partials) and across tiles (filter gradients: a wave's run
     instead of a workgroup's).  Whole network: identical predictions (the forward pass is untouched), the flat gradient vector to 1e-5 of its max-norm."""
     import numpy as np
-    a, b = str(tmp_path / "w4.npz"), str(tmp_path / "h3t.npz")
+    a, b = str(tmp_path / "w4.npz"), str(tmp_path / "gen1.npz")
     _run({}, B, T, 1, a)
-    _run({"PROBAV_PW_BWD_H3T": "1"}, B, T, 1, b)
+    _run({"PROBAV_PW_BWD_GEN1": "1"}, B, T, 1, b)
     A, Bv = np.load(a), np.load(b)
     assert np.array_equal(A["pred"], Bv["pred"])
     assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-5 * np.abs(Bv["grad"]).max()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
-def test_mfma_shapes_of_the_32_channel_strip_kernel_agree(B, T, tmp_path):
-    """conv3_pp_kernel with 32 input channels (backward-data of the residual blocks, the reducers) runs on v_mfma_f32_16x16x32_f16 by default and
-    on v_mfma_f32_32x32x16_f16 under PROBAV_PP_K16=1.  Same pieces, same products; the matrix pipe sums 32 against 16 of them per instruction,
-    so the fp32 results may differ in the last bits and no more: predictions to 1e-6 of their range, the flat gradient vector to 1e-5 of its max-norm."""
-    import numpy as np
-    a, b = str(tmp_path / "k32.npz"), str(tmp_path / "k16.npz")
-    _run({}, B, T, 1, a)
-    _run({"PROBAV_PP_K16": "1"}, B, T, 1, b)
-    A, Bv = np.load(a), np.load(b)
-    assert np.abs(A["pred"] - Bv["pred"]).max() <= 1e-6 * np.abs(Bv["pred"]).max()
-    assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-5 * np.abs(Bv["grad"]).max()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
-def test_pair_split_form_of_the_25_channel_strip_kernel_agrees(B, T, tmp_path):
-    """The 25-channel strip kernel (normConv forward) lets the two waves of a pair split a 64-voxel tile's k-blocks and adds their partial sums
-    (default); PROBAV_PP_OLD25=1 keeps one wave per 32-voxel tile.  Same products, another order of the fp32 additions: the FORWARD results agree to
-    the last bits (1e-6 of the predictions' range).  The gradients are held to SURVEY section 8c's bar only (1e-3 of the max norm): a last-bit
-    difference of a hidden pre-activation that sits at zero flips its ReLU gate, and every gradient upstream of that block then differs by that one
-    voxel's contribution (seen: one flip in block 8 of 12 at B = 5, 1e-4 of the max norm from there down, 1e-7 above it) -- the reason why the
-    oracle comparisons take the device's gates (tests/test_gpu_parity.py)."""
-    import numpy as np
-    a, b = str(tmp_path / "pair.npz"), str(tmp_path / "single.npz")
-    _run({}, B, T, 1, a)
-    _run({"PROBAV_PP_OLD25": "1"}, B, T, 1, b)
-    A, Bv = np.load(a), np.load(b)
-    assert np.abs(A["pred"] - Bv["pred"]).max() <= 1e-6 * np.abs(Bv["pred"]).max()
-    assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-3 * np.abs(Bv["grad"]).max()

@@ -182,13 +182,6 @@ int main(int argc, char** argv)
 #endif
     timeit("pstrip<25> normConv forward + skip", iters, gv * 21600, [&] { x6_conv_strip_forward(gf, x25, nullptr, wf, bias, y32, z32, 2, am, 0); });
     timeit("pstrip<32> normConv backward-data", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });
-    g_pp_k16 = 1;
-    timeit("pstrip<32> ... 32x32x16 form", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });
-    g_pp_k16 = 0;
-    timeit("pstrip<32> ... 16x16x32 form again", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });
-    g_pp_k16 = 1;
-    timeit("pstrip<32> ... 32x32x16 form again", iters, gv * 21600, [&] { x6_conv_strip_forward(gb, x32, nullptr, wf, nullptr, nullptr, y25, 2, am, 0); });
-    g_pp_k16 = 0;
     timeit("wgrad<25> normConv backward-filter", iters, gv * 21600, [&] { x6_conv_wgrad(gf, x25, y32, nullptr, dw, db, part, 2, am, 0); });
     }
     return 0;

@@ -1,4 +1,4 @@
-// Diagnostic (not part of the product): the one-wave-per-SIMD fused pointwise backward (kernels_pw4.hip) against round 4's kernel on random data --
+// Diagnostic (not part of the product): the one-wave-per-SIMD fused pointwise backward (kernels_pw4.hip) against the general eight-wave form (pw_bwd_x6_kernel<H3>) on random data --
 // element-wise agreement of dX, dW1, dW2, db1, db2 at several batch sizes, then both timed at the benchmark's shape (batch 128, T = 9).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I proba-v_amd/csrc -I include tools/pw4bench.hip -L proba-v_amd/csrc -lprobav_hip -Wl,-rpath,'$ORIGIN/../proba-v_amd/csrc' -o tools/pw4bench.bin
 #include "kernels_x6.h"
@@ -71,7 +71,7 @@ int main(int argc, char** argv)
     for (auto& cs : cases) {
         const int B = cs[0]; const long vps = cs[1];
         hipMemset(dX, 0xff, nvmax * 32 * 4);
-        if (run(0, B, vps)) { printf("old kernel failed: %s\n", last_error()); return 1; }
+        if (run(0, B, vps)) { printf("general form failed: %s\n", last_error()); return 1; }
         Out a = fetch(B, vps);
         hipMemset(dX, 0xff, nvmax * 32 * 4); hipMemset(dW1, 0xff, 8192 * 4); hipMemset(dW2, 0xff, 256 * D * 4); hipMemset(db1, 0xff, 256 * 4); hipMemset(db2, 0xff, D * 4);
         if (run(1, B, vps)) { printf("new kernel failed: %s\n", last_error()); return 1; }
@@ -104,7 +104,7 @@ int main(int argc, char** argv)
             hipEventRecord(eb, 0); hipEventSynchronize(eb);
             float ms = 0; hipEventElapsedTime(&ms, ea, eb);
             const double us = ms * 1e3 / iters;
-            if (pass) printf("pass %d  %s  %8.1f us per launch (incl. the slab sum)  %7.1f TFLOP/s algorithmic fp32\n", pass, k ? "pw_bwd_w4 (round 5)" : "pw_bwd_h3t (round 4)", us, gflop / us * 1e3);
+            if (pass) printf("pass %d  %s  %8.1f us per launch (incl. the slab sum)  %7.1f TFLOP/s algorithmic fp32\n", pass, k ? "pw_bwd_w4 (one wave per SIMD)" : "pw_bwd_x6<H3> (general form)", us, gflop / us * 1e3);
         }
     printf(bad ? "FAILED: %d case(s) mismatch\n" : "all cases agree\n", bad);
     return bad ? 2 : 0;
