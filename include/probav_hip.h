@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROBAV_ABI_VERSION 6
+#define PROBAV_ABI_VERSION 7
 
 /* Hyper-parameters of WDSRConv3D(name, band, mean, std, maxShift).build(scale, numFilters, kernelSize=3,
  * numResBlocks, expRate, decayRate, numImgLR, patchSizeLR, isGrayScale)   (models/modelsTF.py:8-17) */
@@ -228,6 +228,10 @@ int probav_workspace_view(const probav_engine* e, int batch, int training, int k
 int probav_debug_hidden(probav_engine* e, const float* params, const void* ws /* saved state: read only */, size_t ws_bytes, int batch, int block, float* hidden,
                         float* dec_scratch /* [voxels][dec channels] floats: the launch's regular output, discarded */,
                         const void* wcache /* the weight cache the forward pass ran from, or NULL */, void* stream);
+/* ABI 7.  Which arrangement probav_debug_hidden evaluates the tile in (kernel family 4): 0 (default) the 32x32x16 one, whose order of additions is the one the
+ * reverse pass recomputes the tile -- and decides its ReLU gates -- in; 1 the forward kernel's own (16x16x32).  The two sum the same piece products in different
+ * orders; a pre-activation that is zero to rounding can be open in one and closed in the other (tests/test_gpu_parity.py bounds how many, and how large).  Process-wide. */
+int probav_debug_hidden_from_forward_kernel(int on);
 
 #ifdef __cplusplus
 }

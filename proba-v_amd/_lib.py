@@ -68,6 +68,7 @@ SIGNATURES = {
     "probav_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "probav_mfma_probe_shape": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "probav_debug_hidden": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "probav_debug_hidden_from_forward_kernel": (c_int, [c_int]),
     "probav_workspace_split": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "probav_backward_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
     "probav_weight_cache_bytes": (c_size_t, [c_void_p]),
@@ -96,7 +97,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if L.probav_abi_version() != 6:
+        if L.probav_abi_version() != 7:
             raise RuntimeError("libprobav_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -1048,6 +1048,8 @@ int probav_debug_hidden(probav_engine* e, const float* params, const void* ws, s
                          (hipStream_t)stream, hidden);
 }
 
+int probav_debug_hidden_from_forward_kernel(int on) { x6_pw_dump_from_forward_kernel(on); return PROBAV_OK; }
+
 // ---- single operators ---------------------------------------------------------------------------
 static ConvGeom geom_from(const int32_t a[17])
 {

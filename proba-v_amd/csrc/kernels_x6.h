@@ -17,6 +17,9 @@ struct PwAmax { const unsigned* x = nullptr; const unsigned* w1 = nullptr; const
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                   long nvox, long vps, int D, int arith, const PwAmax& am, hipStream_t s, float* hdump = nullptr);
 
+// tests: the hidden-tile dump of x6_pw_forward(…, hdump) (H3) comes from the forward kernel itself (pw_fwd_h3k_kernel, 16x16x32) instead of the 32x32x16 arrangement
+void x6_pw_dump_from_forward_kernel(int on);
+
 // reverse pass of the fused pair; w1f = PACK_X6_PW_W1, w2kf = PACK_X6_PW_W2K, w1cf = PACK_X6_PW_W1C fragments;
 // slabs: mfma_pw_backward_slab_floats(D) floats
 int x6_pw_backward(const float* x, const float* dT, const float* dOut, const float* w1f, const float* w2kf, const float* w1cf,

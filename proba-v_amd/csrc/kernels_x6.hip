@@ -223,9 +223,10 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
 // The hidden tile's sums are NOT bit-identical to the 32x32x16 kernel's (32 against 16 products per instruction); the backward pass recomputes the tile
 // with the 32x32x16 arrangement, and so does probav_debug_hidden: gates of pre-activations that sit at zero to the last bit can differ between the passes.
 // ---------------------------------------------------------------------------------------------------
+template <bool DUMP>      // DUMP (tests only): the post-ReLU hidden tile also goes to hdump [nvox][256], at the hidden tile's own power-of-two scale (as pw_fwd_x6_kernel's)
 __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restrict__ x, const uint4* __restrict__ w1frag, const uint4* __restrict__ w2frag,
                                                             const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ dec,
-                                                            long nvox, int vps, int D, PwAmax am)
+                                                            long nvox, int vps, int D, PwAmax am, float* __restrict__ hdump)
 {
     XS_ENTRY;
     using AR = H3;
@@ -366,6 +367,14 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
 #endif
                 }
                 cut8_scaled<AR>(hs, hb[u]);
+                if constexpr (DUMP) {                            // hs[i] = hidden 32 c + 4 kq + i, hs[4 + i] = hidden 32 c + 16 + 4 kq + i of voxel 32 j + 16 u + m16
+                    const int vl = 32 * j + 16 * u + m16;
+                    if (vl < vps) {
+                        float* hp_ = hdump + ((long)n * vps + vl) * 256 + 32 * c + 4 * kq;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { hp_[i] = hs[i]; hp_[16 + i] = hs[4 + i]; }
+                    }
+                }
             }
             PWK(T[0][0], a2[0], 1, hb[0], 0); PWK(T[0][1], a2[0], 1, hb[1], 0); PWK(T[1][0], a2[1], 1, hb[0], 0); PWK(T[1][1], a2[1], 1, hb[1], 0);
             PWK(T[0][0], a2[0], 0, hb[0], 1); PWK(T[0][1], a2[0], 0, hb[1], 1); PWK(T[1][0], a2[1], 0, hb[0], 1); PWK(T[1][1], a2[1], 0, hb[1], 1);
@@ -406,6 +415,9 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
     XS_OUT;
 }
 
+static int g_pw_dump_h3k = 0;
+void x6_pw_dump_from_forward_kernel(int on) { g_pw_dump_h3k = on ? 1 : 0; }
+
 int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec,
                   long nvox, long vps, int D, int arith, const PwAmax& am, hipStream_t s, float* hdump)
 {
@@ -414,15 +426,19 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<X6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_x6_kernel<H3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_h3k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_h3k_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_fwd_h3k_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     if (vps <= 0 || vps > nvox) vps = nvox;                          // one "sample"
     if (nvox % vps || vps > 0x7fffffffL) { set_error("x6_pw_forward: nvox must be a multiple of the voxels per sample", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2c || !am.b1) { set_error("x6_pw_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
         const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32 + 8 * 256) * sizeof(float);      // (+ pw_fwd_h3k_kernel's per-wave bias tables; two workgroups per CU still fit)
-        if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
+        // hdump (tests): from the 32x32x16 arrangement -- the order the reverse pass recomputes the tile in (pw_bwd_w4_kernel) -- or, after
+        // x6_pw_dump_from_forward_kernel(1), from the forward kernel itself
+        if (hdump && g_pw_dump_h3k) hipLaunchKernelGGL(pw_fwd_h3k_kernel<true>, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am, hdump);
+        else if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                                       b1, b2, dec, nvox, (int)vps, D, am, hdump);
-        else hipLaunchKernelGGL(pw_fwd_h3k_kernel, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am);      // (the 32x32x16 form pw_fwd_x6_kernel<H3> stays for the hidden-tile dump of the parity tests)
+        else hipLaunchKernelGGL(pw_fwd_h3k_kernel<false>, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am, nullptr);
     } else {
         const size_t lds = (size_t)2 * 8 * 2 * X6::NP * 64 * 16 + (256 + 32 + 32) * sizeof(float);
         if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<X6, true>), dim3(256 * PwfShape<X6>::WGS), dim3(64 * PwfShape<X6>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,

@@ -51,3 +51,23 @@ def device_gates(m, flat_used, B, T=9, samples=None):
             break
         k += 1
     return gates
+
+
+def hidden_tile(m, flat_used, B, block, T=9, from_forward_kernel=False):
+    """relu(expConv_block(x)) [B, voxels, 256] of the last training forward of `m`, each sample at its hidden tile's own power-of-two scale, as the
+    32x32x16 arrangement evaluates it (default: the order of additions the reverse pass recomputes the tile -- and decides its gates -- in) or as the
+    forward kernel itself does (pw_fwd_h3k_kernel; `probav_debug_hidden_from_forward_kernel`)."""
+    L = _lib.lib()
+    h, ws = m._handle(), m._workspace(B, True)
+    wc = m.weight_cache()
+    hin = m.patchSizeLR + m.maxShift
+    nvox = B * hin * hin * T
+    hid = torch.empty(nvox * m.numFilters * m.expRate, device=ws.device)
+    dec = torch.empty(nvox * 32, device=ws.device)
+    _lib.check(L.probav_debug_hidden_from_forward_kernel(1 if from_forward_kernel else 0), "probav_debug_hidden_from_forward_kernel")
+    try:
+        _lib.check(L.probav_debug_hidden(h, _lib.ptr(flat_used), _lib.ptr(ws), ws.numel() * 4, B, block, _lib.ptr(hid), _lib.ptr(dec), _lib.ptr(wc),
+                                         _lib.current_stream()), "probav_debug_hidden")
+    finally:
+        _lib.check(L.probav_debug_hidden_from_forward_kernel(0), "probav_debug_hidden_from_forward_kernel")
+    return hid.view(B, -1, m.numFilters * m.expRate)

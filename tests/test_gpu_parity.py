@@ -747,6 +747,48 @@ def _gate_masked_parity(dev, impl, T, B, C):
     print("impl %d: worst per-tensor max-norm gradient error with the device's gates: %.3g (%s)" % (impl, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize("B", [2, 128], ids=["golden-b2", "b128"])
+def test_forward_and_reverse_pass_decide_the_same_relu_gates(dev, B, monkeypatch):
+    """The 256-channel hidden tile never reaches memory: the forward kernel (pw_fwd_h3k_kernel, v_mfma 16x16x32) and the reverse pass's recompute of it
+    (pw_bwd_w4_kernel, 32x32x16) sum the same piece products in different orders, so a pre-activation that is zero to rounding can be open in one and
+    closed in the other -- the gradient is then taken at a gate the forward did not use.  Bounded here, on the golden inputs
+    and at the benchmark's batch: per block, the gates that differ are a vanishing share, and every one of them is a value below 1e-6 of its sample's
+    rms in BOTH evaluations (its forward contribution is that value; its gradient contribution is what a +-1e-6 rms perturbation of the pre-activation
+    would also flip)."""
+    monkeypatch.setenv("PROBAV_KEEP_WS", "1")
+    from probav_amd.introspect import hidden_tile
+    T = 9
+    if B == 2:
+        z = np.load(os.path.join(GOLD, "wdsr_t9_b2.npz"))
+        x = torch.as_tensor(z["x"]).to(dev)
+    else:
+        x = torch.as_tensor(synth.synth_batch(B, seed=4242)[0]).to(dev)
+    m = _model(dev, T, synth.synth_params(seed=101, perturb=True))
+    m(x, training=True)
+    flat = m.flat.detach()
+    total = differ = 0
+    worst = 0.0
+    for blk in range(m.numResBlocks):
+        a = hidden_tile(m, flat, B, blk, T)                                   # the order of the reverse pass
+        f = hidden_tile(m, flat, B, blk, T, from_forward_kernel=True)         # the forward kernel's own
+        # each dump is at a power-of-two scale of its kernel's choosing: compare in units of the sample's rms.  The forward kernel brings its tile to scale by an
+        # integer add on the exponent field, which turns an exact zero into 2^-111 (both fp16 pieces of which are zero): below 1e-30 is closed
+        f = torch.where(f < 1e-30, torch.zeros_like(f), f)
+        a = a / torch.sqrt((a.double() ** 2).mean(dim=(1, 2), keepdim=True)).float()
+        f = f / torch.sqrt((f.double() ** 2).mean(dim=(1, 2), keepdim=True)).float()
+        d = (a > 0) != (f > 0)
+        nd = int(d.sum())
+        total += a.numel(); differ += nd
+        if nd:
+            worst = max(worst, float(torch.maximum(a, f)[d].max()))
+        # away from zero the two evaluations agree to fp32 rounding of the tile's scale
+        assert float((a - f).abs().max()) < 2e-5, blk
+    print("B = %d: %d of %d hidden gates differ between the forward kernel and the reverse pass's recompute; the largest value among them is %.3g of its sample's rms"
+          % (B, differ, total, worst))
+    assert differ <= 1e-5 * total, (differ, total)
+    assert worst < 1e-6, worst
+
+
 @pytest.mark.parametrize("T", [9])
 def test_batch128_backward_of_a_sub_batch_matches_the_oracle(dev, T):
     """The reverse pass AT THE BENCHMARK'S SIZE against the oracle (at batch 128 the backward was covered by properties only).

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for n in names:
         assert hasattr(L, n), "libprobav_hip.so does not export %s" % n
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.lib().probav_abi_version() == 6
+    assert _lib.lib().probav_abi_version() == 7
 
 
 def test_no_torch_types_in_the_abi():
