@@ -88,7 +88,23 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     const int n = gw / wps, jw = gw - n * wps;
     const bool active = n < nsamp;
     const int tps = (vps + 31) >> 5;
-    const int tb = active ? (int)((long)tps * jw / wps) : 0, te = active ? (int)((long)tps * (jw + 1) / wps) : 0;
+    // The sample's tiles over its wps waves: tps / wps each, and the remainder one apiece to the waves of EVEN workgroups first.  Workgroup b runs on XCD b % 8, the odd
+    // XCDs hold ~2.5 % less clock than the even ones in every kernel looked at ('The XCDs do not run at one speed'), and the launch ends with its
+    // slowest wave: 137 tiles over 8 waves leave one wave with 18, which the plain split tps * jw / wps puts into an odd workgroup.  (Speed only: any split is correct.)
+    int tb = 0, te = 0;
+    if (active) {
+        const int q = tps / wps, r = tps - q * wps;
+        auto extra_before = [&](int j) {                            // how many of the waves 0 .. j-1 carry an extra tile
+            if (wps & 7) return j < r ? j : r;                        // (waves per sample not a multiple of 8: workgroups are not aligned with samples -- plain order)
+            // rank of wave j in the order [waves of even workgroups, then waves of odd ones]: even workgroups hold j with (j >> 2) even
+            const int ne = wps / 2;                                   // waves in even workgroups
+            const int re = r < ne ? r : ne, ro = r - re;              // extras that go to even / odd workgroups
+            const int je = (j >> 3) * 4 + (((j >> 2) & 1) ? 4 : (j & 3)), jo = (j >> 3) * 4 + (((j >> 2) & 1) ? (j & 3) : 0);      // waves of even / odd workgroups among 0 .. j-1
+            return (je < re ? je : re) + (jo < ro ? jo : ro);
+        };
+        tb = q * jw + extra_before(jw);
+        te = q * (jw + 1) + extra_before(jw + 1);
+    }
     const unsigned aw1 = *am.w1, aw2 = *am.w2, ab1 = *am.b1;
     const int ew1 = h3_exp_w(aw1), ew2 = h3_exp_w(aw2);
     int ex = 0, ed = 0, eh = 0, eg = 0;
@@ -659,10 +675,12 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) R[((wave * 8 + c) * 16 + r) * 64 + lane2] = ldexpf(dW1[c][r], -(ex + eg));
     __syncthreads();
-    for (int e = tid2; e < 8192; e += 256) {
-        const float v = ((R[e] + R[8192 + e]) + R[2 * 8192 + e]) + R[3 * 8192 + e];
-        const int l = e & 63, r = (e >> 6) & 15, c = e >> 10;
-        sl[(long)rowmap(r, l >> 5) * 256 + 32 * c + (l & 31)] = v;                              // [cin][hidden]
+    for (int e4 = tid2; e4 < 2048; e4 += 256) {                    // four consecutive lanes = four consecutive hidden channels of one cin row: 16-byte LDS reads
+        const float4 a = reinterpret_cast<const float4*>(R)[e4], b = reinterpret_cast<const float4*>(R + 8192)[e4],
+                     c4 = reinterpret_cast<const float4*>(R + 2 * 8192)[e4], d = reinterpret_cast<const float4*>(R + 3 * 8192)[e4];
+        const int e = 4 * e4, l = e & 63, r = (e >> 6) & 15, c = e >> 10;
+        float* o = sl + (long)rowmap(r, l >> 5) * 256 + 32 * c + (l & 31);                      // [cin][hidden]  (a slab is an odd number of floats long: no 16-byte stores)
+        o[0] = ((a.x + b.x) + c4.x) + d.x; o[1] = ((a.y + b.y) + c4.y) + d.y; o[2] = ((a.z + b.z) + c4.z) + d.z; o[3] = ((a.w + b.w) + c4.w) + d.w;
     }
     __syncthreads();
 #pragma unroll
