@@ -50,7 +50,7 @@ DTYPES = {3: "f32 (products as 6 bf16-piece MFMA products, f32 accumulate)", 4: 
 
 
 def hbm_profile_path():
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             return p
