@@ -74,4 +74,13 @@ int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, f
 int mfma_pw_backward_reduce(const float* slabs, int D, float* dW1, float* dW2, float* db1, float* db2, hipStream_t s);
 int mfma_pw_backward_grid();
 
+// 3x3x3 'same' convolution of the residual blocks (25 -> 32 channels, and its backward-data 32 -> 25 / 32) as ONE-WAVE-PER-SIMD kernel (kernels_cw4.hip; H3
+// arithmetic only): the filter's first pieces stay in registers for the whole launch.  x6_conv_strip_forward dispatches to it when cw4_conv_supported();
+// cw4_set_enabled(0) (or PROBAV_GEN1=1 in the environment, which also selects the general pointwise backward) keeps conv3_pp_kernel.
+// wfrag: PACK_H3_CONVP (25 input channels) / PACK_H3_CONV (32) fragments, as conv3_pp_kernel reads them
+bool cw4_conv_supported(const ConvGeom& g, const float* gate);
+bool cw4_enabled();
+void cw4_set_enabled(int on);
+int cw4_conv_forward(const ConvGeom& g, const float* x, const float* wfrag, const float* bias, const float* skip, float* y, const Amax& am, hipStream_t s);
+
 }  // namespace probav

@@ -2493,6 +2493,7 @@ static int strip_launch(const ConvGeom& g, const float* x, const float* gate, co
 {
     if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_strip_forward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2 && x6_strip_wants_tap_fragments(g, arith)) {               // H3: the piece-ring kernel (filters: PACK_H3_CONV)
+        if (cw4_enabled() && cw4_conv_supported(g, gate)) return cw4_conv_forward(g, x, wfrag, bias, skip, y, am, s);      // one wave per SIMD, the filter in registers (kernels_cw4.hip)
         StripPlan pp;
         int rvp = 2;
         if (pp_plan(g, pp, rvp)) {

@@ -28,7 +28,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
 
 // the same reverse pass as ONE-WAVE-PER-SIMD kernel (kernels_pw4.hip; H3 arithmetic only): four independent waves per workgroup, each with a run of
 // tiles of one sample and all eight hidden chunks, dW1 / dW2 of the run in 256 accumulator registers.  x6_pw_backward dispatches to it when
-// pw4_backward_supported(); pw4_set_enabled(0) (or PROBAV_PW_BWD_GEN1=1 in the environment) keeps the general eight-wave form pw_bwd_x6_kernel<H3>
+// pw4_backward_supported(); pw4_set_enabled(0) (or PROBAV_GEN1=1 in the environment) keeps the general eight-wave form pw_bwd_x6_kernel<H3>
 bool pw4_backward_supported(long nvox, long vps, int D);
 bool pw4_enabled();
 void pw4_set_enabled(int on);

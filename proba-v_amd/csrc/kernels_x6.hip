@@ -896,7 +896,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
     if (arith == 2) {
         if (!am.x || !am.w1 || !am.w2 || !am.b1 || !am.dt || !am.w1r) { set_error("x6_pw_backward: H3 arithmetic needs the operands' amax slots", hipSuccess); return PROBAV_EINVAL; }
         // round 5: one wave per SIMD, 512 registers, no barrier in the tile loop (kernels_pw4.hip).  pw_bwd_x6_kernel<H3> below is the general form: any
-        // batch, any D <= 32 (and PROBAV_PW_BWD_GEN1=1 / pw4_set_enabled(0) for A/B runs); rounds 3 and 4's schedules of it (pw_bwd_h3s / h3t) left with round 5
+        // batch, any D <= 32 (and PROBAV_GEN1=1 / pw4_set_enabled(0) for A/B runs); rounds 3 and 4's schedules of it (pw_bwd_h3s / h3t) left with round 5
         if (pw4_enabled() && pw4_backward_supported(nvox, vps, D))
             return pw4_backward(x, dT, dOut, w1f, w2kf, w1cf, b1, dX, dW1, dW2, db1, db2, slabs, nvox, vps, D, am, s);
         const size_t lds = (size_t)4 * H3::NP * PB_IMG + ((size_t)16 * PB_TB + 256) * sizeof(float) + (size_t)8 * 2 * H3::NP * PT_IMG;   // (two transpose images per wave)

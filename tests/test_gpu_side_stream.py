@@ -103,13 +103,13 @@ def test_training_step_replays_from_a_captured_graph():
 @pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
 def test_one_wave_per_simd_pointwise_backward_agrees_with_the_general_form(B, T, tmp_path):
     """The fused pointwise backward of round 5 (pw_bwd_w4_kernel: one wave per SIMD, a wave owns a tile and all eight hidden chunks) evaluates the products
-    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_PW_BWD_GEN1=1) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
+    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_GEN1=1) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
     the order of the fp32 additions across chunks (dX: one accumulator chain instead of eight partials) and across tiles (filter gradients: a wave's run
     instead of a workgroup's).  Whole network: identical predictions (the forward pass is untouched), the flat gradient vector to 1e-5 of its max-norm."""
     import numpy as np
     a, b = str(tmp_path / "w4.npz"), str(tmp_path / "gen1.npz")
     _run({}, B, T, 1, a)
-    _run({"PROBAV_PW_BWD_GEN1": "1"}, B, T, 1, b)
+    _run({"PROBAV_GEN1": "1"}, B, T, 1, b)
     A, Bv = np.load(a), np.load(b)
     assert np.array_equal(A["pred"], Bv["pred"])
     assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-5 * np.abs(Bv["grad"]).max()

@@ -6,12 +6,17 @@
 #include <algorithm>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_out[4096 * 2];
 
 template <int MODE, int NF, int FK>
 __global__ __launch_bounds__(256, 1) void k(const f16x8* __restrict__ src, float* __restrict__ sink, int iters)
 {
     const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsb[16384 + 4096];
+    for (int i = lane; i < 4096 + 1024; i += 256) reinterpret_cast<unsigned*>(ldsb)[i] = i;
+    __syncthreads();
+    u32x4 lt[4] = {};
     f16x8 a = src[lane], b = src[lane + 256];
     f32x16 acc, acc2;
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
@@ -25,6 +30,9 @@ __global__ __launch_bounds__(256, 1) void k(const f16x8* __restrict__ src, float
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
             else if (MODE == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+            else if (MODE == 3) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));      // A operand in the accumulator half, C/D in the vector half (kernels_cw4.hip)
+            else if (MODE == 4) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b)); u32x4 t = *reinterpret_cast<const u32x4*>(ldsb + lane * 16 + (u & 3) * 4096); asm volatile("" :: "v"(t)); }      // + one ds_read_b128 per gap (waited for: the asm consumes it)
+            else if (MODE == 5) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b)); lt[u & 3] = *reinterpret_cast<const u32x4*>(ldsb + lane * 16 + (u & 3) * 4096); if ((u & 3) == 3) asm volatile("" :: "v"(lt[0]), "v"(lt[1]), "v"(lt[2]), "v"(lt[3])); }      // + one ds_read_b128 per gap, consumed four gaps later
             else if (MODE == 2) { if (u & 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0); }
 #pragma unroll
             for (int q = 0; q < NF; ++q) {
@@ -61,7 +69,7 @@ int main()
     std::vector<unsigned short> h(512 * 8);
     for (size_t i = 0; i < h.size(); ++i) { _Float16 v = (_Float16)(((int)(i * 2654435761u % 2001) - 1000) * 0.001f); h[i] = *reinterpret_cast<unsigned short*>(&v); }
     hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-#define R3(NF, FK) run<0, NF, FK>("VGPR-form builtin, one accumulator chain", src, sink); run<1, NF, FK>("AGPR asm, one accumulator chain", src, sink); run<2, NF, FK>("VGPR-form builtin, two chains alternating", src, sink);
-    R3(0, 0) R3(3, 0) R3(5, 0) R3(6, 0) R3(8, 0) R3(5, 1) R3(3, 2) R3(3, 3) R3(4, 3)
+#define R3(NF, FK) run<0, NF, FK>("VGPR-form builtin, one accumulator chain", src, sink); run<3, NF, FK>("A operand in a[], C/D in v[]", src, sink); run<4, NF, FK>("the same + ds_read_b128 per gap, waited", src, sink); run<5, NF, FK>("the same + ds_read_b128 per gap, 4 ahead", src, sink);
+    R3(0, 0) R3(2, 0) R3(3, 0) R3(4, 0) R3(5, 0) R3(2, 2) R3(3, 2) R3(2, 3) R3(3, 3) R3(4, 3)
     return 0;
 }
