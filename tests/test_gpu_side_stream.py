@@ -103,13 +103,32 @@ def test_training_step_replays_from_a_captured_graph():
 @pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
 def test_one_wave_per_simd_pointwise_backward_agrees_with_the_general_form(B, T, tmp_path):
     """The fused pointwise backward of round 5 (pw_bwd_w4_kernel: one wave per SIMD, a wave owns a tile and all eight hidden chunks) evaluates the products
-    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_GEN1=1) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
+    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_GEN1=pw) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
     the order of the fp32 additions across chunks (dX: one accumulator chain instead of eight partials) and across tiles (filter gradients: a wave's run
     instead of a workgroup's).  Whole network: identical predictions (the forward pass is untouched), the flat gradient vector to 1e-5 of its max-norm."""
     import numpy as np
     a, b = str(tmp_path / "w4.npz"), str(tmp_path / "gen1.npz")
     _run({}, B, T, 1, a)
-    _run({"PROBAV_GEN1": "1"}, B, T, 1, b)
+    _run({"PROBAV_GEN1": "pw"}, B, T, 1, b)
     A, Bv = np.load(a), np.load(b)
     assert np.array_equal(A["pred"], Bv["pred"])
     assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-5 * np.abs(Bv["grad"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(5, 9), (2, 7)], ids=["b5-t9", "b2-t7"])
+def test_one_wave_per_simd_convolution_agrees_with_the_general_form(B, T, tmp_path):
+    """The residual blocks' 3x3x3 convolution of round 5 (conv3_w4_kernel: one wave per SIMD, the filter's first pieces in registers, a tile's 45 / 54 k-blocks ONE
+    accumulation chain that starts from the bias) evaluates the products of the eight-wave piece-ring kernel (conv3_pp_kernel, PROBAV_GEN1=conv: two waves' partial sums
+    added, the bias added behind the scaling) -- the same scaled fp16 pieces, another order of the fp32 additions.  Whole network: the predictions agree to 1e-5 of their max-norm.  The reverse
+    pass is held to 1e-3 of the gradient's max-norm only: a forward pass that differs in the last bits flips the ReLU gate of hidden values that sit at zero (12 blocks x 256
+    channels x every voxel of the batch), and a flipped gate adds or drops a whole term of dX and dW1 -- with the forward pass untouched (the pointwise test above) the
+    same comparison holds 1e-5.  (Each kernel against the fp32 oracle: tests/test_gpu_parity.py.)"""
+    import numpy as np
+    a, b = str(tmp_path / "w4.npz"), str(tmp_path / "gen1.npz")
+    _run({}, B, T, 1, a)
+    _run({"PROBAV_GEN1": "conv"}, B, T, 1, b)
+    A, Bv = np.load(a), np.load(b)
+    assert not np.array_equal(A["grad"], Bv["grad"])                      # (the switch did select another kernel)
+    assert np.abs(A["pred"] - Bv["pred"]).max() <= 1e-5 * np.abs(Bv["pred"]).max()
+    assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-3 * np.abs(Bv["grad"]).max()
