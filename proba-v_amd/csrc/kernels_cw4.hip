@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
         return qdiv(vlast, nvr, a.mNvr) + 2;
     };
 
+    CW4_ST(3);
     // ---- prologue: every request first -- the rows of round 0 (at most four: nvr >= 64), the second pieces bound for LDS, the first pieces, the tables ----
     int hiq = nround > 0 ? need(0) : -1;
     Staged p0[4];
@@ -263,17 +264,20 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
         ewb[i] = am.w[cc];
         bv[i] = bsrc[cc];
     }
+    CW4_ST(4);
     {
         uint4* z = reinterpret_cast<uint4*>(lds);
         for (int i = tid; i < NS * ROW / 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS only: the requests above stay in flight)
+    CW4_ST(5);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                         // (a row beyond the round's need repeats row 0)
         Cut c;
 #pragma unroll
         for (int m = 0; m < ROW_MOPS; ++m) stage_mop(m, p0_slot[q], p0_rok[q], p0[q], c, false, 0);
     }
+    CW4_ST(6);
     const int w1a = NS * ROW + lane * 16;                                // LDS address of the lane's 16 bytes of second-piece fragment NW1R
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
 #pragma unroll
     for (int K = 0; K < NW1R; ++K) asm volatile("" : "+a"(w1r[K]));
     if (BIAS) asm volatile("" : "+a"(bias16));
+    CW4_ST(7);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- output / skip through buffer descriptors of the strip: an invalid voxel's offset lies beyond num_records (no branch around a load or a store) ----
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
         if (K >= NW1R) wf.u = *reinterpret_cast<const uint4*>(lds + w1a + (K - NW1R) * 1024);
     };
 
-    CW4_ST(2);
+    CW4_ST(2);                                                           // (diagnostic build: 3 constants, 4 requests issued, 5 ring cleared + barrier, 6 first rows cut, 7 second pieces stored + tables, 2 the rest of the prologue)
     // ---- the rounds ----
     f32x16 accA, accB;
 #pragma unroll

@@ -45,10 +45,10 @@ int main(int argc, char** argv)
 #ifdef CW4_STAMP
         std::vector<unsigned long long> st(1024 * 8);
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(diag::g_cw4_stamps), st.size() * 8);
-        const char* nm[8] = {"whole kernel (cycles)", "whole kernel (100 MHz ticks)", "prologue", "round start -> barrier", "wait at the barrier", "barrier -> round end", "-", "-"};
+        const char* nm[8] = {"whole kernel (cycles)", "whole kernel (100 MHz ticks)", "prologue: the rest", "prologue: constants", "prologue: requests issued", "prologue: ring cleared, barrier", "prologue: first rows cut", "prologue: W1 stored, tables"};
         auto stat = [&](int k, double& md, double& mx, double& mn) { std::vector<double> v; for (int wv = 0; wv < 1024; ++wv) if (st[wv * 8]) v.push_back((double)st[wv * 8 + k]); std::sort(v.begin(), v.end()); md = v[v.size() / 2]; mx = v.back(); mn = v[0]; };
         const double rounds = 18.0;
-        for (int k = 0; k < 3; ++k) { double md, mx, mn; stat(k, md, mx, mn); printf("  slot %d  %-30s median %10.0f  min %10.0f  max %10.0f   per round %8.0f\n", k, nm[k], md, mn, mx, md / rounds); }
+        for (int k = 0; k < 8; ++k) { double md, mx, mn; stat(k, md, mx, mn); printf("  slot %d  %-30s median %10.0f  min %10.0f  max %10.0f   per round %8.0f\n", k, nm[k], md, mn, mx, md / rounds); }
         { double c, t, a, b; stat(0, c, a, b); stat(1, t, a, b); printf("  in-kernel clock %.2f GHz; kernel %.1f us per wave\n", c / t * 0.1, t * 0.01); }
 #endif
     }
