@@ -243,33 +243,74 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
     constexpr int NQ = ((KB - NW1R) * 64 + 255) / 256;
     u32x4b w1q[NQ];
     const u32x4b* wfrag4 = reinterpret_cast<const u32x4b*>(wfrag);
+    // The register-resident fragments (KB first pieces, NW1R second pieces) are the same for the four waves: four private copies are 180-216 KB through the CU's
+    // one 64 B/clk vector L1 -- 7 700 cycles of request issue at kernel entry (tools/cw4diag.hip).  Each wave requests a QUARTER of them; they meet in LDS (the ring's
+    // bytes, before the ring exists) and every wave reads all of them from there, straight into a[...].
+    const int Z0c = a.Wp * (TP - 2);                                      // records per plane of a ring row (the zero zone starts there)
+    constexpr int NF = KB + NW1R, NF4 = (NF + 3) / 4;
+    u32x4b xq[NF4];
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+        int f = 4 * i + wave;
+        f = f < NF ? f : NF - 1;                                         // (beyond the end: the last fragment again, the same bytes to the same place)
+        xq[i] = wfrag4[(f < KB ? 2 * f : 2 * (f - KB) + 1) * 64 + lane];
+    }
+    // the output channels' exponents and biases: lane c of the first wave works out channel c's, two 32-entry tables behind the second pieces in LDS hand them to
+    // every lane in the accumulator's layout (register 4 jj + i of a lane = channel 8 jj + 4 half + i: four 16-byte reads per table)
+    const int tab = NS * ROW + (KB - NW1R) * 1024;
+    const int tc = tid < g.Cout ? tid : 0;
+    const unsigned tew = am.w[tc];
+    const float tbv = (bias ? bias : reinterpret_cast<const float*>(am.w))[tc];
+    // (the LDS-bound second pieces are requested LAST: every CU of the launch is in its prologue at once and gets ~11 bytes per cycle -- the first bytes should be the ones the exchange waits for)
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         int e = tid + 256 * i;
         e = e < (KB - NW1R) * 64 ? e : (KB - NW1R) * 64 - 1;               // (beyond the end: the last element again)
         w1q[i] = wfrag4[(2 * (NW1R + (e >> 6)) + 1) * 64 + (e & 63)];
     }
+    CW4_ST(4);
+    if (tid < 32) {
+        const int e = -(ea + h3_exp_w(tew));
+        reinterpret_cast<int*>(lds + tab)[tid] = e;
+        reinterpret_cast<float*>(lds + tab + 128)[tid] = (BIAS && bias && tid < g.Cout) ? ldexpf(tbv, -e) : 0.f;      // the bias at the accumulator's scale (a power-of-two factor, exact)
+    }
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+        int f = 4 * i + wave;
+        f = f < NF ? f : NF - 1;
+        *reinterpret_cast<u32x4b*>(lds + f * 1024 + lane * 16) = xq[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS only: the other requests stay in flight)
     f16x8 w0[KB], w1r[NW1R > 0 ? NW1R : 1];
 #pragma unroll
-    for (int K = 0; K < KB; ++K) { Frag f; f.u = wfrag[(2 * K) * 64 + lane]; w0[K] = f.h; }
+    for (int K = 0; K < KB; ++K) { Frag f; f.u = *reinterpret_cast<const uint4*>(lds + K * 1024 + lane * 16); w0[K] = f.h; }
 #pragma unroll
-    for (int K = 0; K < NW1R; ++K) { Frag f; f.u = wfrag[(2 * K + 1) * 64 + lane]; w1r[K] = f.h; }
-    // the output channels' exponents and biases in the accumulator's layout: register 4 jj + i of a lane = channel 8 jj + 4 half + i
-    unsigned ewb[16];
-    float bv[16];
-    const float* bsrc = bias ? bias : reinterpret_cast<const float*>(am.w);
+    for (int K = 0; K < NW1R; ++K) { Frag f; f.u = *reinterpret_cast<const uint4*>(lds + (KB + K) * 1024 + lane * 16); w1r[K] = f.h; }
+    // pin them in the accumulator half of the file (an MFMA reads its A operand from there): from here on the allocator holds them in a[...]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = 8 * (i >> 2) + 4 * half + (i & 3), cc = c < g.Cout ? c : 0;
-        ewb[i] = am.w[cc];
-        bv[i] = bsrc[cc];
-    }
-    CW4_ST(4);
-    {
+    for (int K = 0; K < KB; ++K) asm volatile("" : "+a"(w0[K]));
+#pragma unroll
+    for (int K = 0; K < NW1R; ++K) asm volatile("" : "+a"(w1r[K]));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave has its copy: the bytes become the ring
+    // What of the ring must be zero: the zero zones behind the records of every plane, the upper halves of the gathered planes' entries (their stores are 8 bytes) --
+    // and, where the row is not cut into column ranges, the halo columns nobody stages: then all of it.
+    if (a.nsplit == 1) {
         uint4* z = reinterpret_cast<uint4*>(lds);
         for (int i = tid; i < NS * ROW / 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        const int nzone = CW4_PSE - Z0c, nplanes = NS * 8;
+        for (int i = tid; i < nzone * nplanes; i += 256) {
+            const int pl = i / nzone, e = i - pl * nzone;
+            *reinterpret_cast<uint4*>(lds + pl * PS + (Z0c + e) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if constexpr (CIN == 25) {
+            for (int i = tid; i < Z0c * NS * 2; i += 256) {
+                const int pl = i / Z0c, e = i - pl * Z0c;                  // pl = 2 slot + piece
+                *reinterpret_cast<uint4*>(lds + (pl >> 1) * ROW + (3 + 4 * (pl & 1)) * PS + e * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS only: the requests above stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     CW4_ST(5);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                         // (a row beyond the round's need repeats row 0)
@@ -286,28 +327,18 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
         *reinterpret_cast<u32x4b*>(lds + NS * ROW + e * 16) = w1q[i];
     }
     int eun[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = 8 * (i >> 2) + 4 * half + (i & 3);
-        eun[i] = -(ea + h3_exp_w(ewb[i]));
-        bv[i] = (bias && c < g.Cout) ? bv[i] : 0.f;
-    }
-    // The bias enters as the accumulator's initial value, at the accumulator's scale (bias * 2^-eun: a power-of-two factor, exact) -- the C operand of a tile's first MFMA,
-    // kept in the accumulator half of the file like the filter: sixteen vector registers and sixteen additions per tile less.
+    // The bias enters as the accumulator's initial value, at the accumulator's scale -- the C operand of a tile's first MFMA, kept in the accumulator half of the
+    // file like the filter: sixteen vector registers and sixteen additions per tile less.
     f32x16 bias16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bias16[i] = BIAS ? ldexpf(bv[i], -eun[i]) : 0.f;
+    for (int jj = 0; jj < 4; ++jj) {
+        const int4 e4 = *reinterpret_cast<const int4*>(lds + tab + (8 * jj + 4 * half) * 4);
+        const float4 b4 = *reinterpret_cast<const float4*>(lds + tab + 128 + (8 * jj + 4 * half) * 4);
+        eun[4 * jj] = e4.x; eun[4 * jj + 1] = e4.y; eun[4 * jj + 2] = e4.z; eun[4 * jj + 3] = e4.w;
+        bias16[4 * jj] = b4.x; bias16[4 * jj + 1] = b4.y; bias16[4 * jj + 2] = b4.z; bias16[4 * jj + 3] = b4.w;
+    }
     const float lo = g.relu ? 0.f : -__builtin_inff();                    // (RELU instances: the layer's flag decides at run time)
     (void)lo;
-    // pin the first pieces in the accumulator half of the file (an MFMA reads its A operand from there): from here on the allocator holds them in a[...]
-#pragma unroll
-#ifdef CW4_ABL_W0V              // (timing-only ablation: the first pieces in the VGPR half)
-    for (int K = 0; K < KB; ++K) asm volatile("" : "+v"(w0[K]));
-#else
-    for (int K = 0; K < KB; ++K) asm volatile("" : "+a"(w0[K]));
-#endif
-#pragma unroll
-    for (int K = 0; K < NW1R; ++K) asm volatile("" : "+a"(w1r[K]));
     if (BIAS) asm volatile("" : "+a"(bias16));
     CW4_ST(7);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -604,7 +635,7 @@ static bool cw4_plan(const ConvGeom& g, Cw4Args& p, size_t& lds_bytes, int& grid
         int nslot = needf(0) + 1;
         for (int r = 0; r + 1 < nround; ++r) nslot = std::max(nslot, needf(r + 1) - (r * 128) / nvr + 1);
         const int kb = g.Cin == 25 ? 45 : 54, nw1r = g.Cin == 25 ? 12 : 8;
-        const size_t need = (size_t)nslot * CW4_ROW + (size_t)(kb - nw1r) * 1024;
+        const size_t need = (size_t)nslot * CW4_ROW + (size_t)(kb - nw1r) * 1024 + 256;      // ring, second pieces, the two channel tables
         if (need > 163840) continue;
         p.g = g; p.Wp = wp; p.Wt = wt; p.nsplit = ns; p.SR = SR; p.nstrips = nstrips; p.nslot = nslot;
         p.mTo = qmagic(g.To); p.mNvr = qmagic(nvr); p.mTi = qmagic(g.Ti); p.mNslot = qmagic(nslot);
