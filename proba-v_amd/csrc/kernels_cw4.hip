@@ -569,6 +569,9 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
         row_of(n0, ro, rk); stage_load_items(ro, sv[0]); stage_load_g3(ro, sv[0]);
         row_of(n1, ro, rk); stage_load_items(ro, sv[1]); stage_load_g3(ro, sv[1]);
     }
+    // (The strip's 69th tile -- two voxels -- costs a whole round in which three SIMDs idle.  Splitting its k-blocks over the four waves was built and measured: -3 % per
+    // launch.  It is not here because its four partial chains round differently from the one chain every other tile sums in, and which voxels sit in a lone tile depends
+    // on how the batch size cuts the strips: a sample's result would depend on its batch in the last bits -- tests/test_gpu_parity.py, test_full_size_batch128_properties.)
     // (rounds in pairs, the second one unconditional -- an odd count runs one round on tiles beyond the strip, whose stores are dropped: a conditional second
     // round is its own basic block, and the optimiser sinks the first round's requests for it into that block)
 #pragma unroll 1

@@ -46,7 +46,7 @@ int main(int argc, char** argv)
         {1, 22, 22, 9, 25, 32, 1, 1, 0}, {2, 22, 22, 9, 25, 32, 1, 1, 0}, {3, 22, 22, 9, 25, 32, 0, 0, 1}, {128, 22, 22, 9, 25, 32, 1, 1, 0},
         {1, 22, 22, 9, 32, 25, 0, 0, 0}, {2, 22, 22, 9, 32, 25, 0, 1, 0}, {5, 22, 22, 9, 32, 25, 1, 1, 1}, {128, 22, 22, 9, 32, 25, 0, 0, 0},
         {2, 22, 22, 9, 32, 32, 1, 1, 0}, {3, 22, 22, 7, 25, 32, 1, 1, 0}, {3, 22, 22, 7, 32, 25, 0, 0, 0}, {2, 16, 16, 9, 25, 32, 1, 1, 0}, {4, 10, 22, 9, 32, 25, 0, 0, 0},
-        {100, 22, 22, 9, 25, 32, 1, 1, 0},
+        {100, 22, 22, 9, 25, 32, 1, 1, 0}, {128, 22, 22, 9, 25, 32, 0, 0, 0}, {64, 22, 22, 9, 25, 32, 0, 1, 0}, {6, 22, 22, 7, 25, 32, 0, 0, 1},      // (128 x T 9 and T 7: strips of 4 m + 1 tiles, the lone last tile's k-split)
     };
     int bad = 0;
     for (const Case& c : cases) {
