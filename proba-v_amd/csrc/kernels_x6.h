@@ -36,6 +36,15 @@ int pw4_backward(const float* x, const float* dT, const float* dOut, const float
                  const float* b1, float* dX, float* dW1, float* dW2, float* db1, float* db2, float* slabs, long nvox, long vps, int D,
                  const PwAmax& am, hipStream_t s);
 
+// the fused pointwise forward as ONE-WAVE-PER-SIMD kernel (kernels_pf4.hip; H3 arithmetic only): the arithmetic of pw_fwd_x6_kernel<H3> -- the order in which the reverse
+// pass recomputes the hidden tile --, the weight fragments in registers, no LDS traffic in the tile loop.  x6_pw_forward dispatches to it when pf4_forward_supported();
+// pf4_set_enabled(0) (or PROBAV_GEN1=1 / pw in the environment) keeps pw_fwd_h3k_kernel
+bool pf4_forward_supported(long nvox, long vps, int D);
+bool pf4_enabled();
+void pf4_set_enabled(int on);
+int pf4_forward(const float* x, const float* w1frag, const float* w2frag, const float* b1, const float* b2, float* dec, long nvox, long vps, int D,
+                const PwAmax& am, hipStream_t s, float* hdump = nullptr);
+
 // backward-filter of a 3x3x3 convolution with Cin = 25 or 32 and Cout = 32 (normConv, reducers; pads 0/1, reflect, ReLU gate);
 // partial: x6_wgrad_partial_floats(g) floats
 bool x6_wgrad_supported(const ConvGeom& g);

@@ -435,6 +435,8 @@ int x6_pw_forward(const float* x, const float* w1frag, const float* w2frag, cons
         const size_t lds = (size_t)2 * 8 * 2 * H3::NP * 64 * 16 + (256 + 32 + 32 + 8 * 256) * sizeof(float);      // (+ pw_fwd_h3k_kernel's per-wave bias tables; two workgroups per CU still fit)
         // hdump (tests): from the 32x32x16 arrangement -- the order the reverse pass recomputes the tile in (pw_bwd_w4_kernel) -- or, after
         // x6_pw_dump_from_forward_kernel(1), from the forward kernel itself
+        if (pf4_enabled() && pf4_forward_supported(nvox, vps, D) && (!hdump || g_pw_dump_h3k))          // one wave per SIMD (kernels_pf4.hip); its dump IS "from the forward kernel"
+            return pf4_forward(x, w1frag, w2frag, b1, b2, dec, nvox, vps, D, am, s, hdump);
         if (hdump && g_pw_dump_h3k) hipLaunchKernelGGL(pw_fwd_h3k_kernel<true>, dim3(256 * 2), dim3(512), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag, b1, b2, dec, nvox, (int)vps, D, am, hdump);
         else if (hdump) hipLaunchKernelGGL((pw_fwd_x6_kernel<H3, true>), dim3(256 * PwfShape<H3>::WGS), dim3(64 * PwfShape<H3>::WAVES), lds, s, x, (const uint4*)w1frag, (const uint4*)w2frag,
                                       b1, b2, dec, nvox, (int)vps, D, am, hdump);
