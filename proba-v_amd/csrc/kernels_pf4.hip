@@ -125,11 +125,12 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
     };
 
     // ---- the pipeline's registers ----
-    f32x16 H[2], T, Tp;
+    f32x16 H[2], T;
+    float tp[16];                                                                // the previous tile's sums while its epilogue runs
     Frag xb[2][2], xbn[2][2], hb[2][2][2];                                       // X pieces of the tile / the next tile [kb][piece]; H' pieces [chunk parity][kb][piece]
     f32x16 zero;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { zero[i] = 0.f; T[i] = 0.f; Tp[i] = 0.f; H[0][i] = 0.f; H[1][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { zero[i] = 0.f; T[i] = 0.f; tp[i] = 0.f; H[0][i] = 0.f; H[1][i] = 0.f; }
 #pragma unroll
     for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
@@ -172,8 +173,6 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
         vo = vl < vps ? (unsigned)((n * vps + vl) * D) * 4u : PF4_OOB;
         hv = n * vps + (vl < vps ? vl : vps - 1);
     }
-    Frag w2s[2];                                                                 // second pieces of W2 of the chunk whose second product comes next
-    w2s[0].u = *reinterpret_cast<const uint4*>(w2l + 14 * 2048); w2s[1].u = *reinterpret_cast<const uint4*>(w2l + 15 * 2048);
     int np = n, flp = 0;                                                         // sample and table copy of the previous tile (its epilogue runs a tile later)
     float sxn = sx, chn = ch;                                                    // scales of the NEXT tile's sample
     int nn = n, fln = 0;
@@ -182,31 +181,30 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
     // for C = 7), and in their gaps chunk C's vector work -- and the tile's other work, dealt out over the eight iterations.
     auto iter = [&](auto c_tag, long tile) __attribute__((always_inline)) {
         constexpr int C = decltype(c_tag)::value, CP = (C + 7) & 7, CN = (C + 1) & 7, P = C & 1;
+        Frag w2s[2];                                                              // second pieces of W2, chunk CP (requested behind the first MFMA, used from the seventh on)
         float hs[16];
         unsigned q0[4][2], q1[4][2];                                              // first / second pieces of the four groups (two dwords each)
 #pragma unroll
         for (int G = 0; G < 12; ++G) {
-            // ---- the MFMA ----
-            if (G < 6) {                                                          // T += W2c^T H' of chunk CP: per k-block w1 h0 + w0 h1 + w0 h0
+            // ---- the MFMA: first the next chunk's first product (its result is read an iteration later), then the previous chunk's second product ----
+            if (G < 6) {                                                          // H of chunk CN = W1c X^T: per k-block w1 x0 + w0 x1 + w0 x0
                 const int kb = G / 3, r = G % 3;
-                const f16x8 wa = r == 0 ? w2s[kb].h : w2a[CP][kb];
-                const f16x8 hbv = r == 1 ? hb[P ^ 1][kb][1].h : hb[P ^ 1][kb][0].h;
-                if (CP == 0 && G == 0) T = PF4_MFMA(wa, hbv, zero); else T = PF4_MFMA(wa, hbv, T);
-            } else {                                                              // H of chunk CN = W1c X^T
-                const int kb = (G - 6) / 3, r = (G - 6) % 3;
                 const f16x8 wa = r == 0 ? w1a[CN][kb][1] : w1a[CN][kb][0];
                 const f16x8 xv = C == 7 ? (r == 1 ? xbn[kb][1].h : xbn[kb][0].h) : (r == 1 ? xb[kb][1].h : xb[kb][0].h);
-                if (G == 6) H[P ^ 1] = PF4_MFMA(wa, xv, zero); else H[P ^ 1] = PF4_MFMA(wa, xv, H[P ^ 1]);
+                if (G == 0) H[P ^ 1] = PF4_MFMA(wa, xv, zero); else H[P ^ 1] = PF4_MFMA(wa, xv, H[P ^ 1]);
+            } else {                                                              // T += W2c^T H' of chunk CP
+                const int kb = (G - 6) / 3, r = (G - 6) % 3;
+                const f16x8 wa = r == 0 ? w2s[kb].h : w2a[CP][kb];
+                const f16x8 hbv = r == 1 ? hb[P ^ 1][kb][1].h : hb[P ^ 1][kb][0].h;
+                if (CP == 0 && G == 6) T = PF4_MFMA(wa, hbv, zero); else T = PF4_MFMA(wa, hbv, T);
             }
             PF4_SBAR();
             // ---- chunk C's vector work: H' = max(fma(H, ch, b), 0), cut into pieces; group g = registers 4 g .. 4 g + 3 = hidden 32 C + 8 g + 4 half + (0..3) ----
             if (G < 8) {                                                          // two values per gap
-#pragma unroll
-                for (int e = 2 * G; e < 2 * G + 2; ++e) {
-                    const float4 b4 = bq[e >> 2];
-                    const float bb = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
-                    hs[e] = fmaxf(fmaf(H[P][e], ch, bb), 0.f);
-                }
+                const float4 b4 = bq[G >> 1];
+                // (a packed fma -- v_pk_fma_f32 through asm -- was tried: the compiler copies its operands into aligned pairs and pads hazards, 74 against 58 us)
+                hs[2 * G] = fmaxf(fmaf(H[P][2 * G], ch, (G & 1) ? b4.z : b4.x), 0.f);
+                hs[2 * G + 1] = fmaxf(fmaf(H[P][2 * G + 1], ch, (G & 1) ? b4.w : b4.y), 0.f);
             }
             // first pieces of group g behind its four values, the second pieces one and two gaps later
             if (G == 2 || G == 5 || G == 8 || G == 9) {
@@ -214,14 +212,11 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
                 q0[g][0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){hs[4 * g], hs[4 * g + 1]}, f16x2));
                 q0[g][1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){hs[4 * g + 2], hs[4 * g + 3]}, f16x2));
             }
-            if (G == 3 || G == 6 || G == 8 || G == 10) {
-                const int g = G == 3 ? 0 : G == 6 ? 1 : G == 8 ? 2 : 3;
-                if (G == 8) { /* (group 2's first pieces are cut in this gap too: its second pieces follow in gap 9) */ }
-                else asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
-                         : "=&v"(q1[g][0]), "=&v"(q1[g][1]) : "v"(q0[g][0]), "v"(q0[g][1]), "v"(hs[4 * g]), "v"(hs[4 * g + 2]));
+            if (G == 3 || G == 6 || G == 9 || G == 10) {
+                const int g = G == 3 ? 0 : G == 6 ? 1 : G == 9 ? 2 : 3;
+                asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
+                    : "=&v"(q1[g][0]), "=&v"(q1[g][1]) : "v"(q0[g][0]), "v"(q0[g][1]), "v"(hs[4 * g]), "v"(hs[4 * g + 2]));
             }
-            if (G == 9) asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
-                            : "=&v"(q1[2][0]), "=&v"(q1[2][1]) : "v"(q0[2][0]), "v"(q0[2][1]), "v"(hs[8]), "v"(hs[10]));
             if (G == 4 || G == 7 || G == 10 || G == 11) {
                 const int g = G == 4 ? 0 : G == 7 ? 1 : G == 10 ? 2 : 3;
                 asm("v_fma_mixhi_f16 %0, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -236,38 +231,38 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
                     }
                 }
             }
-            // ---- requests of the next iteration: the second pieces of W2 of chunk C (gap 10), the biases of chunk C + 1 (gap 11; of the next tile's sample for C = 7) ----
-            if (G == 10) { w2s[0].u = *reinterpret_cast<const uint4*>(w2l + (C * 2) * 2048); w2s[1].u = *reinterpret_cast<const uint4*>(w2l + (C * 2 + 1) * 2048); }
-            if (G == 11) {
+            // ---- requests: the second pieces of W2 of chunk CP (used six gaps on), the biases of chunk C + 1 (of the next tile's sample for C = 7) behind this chunk's last use of them ----
+            if (G == 0) { w2s[0].u = *reinterpret_cast<const uint4*>(w2l + (CP * 2) * 2048); w2s[1].u = *reinterpret_cast<const uint4*>(w2l + (CP * 2 + 1) * 2048); }
+            if (G == 8) {
                 const float* bsrc = sBw + (C == 7 ? fln : flip) * 256 + 32 * CN + 4 * half;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bsrc + 8 * g);
             }
             // ---- the tile's other work ----
-            // C = 0: the previous tile's sums are complete behind the sixth MFMA: copy them (its epilogue runs in C = 1 .. 4 while T collects this tile's)
-            if (C == 0 && G >= 6 && G < 10) {
+            // C = 1: the previous tile's sums were complete behind the last MFMA of C = 0: copy them (its epilogue runs in C = 2 .. 5; T collects this tile's from this iteration's seventh MFMA on)
+            if (C == 1 && G < 4) {
 #pragma unroll
-                for (int i = 4 * (G - 6); i < 4 * (G - 6) + 4; ++i) Tp[i] = T[i];
+                for (int i = 4 * G; i < 4 * G + 4; ++i) tp[i] = T[i];
             }
-            // C = 1 .. 4: the previous tile's epilogue, group g = C - 1: four values (one multiply-add each: the multiplier 2^-(e2 + eh) and the bias come from the wave's
+            // C = 2 .. 5: the previous tile's epilogue, group g = C - 2: four values (one multiply-add each: the multiplier 2^-(e2 + eh) and the bias come from the wave's
             // table), their largest magnitude, a 16-byte store
-            if (C >= 1 && C <= 4 && (G == 0 || G == 1 || G == 11)) {
-                const int g = C - 1;
+            if (C >= 2 && C <= 5 && (G == 0 || G == 1 || G == 11)) {
+                const int g = C - 2;
                 if (G == 0) {
                     const float4 mm = *reinterpret_cast<const float4*>(sMw + flp * 32 + 8 * g + 4 * half), b4 = *reinterpret_cast<const float4*>(sB2 + 8 * g + 4 * half);
-                    Tp[4 * g] = fmaf(Tp[4 * g], mm.x, b4.x); Tp[4 * g + 1] = fmaf(Tp[4 * g + 1], mm.y, b4.y);
-                    Tp[4 * g + 2] = fmaf(Tp[4 * g + 2], mm.z, b4.z); Tp[4 * g + 3] = fmaf(Tp[4 * g + 3], mm.w, b4.w);
+                    tp[4 * g] = fmaf(tp[4 * g], mm.x, b4.x); tp[4 * g + 1] = fmaf(tp[4 * g + 1], mm.y, b4.y);
+                    tp[4 * g + 2] = fmaf(tp[4 * g + 2], mm.z, b4.z); tp[4 * g + 3] = fmaf(tp[4 * g + 3], mm.w, b4.w);
                 }
                 if (G == 1) {                                                     // (rows of the filter beyond D are whatever the packed fragments hold: not part of the tensor)
                     const bool whole = DT ? 8 * g + 8 <= DT : false;
-                    const float t0 = whole ? Tp[4 * g] : Tp[4 * g] * omask[4 * g], t1 = whole ? Tp[4 * g + 1] : Tp[4 * g + 1] * omask[4 * g + 1];
-                    const float t2 = whole ? Tp[4 * g + 2] : Tp[4 * g + 2] * omask[4 * g + 2], t3 = whole ? Tp[4 * g + 3] : Tp[4 * g + 3] * omask[4 * g + 3];
+                    const float t0 = whole ? tp[4 * g] : tp[4 * g] * omask[4 * g], t1 = whole ? tp[4 * g + 1] : tp[4 * g + 1] * omask[4 * g + 1];
+                    const float t2 = whole ? tp[4 * g + 2] : tp[4 * g + 2] * omask[4 * g + 2], t3 = whole ? tp[4 * g + 3] : tp[4 * g + 3] * omask[4 * g + 3];
                     asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omax) : "v"(t0), "v"(t1));
                     asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omax) : "v"(t2), "v"(t3));
                 }
                 if (G == 11) {
                     const int c0 = 8 * g + 4 * half;
-                    const u32x4p o = {__float_as_uint(Tp[4 * g]), __float_as_uint(Tp[4 * g + 1]), __float_as_uint(Tp[4 * g + 2]), __float_as_uint(Tp[4 * g + 3])};
+                    const u32x4p o = {__float_as_uint(tp[4 * g]), __float_as_uint(tp[4 * g + 1]), __float_as_uint(tp[4 * g + 2]), __float_as_uint(tp[4 * g + 3])};
                     if (c0 + 4 <= D) __builtin_amdgcn_raw_buffer_store_b128(o, yrs, vop + 4u * c0, 0, 0);
                     else {
                         if (c0 < D) __builtin_amdgcn_raw_buffer_store_b32(o[0], yrs, vop + 4u * c0, 0, 0);
@@ -276,8 +271,8 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
                     }
                 }
             }
-            // C = 5: the previous tile is finished: its sample's largest magnitude leaves when the run has left the sample (or this is the run's first tile: nothing was finished)
-            if (C == 5 && G == 0) {
+            // C = 6: the previous tile is finished: its sample's largest magnitude leaves when the run has left the sample (or this is the run's first tile: nothing was finished)
+            if (C == 6 && G == 0) {
                 if (tile == tb) omax = 0.f;
                 else if (np != n) { if (am.y) amax_commit(omax, am.y + np); omax = 0.f; }
             }
@@ -288,8 +283,8 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
             }
             // C = 4: the rows of the tile after the next one are requested (the registers are free: the cut above has read them)
             if (C == 4 && G == 10) { if (tile + 2 < te) load_x(n2, j2); }
-            // C = 6, behind the last use of xb (the first product of chunk 7 was issued in this iteration's second half): xb = the next tile's pieces
-            if (C == 6 && G == 11) {
+            // C = 6, behind the last use of xb (the first product of chunk 7 was issued in this iteration's first half): xb = the next tile's pieces
+            if (C == 6 && G == 7) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -319,6 +314,8 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
     }
     // ---- drain: the last tile's second product of chunk 7, its epilogue ----
     {
+        Frag w2s[2];
+        w2s[0].u = *reinterpret_cast<const uint4*>(w2l + 14 * 2048); w2s[1].u = *reinterpret_cast<const uint4*>(w2l + 15 * 2048);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             T = PF4_MFMA(w2s[kb].h, hb[1][kb][0].h, T); T = PF4_MFMA(w2a[7][kb], hb[1][kb][1].h, T); T = PF4_MFMA(w2a[7][kb], hb[1][kb][0].h, T);
