@@ -652,7 +652,7 @@ static bool cw4_plan(const ConvGeom& g, Cw4Args& p, size_t& lds_bytes, int& grid
 static int g_cw4_enabled = -1;
 bool cw4_enabled()
 {
-    if (g_cw4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_cw4_enabled = !(e && (e[0] == '1' || e[0] == 'c')); }      // PROBAV_GEN1 = 1 (both general forms) | conv | pw
+    if (g_cw4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_cw4_enabled = !(e && (e[0] == '1' || e[0] == 'c')); }      // PROBAV_GEN1 = 1 (every general form) | conv | pw | pwf | pwb
     return g_cw4_enabled != 0;
 }
 void cw4_set_enabled(int on) { g_cw4_enabled = on ? 1 : 0; }

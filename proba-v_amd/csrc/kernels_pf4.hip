@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void pw_fwd_w4_kernel(const float* __restri
 static int g_pf4_enabled = -1;
 bool pf4_enabled()
 {
-    if (g_pf4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_pf4_enabled = !(e && (e[0] == '1' || e[0] == 'p')); }      // PROBAV_GEN1 = 1 | pw | conv (kernels_pw4.hip)
+    if (g_pf4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_pf4_enabled = !(e && (e[0] == '1' || (e[0] == 'p' && e[1] == 'w' && e[2] != 'b'))); }      // PROBAV_GEN1 = 1 | pw | pwf | pwb | conv
     return g_pf4_enabled != 0;
 }
 void pf4_set_enabled(int on) { g_pf4_enabled = on ? 1 : 0; }

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
 static int g_pw4_enabled = -1;
 bool pw4_enabled()
 {
-    if (g_pw4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_pw4_enabled = !(e && (e[0] == '1' || e[0] == 'p')); }      // PROBAV_GEN1 = 1 (both general forms) | pw | conv
+    if (g_pw4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_pw4_enabled = !(e && (e[0] == '1' || (e[0] == 'p' && e[1] == 'w' && e[2] != 'f'))); }      // PROBAV_GEN1 = 1 (every general form) | pw (both pointwise kernels) | pwf | pwb (forward / backward only) | conv
     return g_pw4_enabled != 0;
 }
 void pw4_set_enabled(int on) { g_pw4_enabled = on ? 1 : 0; }

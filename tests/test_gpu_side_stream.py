@@ -103,16 +103,34 @@ def test_training_step_replays_from_a_captured_graph():
 @pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
 def test_one_wave_per_simd_pointwise_backward_agrees_with_the_general_form(B, T, tmp_path):
     """The fused pointwise backward of round 5 (pw_bwd_w4_kernel: one wave per SIMD, a wave owns a tile and all eight hidden chunks) evaluates the products
-    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_GEN1=pw) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
+    of the general eight-wave form (pw_bwd_x6_kernel<H3>, PROBAV_GEN1=pwb) per tile and chunk, with the same recomputed hidden tile and so the same ReLU gates; what differs is
     the order of the fp32 additions across chunks (dX: one accumulator chain instead of eight partials) and across tiles (filter gradients: a wave's run
     instead of a workgroup's).  Whole network: identical predictions (the forward pass is untouched), the flat gradient vector to 1e-5 of its max-norm."""
     import numpy as np
     a, b = str(tmp_path / "w4.npz"), str(tmp_path / "gen1.npz")
     _run({}, B, T, 1, a)
-    _run({"PROBAV_GEN1": "pw"}, B, T, 1, b)
+    _run({"PROBAV_GEN1": "pwb"}, B, T, 1, b)
     A, Bv = np.load(a), np.load(b)
     assert np.array_equal(A["pred"], Bv["pred"])
     assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-5 * np.abs(Bv["grad"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(5, 9), (3, 13)], ids=["b5-t9", "b3-t13"])
+def test_one_wave_per_simd_pointwise_forward_agrees_with_the_eight_wave_kernel(B, T, tmp_path):
+    """The fused pointwise forward of round 5 (pw_fwd_w4_kernel: one wave per SIMD, the weight fragments in registers) sums the 32 input channels of a hidden value in two
+    k-blocks of v_mfma_f32_32x32x16_f16 -- the order of the reverse pass' recompute --, pw_fwd_h3k_kernel (PROBAV_GEN1=pwf) in one 16x16x32 instruction: the same scaled fp16
+    pieces, another order of the fp32 additions.  Whole network: predictions to 1e-5 of their max-norm; the gradient to 1e-3 (a forward pass that differs in the last bits
+    flips gates of hidden values at zero, see the convolution test below).  Bit-for-bit agreement with the 32x32x16 arrangement itself: tools/pf4bench.hip and
+    test_forward_and_reverse_pass_decide_the_same_relu_gates."""
+    import numpy as np
+    a, b = str(tmp_path / "w4.npz"), str(tmp_path / "h3k.npz")
+    _run({}, B, T, 1, a)
+    _run({"PROBAV_GEN1": "pwf"}, B, T, 1, b)
+    A, Bv = np.load(a), np.load(b)
+    assert not np.array_equal(A["pred"], Bv["pred"])                      # (the switch did select another kernel)
+    assert np.abs(A["pred"] - Bv["pred"]).max() <= 1e-5 * np.abs(Bv["pred"]).max()
+    assert np.abs(A["grad"] - Bv["grad"]).max() <= 1e-3 * np.abs(Bv["grad"]).max()
 
 
 @pytest.mark.gpu
