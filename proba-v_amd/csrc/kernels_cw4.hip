@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
     // One round: the tile's MFMAs into `acc`.  In their gaps a few instructions each (a single wave issues one instruction per 4-5 cycles, whatever its kind, and an
     // MFMA leaves 24 of its 32 cycles; the operand requests take their share): the epilogue of the previous tile (`pacc`, skq, eo_prev), the skip loads of this
     // tile, the next tile's constants, and the staging of TWO ring rows for round r + 1 -- a round needs one or two new rows; when it needs one the second is that row
-    // again (the same bytes twice: no branch).  The rows' values were requested a whole round earlier, into the registers the cut of that round had just read.
+    // again (the same bytes twice: no branch -- skipping the second row's micro-operations behind one uniform branch per gap was measured: the branches cost what the
+    // skipped cuts save).  The rows' values were requested a whole round earlier, into the registers the cut of that round had just read.
     // Placement, by k-block K and MFMA j of it: epilogue value e behind (K = e, j = 2), the group stores behind (4, 8, 12, 16; 1), tile constants (1..10; 1), the
     // barrier (11; 1), skip loads (17, 18; 1, 2), cuts and stores (with the next round's requests among them) three behind each of (KS0..; 1, 2).
     auto round = [&](int r, f32x16& acc, f32x16& pacc) __attribute__((always_inline)) {
