@@ -157,6 +157,9 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
         }
     };
     auto stage_load_g3 = [&](int rowoff, Staged& sv) {
+#ifdef CW4_ABL_NOG3             // (timing-only ablation: the gathered chunk's three 4-byte requests per item -- 64 cache lines per wave-instruction -- are not made)
+        sv.g3[0] = sv.g3[1] = sv.g3[2] = 0u; return;
+#endif
         if constexpr (CIN == 25) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) sv.g3[j] = __builtin_amdgcn_raw_buffer_load_b32(xrs, s3_o[j], rowoff, 0);
