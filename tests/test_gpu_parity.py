@@ -25,14 +25,14 @@ def _keep_workspaces(monkeypatch):
     monkeypatch.setenv("PROBAV_KEEP_WS", "1")
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-# Un-gated golden gradients, relative L2 per tensor: twice the worst value measured over every tensor and implementation on MI355X
-# (round 4: T=9 2.7e-4 on the MFMA paths and 3.1e-3 on the scalar path, T=13 6.5e-4, T=7 2.7e-3, T=19 2.4e-3).  What is left in these
-# numbers is ReLU gates at ~0 that an fp32 and an fp64 evaluation set differently, which is why they move with T and with the summation
-# order and not with the arithmetic: the gate-masked tests further down hold the same gradients to 1e-5.
+# Un-gated golden gradients, relative L2 per tensor: ONE fixed bar for every depth and kernel family, 5e-3 -- not a number fitted to what a build happens to measure
+# (ADVICE r4).  Where it comes from: the gradient of this network is discontinuous in its ReLU gates; an fp32 and an fp64 evaluation set the gates of pre-activations at ~0
+# differently, and each flipped gate moves a filter-gradient entry by ~1/sqrt(#voxels) of its norm.  With B = 2 (8 712 voxels per block) that is the 1e-3 ... 3e-3 every
+# correct fp32 evaluation shows, whatever its summation order (measured on MI355X, rounds 4 / 5: T = 9 2.7e-4 ... 3.1e-3 by family, T = 13 6.5e-4, T = 7 2.7e-3, T = 19 2.4e-3).
+# What the bar cannot see -- an arithmetic error below it -- is what the gate-masked tests further down are for: the same gradients, the device's gates imposed on the
+# oracle, held to 1e-5.
 def _grad_l2_tol(T, impl):
-    if T == 9:
-        return 6.2e-3 if impl == 0 else 6e-4
-    return {13: 1.3e-3, 7: 5.4e-3, 19: 5e-3}[T]
+    return 5e-3
 
 
 IMPLS = [0, 1, 2, 3, 4]   # 4 = H3 kernels (three products of scaled fp16 piece pairs), same tolerances; 3 = x6 kernels (fp32 products as six bf16-piece MFMA products), held to the SAME tolerances
