@@ -1,0 +1,417 @@
+// Backward-filter of the residual blocks' 3x3x3 convolution (normConv: 25 -> 32 channels), H3 arithmetic -- ONE WAVE PER SIMD (round 5).
+// Reference semantics: tape.gradient (models/trainClass.py:131) through models/modelsTF.py:185-186 (normConv_i of ResConv3D):
+//   dW[tap][ci][co] = sum over the voxels v of all samples of X[v + tap][ci] dY[v][co],   db[co] = sum_v dY[v][co].
+//
+// What conv3_wgrad_x6_kernel (kernels_x6.hip: the general form -- any extent, pads, reflect, gate, 32 input channels) measured in the step: 108 us per launch, matrix pipe 37 %
+// busy, 47 % of its LDS cycles bank conflicts, two waves per SIMD that each wait for the four transposed reads of the NEXT tap tile only.  The contraction has no operand
+// reuse to speak of (N = 32 output channels is all there is: every (tap, channel, voxel) element of the A operand feeds ONE MFMA triple), so the A operand's LDS
+// reads are the kernel, and their latency and their conflicts were what it waited for.  This kernel keeps the arithmetic (the products and their order per k-block:
+// x1 d0 + x0 d1 + x0 d0; one scale per operand tensor) and changes the shape:
+//   * ONE WAVE PER SIMD, ONE INSTRUCTION STREAM per output row: 27 tap tiles (32 rows each: the 25 channels of one tap, padded) dealt 7 / 7 / 7 / 6 to the four waves,
+//     every wave takes ALL k-blocks of its tiles (no parity exchange at the end); a row = NKB k-blocks x 7 tiles x 3 MFMAs, fully unrolled, the transposed reads two tiles ahead
+//     in a seven-deep register ring.
+//   * A CONFLICT-FREE IMAGE: the input ring is [slot][piece][column][depth + 2][32 channels] fp16 -- 64 bytes per voxel and piece, so the four voxel rows x eight channel
+//     quads of a 32-lane half of a transposed read are 256 consecutive bytes (all 64 banks once) unless the four voxels straddle a depth wrap.  (The general form packs
+//     28 rows per tap into 24 tiles and interleaves the pieces at 112 bytes per voxel: 12.5 % fewer MFMAs, every read two-way conflicted -- tools/lds_conflict_model.py.)
+//   * dY IS NOT STAGED: the B operand of a k-block is eight 4-byte loads per lane straight from memory (through a buffer descriptor of the row: the voxels behind the row's end
+//     read as zero), requested three k-blocks ahead and cut into pieces in the MFMA gaps of the k-block before its own; the bias gradient is summed from the same registers.
+//   * FOUR RING SLOTS, ONE BARRIER PER ROW: while row r reads input rows r - 1 .. r + 1, row r + 2 is cut and stored into the fourth slot (its values were requested a whole
+//     row earlier, into the registers the previous cut had just read); the barrier sits behind the second tile of a row's first k-block, whose reads are dh = 0 taps.
+// Workgroup = (sample, strip of rows); one slab per workgroup, summed by mfma_wgrad_reduce (fp64, fixed order) like the general form's.
+#include "kernels_x6.h"
+#include "x6_device.h"
+#include <cstdlib>
+#include <mutex>
+
+namespace probav {
+#ifdef WG4_DIAG                 // tools/wg4bench.hip includes this file as probav::diag (stamped / ablated builds beside the product's copy in the library)
+namespace diag {
+#endif
+
+struct Wg4Args { int N, H, SR, nstrips; };
+
+namespace {
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+}
+
+#ifdef WG4_STAMP
+__device__ unsigned long long g_wg4_stamps[1024 * 8];
+#endif
+
+#ifdef WG4_STAMP                 // diagnostic build only: cycles per phase summed over a wave's rows -- [wave][slot]: 0 whole kernel, 1 its 100-MHz ticks, 2 prologue, 3 row start -> barrier (and the rest of the row), 4 wait at the barrier
+#define WG4_ST(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define WG4_ST(k) do { } while (0)
+#endif
+#define WG4_SBAR() __builtin_amdgcn_sched_barrier(0)
+#define WG4_PIN(v) asm volatile("" : "+v"(v))
+
+template <int TP, int RT>       // depth + 2; GEMM rows per tap (32: a tile is a tap; 28: the taps' 25 + 3 rows packed, 24 tiles -- every tile straddles taps)
+__global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                               float* __restrict__ partial_b, Amax am)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int CIN = 25, W = 22, T = TP - 2, WP = W + 2, NV = W * T, NKB = (NV + 15) / 16;
+    constexpr int PP = WP * TP * 64, ROWB = 2 * PP;                      // bytes of one piece plane / of one ring row (slot)
+    constexpr int NQI = NV * 7, NIT = (NQI + 255) / 256;                 // staging items (voxel, channel quad) of a row; per thread
+    constexpr int NT = (27 * RT + 31) / 32, NJ = (NT + 3) / 4;          // M tiles; per wave (tile w + 4 j)
+    constexpr int RS = 5;                                                // register sets of the dY pipeline (raw values, cut fragments): set = k-block % RS
+    static_assert((NKB - 1) % RS != 0 && (NKB - 2) % RS != 0 && (NKB - 1) % RS != 1, "dY register sets: a row's last k-blocks and the next row's first must not share a set");
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31, li = lane & 15, gcol = (lane >> 4) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
+    const int hb = strip * a.SR;
+    const int SRr = a.H - hb < a.SR ? a.H - hb : a.SR;
+#ifdef WG4_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_pro = 0, st_prev = st_t0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    // H3: both operands are contracted over the voxels of ALL samples, so each takes ONE scale: that of its largest sample (as the general form)
+    const int ex = h3_exp(amax_over_samples(am.x, a.N)), ed = h3_exp(amax_over_samples(am.w, a.N));
+    const float sx = pow2i(ex), sd = pow2i(ed);
+    const int kun = -(ex + ed);
+
+    // ---- staging constants: item i <-> (voxel i / 7 of the row, channel quad i % 7); a thread's items are the same for every row.  Quad 6 is channel 24 and three values of
+    // the next voxel, which take the scale 0.  A thread beyond the last item repeats it (the same bytes to the same place): no predicate anywhere in the staging.
+    int s_src[NIT], s_dst[NIT];
+    float s_scz[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        const int ic = i < NQI ? i : NQI - 1;
+        const int vox = ic / 7, quad = ic - 7 * vox;
+        const int w = vox / T, t = vox - w * T;
+        s_src[k] = (vox * CIN + 4 * quad) * 4;
+        s_dst[k] = ((w + 1) * TP + t + 1) * 64 + quad * 8;
+        s_scz[k] = quad == 6 ? 0.f : 1.f;
+    }
+    const long xsample = (long)a.H * W * T * CIN;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * xsample), 0, (unsigned)xsample * 4u, 0x00020000);
+    constexpr int xrowb = W * T * CIN * 4;
+    auto row_of = [&](int key, int& rowoff, float& rokf) {               // ring key k <-> input row hb - 1 + k (clamped); 1.0 / 0.0 = inside / outside the patch
+        const int ih = hb - 1 + key;
+        const bool rok = ih >= 0 && ih < a.H;
+        rowoff = (rok ? ih : 0) * xrowb;
+        rokf = rok ? 1.f : 0.f;
+    };
+    u32x4b sv[NIT];                                                      // the row the current tile cuts (requested a tile earlier)
+    auto stage_load = [&](int rowoff, u32x4b (&q)[NIT]) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, s_src[k], rowoff, 0);
+    };
+    // One row's cut and stores as micro-operations of one instruction each (dealt out over MFMA gaps).  Per item: its scale; the four first pieces fp16(v s) and the four
+    // second pieces fp16(v s - h0) -- one mixed-precision fma each: v s is exact (a power of two) and so is the difference, the bits are those of multiply / convert / subtract /
+    // convert --; the slot address; two 8-byte stores.  reload: the item's registers are requested again (the row the NEXT tile cuts) behind their last read.
+    struct Cut { float sc; unsigned h0a, h0b, h1a, h1b; int adr; };
+    constexpr int ROW_MOPS = NIT * 12;
+    auto stage_mop = [&](int m, int slotoff, float sxr, u32x4b (&q)[NIT], Cut& c, bool reload, int rel) {
+        const int k = m / 12, op = m % 12;
+        if (op == 0) c.sc = s_scz[k] * sxr;
+        // (order: a register's two halves are never written by consecutive instructions -- the partial write forwards one wait state late, and hipcc puts an s_nop between them)
+        if (op == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h0a) : "v"(q[k][0]), "v"(sxr));
+        if (op == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h0a) : "v"(q[k][1]), "v"(c.sc));
+        if (op == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h0b) : "v"(q[k][2]), "v"(c.sc));
+        if (op == 4) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h0b) : "v"(q[k][3]), "v"(c.sc));
+        if (op == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.h1a) : "v"(q[k][0]), "v"(sxr), "v"(c.h0a));
+        if (op == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c.h1a) : "v"(q[k][1]), "v"(c.sc), "v"(c.h0a));
+        if (op == 6) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.h1b) : "v"(q[k][2]), "v"(c.sc), "v"(c.h0b));
+        if (op == 8) {
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c.h1b) : "v"(q[k][3]), "v"(c.sc), "v"(c.h0b));
+            if (reload) q[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, s_src[k], rel, 0);
+        }
+        if (op == 9) c.adr = s_dst[k] + slotoff;
+        if (op == 10) *reinterpret_cast<u32x2b*>(lds + c.adr) = (u32x2b){c.h0a, c.h0b};
+        if (op == 11) *reinterpret_cast<u32x2b*>(lds + c.adr + PP) = (u32x2b){c.h1a, c.h1b};
+    };
+
+    // ---- prologue: the requests first (ring keys 0 .. 2 = this strip's first three input rows, key 3 for the first tile's staging), then the ring is cleared ----
+    u32x4b p0[3][NIT];
+    float p0_rok[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { int ro; row_of(q, ro, p0_rok[q]); stage_load(ro, p0[q]); }
+    { int ro; float rk; row_of(3, ro, rk); stage_load(ro, sv); }
+    // dY of an output row through its own descriptor: the k-blocks' tail voxels (beyond the row) are out of range and read as zero; a row beyond the strip has no records at all
+    const long dyrow0 = (((long)n * a.H + hb) * W) * T * 32;
+    auto dy_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + dyrow0 + (long)i * NV * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
+    const int dvo = (8 * h) * 128 + col * 4;                             // lane: output channel col, voxels 8 h .. 8 h + 7 of a k-block
+    float raw[RS][8];
+    unsigned bq[RS][2][4];                                               // cut fragments: [set][piece][pair of voxels]
+    __amdgpu_buffer_rsrc_t drs = dy_rsrc(0), drsN = dy_rsrc(1);
+    auto dy_load = [&](const __amdgpu_buffer_rsrc_t& rs, int K, float (&r)[8]) {
+        const int vo = dvo + K * 2048;
+#pragma unroll
+        for (int i = 7; i >= 0; --i) r[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo + i * 128, 0, 0));
+    };
+#pragma unroll
+    for (int K = 0; K < 3; ++K) dy_load(drs, K, raw[K]);
+    for (int i = tid; i < (4 * ROWB + 1024) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // transposed-read addresses of the lane, per (k-block, half of its eight voxels): voxel 16 kb + 8 h + 4 jj + (li >> 2) at tap (0, 0), channel quad 16 gcol + 4 (li & 3)
+    int addrs[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int vi = 16 * kb + 8 * h + 4 * jj + (li >> 2);
+            addrs[kb][jj] = (vi + 2 * (vi / T)) * 64;
+        }
+    // the wave's tiles: wave + 4 j.  A lane's four rows of a tile (16 gcol + 4 (li & 3) .. + 3) are four consecutive channels of ONE tap (RT is a multiple of 4): its tap's
+    // ring-row step and (column, depth) offset plus the channels' byte offset.  (RT = 32: a tile beyond the 27th is tap 26 again: computed, dropped.)
+    int tdh[NJ], tcc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int R0 = 32 * (wave + 4 * j) + 16 * gcol + 4 * (li & 3);
+        int tau = R0 / RT;
+        const int ci0 = R0 - tau * RT;
+        tau = tau < 27 ? tau : 26;
+        const int dh = tau / 9, dw = (tau / 3) % 3, dt = tau % 3;
+        tdh[j] = dh; tcc[j] = (dw * TP + dt) * 64 + ci0 * 2;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // ring cleared
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        Cut c;
+        const float sxr = sx * p0_rok[q];
+#pragma unroll
+        for (int m = 0; m < ROW_MOPS; ++m) stage_mop(m, q * ROWB, sxr, p0[q], c, false, 0);
+    }
+    // cut of one k-block's dY values as sixteen micro-operations (the pairs (2 p, 2 p + 1) of a lane's eight voxels -> word p of the fragment), eight more for the bias sums
+    float bsum[2] = {0.f, 0.f};
+    auto dy_mop = [&](int m, float (&r)[8], unsigned (&q)[2][4]) {
+        if (m < 16) {
+            // (order, two pairs at a time: lo a, lo b, hi a, hi b of the first pieces, then of the second -- no register's halves by consecutive instructions, see stage_mop)
+            const int p = 2 * (m >> 3) + (m & 1), op = (m >> 1) & 3;
+            if (op == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(q[0][p]) : "v"(r[2 * p]), "v"(sd));
+            if (op == 1) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(q[0][p]) : "v"(r[2 * p + 1]), "v"(sd));
+            if (op == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(q[1][p]) : "v"(r[2 * p]), "v"(sd), "v"(q[0][p]));
+            if (op == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(q[1][p]) : "v"(r[2 * p + 1]), "v"(sd), "v"(q[0][p]));
+        } else {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[m & 1]) : "v"(r[m - 16]));
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < 24; ++m) dy_mop(m, raw[0], bq[0]);
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the first three rows are in the ring
+
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    Frag A[NJ][2];                                                        // ring of operand fragments: [tile of the k-block][piece]
+    int tapoff[NJ], tapoffN[NJ];
+    auto set_taps = [&](int i, int (&to)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) to[j] = ((i + tdh[j]) & 3) * ROWB + tcc[j];
+    };
+    set_taps(0, tapoff);
+    auto read_A = [&](int K, int j, const int (&to)[NJ], int piece) {
+        const unsigned char* p0 = lds + addrs[K][0] + to[j];
+        const unsigned char* p1 = lds + addrs[K][1] + to[j];
+        A[j][piece].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + piece * PP));
+        A[j][piece].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + piece * PP));
+    };
+    constexpr int PD = 2;                                                // tiles the operand reads run ahead
+#pragma unroll
+    for (int j = 0; j < PD; ++j) { read_A(0, j, tapoff, 0); read_A(0, j, tapoff, 1); }
+#ifdef WG4_STAMP
+    st_pro = __builtin_amdgcn_s_memtime() - st_t0;
+    st_prev = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- the rows ----
+    // A single wave issues one instruction per ~4.9 cycles whatever its kind (MI355X_MICROARCH.md), an MFMA leaves room for five or six beside itself.  Per tile
+    // the gap behind the first MFMA takes the two address sums and two transposed reads of the tile PD ahead (piece 0), the second gap the other two reads and three
+    // fillers, the third five fillers.  A k-block's filler list: the cut of k-block K + 1 (16) and its bias sums (8); staging (k-blocks 1 .. NKB - 3); the address and the
+    // eight requests of k-block K + 3.
+    constexpr int NSK = NKB - 3;
+    constexpr int STG = (ROW_MOPS + NSK - 1) / NSK;
+    constexpr int CAP1 = RT == 32 ? 2 : 3, CAP2 = 4;
+    static_assert(24 + STG + 9 <= (CAP1 + CAP2) * NJ, "a k-block's fillers must fit its gaps");
+#pragma unroll 1
+    for (int i = 0; i < SRr; ++i) {
+        set_taps(i + 1, tapoffN);
+        int rel, dummy;
+        float rokf, rokn;
+        row_of(i + 3, dummy, rokf);                                      // the row cut and stored now (slot of key i + 3 = the slot of key i - 1)
+        row_of(i + 4, rel, rokn);                                        // the row requested now
+        float sxr = sx * rokf;
+        WG4_PIN(sxr);
+        const int slotoff = ((i + 3) & 3) * ROWB;
+        Cut cut;
+#pragma unroll
+        for (int K = 0; K < NKB; ++K) {
+            const int nstg = (K >= 1 && K <= NSK) ? STG : 0;
+            const int NF = 24 + nstg + 9;
+            const int Kc = K + 1 < NKB ? K + 1 : 0;                      // k-block cut now (K + 1 == NKB: the next row's first)
+            const int Kl = K + 3 < NKB ? K + 3 : K + 3 - NKB;            // k-block requested now
+            int dvoK = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    {
+                        const f16x8 af = (m == 0) ? A[j][1].h : A[j][0].h;
+                        Frag bf;
+                        const int bp = (m == 1) ? 1 : 0;
+                        bf.u = make_uint4(bq[K % RS][bp][0], bq[K % RS][bp][1], bq[K % RS][bp][2], bq[K % RS][bp][3]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf.h, acc[j], 0, 0, 0);
+                    }
+                    WG4_SBAR();
+                    // operand requests PD tiles ahead (a row's last PD: the next row's first, through its slots)
+#ifndef WG4_ABL_NOREAD           // (timing-only ablations of the diagnostic build: tools/wg4diag.hip)
+                    if (m < 2) {
+                        const int sn = j + PD;
+                        if (sn < NJ) read_A(K, sn, tapoff, m);
+                        else if (K + 1 < NKB) read_A(K + 1, sn - NJ, tapoff, m);
+                        else read_A(0, sn - NJ, tapoffN, m);
+                    }
+#endif
+                    // The row's barrier, in the middle of its LAST k-block.  In front of it: every store of the row this tile staged (they end with k-block NKB - 3;
+                    // lgkmcnt(8): whatever is older than the last eight LDS operations has completed) and the last reads of ring row i, the slot the next tile overwrites
+                    // (the dh = 0 taps are the wave's first tiles).  Behind it the next tile's first operands are requested, from any row.
+#ifndef WG4_ABL_NOBAR
+#ifdef WG4_BAR_EARLY
+                    if (K == 0 && j == 0 && m == 1)
+#else
+                    if (K == NKB - 1 && j == NJ - PD - 1 && m == 2)
+#endif
+                    { WG4_ST(3); asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory"); WG4_ST(4); }
+#endif
+                    // fillers
+                    const int f0 = (CAP1 + CAP2) * j + (m == 2 ? CAP1 : 0), f1 = m == 0 ? f0 : f0 + (m == 1 ? CAP1 : CAP2);
+#pragma unroll
+                    for (int f = f0; f < f1; ++f) {
+                        if (f >= NF) continue;
+#ifdef WG4_ABL_NOFILL
+                        continue;
+#endif
+#ifdef WG4_ABL_NODY
+                        if (f < 24 || f >= 24 + nstg) continue;
+#endif
+#ifdef WG4_ABL_NOSTAGE
+                        if (f >= 24 && f < 24 + nstg) continue;
+#endif
+                        if (f < 24) dy_mop(f, raw[Kc % RS], bq[Kc % RS]);
+                        else if (f < 24 + nstg) {
+                            const int ms = (K - 1) * STG + (f - 24);
+                            if (ms < ROW_MOPS) stage_mop(ms, slotoff, sxr, sv, cut, true, rel);
+                        } else if (f == 24 + nstg) { dvoK = dvo + Kl * 2048; WG4_PIN(dvoK); }
+                        else {
+                            const int e = 7 - (f - 25 - nstg);             // (last voxel first: the cut starts with voxel 0, the NEWEST request -- one s_waitcnt per k-block instead of eight)
+                            raw[Kl % RS][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(K + 3 < NKB ? drs : drsN, dvoK + e * 128, 0, 0));
+                        }
+                    }
+                    WG4_SBAR();
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) tapoff[j] = tapoffN[j];
+        drs = drsN;
+        drsN = dy_rsrc(i + 2);
+    }
+
+#ifdef WG4_STAMP
+    const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the slab of this workgroup: [27 * 25][32] (+ the bias sums).  Through a buffer descriptor: a GEMM row that is no (tap, input channel) pair gets an offset beyond
+    // the slab and the store is dropped ----
+    {
+        float* pp = partial + (long)blockIdx.x * 27 * CIN * 32;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pp, 0, 27 * CIN * 32 * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int Tl = wave + 4 * j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // registers 4 q .. 4 q + 3 of a lane are four consecutive rows R0 .. R0 + 3 of the GEMM with R0 a multiple of 4, and RT is one too: they belong to ONE tap
+                const int R0 = 32 * Tl + 8 * q + 4 * h;
+                const int tau = R0 / RT, ci0 = R0 - tau * RT;
+                const int base = (Tl < NT && tau < 27) ? ((tau * CIN + ci0) * 32 + col) * 4 : (int)0x40000000;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int off = ci0 + e < CIN ? base + e * 128 : (int)0x40000000;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[j][4 * q + e], kun)), rs, off, 0, 0);
+                }
+            }
+        }
+        float b = bsum[0] + bsum[1];
+        b += __shfl_xor(b, 32, 64);
+        if (tid < 32) partial_b[(long)blockIdx.x * 32 + col] = b;
+    }
+#ifdef WG4_STAMP
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_wg4_stamps + (blockIdx.x * 4 + wave) * 8;
+        const unsigned long long te = __builtin_amdgcn_s_memtime();
+        o[0] = te - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = st_pro; o[3] = st_acc[3]; o[4] = st_acc[4]; o[5] = te - st_end;
+    }
+#endif
+}
+
+// ---- host side ----
+#ifndef WG4_RT
+#define WG4_RT 32
+#endif
+static bool wg4_plan(const ConvGeom& g, Wg4Args& p, int& grid)
+{
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.reflect_t) return false;
+    if (g.Cin != 25 || g.Cout != 32) return false;
+    if (g.ph != 1 || g.pw != 1 || g.pt != 1) return false;               // 'same' padding (normConv)
+    if (g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return false;
+    if (g.Wo != 22 || (g.To != 9 && g.To != 7)) return false;            // the instantiated row shapes
+    if (g.N < 1 || g.N > 256 || g.Ho < 1) return false;                  // one slab per workgroup, at most 256 of them (x6_wgrad_partial_floats)
+    int nstrips = 256 / g.N;
+    if (nstrips > g.Ho) nstrips = g.Ho;
+    const int SR = (g.Ho + nstrips - 1) / nstrips;
+    nstrips = (g.Ho + SR - 1) / SR;
+    p.N = g.N; p.H = g.Ho; p.SR = SR; p.nstrips = nstrips;
+    grid = g.N * nstrips;
+    return true;
+}
+
+#ifndef WG4_DIAG
+static int g_wg4_enabled = -1;
+bool wg4_enabled()
+{
+    if (g_wg4_enabled < 0) { const char* e = getenv("PROBAV_GEN1"); g_wg4_enabled = !(e && (e[0] == '1' || e[0] == 'w')); }      // PROBAV_GEN1 = 1 (every general form) | conv | wg | pw | pwf | pwb
+    return g_wg4_enabled != 0;
+}
+void wg4_set_enabled(int on) { g_wg4_enabled = on ? 1 : 0; }
+#endif
+
+bool wg4_wgrad_supported(const ConvGeom& g, const float* gate)
+{
+    Wg4Args p;
+    int grid;
+    return gate == nullptr && wg4_plan(g, p, grid);
+}
+
+int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, const Amax& am, hipStream_t s)
+{
+    Wg4Args p;
+    int grid;
+    if (!wg4_plan(g, p, grid)) { set_error("wg4_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (!am.x || !am.w) { set_error("wg4_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<11, WG4_RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<9, WG4_RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); });
+    const long nw = (long)27 * g.Cin * g.Cout;
+    float* partial_b = partial + (size_t)grid * nw;
+    const int Tp = g.To + 2;
+    const size_t lds_bytes = (size_t)4 * 2 * 24 * Tp * 64 + 1024;
+    if (g.To == 9) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<11, WG4_RT>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, partial, partial_b, am);
+    else hipLaunchKernelGGL((conv3_wgrad_w4_kernel<9, WG4_RT>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, partial, partial_b, am);
+    int rc = check_launch("conv3_wgrad_w4");
+    if (rc) return rc;
+    return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);
+}
+
+#ifdef WG4_DIAG
+}  // namespace diag
+#endif
+}  // namespace probav
