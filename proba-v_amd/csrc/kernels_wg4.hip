@@ -39,6 +39,49 @@ typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
 __device__ unsigned long long g_wg4_stamps[1024 * 8];
 #endif
 
+// ---- the compile-time schedule of a row's k-blocks (conv3_wgrad_w4_kernel: "the rows") ----
+// k-block in which unit u (the dY fragments of k-block u) is cut and stored: units MB + 1 .. of a row in that row's k-blocks 0 .., units 0 .. MB of the NEXT row in k-blocks MB .. NKB - 2
+template <int NKB, int MB>
+__host__ __device__ constexpr int wg4_cutK(int u)
+{
+    constexpr int nB = MB + 1, kB = NKB - 1 - MB, extra = nB - kB;
+    return u > MB ? u - (MB + 1) : (u < 2 * extra ? MB + u / 2 : MB + u - extra);
+}
+// fillers of k-block K: the units it cuts (8 micro-operations each), the units it requests (3 each; three k-blocks ahead of their cut), the staging micro-operations
+template <int NKB, int MB>
+__host__ __device__ constexpr int wg4_ncut(int K) { int c = 0; for (int u = 0; u < NKB; ++u) c += wg4_cutK<NKB, MB>(u) == K ? 1 : 0; return c; }
+template <int NKB, int MB>
+__host__ __device__ constexpr int wg4_nld(int K) { int c = 0; for (int u = 0; u < NKB; ++u) c += (wg4_cutK<NKB, MB>(u) + NKB - 3) % NKB == K ? 1 : 0; return c; }
+// first filler of filler gap gi (0 .. 2 NJ - 1) when NF fillers are dealt over a k-block: NF / 2 NJ per gap, the remainder one each to the FIRST gaps (a k-block's stores come early)
+__host__ __device__ constexpr int wg4_deal(int gi, int NF, int NG) { return gi * (NF / NG) + (gi < NF % NG ? gi : NF % NG); }
+// LDS operations a wave issues in k-block K BEHIND its last LDS store of that k-block (mirrors the dealing in the kernel: per tile j the gaps m = 0, 1 carry two transposed
+// reads each, gap (1, 2) the two fragment reads of the next k-block, the fillers [wg4_deal(gi), wg4_deal(gi + 1)) sit behind the reads of gap gi = 2 j + m - 1): what
+// s_waitcnt lgkmcnt(...) in front of the barrier that follows the k-block may leave outstanding
+template <int NKB, int MB, int NJ, int STG, int ROW_MOPS>
+__host__ __device__ constexpr int wg4_lds_behind_last_store(int K)
+{
+    const int ncut = wg4_ncut<NKB, MB>(K), nld = wg4_nld<NKB, MB>(K);
+    const int nstg = (K >= MB && K <= NKB - 3) ? STG : 0;
+    const int NF = 8 * ncut + 3 * nld + nstg;
+    int last = -1;
+    for (int f = 0; f < NF; ++f) {
+        bool st = false;
+        if (f < 8 * ncut) st = (f % 8 == 5) || (f % 8 == 7);
+        else if (f >= 8 * ncut + 3 * nld) { const int ms = (K - MB) * STG + f - 8 * ncut - 3 * nld; st = ms < ROW_MOPS && ms % 12 >= 10; }
+        if (st) last = f;
+    }
+    if (last < 0) return 15;
+    int gl = 0;
+    for (int gi = 0; gi < 2 * NJ; ++gi) if (wg4_deal(gi, NF, 2 * NJ) <= last && last < wg4_deal(gi + 1, NF, 2 * NJ)) gl = gi;
+    int n = 0;
+    for (int j = 0; j < NJ; ++j)
+        for (int m = 0; m < 3; ++m) {
+            const int pos = 3 * j + m, lpos = 3 * (gl / 2) + gl % 2 + 1;      // (the store's gap: its own reads come in front of it)
+            if (pos > lpos) n += (m < 2 ? 2 : 0) + ((j == 1 && m == 2) ? 2 : 0);
+        }
+    return n < 15 ? n : 15;
+}
+
 #ifdef WG4_STAMP                 // diagnostic build only: cycles per phase summed over a wave's rows -- [wave][slot]: 0 whole kernel, 1 its 100-MHz ticks, 2 prologue, 3 row start -> barrier (and the rest of the row), 4 wait at the barrier
 #define WG4_ST(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
 #else
@@ -56,8 +99,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     constexpr int PP = WP * TP * 64, ROWB = 2 * PP;                      // bytes of one piece plane / of one ring row (slot)
     constexpr int NQI = NV * 7, NIT = (NQI + 255) / 256;                 // staging items (voxel, channel quad) of a row; per thread
     constexpr int NT = (27 * RT + 31) / 32, NJ = (NT + 3) / 4;          // M tiles; per wave (tile w + 4 j)
-    constexpr int RS = 5;                                                // register sets of the dY pipeline (raw values, cut fragments): set = k-block % RS
-    static_assert((NKB - 1) % RS != 0 && (NKB - 2) % RS != 0 && (NKB - 1) % RS != 1, "dY register sets: a row's last k-blocks and the next row's first must not share a set");
+    constexpr int RS = 5;                                                // register sets of the dY fragments: set = k-block % RS
+    static_assert((NKB - 1) % RS != 0, "dY fragment sets: a row's last k-block and the next row's first must not share a set");
+    constexpr int FB0 = 4 * ROWB + 1024;                                 // the row's dY fragments: [k-block][piece][lane] x 16 bytes, behind the ring (and 1 KB that a tail k-block's reads may run into)
+    constexpr int MB = NKB / 2;                                          // the row's second barrier stands in front of k-block MB
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31, li = lane & 15, gcol = (lane >> 4) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
@@ -68,11 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     unsigned long long st_pro = 0, st_prev = st_t0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-    // H3: both operands are contracted over the voxels of ALL samples, so each takes ONE scale: that of its largest sample (as the general form)
-    const int ex = h3_exp(amax_over_samples(am.x, a.N)), ed = h3_exp(amax_over_samples(am.w, a.N));
-    const float sx = pow2i(ex), sd = pow2i(ed);
-    const int kun = -(ex + ed);
-
+    float sx = 1.f, sd = 1.f;                                            // H3 scales of x and dY (set in the prologue, behind its requests)
     // ---- staging constants: item i <-> (voxel i / 7 of the row, channel quad i % 7); a thread's items are the same for every row.  Quad 6 is channel 24 and three values of
     // the next voxel, which take the scale 0.  A thread beyond the last item repeats it (the same bytes to the same place): no predicate anywhere in the staging.
     int s_src[NIT], s_dst[NIT];
@@ -131,22 +172,52 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     float p0_rok[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) { int ro; row_of(q, ro, p0_rok[q]); stage_load(ro, p0[q]); }
-    { int ro; float rk; row_of(3, ro, rk); stage_load(ro, sv); }
-    // dY of an output row through its own descriptor: the k-blocks' tail voxels (beyond the row) are out of range and read as zero; a row beyond the strip has no records at all
+    // dY of an output row through its own descriptor: the k-blocks' tail voxels (beyond the row) are out of range and read as zero; a row beyond the strip has no records at all.
+    // The B operand of a k-block (16 voxels x 32 channels) is cut ONCE per workgroup: a UNIT = one k-block's fragments, a quarter per wave -- lane l of wave w takes the
+    // voxel pair l >> 4 of fragment lane 16 w + (l & 15): two 4-byte requests, four mixed fmas, two bias-sum additions, two 4-byte LDS stores (a wave's 64 stores of a piece
+    // are 256 consecutive bytes).  Every wave then reads a k-block's two fragments with two ds_read_b128.  (Cut by every wave for itself -- the first version -- the
+    // eight requests, sixteen fmas and eight additions per k-block were a third of all the instructions between the MFMAs.)
     const long dyrow0 = (((long)n * a.H + hb) * W) * T * 32;
     auto dy_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + dyrow0 + (long)i * NV * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
-    const int dvo = (8 * h) * 128 + col * 4;                             // lane: output channel col, voxels 8 h .. 8 h + 7 of a k-block
-    float raw[RS][8];
-    unsigned bq[RS][2][4];                                               // cut fragments: [set][piece][pair of voxels]
+    const int lp = 16 * wave + li, pp = lane >> 4;                       // fragment lane (channel lp & 31, voxels 8 (lp >> 5) ..), pair of its eight voxels
+    const int dvo = (8 * (lp >> 5) + 2 * pp) * 128 + (lp & 31) * 4;
+    const int fbw = FB0 + lp * 16 + pp * 4, fbr = FB0 + lane * 16;
+    float raw[NKB][2];                                                   // requested values of the units in flight (indexed by unit: compile-time everywhere)
     __amdgpu_buffer_rsrc_t drs = dy_rsrc(0), drsN = dy_rsrc(1);
-    auto dy_load = [&](const __amdgpu_buffer_rsrc_t& rs, int K, float (&r)[8]) {
-        const int vo = dvo + K * 2048;
-#pragma unroll
-        for (int i = 7; i >= 0; --i) r[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo + i * 128, 0, 0));
+    // Schedule (compile-time): unit u of a row is CUT in k-block cutK(u) -- units MB + 1 .. of the row itself in its k-blocks 0 .. (they are read from k-block MB on, behind
+    // the second barrier), units 0 .. MB of the NEXT row in k-blocks MB .. NKB - 2 (their slots are free behind the second barrier; they are read from k-block NKB - 1 on,
+    // behind the row barrier) -- and REQUESTED three k-blocks earlier.
+    auto cutK = [](int u) -> int { return wg4_cutK<NKB, MB>(u); };
+    int vo_t = 0;
+    unsigned cq0 = 0u, cq1 = 0u;
+    float bsum[2] = {0.f, 0.f};
+    auto dy_load_op = [&](int u, int op, const __amdgpu_buffer_rsrc_t& rs) {
+        if (op == 0) { vo_t = dvo + u * 2048; WG4_PIN(vo_t); }
+        if (op == 1) raw[u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo_t, 0, 0));
+        if (op == 2) raw[u][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo_t + 128, 0, 0));
+    };
+    auto dy_cut_op = [&](int u, int op) {                                 // (order: no register's halves by consecutive instructions, see stage_mop)
+        if (op == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(cq0) : "v"(raw[u][0]), "v"(sd));
+        if (op == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(raw[u][0]));
+        if (op == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(cq0) : "v"(raw[u][1]), "v"(sd));
+        if (op == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[1]) : "v"(raw[u][1]));
+        if (op == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(cq1) : "v"(raw[u][0]), "v"(sd), "v"(cq0));
+        if (op == 5) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048) = cq0;
+        if (op == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(cq1) : "v"(raw[u][1]), "v"(sd), "v"(cq0));
+        if (op == 7) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048 + 1024) = cq1;
     };
 #pragma unroll
-    for (int K = 0; K < 3; ++K) dy_load(drs, K, raw[K]);
-    for (int i = tid; i < (4 * ROWB + 1024) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int u = 0; u < NKB; ++u)
+        if (u <= MB || cutK(u) < 3) {                                     // the first row's units 0 .. MB are cut here, and the units its first three k-blocks cut are requested
+#pragma unroll
+            for (int op = 0; op < 3; ++op) dy_load_op(u, op, drs);
+        }
+    // H3: both operands are contracted over the voxels of ALL samples, so each takes ONE scale: that of its largest sample (as the general form).  (Worked out HERE, behind
+    // the prologue's requests: the two slot reads are two memory round trips in a row, and in front of the requests they were 4 000 cycles in which nothing was in flight.)
+    const int ex = h3_exp(amax_over_samples(am.x, a.N)), ed = h3_exp(amax_over_samples(am.w, a.N));
+    sx = pow2i(ex); sd = pow2i(ed);
+    const int kun = -(ex + ed);
+    for (int i = tid; i < (FB0 + NKB * 2048) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
     // transposed-read addresses of the lane, per (k-block, half of its eight voxels): voxel 16 kb + 8 h + 4 jj + (li >> 2) at tap (0, 0), channel quad 16 gcol + 4 (li & 3)
     int addrs[NKB][2];
 #pragma unroll
@@ -168,7 +239,30 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         const int dh = tau / 9, dw = (tau / 3) % 3, dt = tau % 3;
         tdh[j] = dh; tcc[j] = (dw * TP + dt) * 64 + ci0 * 2;
     }
+#ifdef WG4_STAMP
+    const unsigned long long st_p1 = __builtin_amdgcn_s_memtime();
+#endif
+    // byte offsets of the lane's accumulator registers in the workgroup's slab [27 * 25][32] (worked out here, where the wave waits for its requests anyway): registers
+    // 4 q .. 4 q + 3 of a lane are four consecutive rows R0 .. R0 + 3 of the GEMM with R0 a multiple of 4, and RT is one too: they belong to ONE tap.  A row that is no
+    // (tap, input channel) pair gets an offset beyond the slab's descriptor and its store is dropped: so0 for register 4 q, so1 (+ 128 e) for registers 4 q + e
+    int so0[NJ][4], so1[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int Tl = wave + 4 * j, R0 = 32 * Tl + 8 * q + 4 * h;
+            const int tau = R0 / RT, ci0 = R0 - tau * RT;
+            const bool ok = Tl < NT && tau < 27;
+            so0[j][q] = (ok && ci0 < CIN) ? ((tau * CIN + ci0) * 32 + col) * 4 : (int)0x40000000;
+            so1[j][q] = (ok && ci0 + 3 < CIN) ? so0[j][q] : (int)0x40000000;
+        }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // ring cleared
+#ifdef WG4_STAMP
+    const unsigned long long st_p2 = __builtin_amdgcn_s_memtime();
+#endif
+    // (the row the first tile stages is requested behind the rows the first tile reads: every workgroup of the launch is in its prologue at once, and the 80 KB each
+    //  asks for are what the prologue waits for -- 256 workgroups x 80 KB at the memory's rate)
+    { int ro; float rk; row_of(3, ro, rk); stage_load(ro, sv); }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         Cut c;
@@ -176,23 +270,14 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #pragma unroll
         for (int m = 0; m < ROW_MOPS; ++m) stage_mop(m, q * ROWB, sxr, p0[q], c, false, 0);
     }
-    // cut of one k-block's dY values as sixteen micro-operations (the pairs (2 p, 2 p + 1) of a lane's eight voxels -> word p of the fragment), eight more for the bias sums
-    float bsum[2] = {0.f, 0.f};
-    auto dy_mop = [&](int m, float (&r)[8], unsigned (&q)[2][4]) {
-        if (m < 16) {
-            // (order, two pairs at a time: lo a, lo b, hi a, hi b of the first pieces, then of the second -- no register's halves by consecutive instructions, see stage_mop)
-            const int p = 2 * (m >> 3) + (m & 1), op = (m >> 1) & 3;
-            if (op == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(q[0][p]) : "v"(r[2 * p]), "v"(sd));
-            if (op == 1) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(q[0][p]) : "v"(r[2 * p + 1]), "v"(sd));
-            if (op == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(q[1][p]) : "v"(r[2 * p]), "v"(sd), "v"(q[0][p]));
-            if (op == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(q[1][p]) : "v"(r[2 * p + 1]), "v"(sd), "v"(q[0][p]));
-        } else {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[m & 1]) : "v"(r[m - 16]));
-        }
-    };
 #pragma unroll
-    for (int m = 0; m < 24; ++m) dy_mop(m, raw[0], bq[0]);
+    for (int u = 0; u <= MB; ++u)
+#pragma unroll
+        for (int op = 0; op < 8; ++op) dy_cut_op(u, op);
 
+#ifdef WG4_STAMP
+    const unsigned long long st_p3 = __builtin_amdgcn_s_memtime();
+#endif
     f32x16 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -202,6 +287,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     Frag A[NJ][2];                                                        // ring of operand fragments: [tile of the k-block][piece]
+    Frag Bf[RS][2];                                                       // dY fragments of k-block K in set K % RS
+    auto read_B = [&](int K) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) Bf[K % RS][p].u = *reinterpret_cast<const uint4*>(lds + fbr + K * 2048 + p * 1024);
+    };
+    read_B(0);
     int tapoff[NJ], tapoffN[NJ];
     auto set_taps = [&](int i, int (&to)[NJ]) {
 #pragma unroll
@@ -223,14 +314,17 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #endif
 
     // ---- the rows ----
-    // A single wave issues one instruction per ~4.9 cycles whatever its kind (MI355X_MICROARCH.md), an MFMA leaves room for five or six beside itself.  Per tile
-    // the gap behind the first MFMA takes the two address sums and two transposed reads of the tile PD ahead (piece 0), the second gap the other two reads and three
-    // fillers, the third five fillers.  A k-block's filler list: the cut of k-block K + 1 (16) and its bias sums (8); staging (k-blocks 1 .. NKB - 3); the address and the
-    // eight requests of k-block K + 3.
-    constexpr int NSK = NKB - 3;
+    // A single wave issues one instruction per ~4.9 cycles whatever its kind (MI355X_MICROARCH.md): an MFMA leaves room for about five beside itself.  Per tile
+    // the gap behind the first MFMA takes the two address sums and two transposed reads of the tile PD ahead (piece 0), the second gap the other two reads; a k-block's
+    // fillers -- the units it cuts (8 each) and requests (3 each), the staging micro-operations (k-blocks MB .. NKB - 2) -- are dealt evenly over its second and third gaps.
+    // Two barriers per row (a wave arrives with s_waitcnt lgkmcnt(n), n = the LDS operations it has issued behind its last LDS store -- wg4_lds_behind_last_store):
+    //   in front of k-block MB -- behind it the slots of units 0 .. MB are free (their fragments have been read) and the ring slot of input row i - 1 is (every wave has
+    //   finished output row i - 1); in front of it the row's own units MB + 1 .. were stored;
+    //   in front of k-block NKB - 1 -- behind it the next row's unit 0 and its first operands are read; in front of it the staged input row and the next row's units 0 .. MB were stored.
+    constexpr int NSK = NKB - 2 - MB;                                    // k-blocks MB .. NKB - 3 carry the staging
     constexpr int STG = (ROW_MOPS + NSK - 1) / NSK;
-    constexpr int CAP1 = RT == 32 ? 2 : 3, CAP2 = 4;
-    static_assert(24 + STG + 9 <= (CAP1 + CAP2) * NJ, "a k-block's fillers must fit its gaps");
+    constexpr int WAIT_MB = wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS>(MB - 1), WAIT_RB = wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS>(NKB - 2);
+    static_assert(wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS>(NKB - 1) == 15 && wg4_ncut<NKB, MB>(NKB - 1) == 0, "no LDS store in a row's last k-block");
 #pragma unroll 1
     for (int i = 0; i < SRr; ++i) {
         set_taps(i + 1, tapoffN);
@@ -244,21 +338,32 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         Cut cut;
 #pragma unroll
         for (int K = 0; K < NKB; ++K) {
-            const int nstg = (K >= 1 && K <= NSK) ? STG : 0;
-            const int NF = 24 + nstg + 9;
-            const int Kc = K + 1 < NKB ? K + 1 : 0;                      // k-block cut now (K + 1 == NKB: the next row's first)
-            const int Kl = K + 3 < NKB ? K + 3 : K + 3 - NKB;            // k-block requested now
-            int dvoK = 0;
+            // the k-block's filler list
+            const int ncut = wg4_ncut<NKB, MB>(K), nld = wg4_nld<NKB, MB>(K);
+            const int nstg = (K >= MB && K <= NKB - 3) ? STG : 0;
+            const int NF = 8 * ncut + 3 * nld + nstg;
+            auto filler = [&](int f) {
+#pragma unroll
+                for (int u = 0; u < NKB; ++u) if (cutK(u) == K) { if (f >= 0 && f < 8) dy_cut_op(u, f); f -= 8; }
+#pragma unroll
+                for (int u = 0; u < NKB; ++u) if ((cutK(u) + NKB - 3) % NKB == K) {
+                    // (a unit of the next row, or one of this row's successor that its first three k-blocks cut: the next row's descriptor)
+                    if (f >= 0 && f < 3) dy_load_op(u, f, (u <= MB || cutK(u) < 3) ? drsN : drs);
+                    f -= 3;
+                }
+                if (f >= 0 && f < nstg) { const int ms = (K - MB) * STG + f; if (ms < ROW_MOPS) stage_mop(ms, slotoff, sxr, sv, cut, true, rel); }
+            };
+#ifndef WG4_ABL_NOBAR
+            if (K == MB) { WG4_ST(3); asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(WAIT_MB) : "memory"); WG4_ST(4); }
+            if (K == NKB - 1) { WG4_ST(3); asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(WAIT_RB) : "memory"); WG4_ST(4); }
+#endif
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     {
                         const f16x8 af = (m == 0) ? A[j][1].h : A[j][0].h;
-                        Frag bf;
-                        const int bp = (m == 1) ? 1 : 0;
-                        bf.u = make_uint4(bq[K % RS][bp][0], bq[K % RS][bp][1], bq[K % RS][bp][2], bq[K % RS][bp][3]);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf.h, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, Bf[K % RS][m == 1 ? 1 : 0].h, acc[j], 0, 0, 0);
                     }
                     WG4_SBAR();
                     // operand requests PD tiles ahead (a row's last PD: the next row's first, through its slots)
@@ -269,40 +374,17 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
                         else if (K + 1 < NKB) read_A(K + 1, sn - NJ, tapoff, m);
                         else read_A(0, sn - NJ, tapoffN, m);
                     }
-#endif
-                    // The row's barrier, in the middle of its LAST k-block.  In front of it: every store of the row this tile staged (they end with k-block NKB - 3;
-                    // lgkmcnt(8): whatever is older than the last eight LDS operations has completed) and the last reads of ring row i, the slot the next tile overwrites
-                    // (the dh = 0 taps are the wave's first tiles).  Behind it the next tile's first operands are requested, from any row.
-#ifndef WG4_ABL_NOBAR
-#ifdef WG4_BAR_EARLY
-                    if (K == 0 && j == 0 && m == 1)
-#else
-                    if (K == NKB - 1 && j == NJ - PD - 1 && m == 2)
-#endif
-                    { WG4_ST(3); asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory"); WG4_ST(4); }
+                    if (j == 1 && m == 2) read_B(K + 1 < NKB ? K + 1 : 0);      // the next k-block's dY fragments
 #endif
                     // fillers
-                    const int f0 = (CAP1 + CAP2) * j + (m == 2 ? CAP1 : 0), f1 = m == 0 ? f0 : f0 + (m == 1 ? CAP1 : CAP2);
+                    if (m > 0) {
+                        const int gi = 2 * j + m - 1, f0 = wg4_deal(gi, NF, 2 * NJ), f1 = wg4_deal(gi + 1, NF, 2 * NJ);
 #pragma unroll
-                    for (int f = f0; f < f1; ++f) {
-                        if (f >= NF) continue;
+                        for (int f = f0; f < f1; ++f) {
 #ifdef WG4_ABL_NOFILL
-                        continue;
+                            continue;
 #endif
-#ifdef WG4_ABL_NODY
-                        if (f < 24 || f >= 24 + nstg) continue;
-#endif
-#ifdef WG4_ABL_NOSTAGE
-                        if (f >= 24 && f < 24 + nstg) continue;
-#endif
-                        if (f < 24) dy_mop(f, raw[Kc % RS], bq[Kc % RS]);
-                        else if (f < 24 + nstg) {
-                            const int ms = (K - 1) * STG + (f - 24);
-                            if (ms < ROW_MOPS) stage_mop(ms, slotoff, sxr, sv, cut, true, rel);
-                        } else if (f == 24 + nstg) { dvoK = dvo + Kl * 2048; WG4_PIN(dvoK); }
-                        else {
-                            const int e = 7 - (f - 25 - nstg);             // (last voxel first: the cut starts with voxel 0, the NEWEST request -- one s_waitcnt per k-block instead of eight)
-                            raw[Kl % RS][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(K + 3 < NKB ? drs : drsN, dvoK + e * 128, 0, 0));
+                            filler(f);
                         }
                     }
                     WG4_SBAR();
@@ -324,37 +406,33 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         float* pp = partial + (long)blockIdx.x * 27 * CIN * 32;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pp, 0, 27 * CIN * 32 * 4, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int Tl = wave + 4 * j;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // registers 4 q .. 4 q + 3 of a lane are four consecutive rows R0 .. R0 + 3 of the GEMM with R0 a multiple of 4, and RT is one too: they belong to ONE tap
-                const int R0 = 32 * Tl + 8 * q + 4 * h;
-                const int tau = R0 / RT, ci0 = R0 - tau * RT;
-                const int base = (Tl < NT && tau < 27) ? ((tau * CIN + ci0) * 32 + col) * 4 : (int)0x40000000;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int off = ci0 + e < CIN ? base + e * 128 : (int)0x40000000;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[j][4 * q + e], kun)), rs, off, 0, 0);
-                }
-            }
-        }
+                for (int e = 0; e < 4; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[j][4 * q + e], kun)), rs, e ? so1[j][q] + e * 128 : so0[j][q], 0, 0);
+        // bias sums: a lane summed the voxel pairs pp of channel lp & 31; lanes l, l + 16, l + 32, l + 48 share the channel, and so do waves w and w + 2
         float b = bsum[0] + bsum[1];
+        b += __shfl_xor(b, 16, 64);
         b += __shfl_xor(b, 32, 64);
-        if (tid < 32) partial_b[(long)blockIdx.x * 32 + col] = b;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (the ring is dead)
+        if (lane < 16) reinterpret_cast<float*>(lds)[wave * 16 + lane] = b;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < 32) partial_b[(long)blockIdx.x * 32 + tid] = reinterpret_cast<const float*>(lds)[(tid >> 4) * 16 + (tid & 15)] + reinterpret_cast<const float*>(lds)[((tid >> 4) + 2) * 16 + (tid & 15)];
     }
 #ifdef WG4_STAMP
     if (lane == 0 && blockIdx.x < 256) {
         unsigned long long* o = g_wg4_stamps + (blockIdx.x * 4 + wave) * 8;
         const unsigned long long te = __builtin_amdgcn_s_memtime();
-        o[0] = te - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = st_pro; o[3] = st_acc[3]; o[4] = st_acc[4]; o[5] = te - st_end;
+        o[0] = te - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = st_pro; o[3] = st_acc[3]; o[4] = st_acc[4]; o[5] = te - st_end; o[6] = st_p2 - st_t0; o[7] = st_p3 - st_p2; o[3] = st_p1 - st_t0;
     }
 #endif
 }
 
 // ---- host side ----
 #ifndef WG4_RT
-#define WG4_RT 32
+#define WG4_RT 28                // (32: 27 tap tiles, conflict-free reads, 12.5 % more MFMAs -- measured 9 % slower)
 #endif
 static bool wg4_plan(const ConvGeom& g, Wg4Args& p, int& grid)
 {
@@ -403,7 +481,7 @@ int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
     const int Tp = g.To + 2;
-    const size_t lds_bytes = (size_t)4 * 2 * 24 * Tp * 64 + 1024;
+    const size_t lds_bytes = (size_t)4 * 2 * 24 * Tp * 64 + 1024 + (size_t)((22 * g.To + 15) / 16) * 2048;      // ring, slack, the row's dY fragments
     if (g.To == 9) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<11, WG4_RT>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, partial, partial_b, am);
     else hipLaunchKernelGGL((conv3_wgrad_w4_kernel<9, WG4_RT>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, partial, partial_b, am);
     int rc = check_launch("conv3_wgrad_w4");

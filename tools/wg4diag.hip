@@ -54,9 +54,9 @@ int main(int argc, char** argv)
 #ifdef WG4_STAMP
     std::vector<unsigned long long> st(1024 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(diag::g_wg4_stamps), st.size() * 8);
-    const char* nm[6] = {"whole kernel (cycles)", "whole kernel (100 MHz ticks)", "prologue", "rows without the barrier waits", "waits at the barriers", "epilogue (slab stores)"};
+    const char* nm[8] = {"whole kernel (cycles)", "whole kernel (100 MHz ticks)", "prologue", "prologue: entry -> LDS cleared (issue)", "waits at the barriers", "epilogue (slab stores)", "prologue: entry -> behind the clear barrier", "prologue: three rows + dY units cut"};
     auto stat = [&](int k, double& md, double& mx, double& mn) { std::vector<double> v; for (int wv = 0; wv < 1024; ++wv) if (st[wv * 8]) v.push_back((double)st[wv * 8 + k]); std::sort(v.begin(), v.end()); md = v[v.size() / 2]; mx = v.back(); mn = v[0]; };
-    for (int k = 0; k < 6; ++k) { double md, mx, mn; stat(k, md, mx, mn); printf("  slot %d  %-32s median %10.0f  min %10.0f  max %10.0f   per row %8.0f\n", k, nm[k], md, mn, mx, md / 11.0); }
+    for (int k = 0; k < 8; ++k) { double md, mx, mn; stat(k, md, mx, mn); printf("  slot %d  %-32s median %10.0f  min %10.0f  max %10.0f   per row %8.0f\n", k, nm[k], md, mn, mx, md / 11.0); }
     { double c, t, a, b; stat(0, c, a, b); stat(1, t, a, b); printf("  in-kernel clock %.2f GHz; kernel %.1f us per wave\n", c / t * 0.1, t * 0.01); }
     for (int w = 0; w < 4; ++w) printf("  workgroup 0 wave %d: whole %llu, rows %llu, barrier waits %llu\n", w, st[w * 8], st[w * 8 + 3], st[w * 8 + 4]);
 #endif
