@@ -87,6 +87,9 @@ __host__ __device__ constexpr int wg4_lds_behind_last_store(int K)
 #else
 #define WG4_ST(k) do { } while (0)
 #endif
+#ifndef WG4_PD
+#define WG4_PD 2
+#endif
 #define WG4_SBAR() __builtin_amdgcn_sched_barrier(0)
 #define WG4_PIN(v) asm volatile("" : "+v"(v))
 
@@ -114,6 +117,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #endif
 
     float sx = 1.f, sd = 1.f;                                            // H3 scales of x and dY (set in the prologue, behind its requests)
+    // the operands' per-sample amax slots (at most 256 samples: wg4_plan), requested FIRST and read last: two dependent round trips through a loop (amax_over_samples)
+    // in front of everything else were 4 000 cycles of the prologue
+    unsigned amx[4], amw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int idx = lane + 64 * k < a.N ? lane + 64 * k : 0; amx[k] = am.x[idx]; amw[k] = am.w[idx]; }
     // ---- staging constants: item i <-> (voxel i / 7 of the row, channel quad i % 7); a thread's items are the same for every row.  Quad 6 is channel 24 and three values of
     // the next voxel, which take the scale 0.  A thread beyond the last item repeats it (the same bytes to the same place): no predicate anywhere in the staging.
     int s_src[NIT], s_dst[NIT];
@@ -212,11 +220,17 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #pragma unroll
             for (int op = 0; op < 3; ++op) dy_load_op(u, op, drs);
         }
-    // H3: both operands are contracted over the voxels of ALL samples, so each takes ONE scale: that of its largest sample (as the general form).  (Worked out HERE, behind
-    // the prologue's requests: the two slot reads are two memory round trips in a row, and in front of the requests they were 4 000 cycles in which nothing was in flight.)
-    const int ex = h3_exp(amax_over_samples(am.x, a.N)), ed = h3_exp(amax_over_samples(am.w, a.N));
+    // H3: both operands are contracted over the voxels of ALL samples, so each takes ONE scale: that of its largest sample (as the general form)
+    unsigned mx = 0u, mw = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (lane + 64 * k < a.N) { mx = amx[k] > mx ? amx[k] : mx; mw = amw[k] > mw ? amw[k] : mw; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned vx = (unsigned)__shfl_xor((int)mx, o, 64), vw = (unsigned)__shfl_xor((int)mw, o, 64); mx = vx > mx ? vx : mx; mw = vw > mw ? vw : mw; }
+    const int ex = h3_exp(mx), ed = h3_exp(mw);
     sx = pow2i(ex); sd = pow2i(ed);
     const int kun = -(ex + ed);
+    // (All of it: what must be zero are the pad entries, the channel quad 28 .. 31 the staging never writes and the KB behind the ring -- 47 KB of the 160 --, but clearing
+    //  just those was measured slower: the index arithmetic of the scattered 8-byte stores costs more than the 3 400 cycles the LDS takes for everything at 48 bytes per cycle.)
     for (int i = tid; i < (FB0 + NKB * 2048) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
     // transposed-read addresses of the lane, per (k-block, half of its eight voxels): voxel 16 kb + 8 h + 4 jj + (li >> 2) at tap (0, 0), channel quad 16 gcol + 4 (li & 3)
     int addrs[NKB][2];
@@ -247,15 +261,18 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     // (tap, input channel) pair gets an offset beyond the slab's descriptor and its store is dropped: so0 for register 4 q, so1 (+ 128 e) for registers 4 q + e
     int so0[NJ][4], so1[NJ][4];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
+        const int Tl = wave + 4 * j, Rj = 32 * Tl + 4 * h;
+        int tau = Rj / RT, ci0 = Rj - tau * RT;                          // (one division per tile: the next quad is eight rows on, at most one tap further)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int Tl = wave + 4 * j, R0 = 32 * Tl + 8 * q + 4 * h;
-            const int tau = R0 / RT, ci0 = R0 - tau * RT;
             const bool ok = Tl < NT && tau < 27;
             so0[j][q] = (ok && ci0 < CIN) ? ((tau * CIN + ci0) * 32 + col) * 4 : (int)0x40000000;
             so1[j][q] = (ok && ci0 + 3 < CIN) ? so0[j][q] : (int)0x40000000;
+            ci0 += 8;
+            if (ci0 >= RT) { ci0 -= RT; ++tau; }
         }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // ring cleared
 #ifdef WG4_STAMP
     const unsigned long long st_p2 = __builtin_amdgcn_s_memtime();
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         A[j][piece].hs[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + piece * PP));
         A[j][piece].hs[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p1 + piece * PP));
     };
-    constexpr int PD = 2;                                                // tiles the operand reads run ahead
+    constexpr int PD = WG4_PD;                                           // tiles the operand reads run ahead
 #pragma unroll
     for (int j = 0; j < PD; ++j) { read_A(0, j, tapoff, 0); read_A(0, j, tapoff, 1); }
 #ifdef WG4_STAMP
