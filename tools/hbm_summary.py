@@ -10,7 +10,7 @@ import glob
 import json
 import sys
 
-CLASS_OF = [("pw_bwd_w4_kernel", "conv1x1x1_bwd_data_x6"), ("pw_bwd_x6_kernel", "conv1x1x1_bwd_data_x6"), ("pw_fwd_w4_kernel", "conv1x1x1_fwd_x6"), ("pw_fwd_x6_kernel", "conv1x1x1_fwd_x6"), ("pw_fwd_h3k_kernel", "conv1x1x1_fwd_x6"), ("conv3_wgrad_x6_kernel", "conv3x3x3_wgrad_x6"), ("conv3_wgrad_w4_kernel", "conv3x3x3_wgrad_x6"),
+CLASS_OF = [("pw_bwd_w4_kernel", "conv1x1x1_bwd_data_x6"), ("pw_bwd_x6_kernel", "conv1x1x1_bwd_data_x6"), ("pw_fwd_w4_kernel", "conv1x1x1_fwd_x6"), ("pw_fwd_x6_kernel", "conv1x1x1_fwd_x6"), ("pw_fwd_h3k_kernel", "conv1x1x1_fwd_x6"), ("conv3_wgrad_w4_kernel", "conv3x3x3_wgrad_x6"), ("conv3_wgrad_x6_kernel", "conv3x3x3_wgrad_x6"),
             ("conv3_w4_kernel<25, 32, 11, false", "conv3x3x3_fwd_x6"), ("conv3_w4_kernel<32, 25, 11, false", "conv3x3x3_bwd_data_x6"),
             ("conv3_pp_kernel<25, false", "conv3x3x3_fwd_x6"), ("conv3_pp_kernel<32, false", "conv3x3x3_bwd_data_x6"),
             ("conv3_pstrip_kernel<25", "conv3x3x3_fwd_x6"), ("conv3_pstrip_kernel<32", "conv3x3x3_bwd_data_x6"), ("conv3_strip_kernel<25", "conv3x3x3_fwd_x6"), ("conv3_strip_kernel<32", "conv3x3x3_bwd_data_x6"),
