@@ -492,13 +492,11 @@ __global__ __launch_bounds__(256, 1) void conv3_w4_kernel(Cw4Args a, const float
                 CW4_SBAR();
                 // ---- operand requests PD k-blocks ahead (the last PD of a tile: the next tile's first) ----
 #ifndef CW4_ABL_NOREAD          // (timing-only ablation of the diagnostic build: the operand registers are never reloaded)
+                // (the filter's second piece FIRST: LDS reads return in order, so the wait for the k-block's A operand covers it -- one s_waitcnt per k-block instead of two)
                 if (j == 0) {
                     const int KN = K + PD, sn = KN % (PD + 1);
-                    if (KN < KB) read_A(bs, KN, A[sn]); else read_A(nbs, KN - KB, A[sn]);
-                }
-                if (j == 1) {
-                    const int KN = K + PD, sn = KN % (PD + 1);
                     read_W1(KN < KB ? KN : KN - KB, W1[sn]);
+                    if (KN < KB) read_A(bs, KN, A[sn]); else read_A(nbs, KN - KB, A[sn]);
                 }
 #endif
                 // ---- the fillers ----
