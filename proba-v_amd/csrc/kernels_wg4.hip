@@ -47,27 +47,27 @@ __host__ __device__ constexpr int wg4_cutK(int u)
     constexpr int nB = MB + 1, kB = NKB - 1 - MB, extra = nB - kB;
     return u > MB ? u - (MB + 1) : (u < 2 * extra ? MB + u / 2 : MB + u - extra);
 }
-// fillers of k-block K: the units it cuts (8 micro-operations each), the units it requests (3 each; three k-blocks ahead of their cut), the staging micro-operations
+// fillers of k-block K: the units it cuts (COPS micro-operations each), the units it requests (LOPS each; LA k-blocks ahead of their cut), the staging micro-operations (k-blocks MB .. SE)
 template <int NKB, int MB>
 __host__ __device__ constexpr int wg4_ncut(int K) { int c = 0; for (int u = 0; u < NKB; ++u) c += wg4_cutK<NKB, MB>(u) == K ? 1 : 0; return c; }
-template <int NKB, int MB>
-__host__ __device__ constexpr int wg4_nld(int K) { int c = 0; for (int u = 0; u < NKB; ++u) c += (wg4_cutK<NKB, MB>(u) + NKB - 3) % NKB == K ? 1 : 0; return c; }
+template <int NKB, int MB, int LA>
+__host__ __device__ constexpr int wg4_nld(int K) { int c = 0; for (int u = 0; u < NKB; ++u) c += (wg4_cutK<NKB, MB>(u) + NKB - LA) % NKB == K ? 1 : 0; return c; }
 // first filler of filler gap gi (0 .. 2 NJ - 1) when NF fillers are dealt over a k-block: NF / 2 NJ per gap, the remainder one each to the FIRST gaps (a k-block's stores come early)
 __host__ __device__ constexpr int wg4_deal(int gi, int NF, int NG) { return gi * (NF / NG) + (gi < NF % NG ? gi : NF % NG); }
 // LDS operations a wave issues in k-block K BEHIND its last LDS store of that k-block (mirrors the dealing in the kernel: per tile j the gaps m = 0, 1 carry two transposed
 // reads each, gap (1, 2) the two fragment reads of the next k-block, the fillers [wg4_deal(gi), wg4_deal(gi + 1)) sit behind the reads of gap gi = 2 j + m - 1): what
 // s_waitcnt lgkmcnt(...) in front of the barrier that follows the k-block may leave outstanding
-template <int NKB, int MB, int NJ, int STG, int ROW_MOPS>
+template <int NKB, int MB, int NJ, int STG, int ROW_MOPS, int LA, int LOPS, int COPS, int SE>
 __host__ __device__ constexpr int wg4_lds_behind_last_store(int K)
 {
-    const int ncut = wg4_ncut<NKB, MB>(K), nld = wg4_nld<NKB, MB>(K);
-    const int nstg = (K >= MB && K <= NKB - 3) ? STG : 0;
-    const int NF = 8 * ncut + 3 * nld + nstg;
+    const int ncut = wg4_ncut<NKB, MB>(K), nld = wg4_nld<NKB, MB, LA>(K);
+    const int nstg = (K >= MB && K <= SE) ? STG : 0;
+    const int NF = COPS * ncut + LOPS * nld + nstg;
     int last = -1;
     for (int f = 0; f < NF; ++f) {
         bool st = false;
-        if (f < 8 * ncut) st = (f % 8 == 5) || (f % 8 == 7);
-        else if (f >= 8 * ncut + 3 * nld) { const int ms = (K - MB) * STG + f - 8 * ncut - 3 * nld; st = ms < ROW_MOPS && ms % 12 >= 10; }
+        if (f < COPS * ncut) st = (f % COPS == COPS - 3) || (f % COPS == COPS - 1);
+        else if (f >= COPS * ncut + LOPS * nld) { const int ms = (K - MB) * STG + f - COPS * ncut - LOPS * nld; st = ms < ROW_MOPS && ms % 12 >= 10; }
         if (st) last = f;
     }
     if (last < 0) return 15;
@@ -93,19 +93,27 @@ __host__ __device__ constexpr int wg4_lds_behind_last_store(int K)
 #define WG4_SBAR() __builtin_amdgcn_sched_barrier(0)
 #define WG4_PIN(v) asm volatile("" : "+v"(v))
 
-template <int TP, int RT>       // depth + 2; GEMM rows per tap (32: a tile is a tap; 28: the taps' 25 + 3 rows packed, 24 tiles -- every tile straddles taps)
-__global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-                                                               float* __restrict__ partial_b, Amax am)
+// TP: entries per column of a ring row = output depth + 2; RT: GEMM rows per tap (32: a tile is a tap; 28: the taps' 25 + 3 rows packed, 24 tiles -- every tile straddles taps);
+// CIN: input channels (25: normConv; 32: the reducers); REFL: the reducers' layer -- the input is tf.pad(REFLECT) in rows and columns and NOT padded in depth (input depth TP,
+// output depth TP - 2: a ring row holds all TP depths of all W + 2 columns, the pad columns as data), and dY is masked by the layer's own output (`gate` > 0: its ReLU)
+template <int TP, int RT, int CIN, bool REFL>
+__global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gate,
+                                                               float* __restrict__ partial, float* __restrict__ partial_b, Amax am)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int CIN = 25, W = 22, T = TP - 2, WP = W + 2, NV = W * T, NKB = (NV + 15) / 16;
+    static_assert((CIN == 25 && !REFL) || CIN == 32, "25 channels: the zero-padded 'same' layer only");
+    constexpr int W = 22, T = TP - 2, WP = W + 2, NV = W * T, NKB = (NV + 15) / 16;
+    constexpr int TD = REFL ? TP : T;                                    // depth of the input tensor
     constexpr int PP = WP * TP * 64, ROWB = 2 * PP;                      // bytes of one piece plane / of one ring row (slot)
-    constexpr int NQI = NV * 7, NIT = (NQI + 255) / 256;                 // staging items (voxel, channel quad) of a row; per thread
+    constexpr int NQV = REFL ? WP * TP : NV, QPV = CIN == 25 ? 7 : 8;    // voxels a row stages (REFL: the pad columns too); channel quads per voxel
+    constexpr int NQI = NQV * QPV, NIT = (NQI + 255) / 256;             // staging items (voxel, channel quad) of a row; per thread
     constexpr int NT = (27 * RT + 31) / 32, NJ = (NT + 3) / 4;          // M tiles; per wave (tile w + 4 j)
     constexpr int RS = 5;                                                // register sets of the dY fragments: set = k-block % RS
     static_assert((NKB - 1) % RS != 0, "dY fragment sets: a row's last k-block and the next row's first must not share a set");
     constexpr int FB0 = 4 * ROWB + 1024;                                 // the row's dY fragments: [k-block][piece][lane] x 16 bytes, behind the ring (and 1 KB that a tail k-block's reads may run into)
     constexpr int MB = NKB / 2;                                          // the row's second barrier stands in front of k-block MB
+    constexpr int LA = MB < 3 ? MB : 3;                                  // k-blocks a unit's requests run ahead of its cut
+    constexpr int LOPS = REFL ? 5 : 3, COPS = REFL ? 10 : 8;             // micro-operations of a unit's requests / of its cut (REFL: + the gate values, + two selects)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31, li = lane & 15, gcol = (lane >> 4) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
@@ -130,20 +138,34 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     for (int k = 0; k < NIT; ++k) {
         const int i = tid + 256 * k;
         const int ic = i < NQI ? i : NQI - 1;
-        const int vox = ic / 7, quad = ic - 7 * vox;
-        const int w = vox / T, t = vox - w * T;
-        s_src[k] = (vox * CIN + 4 * quad) * 4;
-        s_dst[k] = ((w + 1) * TP + t + 1) * 64 + quad * 8;
-        s_scz[k] = quad == 6 ? 0.f : 1.f;
+        const int vox = ic / QPV, quad = ic - QPV * vox;
+        if constexpr (REFL) {                                             // ring column cw <-> input column cw - 1, mirrored at both ends (tf.pad REFLECT); all TP depths
+            const int cw = vox / TP, t = vox - cw * TP;
+            const int sw = cw == 0 ? 1 : cw == WP - 1 ? W - 2 : cw - 1;
+            s_src[k] = ((sw * TP + t) * CIN + 4 * quad) * 4;
+            s_dst[k] = (cw * TP + t) * 64 + quad * 8;
+            s_scz[k] = 1.f;
+        } else {
+            const int w = vox / T, t = vox - w * T;
+            s_src[k] = (vox * CIN + 4 * quad) * 4;
+            s_dst[k] = ((w + 1) * TP + t + 1) * 64 + quad * 8;
+            s_scz[k] = (CIN == 25 && quad == 6) ? 0.f : 1.f;
+        }
     }
-    const long xsample = (long)a.H * W * T * CIN;
+    const long xsample = (long)a.H * W * TD * CIN;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * xsample), 0, (unsigned)xsample * 4u, 0x00020000);
-    constexpr int xrowb = W * T * CIN * 4;
-    auto row_of = [&](int key, int& rowoff, float& rokf) {               // ring key k <-> input row hb - 1 + k (clamped); 1.0 / 0.0 = inside / outside the patch
-        const int ih = hb - 1 + key;
-        const bool rok = ih >= 0 && ih < a.H;
-        rowoff = (rok ? ih : 0) * xrowb;
-        rokf = rok ? 1.f : 0.f;
+    constexpr int xrowb = W * TD * CIN * 4;
+    auto row_of = [&](int key, int& rowoff, float& rokf) {               // ring key k <-> input row hb - 1 + k: clamped, 1.0 / 0.0 = inside / outside the patch -- REFL: mirrored
+        int ih = hb - 1 + key;
+        if constexpr (REFL) {
+            ih = ih < 0 ? -ih : ih >= a.H ? 2 * a.H - 2 - ih : ih;
+            ih = ih < 0 ? 0 : ih >= a.H ? a.H - 1 : ih;                    // (rows a strip's last tiles stage for nobody)
+            rowoff = ih * xrowb; rokf = 1.f;
+        } else {
+            const bool rok = ih >= 0 && ih < a.H;
+            rowoff = (rok ? ih : 0) * xrowb;
+            rokf = rok ? 1.f : 0.f;
+        }
     };
     u32x4b sv[NIT];                                                      // the row the current tile cuts (requested a tile earlier)
     auto stage_load = [&](int rowoff, u32x4b (&q)[NIT]) {
@@ -190,21 +212,32 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     const int lp = 16 * wave + li, pp = lane >> 4;                       // fragment lane (channel lp & 31, voxels 8 (lp >> 5) ..), pair of its eight voxels
     const int dvo = (8 * (lp >> 5) + 2 * pp) * 128 + (lp & 31) * 4;
     const int fbw = FB0 + lp * 16 + pp * 4, fbr = FB0 + lane * 16;
+    auto gt_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((REFL ? gate : dy) + dyrow0 + (long)i * NV * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
     float raw[NKB][2];                                                   // requested values of the units in flight (indexed by unit: compile-time everywhere)
-    __amdgpu_buffer_rsrc_t drs = dy_rsrc(0), drsN = dy_rsrc(1);
+    float rawg[REFL ? NKB : 1][2];                                       // REFL: the layer's output at the same voxels (its ReLU mask)
+    __amdgpu_buffer_rsrc_t drs = dy_rsrc(0), drsN = dy_rsrc(1), grs = gt_rsrc(0), grsN = gt_rsrc(1);
     // Schedule (compile-time): unit u of a row is CUT in k-block cutK(u) -- units MB + 1 .. of the row itself in its k-blocks 0 .. (they are read from k-block MB on, behind
     // the second barrier), units 0 .. MB of the NEXT row in k-blocks MB .. NKB - 2 (their slots are free behind the second barrier; they are read from k-block NKB - 1 on,
-    // behind the row barrier) -- and REQUESTED three k-blocks earlier.
+    // behind the row barrier) -- and REQUESTED LA k-blocks earlier.
     auto cutK = [](int u) -> int { return wg4_cutK<NKB, MB>(u); };
     int vo_t = 0;
     unsigned cq0 = 0u, cq1 = 0u;
     float bsum[2] = {0.f, 0.f};
-    auto dy_load_op = [&](int u, int op, const __amdgpu_buffer_rsrc_t& rs) {
+    auto dy_load_op = [&](int u, int op, const __amdgpu_buffer_rsrc_t& rs, const __amdgpu_buffer_rsrc_t& gs) {
         if (op == 0) { vo_t = dvo + u * 2048; WG4_PIN(vo_t); }
         if (op == 1) raw[u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo_t, 0, 0));
         if (op == 2) raw[u][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo_t + 128, 0, 0));
+        if constexpr (REFL) {
+            if (op == 3) rawg[u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gs, vo_t, 0, 0));
+            if (op == 4) rawg[u][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gs, vo_t + 128, 0, 0));
+        }
     };
     auto dy_cut_op = [&](int u, int op) {                                 // (order: no register's halves by consecutive instructions, see stage_mop)
+        if constexpr (REFL) {                                             // the ReLU mask first: dY where the layer's output is positive
+            if (op == 0) { raw[u][0] = rawg[u][0] > 0.f ? raw[u][0] : 0.f; WG4_PIN(raw[u][0]); }
+            if (op == 1) { raw[u][1] = rawg[u][1] > 0.f ? raw[u][1] : 0.f; WG4_PIN(raw[u][1]); }
+            op -= 2;
+        }
         if (op == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(cq0) : "v"(raw[u][0]), "v"(sd));
         if (op == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(raw[u][0]));
         if (op == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(cq0) : "v"(raw[u][1]), "v"(sd));
@@ -216,9 +249,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     };
 #pragma unroll
     for (int u = 0; u < NKB; ++u)
-        if (u <= MB || cutK(u) < 3) {                                     // the first row's units 0 .. MB are cut here, and the units its first three k-blocks cut are requested
+        if (u <= MB || cutK(u) < LA) {                                    // the first row's units 0 .. MB are cut here, and the units its first LA k-blocks cut are requested
 #pragma unroll
-            for (int op = 0; op < 3; ++op) dy_load_op(u, op, drs);
+            for (int op = 0; op < LOPS; ++op) dy_load_op(u, op, drs, grs);
         }
     // H3: both operands are contracted over the voxels of ALL samples, so each takes ONE scale: that of its largest sample (as the general form)
     unsigned mx = 0u, mw = 0u;
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #pragma unroll
     for (int u = 0; u <= MB; ++u)
 #pragma unroll
-        for (int op = 0; op < 8; ++op) dy_cut_op(u, op);
+        for (int op = 0; op < COPS; ++op) dy_cut_op(u, op);
 
 #ifdef WG4_STAMP
     const unsigned long long st_p3 = __builtin_amdgcn_s_memtime();
@@ -338,10 +371,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     //   in front of k-block MB -- behind it the slots of units 0 .. MB are free (their fragments have been read) and the ring slot of input row i - 1 is (every wave has
     //   finished output row i - 1); in front of it the row's own units MB + 1 .. were stored;
     //   in front of k-block NKB - 1 -- behind it the next row's unit 0 and its first operands are read; in front of it the staged input row and the next row's units 0 .. MB were stored.
-    constexpr int NSK = NKB - 2 - MB;                                    // k-blocks MB .. NKB - 3 carry the staging
+    constexpr int SE = NKB >= 8 ? NKB - 3 : NKB - 2;                     // k-blocks MB .. SE carry the staging (short rows: up to the row barrier's k-block)
+    constexpr int NSK = SE - MB + 1;
     constexpr int STG = (ROW_MOPS + NSK - 1) / NSK;
-    constexpr int WAIT_MB = wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS>(MB - 1), WAIT_RB = wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS>(NKB - 2);
-    static_assert(wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS>(NKB - 1) == 15 && wg4_ncut<NKB, MB>(NKB - 1) == 0, "no LDS store in a row's last k-block");
+    constexpr int WAIT_MB = wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS, LA, LOPS, COPS, SE>(MB - 1), WAIT_RB = wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS, LA, LOPS, COPS, SE>(NKB - 2);
+    static_assert(wg4_lds_behind_last_store<NKB, MB, NJ, STG, ROW_MOPS, LA, LOPS, COPS, SE>(NKB - 1) == 15 && wg4_ncut<NKB, MB>(NKB - 1) == 0, "no LDS store in a row's last k-block");
 #pragma unroll 1
     for (int i = 0; i < SRr; ++i) {
         set_taps(i + 1, tapoffN);
@@ -356,17 +390,17 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #pragma unroll
         for (int K = 0; K < NKB; ++K) {
             // the k-block's filler list
-            const int ncut = wg4_ncut<NKB, MB>(K), nld = wg4_nld<NKB, MB>(K);
-            const int nstg = (K >= MB && K <= NKB - 3) ? STG : 0;
-            const int NF = 8 * ncut + 3 * nld + nstg;
+            const int ncut = wg4_ncut<NKB, MB>(K), nld = wg4_nld<NKB, MB, LA>(K);
+            const int nstg = (K >= MB && K <= SE) ? STG : 0;
+            const int NF = COPS * ncut + LOPS * nld + nstg;
             auto filler = [&](int f) {
 #pragma unroll
-                for (int u = 0; u < NKB; ++u) if (cutK(u) == K) { if (f >= 0 && f < 8) dy_cut_op(u, f); f -= 8; }
+                for (int u = 0; u < NKB; ++u) if (cutK(u) == K) { if (f >= 0 && f < COPS) dy_cut_op(u, f); f -= COPS; }
 #pragma unroll
-                for (int u = 0; u < NKB; ++u) if ((cutK(u) + NKB - 3) % NKB == K) {
-                    // (a unit of the next row, or one of this row's successor that its first three k-blocks cut: the next row's descriptor)
-                    if (f >= 0 && f < 3) dy_load_op(u, f, (u <= MB || cutK(u) < 3) ? drsN : drs);
-                    f -= 3;
+                for (int u = 0; u < NKB; ++u) if ((cutK(u) + NKB - LA) % NKB == K) {
+                    // (a unit of the next row, or one of this row's successor that its first LA k-blocks cut: the next row's descriptor)
+                    if (f >= 0 && f < LOPS) { if (u <= MB || cutK(u) < LA) dy_load_op(u, f, drsN, grsN); else dy_load_op(u, f, drs, grs); }
+                    f -= LOPS;
                 }
                 if (f >= 0 && f < nstg) { const int ms = (K - MB) * STG + f; if (ms < ROW_MOPS) stage_mop(ms, slotoff, sxr, sv, cut, true, rel); }
             };
@@ -410,8 +444,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) tapoff[j] = tapoffN[j];
-        drs = drsN;
-        drsN = dy_rsrc(i + 2);
+        drs = drsN; grs = grsN;
+        drsN = dy_rsrc(i + 2); grsN = gt_rsrc(i + 2);
     }
 
 #ifdef WG4_STAMP
@@ -451,13 +485,15 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #ifndef WG4_RT
 #define WG4_RT 28                // (32: 27 tap tiles, conflict-free reads, 12.5 % more MFMAs -- measured 9 % slower)
 #endif
-static bool wg4_plan(const ConvGeom& g, Wg4Args& p, int& grid)
+static bool wg4_plan(const ConvGeom& g, const float* gate, Wg4Args& p, int& grid)
 {
-    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_hw || g.reflect_t) return false;
-    if (g.Cin != 25 || g.Cout != 32) return false;
-    if (g.ph != 1 || g.pw != 1 || g.pt != 1) return false;               // 'same' padding (normConv)
-    if (g.Ho != g.Hi || g.Wo != g.Wi || g.To != g.Ti) return false;
-    if (g.Wo != 22 || (g.To != 9 && g.To != 7)) return false;            // the instantiated row shapes
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_t || g.Cout != 32 || g.Wo != 22 || g.Wi != 22 || g.Ho != g.Hi) return false;
+    if (g.ph != 1 || g.pw != 1) return false;
+    if (g.Cin == 25) {                                                   // normConv: 'same' padding with zeros, no gate
+        if (g.reflect_hw || g.pt != 1 || g.To != g.Ti || gate || (g.To != 9 && g.To != 7)) return false;
+    } else if (g.Cin == 32) {                                            // the reducers: tf.pad(REFLECT) in rows / columns, no depth pads, dY masked by the layer's output
+        if (!g.reflect_hw || g.pt != 0 || g.To != g.Ti - 2 || !gate || g.Hi < 2 || (g.To != 7 && g.To != 5 && g.To != 3)) return false;
+    } else return false;
     if (g.N < 1 || g.N > 256 || g.Ho < 1) return false;                  // one slab per workgroup, at most 256 of them (x6_wgrad_partial_floats)
     int nstrips = 256 / g.N;
     if (nstrips > g.Ho) nstrips = g.Ho;
@@ -482,25 +518,30 @@ bool wg4_wgrad_supported(const ConvGeom& g, const float* gate)
 {
     Wg4Args p;
     int grid;
-    return gate == nullptr && wg4_plan(g, p, grid);
+    return wg4_plan(g, gate, p, grid);
 }
 
-int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, const Amax& am, hipStream_t s)
+int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial, const Amax& am, hipStream_t s)
 {
     Wg4Args p;
     int grid;
-    if (!wg4_plan(g, p, grid)) { set_error("wg4_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
+    if (!wg4_plan(g, gate, p, grid)) { set_error("wg4_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     if (!am.x || !am.w) { set_error("wg4_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
     static std::once_flag once;
     std::call_once(once, [] {
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<11, WG4_RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<9, WG4_RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); });
+#define WG4_BIG(TP, RT, C, R) note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<TP, RT, C, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840))
+        WG4_BIG(11, WG4_RT, 25, false); WG4_BIG(9, WG4_RT, 25, false); WG4_BIG(9, 32, 32, true); WG4_BIG(7, 32, 32, true); WG4_BIG(5, 32, 32, true); });
+#undef WG4_BIG
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
     const int Tp = g.To + 2;
     const size_t lds_bytes = (size_t)4 * 2 * 24 * Tp * 64 + 1024 + (size_t)((22 * g.To + 15) / 16) * 2048;      // ring, slack, the row's dY fragments
-    if (g.To == 9) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<11, WG4_RT>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, partial, partial_b, am);
-    else hipLaunchKernelGGL((conv3_wgrad_w4_kernel<9, WG4_RT>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, partial, partial_b, am);
+#define WG4_LAUNCH(TP, RT, C, R) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<TP, RT, C, R>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, gate, partial, partial_b, am)
+    if (g.Cin == 25) { if (g.To == 9) WG4_LAUNCH(11, WG4_RT, 25, false); else WG4_LAUNCH(9, WG4_RT, 25, false); }
+    else if (g.To == 7) WG4_LAUNCH(9, 32, 32, true);
+    else if (g.To == 5) WG4_LAUNCH(7, 32, 32, true);
+    else WG4_LAUNCH(5, 32, 32, true);
+#undef WG4_LAUNCH
     int rc = check_launch("conv3_wgrad_w4");
     if (rc) return rc;
     return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);

@@ -53,13 +53,14 @@ size_t x6_wgrad_partial_floats(const ConvGeom& g);
 int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial,
                   int arith, const Amax& am, hipStream_t s);
 
-// the residual blocks' backward-filter (25 -> 32 channels, 'same' padding, rows of 22 columns, depth 9 or 7, at most 256 samples) as ONE-WAVE-PER-SIMD kernel
+// the backward-filter of the residual blocks (25 -> 32 channels, 'same' padding, depth 9 or 7) and of the reducers (32 -> 32, tf.pad(REFLECT) rows / columns, no depth pads,
+// output depth 7 / 5 / 3, dY masked by `gate` = the layer's output) on rows of 22 columns and at most 256 samples as ONE-WAVE-PER-SIMD kernel
 // (kernels_wg4.hip; H3 arithmetic only): a conflict-free piece image of the input ring, dY straight from memory, one instruction stream per output row.
 // x6_conv_wgrad dispatches to it when wg4_wgrad_supported(); wg4_set_enabled(0) (or PROBAV_GEN1=1 / wg in the environment) keeps conv3_wgrad_x6_kernel.
 // partial: x6_wgrad_partial_floats(g) floats, as for the general form
 bool wg4_wgrad_supported(const ConvGeom& g, const float* gate);
 bool wg4_enabled();
 void wg4_set_enabled(int on);
-int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* partial, const Amax& am, hipStream_t s);
+int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* gate, float* dw, float* db, float* partial, const Amax& am, hipStream_t s);
 
 }  // namespace probav

@@ -1422,7 +1422,7 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
     // round 5: the residual blocks' layer as one-wave-per-SIMD kernel (kernels_wg4.hip); this kernel is the general form (any extent, pads, reflect, gate, 32 channels)
-    if (arith == 2 && wg4_enabled() && wg4_wgrad_supported(g, gate)) return wg4_conv_wgrad(g, x, dy, dw, db, partial, am, s);
+    if (arith == 2 && wg4_enabled() && wg4_wgrad_supported(g, gate)) return wg4_conv_wgrad(g, x, dy, gate, dw, db, partial, am, s);
     if (arith == 2 && x6_wgrad_split(g, 2) == 0) arith = 1;                  // (the H3 form also needs room for the dY image; the scale-free form serves the rest)
     WgArgs a;
     a.nsplit = x6_wgrad_split(g, arith); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;

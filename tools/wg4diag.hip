@@ -28,7 +28,7 @@ int main(int argc, char** argv)
     Amax am; am.x = am_; am.w = am_ + 2048; am.y = nullptr;
     hipEvent_t ea, eb; hipEventCreate(&ea); hipEventCreate(&eb);
     ConvGeom g{B, 22, 22, 9, 25, 22, 22, 9, 32, 3, 3, 3, 1, 1, 1, 0, 0, 0};
-    auto run = [&] { return diag::wg4_conv_wgrad(g, x, d, dw, db, part, am, 0); };
+    auto run = [&] { return diag::wg4_conv_wgrad(g, x, d, nullptr, dw, db, part, am, 0); };
     {   // agreement with the general form (the library's kernel) on this input
         std::vector<float> wa(nw), wb(nw);
         wg4_set_enabled(0);
