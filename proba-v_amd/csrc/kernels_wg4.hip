@@ -1,23 +1,26 @@
-// Backward-filter of the residual blocks' 3x3x3 convolution (normConv: 25 -> 32 channels), H3 arithmetic -- ONE WAVE PER SIMD (round 5).
-// Reference semantics: tape.gradient (models/trainClass.py:131) through models/modelsTF.py:185-186 (normConv_i of ResConv3D):
+// Backward-filter of the 3x3x3 convolutions of the residual blocks (normConv: 25 -> 32 channels) and of the reducers (32 -> 32), H3 arithmetic -- ONE WAVE PER SIMD (round 5).
+// Reference semantics: tape.gradient (models/trainClass.py:131) through models/modelsTF.py:185-186 (normConv_i of ResConv3D) and :123-150 (convReducer_i behind tf.pad REFLECT):
 //   dW[tap][ci][co] = sum over the voxels v of all samples of X[v + tap][ci] dY[v][co],   db[co] = sum_v dY[v][co].
 //
-// What conv3_wgrad_x6_kernel (kernels_x6.hip: the general form -- any extent, pads, reflect, gate, 32 input channels) measured in the step: 108 us per launch, matrix pipe 37 %
+// What conv3_wgrad_x6_kernel (kernels_x6.hip: the general form -- any extent, pads, depth 13, batches above 256) measured in the step: 108 us per launch, matrix pipe 37 %
 // busy, 47 % of its LDS cycles bank conflicts, two waves per SIMD that each wait for the four transposed reads of the NEXT tap tile only.  The contraction has no operand
 // reuse to speak of (N = 32 output channels is all there is: every (tap, channel, voxel) element of the A operand feeds ONE MFMA triple), so the A operand's LDS
 // reads are the kernel, and their latency and their conflicts were what it waited for.  This kernel keeps the arithmetic (the products and their order per k-block:
 // x1 d0 + x0 d1 + x0 d0; one scale per operand tensor) and changes the shape:
-//   * ONE WAVE PER SIMD, ONE INSTRUCTION STREAM per output row: 27 tap tiles (32 rows each: the 25 channels of one tap, padded) dealt 7 / 7 / 7 / 6 to the four waves,
-//     every wave takes ALL k-blocks of its tiles (no parity exchange at the end); a row = NKB k-blocks x 7 tiles x 3 MFMAs, fully unrolled, the transposed reads two tiles ahead
-//     in a seven-deep register ring.
-//   * A CONFLICT-FREE IMAGE: the input ring is [slot][piece][column][depth + 2][32 channels] fp16 -- 64 bytes per voxel and piece, so the four voxel rows x eight channel
-//     quads of a 32-lane half of a transposed read are 256 consecutive bytes (all 64 banks once) unless the four voxels straddle a depth wrap.  (The general form packs
-//     28 rows per tap into 24 tiles and interleaves the pieces at 112 bytes per voxel: 12.5 % fewer MFMAs, every read two-way conflicted -- tools/lds_conflict_model.py.)
-//   * dY IS NOT STAGED: the B operand of a k-block is eight 4-byte loads per lane straight from memory (through a buffer descriptor of the row: the voxels behind the row's end
-//     read as zero), requested three k-blocks ahead and cut into pieces in the MFMA gaps of the k-block before its own; the bias gradient is summed from the same registers.
-//   * FOUR RING SLOTS, ONE BARRIER PER ROW: while row r reads input rows r - 1 .. r + 1, row r + 2 is cut and stored into the fourth slot (its values were requested a whole
-//     row earlier, into the registers the previous cut had just read); the barrier sits behind the second tile of a row's first k-block, whose reads are dh = 0 taps.
-// Workgroup = (sample, strip of rows); one slab per workgroup, summed by mfma_wgrad_reduce (fp64, fixed order) like the general form's.
+//   * ONE WAVE PER SIMD, ONE INSTRUCTION STREAM per output row: the M tiles (25 channels: the taps' 25 + 3 rows packed into 24 tiles, six per wave; 32 channels: 27 tap tiles
+//     dealt 7 / 7 / 7 / 6) stay with their wave for ALL k-blocks (no parity exchange at the end); a row = NKB k-blocks x 6 | 7 tiles x 3 MFMAs, fully unrolled, the transposed reads
+//     two tiles ahead in a register ring; the accumulators live in a[...] and are read once, at the kernel's end.
+//   * 64-BYTE PIECE PLANES: the input ring is [slot][piece][column][depth + 2][32 channels] fp16 -- the four voxel rows x eight channel quads of a 32-lane half of a transposed
+//     read are 256 consecutive bytes (all 64 banks once) unless they straddle a tap (the packed 25-channel tiles always do: two-way conflicts, and still 9 % faster than 27
+//     conflict-free tiles with 14 % more MFMAs: -DWG4_RT=32) or a depth wrap.  (The general form interleaves the pieces at 112 bytes per voxel: every read two-way conflicted.)
+//   * dY IS CUT ONCE PER WORKGROUP: a k-block's two B fragments are a UNIT, a quarter per wave (two 4-byte requests through the row's buffer descriptor -- voxels behind the row's
+//     end read as zero --, four mixed fmas, two bias additions, two 4-byte LDS stores per lane), requested LA k-blocks ahead of its cut by a compile-time schedule; every wave reads a
+//     k-block's fragments with two ds_read_b128.  (Cut by every wave for itself it was a third of all instructions between the MFMAs.)
+//   * FOUR RING SLOTS, TWO BARRIERS PER ROW: while row r reads input rows r - 1 .. r + 1, row r + 2 is cut and stored into the fourth slot (its values were requested a whole
+//     row earlier, into the registers the previous cut had just read); one fragment buffer serves the row being read and the row being cut.  A wave arrives at a barrier with
+//     s_waitcnt lgkmcnt(n), n = the LDS operations it has issued behind its last store (compile time): the reads in flight stay in flight.
+// Workgroup = (sample, strip of rows); one slab per workgroup, summed by mfma_wgrad_reduce (fp64, fixed order) like the general form's.  Instances: normConv (25 -> 32 channels,
+// 'same' zero padding, depth 9 | 7) and the reducers (32 -> 32, tf.pad(REFLECT) rows / columns, no depth pads, output depth 7 | 5 | 3, dY masked by the layer's output).
 #include "kernels_x6.h"
 #include "x6_device.h"
 #include <cstdlib>
