@@ -2686,23 +2686,6 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_mfma_kernel(TileArgs a, in
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int slabs)
-{
-    // 64 elements x 4 interleaved partial sums per block (fixed order => bitwise reproducible), fp64 accumulation
-    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
-    __shared__ double red[4][64];
-    double a0 = 0.0, a1 = 0.0;
-    if (i < n) {
-        int c = part;
-        for (; c + 4 < slabs; c += 8) { a0 += (double)partial[(long)c * n + i]; a1 += (double)partial[(long)(c + 4) * n + i]; }
-        if (c < slabs) a0 += (double)partial[(long)c * n + i];
-    }
-    red[part][threadIdx.x & 63] = a0 + a1;
-    __syncthreads();
-    if (part == 0 && i < n) out[i] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
 static int wgrad_grid(const ConvPlan& p, const ConvGeom& g)
 {
     const int total = g.N * p.a.ntile_rows;
@@ -2747,63 +2730,11 @@ int mfma_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const fl
     return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);
 }
 
-// dw and db in ONE launch.  Filter blocks: 16 float4 columns x 16 interleaved slab groups (each thread: slabs/16 independent
-// 16-byte loads); the last block reduces the bias slabs (32 scalar columns x 8 groups; db need not be 16-byte aligned).  fp64
-// accumulation, fixed order => bitwise reproducible.
-__global__ __launch_bounds__(256) void reduce_slabs4_kernel(const float4* __restrict__ pw, float4* __restrict__ ow, long nw4, int nbw,
-                                                           const float* __restrict__ pb, float* __restrict__ ob, int nb, int slabs)
-{
-    __shared__ double red[16][16][4];
-    if ((int)blockIdx.x >= nbw) {
-        const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
-        double a = 0.0;
-        if (e < nb)
-            for (int c = part; c < slabs; c += 8) a += (double)pb[(long)c * nb + e];
-        double* r = &red[0][0][0];
-        r[part * 32 + e] = a;
-        __syncthreads();
-        if (part != 0 || e >= nb) return;
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += r[k * 32 + e];
-        ob[e] = (float)t;
-        return;
-    }
-    const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + e;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (i < nw4) {
-#pragma unroll 4
-        for (int c = part; c < slabs; c += 16) {
-            const float4 v = pw[(long)c * nw4 + i];
-            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
-        }
-    }
-    red[part][e][0] = a0; red[part][e][1] = a1; red[part][e][2] = a2; red[part][e][3] = a3;
-    __syncthreads();
-    if (part != 0 || i >= nw4) return;
-    double t[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] += red[k][e][q];
-    ow[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
-}
-
 int mfma_wgrad_reduce(const float* partial, const float* partial_b, float* dw, float* db, long nw, int Cout, int slabs, hipStream_t s0)
 {
-    return reduce_later(s0, [=](hipStream_t s) -> int {                       // (the engine's side stream during a backward pass, at its next flush)
-    const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0;
-    if ((nw & 3) == 0 && Cout <= 32 && al) {
-        const int nbw = (int)((nw / 4 + 15) / 16);
-        hipLaunchKernelGGL(reduce_slabs4_kernel, dim3((unsigned)(nbw + (db ? 1 : 0))), dim3(256), 0, s, (const float4*)partial, (float4*)dw, nw / 4, nbw,
-                           partial_b, db, Cout, slabs);
-        return check_launch("reduce_slabs4");
-    }
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, partial, dw, nw, slabs);
-    if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, partial_b, db, (long)Cout, slabs);
-    return check_launch("reduce_slabs");
-    });
+    // (the engine's side stream during a backward pass, at its next flush -- batched with the other slab sums of that flush: probav_common.h, slab_sum_later)
+    SlabSumJob jobs[2] = {{partial, dw, nw, (int)nw, slabs}, {partial_b, db, (long)Cout, Cout, slabs}};
+    return slab_sum_later(s0, jobs, db ? 2 : 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3076,43 +3007,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd2_mfma_kernel(
     }
 }
 
-// fixed-order fp64 sum of the workgroup slabs, scattered to the four gradient tensors
-__global__ __launch_bounds__(256) void pw_bwd2_reduce_kernel(const float* __restrict__ slabs, int nslabs, int D,
-                                                            float* __restrict__ dW1, float* __restrict__ dW2,
-                                                            float* __restrict__ db1, float* __restrict__ db2)
-{
-    const long slab_floats = 8192 + 256 * (long)D + 256 + D;
-    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + e;
-    __shared__ double red[8][32];
-    double a0 = 0.0, a1 = 0.0;
-    if (i < slab_floats) {
-        int k = part;
-        for (; k + 8 < nslabs; k += 16) { a0 += (double)slabs[(long)k * slab_floats + i]; a1 += (double)slabs[(long)(k + 8) * slab_floats + i]; }
-        if (k < nslabs) a0 += (double)slabs[(long)k * slab_floats + i];
-    }
-    red[part][e] = a0 + a1;
-    __syncthreads();
-    if (part != 0 || i >= slab_floats) return;
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][e];
-    const float v = (float)t;
-    if (i < 8192) dW1[i] = v;
-    else if (i < 8192 + 256 * (long)D) dW2[i - 8192] = v;
-    else if (i < 8192 + 256 * (long)D + 256) db1[i - 8192 - 256 * (long)D] = v;
-    else db2[i - 8192 - 256 * (long)D - 256] = v;
-}
-
 static const int PW_BWD_GRID = 256;
 
 int mfma_pw_backward_reduce(const float* slabs, int D, float* dW1, float* dW2, float* db1, float* db2, hipStream_t s)
 {
     const long slab_floats = 8192 + 256 * (long)D + 256 + D;
-    return reduce_later(s, [=](hipStream_t rs) -> int {
-        hipLaunchKernelGGL(pw_bwd2_reduce_kernel, dim3((unsigned)((slab_floats + 31) / 32)), dim3(256), 0, rs, slabs, PW_BWD_GRID, D, dW1, dW2, db1, db2);
-        return check_launch("pw_bwd2_reduce");
-    });
+    SlabSumJob jobs[4] = {{slabs, dW1, slab_floats, 8192, PW_BWD_GRID}, {slabs + 8192, dW2, slab_floats, 256 * D, PW_BWD_GRID},
+                          {slabs + 8192 + 256 * (long)D, db1, slab_floats, 256, PW_BWD_GRID}, {slabs + 8192 + 256 * (long)D + 256, db2, slab_floats, D, PW_BWD_GRID}};
+    return slab_sum_later(s, jobs, 4);
 }
 int mfma_pw_backward_grid() { return PW_BWD_GRID; }
 

@@ -925,7 +925,7 @@ int x6_pw_backward(const float* x, const float* dT, const float* dOut, const flo
 // (8 coalesced loads per lane and k-block), cut into pieces once per k-block and reused by the wave's 7 taps.
 // 8 waves: wave w owns taps (w & 3) + 4j (accumulators: 7 x 16 registers) and the k-blocks of parity w >> 2; the two
 // parities are added in a fixed order at the end.  Workgroups walk contiguous (patch, row) runs, so consecutive rows
-// re-stage one row.  One slab per workgroup, summed by reduce_slabs_kernel (fp64, fixed order).
+// re-stage one row.  One slab per workgroup, summed by slab_sum_batch_kernel (fp64, fixed order).
 // ---------------------------------------------------------------------------------------------------
 struct WgArgs {
     int N, H, W, T, Cout;       // OUTPUT extents (rows, columns, depth)
