@@ -894,8 +894,9 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         if (e->impl >= 1 && e->pw_mfma) {
             // fused: H recompute, dH, ReLU gate, dX (+ skip), dW1, dW2, db1, db2 -- nothing 256-wide touches HBM
             const long nvox = (long)B * Hin * Hin * T;
-            ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (2.0 * F * E + 2.0 * E * D), s);   // SURVEY §8d: bwd-data + bwd-filter of expConv and decConv; the recompute of H (F*E more) is not algorithmic work
             unsigned* anew = new_slot();                     // amax slot of dX
+            {   // (the class's bracket ends HERE: the flush below launches the batched slab sums on this stream, and they are no part of this class)
+            ProfScope ps(e, e->impl >= 3 ? CLS_PW_BWD_DATA_X6 : CLS_PW_BWD_DATA, (double)nvox * (2.0 * F * E + 2.0 * E * D), s);   // SURVEY §8d: bwd-data + bwd-filter of expConv and decConv; the recompute of H (F*E more) is not algorithmic work
             if (h3) {
                 PwAmax m; m.x = A.act(i); m.w1 = A.w(le); m.w2 = A.w(ld); m.w1r = A.wrow(le); m.b1 = A.b(le); m.dt = agdec; m.y = anew;
                 CK(x6_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1h[i], Wpack + e->pkW2Kh[i], Wpack + e->pkW1Ch[i],
@@ -906,10 +907,12 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
             else
                 CK(mfma_pw_backward(W + p.act[i], gDec, cur, Wpack + e->pkW1[i], Wpack + e->pkW2B[i], Wpack + e->pkW1C[i],
                                     params + e->layers[le].wn.b_off, oth, dweff(le), dweff(ld), dbias(le), dbias(ld), next_part(), nvox, D, s));
+            }
             float* tmp2 = cur; cur = oth; oth = tmp2;
             acur = anew;
-            // what has been queued for the side stream leaves every fourth block, and before the last one (so that little is left for the join)
-            if (((R - 1 - i) & 3) == 3 || i == 1) CK(reduce_flush(s));       // (flushing later -- behind the first blocks, behind the last one -- measured: +0.7 %)
+            // what has been queued leaves every fourth block, and before the last one: the small launches to the side stream, the slab sums as ONE kernel on this stream
+            // (round 5: slab_sum_later; one flush at the very end instead measured the same, +0.1 %)
+            if (((R - 1 - i) & 3) == 3 || i == 1) CK(reduce_flush(s));
             continue;
         }
         // recompute H = relu(expConv_i(act[i])): the 256-channel tensor is never kept (1 KB/voxel/block)
