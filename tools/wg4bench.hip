@@ -35,7 +35,7 @@ int main(int argc, char** argv)
     Amax am; am.x = am_; am.w = am_ + 2048; am.y = nullptr;
     struct Case { int B, H, T, red; };                                  // T = output depth; red: a reducer layer (32 channels, mirrored rows / columns, input depth T + 2, gate)
     const Case cases[] = {{1, 22, 9, 0}, {2, 22, 9, 0}, {3, 22, 9, 0}, {128, 22, 9, 0}, {100, 22, 9, 0}, {5, 22, 7, 0}, {2, 10, 9, 0}, {7, 3, 9, 0}, {256, 1, 7, 0}, {64, 22, 9, 0},
-                          {1, 22, 7, 1}, {3, 22, 5, 1}, {2, 22, 3, 1}, {128, 22, 7, 1}, {128, 22, 5, 1}, {128, 22, 3, 1}, {5, 2, 7, 1}, {100, 22, 3, 1}};
+                          {50, 22, 9, 0}, {37, 22, 7, 0}, {37, 21, 9, 0}, {1, 22, 7, 1}, {3, 22, 5, 1}, {37, 22, 7, 1}, {2, 22, 3, 1}, {128, 22, 7, 1}, {128, 22, 5, 1}, {128, 22, 3, 1}, {5, 2, 7, 1}, {100, 22, 3, 1}};
     int bad = 0;
     for (const Case& c : cases) {
         ConvGeom g = c.red ? ConvGeom{c.B, c.H, 22, c.T + 2, 32, c.H, 22, c.T, 32, 3, 3, 3, 1, 1, 0, 1, 1, 0} : ConvGeom{c.B, c.H, 22, c.T, 25, c.H, 22, c.T, 32, 3, 3, 3, 1, 1, 1, 0, 0, 0};
