@@ -340,7 +340,7 @@ int conv3d_up_bwd_data(const ConvGeom& g, const float* dy, const float* wT, cons
 // backward-filter.  256 threads = 32 output channels x 8 input-channel groups; every thread keeps
 // TAPS x CI_PER partial sums in registers while the block walks its chunk of output voxels (all
 // threads on the same voxel => bounds tests are scalar and the x loads are 32-lane broadcasts).
-// Per-chunk partials go to scratch and are summed in a fixed order by reduce_partials_kernel, so the
+// Per-chunk partials go to scratch and are summed in a fixed order by slab_sum_batch_kernel (slab_sum_later), so the
 // result is bitwise reproducible (no float atomics).
 // ---------------------------------------------------------------------------------------------------
 template <int KH, int KW, int KT, int CI_PER>
@@ -428,62 +428,12 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(
     }
 }
 
-// Two sums in one launch (a filter gradient and its bias gradient): the first nb1 workgroups take the first, the others the second -- every launch less on the
-// side stream is 5 us less that the command processor may spend there while the launch stream's next kernel waits to be dispatched.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                             long n, int chunks);
-__global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __restrict__ p1, float* __restrict__ o1, long n1, int nb1,
-                                                              const float* __restrict__ p2, float* __restrict__ o2, long n2, int chunks)
+// The slabs / chunk partials of the launches below are summed by slab_sum_later (probav_common.h; kernels_small.hip: slab_sum_batch_kernel): a filter gradient and its bias
+// gradient are two jobs of one launch, fp64 across the slabs in a fixed order (the filter gradient is a sum with heavy cancellation), bitwise reproducible.
+static int sum_partials(const float* p1, float* o1, long n1, const float* p2, float* o2, long n2, int chunks, hipStream_t s)
 {
-    const bool second = (int)blockIdx.x >= nb1;
-    const float* partial = second ? p2 : p1;
-    float* out = second ? o2 : o1;
-    const long n = second ? n2 : n1;
-    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const long i = (long)(second ? blockIdx.x - nb1 : blockIdx.x) * 32 + e;
-    __shared__ double red[8][32];
-    double a0 = 0.0, a1 = 0.0;
-    if (i < n) {
-        int c = part;
-        for (; c + 8 < chunks; c += 16) { a0 += (double)partial[(long)c * n + i]; a1 += (double)partial[(long)(c + 8) * n + i]; }
-        if (c < chunks) a0 += (double)partial[(long)c * n + i];
-    }
-    red[part][e] = a0 + a1;
-    __syncthreads();
-    if (part != 0 || i >= n) return;
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][e];
-    out[i] = (float)t;
-}
-static void launch_reduce_partials(const float* p1, float* o1, long n1, const float* p2, float* o2, long n2, int chunks, hipStream_t s)
-{
-    const int nb1 = (int)((n1 + 31) / 32);
-    if (o2) hipLaunchKernelGGL(reduce_partials2_kernel, dim3((unsigned)(nb1 + (int)((n2 + 31) / 32))), dim3(256), 0, s, p1, o1, n1, nb1, p2, o2, n2, chunks);
-    else hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)nb1), dim3(256), 0, s, p1, o1, n1, chunks);
-}
-
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                             long n, int chunks)
-{
-    // 32 elements x 8 interleaved partial sums per block, fixed order (bitwise reproducible); fp64 across chunks:
-    // the filter gradient is a sum with heavy cancellation
-    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + e;
-    __shared__ double red[8][32];
-    double a0 = 0.0, a1 = 0.0;
-    if (i < n) {
-        int c = part;
-        for (; c + 8 < chunks; c += 16) { a0 += (double)partial[(long)c * n + i]; a1 += (double)partial[(long)(c + 8) * n + i]; }
-        if (c < chunks) a0 += (double)partial[(long)c * n + i];
-    }
-    red[part][e] = a0 + a1;
-    __syncthreads();
-    if (part != 0 || i >= n) return;
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][e];
-    out[i] = (float)t;
+    SlabSumJob jobs[2] = {{p1, o1, n1, (int)n1, chunks}, {p2, o2, n2, (int)n2, chunks}};
+    return slab_sum_later(s, jobs, o2 ? 2 : 1);
 }
 
 
@@ -492,7 +442,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // kernel above walks a few voxels per block with dependent global loads (latency-bound: 0.17 ms for 37 MFLOP).  Here one
 // workgroup takes half a patch: x rows and gated dy rows are staged in LDS once, thread (tap, ci, co) keeps ONE accumulator and
 // walks the half-patch's output voxels with two LDS reads (both broadcasts inside a (tap, ci) / co group) and one fma each.
-// One slab per workgroup, summed in fixed order by reduce_partials_kernel.
+// One slab per workgroup, summed in fixed order by slab_sum_batch_kernel (slab_sum_later).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void wgrad2d_small_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gate, float* __restrict__ partial,
@@ -673,10 +623,7 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
         else hipLaunchKernelGGL(wgrad_cin1_kernel<false>, dim3((unsigned)slabs), dim3(512), lds, s, g, x, dy, gate, partial, pb);
         int rc = check_launch("wgrad_cin1");
         if (rc) return rc;
-        return reduce_later(s, [=](hipStream_t rs) -> int {
-            launch_reduce_partials(partial, dw, (long)27 * 32, pb, db, 32, slabs, rs);
-            return check_launch("reduce_partials");
-        });
+        return sum_partials(partial, dw, (long)27 * 32, pb, db, 32, slabs, s);
     }
     {
         int halves; size_t lds;
@@ -689,10 +636,7 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
             if (rc) return rc;
             const long nw = K * g.Cout;
             const int cout = g.Cout;
-            return reduce_later(s, [=](hipStream_t rs) -> int {
-                launch_reduce_partials(partial, dw, nw, pb, db, cout, slabs, rs);
-                return check_launch("reduce_partials");
-            });
+            return sum_partials(partial, dw, nw, pb, db, cout, slabs, s);
         }
     }
     float* partial_b = partial + (size_t)chunks * K * g.Cout;
@@ -717,10 +661,7 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     if (rc) return rc;
     const long nw = K * g.Cout;
     const int cout = g.Cout;
-    return reduce_later(s, [=](hipStream_t rs) -> int {
-        launch_reduce_partials(partial, dw, nw, partial_b, db, cout, chunks, rs);
-        return check_launch("reduce_partials");
-    });
+    return sum_partials(partial, dw, nw, partial_b, db, cout, chunks, s);
 }
 
 }  // namespace probav
