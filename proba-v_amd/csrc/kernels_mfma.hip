@@ -1667,7 +1667,10 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
     // channels 0..23; the voxel's fourth chunk GATHERS channel 24 of padded depths t', t'+1, t'+2 and is one extra item per voxel, thread lv).
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int NCH = CIN == 25 ? 3 : 4;
-    const int lw0 = a.nsplit == 1 ? g.pw : 0, Wl = a.nsplit == 1 ? g.Wi : a.Wt + 2;
+    // (one column range and zero pads: the pad columns are never written and stay zero from the clear; MIRRORED pads are data and are staged like a range's halo columns --
+    //  until round 5 they were not when the row was ONE range, which no layer of the reference's networks is: 22 x 22 x 7 and x 5 inputs through the C ABI came out wrong)
+    const bool own_cols = a.nsplit == 1 && !g.reflect_hw;
+    const int lw0 = own_cols ? g.pw : 0, Wl = own_cols ? g.Wi : a.Wt + 2;
     const int nvs = Wl * g.Ti, items = nvs * NCH;                            // pp_plan(): items <= 256 * RVP, nvs <= 256
     struct Staged { float v[RVP][8]; float g3[3]; float m[GATE ? RVP : 1][8]; float m3[3]; };   // m, m3: the gate tensor's values (GATE), applied in stage_store
     int s_src[RVP], s_vd[RVP], s_cc[RVP], s_live[RVP];                      // source offset (floats) inside an input row, record, chunk, 1 = inside the patch's columns
@@ -2391,7 +2394,7 @@ static bool pp_plan(const ConvGeom& g, StripPlan& p, int& rvp)
     for (int ns = 1; ns <= 4; ++ns) {
         if (g.Wo % ns) continue;
         const int wt = g.Wo / ns, nvr = wt * g.To;
-        const int nvs = (ns == 1 ? g.Wi : wt + 2) * g.Ti, items = nvs * (g.Cin == 25 ? 3 : 4);     // staged voxels / items per row (a half = 256 threads stages it)
+        const int nvs = ((ns == 1 && !g.reflect_hw) ? g.Wi : wt + 2) * g.Ti, items = nvs * (g.Cin == 25 ? 3 : 4);     // staged voxels / items per row (a half = 256 threads stages it; mirrored pad columns are staged)
         if (items > 256 * 3 || nvs > 256 || nvr < 32) continue;
         int nstrips = (256 + g.N * ns - 1) / (g.N * ns);
         if (nstrips < 1) nstrips = 1;

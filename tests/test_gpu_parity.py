@@ -99,6 +99,11 @@ CONV_CASES = [
     ("bwd-data of convReducer_3: full 32->32 gated", 2, (18, 18, 3), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
     ("T=7 normConv same 25->32 + skip", 3, (22, 22, 7), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
     ("bwd-data of upscaleConv1: full 9->32, depth 1 -> 3", 3, (16, 16, 1), 9, 32, (3, 3, 3), (2, 2, 2), 0, 0, 0, 0),
+    # the mirrored-pad layer at the other depths conv3_wgrad_w4_kernel is instantiated for (rows of 7 and 5 k-blocks; the T = 13 network's third reducer is the 9 -> 7 case above)
+    ("mirrored-pad reducer, depth 7 -> 5", 3, (22, 22, 7), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    ("mirrored-pad reducer, depth 5 -> 3", 2, (22, 22, 5), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    ("bwd-data of the mirrored-pad reducer 7 -> 5: full 32->32 gated, 24x24x7 out", 2, (22, 22, 5), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
+    ("bwd-data of the mirrored-pad reducer 5 -> 3: full 32->32 gated, 24x24x5 out", 2, (22, 22, 3), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
 ]
 
 
