@@ -102,6 +102,11 @@ CONV_CASES = [
     # the mirrored-pad layer at the other depths conv3_wgrad_w4_kernel is instantiated for (rows of 7 and 5 k-blocks; the T = 13 network's third reducer is the 9 -> 7 case above)
     ("mirrored-pad reducer, depth 7 -> 5", 3, (22, 22, 7), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
     ("mirrored-pad reducer, depth 5 -> 3", 2, (22, 22, 5), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    # odd extents through the one-wave-per-SIMD convolution and backward-filter kernels (or past them, where their plans decline)
+    ("normConv 5x10x9, three patches + skip", 3, (5, 10, 9), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("normConv 13x22x7 relu + skip", 2, (13, 22, 7), 25, 32, (3, 3, 3), (1, 1, 1), 0, 1, 0, 1),
+    ("bwd-data of normConv 9x12x7: same 32->25", 2, (9, 12, 7), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 0, 0),
+    ("same 32->32 on 11x14x9 + skip", 2, (11, 14, 9), 32, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
     ("bwd-data of the mirrored-pad reducer 7 -> 5: full 32->32 gated, 24x24x7 out", 2, (22, 22, 5), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
     ("bwd-data of the mirrored-pad reducer 5 -> 3: full 32->32 gated, 24x24x5 out", 2, (22, 22, 3), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
 ]
