@@ -407,9 +407,13 @@ def test_end_to_end_against_golden(dev, T, impl):
         assert torch.equal(m(x, training=False), pred.detach())
 
 
-@pytest.mark.parametrize("nvox,vps", [(32, 0), (1000, 0), (4356 * 3, 0), (5 * 1640, 1640), (600 * 64, 64)],
+@pytest.mark.parametrize("nvox,vps", [(32, 0), (1000, 0), (4356 * 3, 0), (5 * 1640, 1640), (600 * 64, 64), (7 * 33, 33), (1030 * 40, 40)],
                          ids=["32", "1000", "13068", "5 samples of 1640 (partial last tiles, sample boundaries inside the runs)",
-                              "600 samples of 64 (runs longer than a sample: the general kernel)"])
+                              "600 samples of 64 (runs longer than a sample: the general kernel)", "7 samples of 33 (one full and one one-voxel tile each)",
+                              "1030 samples of 40 (more samples than waves)"])
+# (No case of the benchmark's size here: the comparison is un-gated, and among 130 x 4 356 voxels x 256 hidden channels a handful of pre-activations sit within fp32 rounding of
+#  zero -- every impl, 2 included, then differs from the fp64 reference by a whole term in three or four voxels of dX.  Full-size runs are compared at the device's own
+#  gates: test_full_size_batch128_properties, test_forward_and_reverse_pass_decide_the_same_relu_gates.)
 def test_fused_pointwise_forward_backward(dev, nvox, vps):
     """expConv + ReLU + decConv fused in accumulators (and its fused reverse pass) against fp64 numpy.  vps = voxels per sample (0: one
     sample): H3 scales, tiles and the reverse kernel's runs follow the samples."""
