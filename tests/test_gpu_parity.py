@@ -102,7 +102,10 @@ CONV_CASES = [
     # the mirrored-pad layer at the other depths conv3_wgrad_w4_kernel is instantiated for (rows of 7 and 5 k-blocks; the T = 13 network's third reducer is the 9 -> 7 case above)
     ("mirrored-pad reducer, depth 7 -> 5", 3, (22, 22, 7), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
     ("mirrored-pad reducer, depth 5 -> 3", 2, (22, 22, 5), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
-    # odd extents through the one-wave-per-SIMD convolution and backward-filter kernels (or past them, where their plans decline)
+    # mirrored pads at other extents (rows that are one column range and rows that are cut), odd extents through the one-wave-per-SIMD kernels (or past them, where their plans decline)
+    ("mirrored-pad 16x16x9 -> 7", 2, (16, 16, 9), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    ("mirrored-pad 10x22x5 -> 3", 3, (10, 22, 5), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    ("mirrored-pad 22x22x13 -> 11", 1, (22, 22, 13), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
     ("normConv 5x10x9, three patches + skip", 3, (5, 10, 9), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
     ("normConv 13x22x7 relu + skip", 2, (13, 22, 7), 25, 32, (3, 3, 3), (1, 1, 1), 0, 1, 0, 1),
     ("bwd-data of normConv 9x12x7: same 32->25", 2, (9, 12, 7), 32, 25, (3, 3, 3), (1, 1, 1), 0, 0, 0, 0),
@@ -482,6 +485,31 @@ def test_mfma_engine_matches_direct_engine(dev, batch):
         for n, g0, g1 in zip(m.variable_names, res[0][1], res[other][1]):
             tol = (2e-2 if n.endswith("/g") else 5e-3) * (1.0 if batch >= 5 else 4.0)
             assert float((g0 - g1).norm()) <= tol * float(g0.norm()) + 1e-12, (n, other)
+
+
+@pytest.mark.parametrize("P,T,B", [(24, 9, 3), (32, 9, 2), (16, 7, 4), (20, 13, 2)], ids=["p24-t9", "p32-t9", "p16-t7", "p20-t13"])
+def test_other_patch_sizes_agree_across_engines(dev, P, T, B):
+    """patchSizeLR is a cfg value (`train.py`, `[Patches]`): the one-wave-per-SIMD kernels are instantiated for the reference's 16 (rows of 22 columns) and must hand other
+    sizes to the general forms -- the H3 engine (impl 4) against the generic direct kernels (impl 0) on 30-, 38- and 26-wide inputs: predictions to 1e-5 of their max-norm,
+    the flat gradient in relative L2 (two summation orders flip a few ReLU gates at zero: the sharp per-kernel bars are the single-operator tests)."""
+    from probav_amd.loss import Losses
+    from probav_amd.modelsTF import WDSRConv3D
+    m = WDSRConv3D("t", "NIR", synth.NIR_MEAN, synth.NIR_STD, 6).build(3, 32, (3, 3, 3), 12, 8, 0.8, T, P, True, seed=3).to(dev)
+    rng = np.random.default_rng(P * 100 + T)
+    x = torch.as_tensor((rng.uniform(size=(B, P + 6, P + 6, T, 1)) * 8000).astype(np.float32)).to(dev)
+    hr = torch.as_tensor((rng.uniform(size=(B, 3 * P, 3 * P, 1)) * 8000).astype(np.float32)).to(dev)
+    mask = torch.as_tensor((rng.uniform(size=(B, 3 * P, 3 * P, 1)) > 0.1).astype(np.float32)).to(dev)
+    lo = Losses(targetShape=(3 * P, 3 * P, 1))
+    res = []
+    for impl in (0, 4):
+        m.set_impl(impl)
+        m.flat.grad = None
+        p = m(x, training=True)
+        lo.shiftCompensatedL1Loss(hr, mask, p).backward()
+        res.append((p.detach().clone(), m.flat.grad.detach().clone()))
+    assert torch.isfinite(res[1][0]).all() and torch.isfinite(res[1][1]).all()
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
+    assert float((res[0][1] - res[1][1]).norm()) < 5e-3 * float(res[0][1].norm())
 
 
 @pytest.mark.parametrize("T", [9, 13])
