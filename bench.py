@@ -435,7 +435,10 @@ def run_rank(args):
             s13()
         k3 = max(5, args.steps // 5)
         t3, ms3, _ = timed(s13, k3)
-        other["config3_t13_training"] = {"value": round(B * k3 / t3, 2), "unit": "patches/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "steps": k3, "step_ms": percentiles(ms3),
+        st3 = percentiles(ms3)
+        other["config3_t13_training"] = {"value": round(B * k3 / t3, 2), "unit": "patches/s", "ms_per_step": round(t3 / k3 * 1e3, 4), "steps": k3, "step_ms": st3,
+                                         # (a leg of few steps: one stalled step moves its mean by 15 % -- the median step beside it)
+                                         "value_at_median_step": round(B / (st3["median"] * 1e-3), 2) if isinstance(st3, dict) and st3.get("median") else None,
                                          "workload": "numImgLR 13 (reducer v3), %d patches of [22,22,13,1], fwd + shift-L1 + bwd" % B}
         m13._ws.clear()
         del m13, d13, s13
