@@ -5,8 +5,8 @@
 // What conv3_wgrad_x6_kernel (kernels_x6.hip: the general form -- any extent, pads, depth 13, batches above 256) measured in the step: 108 us per launch, matrix pipe 37 %
 // busy, 47 % of its LDS cycles bank conflicts, two waves per SIMD that each wait for the four transposed reads of the NEXT tap tile only.  The contraction has no operand
 // reuse to speak of (N = 32 output channels is all there is: every (tap, channel, voxel) element of the A operand feeds ONE MFMA triple), so the A operand's LDS
-// reads are the kernel, and their latency and their conflicts were what it waited for.  This kernel keeps the arithmetic (the products and their order per k-block:
-// x1 d0 + x0 d1 + x0 d0; one scale per operand tensor) and changes the shape:
+// reads are the kernel, and their latency and their conflicts were what it waited for.  This kernel keeps the products (per k-block x1 d0, x0 d1, x0 d0; one scale
+// per operand tensor -- since the end of round 5 with LIFTED second pieces and the two cross products in an accumulator of their own: WG4_LIFT below) and changes the shape:
 //   * ONE WAVE PER SIMD, ONE INSTRUCTION STREAM per output row: the M tiles (25 channels: the taps' 25 + 3 rows packed into 24 tiles, six per wave; 32 channels: 27 tap tiles
 //     dealt 7 / 7 / 7 / 6) stay with their wave for ALL k-blocks (no parity exchange at the end); a row = NKB k-blocks x 6 | 7 tiles x 3 MFMAs, fully unrolled, the transposed reads
 //     two tiles ahead in a register ring; the accumulators live in a[...] and are read once, at the kernel's end.
@@ -33,6 +33,17 @@ namespace diag {
 
 struct Wg4Args { int N, H, SR, nstrips; };
 
+// LIFTED SECOND PIECES (round 5).  The contraction runs over the voxels of all samples, so an operand takes ONE scale per tensor, and fp16's five exponent bits
+// used to bound what a channel far below its tensor mates kept: a value's second piece rn16(v s - h0) is 2^-11 of the first and left the normal range 18 binades below the
+// tensor's maximum (a channel at 2^-24 of it got a 1e-2 gradient slice).  Here the second piece is stored LIFTED, h1' = rn16((v s - h0) 2^11) -- v s - h0 is exact in fp32,
+// |h1'| <= |h0| -- so both pieces of a value are normal 29 binades below the maximum, and the two cross products x1' d0 + x0 d1' (2^11 too large, both) go to an accumulator
+// of their own: dW = (sum x0 d0 + 2^-11 sum (x1' d0 + x0 d1')) 2^-(ex + ed).  Same three MFMAs per k-block and tile; one more vector instruction per cut value; 96 / 112 more
+// accumulator registers (a[...]: the kernel has them).  -DWG4_LIFT=0: the plain second pieces and one accumulator (rounds 2 - 4; for A/B builds).
+#ifndef WG4_LIFT
+#define WG4_LIFT 1
+#endif
+constexpr int WG4_IM = WG4_LIFT ? 16 : 12;      // micro-operations of one staging item (stage_mop); the last two are its LDS stores
+
 namespace {
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
@@ -48,6 +59,7 @@ template <int NKB, int MB>
 __host__ __device__ constexpr int wg4_cutK(int u)
 {
     constexpr int nB = MB + 1, kB = NKB - 1 - MB, extra = nB - kB;
+    if (u <= MB && kB == 1) return MB;                                   // (a row of four k-blocks: one k-block between the two barriers takes all of them)
     return u > MB ? u - (MB + 1) : (u < 2 * extra ? MB + u / 2 : MB + u - extra);
 }
 // fillers of k-block K: the units it cuts (COPS micro-operations each), the units it requests (LOPS each; LA k-blocks ahead of their cut), the staging micro-operations (k-blocks MB .. SE)
@@ -70,7 +82,7 @@ __host__ __device__ constexpr int wg4_lds_behind_last_store(int K)
     for (int f = 0; f < NF; ++f) {
         bool st = false;
         if (f < COPS * ncut) st = (f % COPS == COPS - 3) || (f % COPS == COPS - 1);
-        else if (f >= COPS * ncut + LOPS * nld) { const int ms = (K - MB) * STG + f - COPS * ncut - LOPS * nld; st = ms < ROW_MOPS && ms % 12 >= 10; }
+        else if (f >= COPS * ncut + LOPS * nld) { const int ms = (K - MB) * STG + f - COPS * ncut - LOPS * nld; st = ms < ROW_MOPS && ms % WG4_IM >= WG4_IM - 2; }
         if (st) last = f;
     }
     if (last < 0) return 15;
@@ -96,16 +108,19 @@ __host__ __device__ constexpr int wg4_lds_behind_last_store(int K)
 #define WG4_SBAR() __builtin_amdgcn_sched_barrier(0)
 #define WG4_PIN(v) asm volatile("" : "+v"(v))
 
-// TP: entries per column of a ring row = output depth + 2; RT: GEMM rows per tap (32: a tile is a tap; 28: the taps' 25 + 3 rows packed, 24 tiles -- every tile straddles taps);
-// CIN: input channels (25: normConv; 32: the reducers); REFL: the reducers' layer -- the input is tf.pad(REFLECT) in rows and columns and NOT padded in depth (input depth TP,
-// output depth TP - 2: a ring row holds all TP depths of all W + 2 columns, the pad columns as data), and dY is masked by the layer's own output (`gate` > 0: its ReLU)
-template <int TP, int RT, int CIN, bool REFL>
+// W: output columns; TP: entries per column of a ring row = output depth + 2; RT: GEMM rows per tap (32: a tile is a tap; 28: the taps' 25 + 3 rows packed, 24 tiles -- every
+// tile straddles taps); CIN: input channels (25: normConv; 32: the reducers); MODE 0: 'same' zero pads (normConv).  MODE 1: the first reducer -- the input is tf.pad(REFLECT) in
+// rows and columns and NOT padded in depth (input depth TP, output depth TP - 2: a ring row holds all TP depths of all W + 2 columns, the pad columns as data), and dY is masked by
+// the layer's own output (`gate` > 0: its ReLU).  MODE 2: the reducers behind it -- no pads at all (input extents H + 2, W + 2, TP: the ring's outer columns / rows ARE input), dY masked.
+template <int W, int TP, int RT, int CIN, int MODE>
 __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gate,
                                                                float* __restrict__ partial, float* __restrict__ partial_b, Amax am)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr bool REFL = MODE != 0, VALID = MODE == 2;                  // REFL: what the two reducer modes share (no depth pads, outer columns staged as data, dY masked)
     static_assert((CIN == 25 && !REFL) || CIN == 32, "25 channels: the zero-padded 'same' layer only");
-    constexpr int W = 22, T = TP - 2, WP = W + 2, NV = W * T, NKB = (NV + 15) / 16;
+    constexpr int T = TP - 2, WP = W + 2, NV = W * T, NKB = (NV + 15) / 16;
+    constexpr int WI = VALID ? WP : W;                                   // columns of the input tensor
     constexpr int TD = REFL ? TP : T;                                    // depth of the input tensor
     constexpr int PP = WP * TP * 64, ROWB = 2 * PP;                      // bytes of one piece plane / of one ring row (slot)
     constexpr int NQV = REFL ? WP * TP : NV, QPV = CIN == 25 ? 7 : 8;    // voxels a row stages (REFL: the pad columns too); channel quads per voxel
@@ -116,7 +131,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     constexpr int FB0 = 4 * ROWB + 1024;                                 // the row's dY fragments: [k-block][piece][lane] x 16 bytes, behind the ring (and 1 KB that a tail k-block's reads may run into)
     constexpr int MB = NKB / 2;                                          // the row's second barrier stands in front of k-block MB
     constexpr int LA = MB < 3 ? MB : 3;                                  // k-blocks a unit's requests run ahead of its cut
-    constexpr int LOPS = REFL ? 5 : 3, COPS = REFL ? 10 : 8;             // micro-operations of a unit's requests / of its cut (REFL: + the gate values, + two selects)
+    constexpr bool LIFT = WG4_LIFT != 0;
+    constexpr int LOPS = REFL ? 5 : 3, COPS = (REFL ? 10 : 8) + (LIFT ? 2 : 0);             // micro-operations of a unit's requests / of its cut (REFL: + the gate values, + two selects)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31, li = lane & 15, gcol = (lane >> 4) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         const int vox = ic / QPV, quad = ic - QPV * vox;
         if constexpr (REFL) {                                             // ring column cw <-> input column cw - 1, mirrored at both ends (tf.pad REFLECT); all TP depths
             const int cw = vox / TP, t = vox - cw * TP;
-            const int sw = cw == 0 ? 1 : cw == WP - 1 ? W - 2 : cw - 1;
+            const int sw = VALID ? cw : (cw == 0 ? 1 : cw == WP - 1 ? W - 2 : cw - 1);
             s_src[k] = ((sw * TP + t) * CIN + 4 * quad) * 4;
             s_dst[k] = (cw * TP + t) * 64 + quad * 8;
             s_scz[k] = 1.f;
@@ -155,12 +171,16 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
             s_scz[k] = (CIN == 25 && quad == 6) ? 0.f : 1.f;
         }
     }
-    const long xsample = (long)a.H * W * TD * CIN;
+    const long xsample = (long)(a.H + (VALID ? 2 : 0)) * WI * TD * CIN;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * xsample), 0, (unsigned)xsample * 4u, 0x00020000);
-    constexpr int xrowb = W * TD * CIN * 4;
+    constexpr int xrowb = WI * TD * CIN * 4;
     auto row_of = [&](int key, int& rowoff, float& rokf) {               // ring key k <-> input row hb - 1 + k: clamped, 1.0 / 0.0 = inside / outside the patch -- REFL: mirrored
         int ih = hb - 1 + key;
-        if constexpr (REFL) {
+        if constexpr (VALID) {
+            ih = hb + key;
+            ih = ih > a.H + 1 ? a.H + 1 : ih;                               // (rows a strip's last tiles stage for nobody)
+            rowoff = ih * xrowb; rokf = 1.f;
+        } else if constexpr (REFL) {
             ih = ih < 0 ? -ih : ih >= a.H ? 2 * a.H - 2 - ih : ih;
             ih = ih < 0 ? 0 : ih >= a.H ? a.H - 1 : ih;                    // (rows a strip's last tiles stage for nobody)
             rowoff = ih * xrowb; rokf = 1.f;
@@ -178,26 +198,44 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     // One row's cut and stores as micro-operations of one instruction each (dealt out over MFMA gaps).  Per item: its scale; the four first pieces fp16(v s) and the four
     // second pieces fp16(v s - h0) -- one mixed-precision fma each: v s is exact (a power of two) and so is the difference, the bits are those of multiply / convert / subtract /
     // convert --; the slot address; two 8-byte stores.  reload: the item's registers are requested again (the row the NEXT tile cuts) behind their last read.
-    struct Cut { float sc; unsigned h0a, h0b, h1a, h1b; int adr; };
-    constexpr int ROW_MOPS = NIT * 12;
+    struct Cut { float sc, d0, d1; unsigned h0a, h0b, h1a, h1b; int adr; };
+    constexpr int IM = WG4_IM;
+    constexpr int ROW_MOPS = NIT * IM;
+    float k11 = 2048.f;                                                  // (kept in a register: as a literal every use would be a move in front of it)
+    WG4_PIN(k11);
     auto stage_mop = [&](int m, int slotoff, float sxr, u32x4b (&q)[NIT], Cut& c, bool reload, int rel) {
-        const int k = m / 12, op = m % 12;
+        const int k = m / IM, op = m % IM;
         if (op == 0) c.sc = s_scz[k] * sxr;
         // (order: a register's two halves are never written by consecutive instructions -- the partial write forwards one wait state late, and hipcc puts an s_nop between them)
         if (op == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h0a) : "v"(q[k][0]), "v"(sxr));
         if (op == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h0a) : "v"(q[k][1]), "v"(c.sc));
         if (op == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h0b) : "v"(q[k][2]), "v"(c.sc));
         if (op == 4) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h0b) : "v"(q[k][3]), "v"(c.sc));
-        if (op == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.h1a) : "v"(q[k][0]), "v"(sxr), "v"(c.h0a));
-        if (op == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c.h1a) : "v"(q[k][1]), "v"(c.sc), "v"(c.h0a));
-        if (op == 6) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.h1b) : "v"(q[k][2]), "v"(c.sc), "v"(c.h0b));
-        if (op == 8) {
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c.h1b) : "v"(q[k][3]), "v"(c.sc), "v"(c.h0b));
-            if (reload) q[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, s_src[k], rel, 0);
+        if constexpr (LIFT) {
+            // the remainders v s - h0 in fp32 (exact), then lifted by 2^11 into the second pieces
+            if (op == 5) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.d0) : "v"(q[k][0]), "v"(sxr), "v"(c.h0a));
+            if (op == 6) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.d1) : "v"(q[k][2]), "v"(c.sc), "v"(c.h0b));
+            if (op == 7) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h1a) : "v"(c.d0), "v"(k11));
+            if (op == 8) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(c.h1b) : "v"(c.d1), "v"(k11));
+            if (op == 9) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(c.d0) : "v"(q[k][1]), "v"(c.sc), "v"(c.h0a));
+            if (op == 10) {
+                asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(c.d1) : "v"(q[k][3]), "v"(c.sc), "v"(c.h0b));
+                if (reload) q[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, s_src[k], rel, 0);
+            }
+            if (op == 11) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h1a) : "v"(c.d0), "v"(k11));
+            if (op == 12) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(c.h1b) : "v"(c.d1), "v"(k11));
+        } else {
+            if (op == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.h1a) : "v"(q[k][0]), "v"(sxr), "v"(c.h0a));
+            if (op == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c.h1a) : "v"(q[k][1]), "v"(c.sc), "v"(c.h0a));
+            if (op == 6) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c.h1b) : "v"(q[k][2]), "v"(c.sc), "v"(c.h0b));
+            if (op == 8) {
+                asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(c.h1b) : "v"(q[k][3]), "v"(c.sc), "v"(c.h0b));
+                if (reload) q[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, s_src[k], rel, 0);
+            }
         }
-        if (op == 9) c.adr = s_dst[k] + slotoff;
-        if (op == 10) *reinterpret_cast<u32x2b*>(lds + c.adr) = (u32x2b){c.h0a, c.h0b};
-        if (op == 11) *reinterpret_cast<u32x2b*>(lds + c.adr + PP) = (u32x2b){c.h1a, c.h1b};
+        if (op == IM - 3) c.adr = s_dst[k] + slotoff;
+        if (op == IM - 2) *reinterpret_cast<u32x2b*>(lds + c.adr) = (u32x2b){c.h0a, c.h0b};
+        if (op == IM - 1) *reinterpret_cast<u32x2b*>(lds + c.adr + PP) = (u32x2b){c.h1a, c.h1b};
     };
 
     // ---- prologue: the requests first (ring keys 0 .. 2 = this strip's first three input rows, key 3 for the first tile's staging), then the ring is cleared ----
@@ -225,6 +263,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     auto cutK = [](int u) -> int { return wg4_cutK<NKB, MB>(u); };
     int vo_t = 0;
     unsigned cq0 = 0u, cq1 = 0u;
+    float cd0 = 0.f, cd1 = 0.f;
     float bsum[2] = {0.f, 0.f};
     auto dy_load_op = [&](int u, int op, const __amdgpu_buffer_rsrc_t& rs, const __amdgpu_buffer_rsrc_t& gs) {
         if (op == 0) { vo_t = dvo + u * 2048; WG4_PIN(vo_t); }
@@ -245,10 +284,19 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         if (op == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(raw[u][0]));
         if (op == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(cq0) : "v"(raw[u][1]), "v"(sd));
         if (op == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[1]) : "v"(raw[u][1]));
-        if (op == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(cq1) : "v"(raw[u][0]), "v"(sd), "v"(cq0));
-        if (op == 5) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048) = cq0;
-        if (op == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(cq1) : "v"(raw[u][1]), "v"(sd), "v"(cq0));
-        if (op == 7) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048 + 1024) = cq1;
+        if constexpr (LIFT) {
+            if (op == 4) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(cd0) : "v"(raw[u][0]), "v"(sd), "v"(cq0));
+            if (op == 5) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(cd1) : "v"(raw[u][1]), "v"(sd), "v"(cq0));
+            if (op == 6) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(cq1) : "v"(cd0), "v"(k11));
+            if (op == 7) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048) = cq0;
+            if (op == 8) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(cq1) : "v"(cd1), "v"(k11));
+            if (op == 9) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048 + 1024) = cq1;
+        } else {
+            if (op == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(cq1) : "v"(raw[u][0]), "v"(sd), "v"(cq0));
+            if (op == 5) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048) = cq0;
+            if (op == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(cq1) : "v"(raw[u][1]), "v"(sd), "v"(cq0));
+            if (op == 7) *reinterpret_cast<unsigned*>(lds + fbw + u * 2048 + 1024) = cq1;
+        }
     };
 #pragma unroll
     for (int u = 0; u < NKB; ++u)
@@ -331,11 +379,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #ifdef WG4_STAMP
     const unsigned long long st_p3 = __builtin_amdgcn_s_memtime();
 #endif
-    f32x16 acc[NJ];
+    f32x16 acc[NJ], accL[LIFT ? NJ : 1];                                 // LIFT: acc = sum x0 d0, accL = sum (x1' d0 + x0 d1')
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; if (LIFT) accL[LIFT ? j : 0][r] = 0.f; }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the first three rows are in the ring
 
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
@@ -369,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     // ---- the rows ----
     // A single wave issues one instruction per ~4.9 cycles whatever its kind (MI355X_MICROARCH.md): an MFMA leaves room for about five beside itself.  Per tile
     // the gap behind the first MFMA takes the two address sums and two transposed reads of the tile PD ahead (piece 0), the second gap the other two reads; a k-block's
-    // fillers -- the units it cuts (8 each) and requests (3 each), the staging micro-operations (k-blocks MB .. NKB - 2) -- are dealt evenly over its second and third gaps.
+    // fillers -- the units it cuts (COPS each) and requests (LOPS each), the staging micro-operations (k-blocks MB .. NKB - 2) -- are dealt evenly over its second and third gaps.
     // Two barriers per row (a wave arrives with s_waitcnt lgkmcnt(n), n = the LDS operations it has issued behind its last LDS store -- wg4_lds_behind_last_store):
     //   in front of k-block MB -- behind it the slots of units 0 .. MB are free (their fragments have been read) and the ring slot of input row i - 1 is (every wave has
     //   finished output row i - 1); in front of it the row's own units MB + 1 .. were stored;
@@ -417,7 +465,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
                 for (int m = 0; m < 3; ++m) {
                     {
                         const f16x8 af = (m == 0) ? A[j][1].h : A[j][0].h;
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, Bf[K % RS][m == 1 ? 1 : 0].h, acc[j], 0, 0, 0);
+                        if (LIFT && m < 2) accL[LIFT ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, Bf[K % RS][m == 1 ? 1 : 0].h, accL[LIFT ? j : 0], 0, 0, 0);
+                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, Bf[K % RS][m == 1 ? 1 : 0].h, acc[j], 0, 0, 0);
                     }
                     WG4_SBAR();
                     // operand requests PD tiles ahead (a row's last PD: the next row's first, through its slots)
@@ -465,7 +514,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[j][4 * q + e], kun)), rs, e ? so1[j][q] + e * 128 : so0[j][q], 0, 0);
+                {
+                    const float v = LIFT ? fmaf(accL[LIFT ? j : 0][4 * q + e], 1.f / 2048.f, acc[j][4 * q + e]) : acc[j][4 * q + e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(v, kun)), rs, e ? so1[j][q] + e * 128 : so0[j][q], 0, 0);
+                }
         // bias sums: a lane summed the voxel pairs pp of channel lp & 31; lanes l, l + 16, l + 32, l + 48 share the channel, and so do waves w and w + 2
         float b = bsum[0] + bsum[1];
         b += __shfl_xor(b, 16, 64);
@@ -490,12 +542,16 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #endif
 static bool wg4_plan(const ConvGeom& g, const float* gate, Wg4Args& p, int& grid)
 {
-    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_t || g.Cout != 32 || g.Wo != 22 || g.Wi != 22 || g.Ho != g.Hi) return false;
-    if (g.ph != 1 || g.pw != 1) return false;
+    if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_t || g.Cout != 32) return false;
     if (g.Cin == 25) {                                                   // normConv: 'same' padding with zeros, no gate
+        if (g.Wo != 22 || g.Wi != 22 || g.Ho != g.Hi || g.ph != 1 || g.pw != 1) return false;
         if (g.reflect_hw || g.pt != 1 || g.To != g.Ti || gate || (g.To != 9 && g.To != 7)) return false;
-    } else if (g.Cin == 32) {                                            // the reducers: tf.pad(REFLECT) in rows / columns, no depth pads, dY masked by the layer's output
-        if (!g.reflect_hw || g.pt != 0 || g.To != g.Ti - 2 || !gate || g.Hi < 2 || (g.To != 7 && g.To != 5 && g.To != 3)) return false;
+    } else if (g.Cin == 32 && g.reflect_hw) {                            // the first reducer: tf.pad(REFLECT) in rows / columns, no depth pads, dY masked by the layer's output
+        if (g.Wo != 22 || g.Wi != 22 || g.Ho != g.Hi || g.ph != 1 || g.pw != 1) return false;
+        if (g.pt != 0 || g.To != g.Ti - 2 || !gate || g.Hi < 2 || (g.To != 7 && g.To != 5 && g.To != 3)) return false;
+    } else if (g.Cin == 32) {                                            // the reducers behind it: no pads at all, dY masked
+        if (g.ph != 0 || g.pw != 0 || g.pt != 0 || g.Ho != g.Hi - 2 || g.Wo != g.Wi - 2 || g.To != g.Ti - 2 || !gate) return false;
+        if (!((g.Wo == 20 && g.To == 5) || (g.Wo == 18 && g.To == 3))) return false;
     } else return false;
     if (g.N < 1 || g.N > 256 || g.Ho < 1) return false;                  // one slab per workgroup, at most 256 of them (x6_wgrad_partial_floats)
     int nstrips = 256 / g.N;
@@ -532,18 +588,20 @@ int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const flo
     if (!am.x || !am.w) { set_error("wg4_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
     static std::once_flag once;
     std::call_once(once, [] {
-#define WG4_BIG(TP, RT, C, R) note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<TP, RT, C, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840))
-        WG4_BIG(11, WG4_RT, 25, false); WG4_BIG(9, WG4_RT, 25, false); WG4_BIG(9, 32, 32, true); WG4_BIG(7, 32, 32, true); WG4_BIG(5, 32, 32, true); });
+#define WG4_BIG(W, TP, RT, C, M) note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<W, TP, RT, C, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840))
+        WG4_BIG(22, 11, WG4_RT, 25, 0); WG4_BIG(22, 9, WG4_RT, 25, 0); WG4_BIG(22, 9, 32, 32, 1); WG4_BIG(22, 7, 32, 32, 1); WG4_BIG(22, 5, 32, 32, 1);
+        WG4_BIG(20, 7, 32, 32, 2); WG4_BIG(18, 5, 32, 32, 2); });
 #undef WG4_BIG
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
     const int Tp = g.To + 2;
-    const size_t lds_bytes = (size_t)4 * 2 * 24 * Tp * 64 + 1024 + (size_t)((22 * g.To + 15) / 16) * 2048;      // ring, slack, the row's dY fragments
-#define WG4_LAUNCH(TP, RT, C, R) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<TP, RT, C, R>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, gate, partial, partial_b, am)
-    if (g.Cin == 25) { if (g.To == 9) WG4_LAUNCH(11, WG4_RT, 25, false); else WG4_LAUNCH(9, WG4_RT, 25, false); }
-    else if (g.To == 7) WG4_LAUNCH(9, 32, 32, true);
-    else if (g.To == 5) WG4_LAUNCH(7, 32, 32, true);
-    else WG4_LAUNCH(5, 32, 32, true);
+    const size_t lds_bytes = (size_t)4 * 2 * (g.Wo + 2) * Tp * 64 + 1024 + (size_t)((g.Wo * g.To + 15) / 16) * 2048;      // ring, slack, the row's dY fragments
+#define WG4_LAUNCH(W, TP, RT, C, M) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<W, TP, RT, C, M>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, gate, partial, partial_b, am)
+    if (g.Cin == 25) { if (g.To == 9) WG4_LAUNCH(22, 11, WG4_RT, 25, 0); else WG4_LAUNCH(22, 9, WG4_RT, 25, 0); }
+    else if (!g.reflect_hw) { if (g.Wo == 20) WG4_LAUNCH(20, 7, 32, 32, 2); else WG4_LAUNCH(18, 5, 32, 32, 2); }
+    else if (g.To == 7) WG4_LAUNCH(22, 9, 32, 32, 1);
+    else if (g.To == 5) WG4_LAUNCH(22, 7, 32, 32, 1);
+    else WG4_LAUNCH(22, 5, 32, 32, 1);
 #undef WG4_LAUNCH
     int rc = check_launch("conv3_wgrad_w4");
     if (rc) return rc;

@@ -112,6 +112,10 @@ CONV_CASES = [
     ("same 32->32 on 11x14x9 + skip", 2, (11, 14, 9), 32, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
     ("bwd-data of the mirrored-pad reducer 7 -> 5: full 32->32 gated, 24x24x7 out", 2, (22, 22, 5), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
     ("bwd-data of the mirrored-pad reducer 5 -> 3: full 32->32 gated, 24x24x5 out", 2, (22, 22, 3), 32, 32, (3, 3, 3), (2, 2, 2), 0, 0, 1, 0),
+    # the unpadded reducers through conv3_wgrad_w4_kernel's third mode (rows of 20 x 5 and 18 x 3 voxels: 7 and 4 k-blocks), other row counts (uneven strips, one-row strips)
+    ("unpadded reducer 15x22x7 -> 13x20x5", 3, (15, 22, 7), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
+    ("unpadded reducer 9x20x5 -> 7x18x3", 5, (9, 20, 5), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
+    ("unpadded reducer 3x20x5 -> 1x18x3", 2, (3, 20, 5), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
 ]
 
 
