@@ -31,7 +31,7 @@ namespace probav {
 namespace diag {
 #endif
 
-struct Wg4Args { int N, H, SR, nstrips; };
+struct Wg4Args { int N, H, SR, nstrips, nsplit; };
 
 // LIFTED SECOND PIECES (round 5).  The contraction runs over the voxels of all samples, so an operand takes ONE scale per tensor, and fp16's five exponent bits
 // used to bound what a channel far below its tensor mates kept: a value's second piece rn16(v s - h0) is 2^-11 of the first and left the normal range 18 binades below the
@@ -120,10 +120,15 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     constexpr bool REFL = MODE != 0, VALID = MODE == 2;                  // REFL: what the two reducer modes share (no depth pads, outer columns staged as data, dY masked)
     static_assert((CIN == 25 && !REFL) || CIN == 32, "25 channels: the zero-padded 'same' layer only");
     constexpr int T = TP - 2, WP = W + 2, NV = W * T, NKB = (NV + 15) / 16;
-    constexpr int WI = VALID ? WP : W;                                   // columns of the input tensor
+    // W = 11: a workgroup takes HALF the columns of a 22-column row (depth 13: four slots of 24 x 15 entries are 184 KB, of 13 x 15 entries 100 KB) -- ring column 0 of the right
+    // half and ring column W + 1 of the left one are input columns of the other half (mode 1: or the mirror column), the outer one the pad
+    constexpr int NSPLIT = W == 11 ? 2 : 1;
+    static_assert(NSPLIT == 1 || !VALID, "column halves: the padded modes only");
+    constexpr int WOF = W * NSPLIT;                                      // columns of the output tensor
+    constexpr int WI = VALID ? WP : WOF;                                 // columns of the input tensor
     constexpr int TD = REFL ? TP : T;                                    // depth of the input tensor
     constexpr int PP = WP * TP * 64, ROWB = 2 * PP;                      // bytes of one piece plane / of one ring row (slot)
-    constexpr int NQV = REFL ? WP * TP : NV, QPV = CIN == 25 ? 7 : 8;    // voxels a row stages (REFL: the pad columns too); channel quads per voxel
+    constexpr int NQV = REFL ? WP * TP : (NSPLIT == 2 ? (W + 1) * T : NV), QPV = CIN == 25 ? 7 : 8;    // voxels a row stages (REFL: the pad columns too; a half: + the neighbour's column); channel quads per voxel
     constexpr int NQI = NQV * QPV, NIT = (NQI + 255) / 256;             // staging items (voxel, channel quad) of a row; per thread
     constexpr int NT = (27 * RT + 31) / 32, NJ = (NT + 3) / 4;          // M tiles; per wave (tile w + 4 j)
     constexpr int RS = 5;                                                // register sets of the dY fragments: set = k-block % RS
@@ -135,7 +140,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     constexpr int LOPS = REFL ? 5 : 3, COPS = (REFL ? 10 : 8) + (LIFT ? 2 : 0);             // micro-operations of a unit's requests / of its cut (REFL: + the gate values, + two selects)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31, li = lane & 15, gcol = (lane >> 4) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.x / a.nstrips, strip = blockIdx.x - n * a.nstrips;
+    const int per = a.nstrips * NSPLIT;
+    const int n = blockIdx.x / per, srem = blockIdx.x - n * per;
+    const int strip = srem / NSPLIT, sp = srem - strip * NSPLIT;         // sp: the workgroup's column half (0 without the split)
     const int hb = strip * a.SR;
     const int SRr = a.H - hb < a.SR ? a.H - hb : a.SR;
 #ifdef WG4_STAMP
@@ -160,14 +167,16 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
         const int vox = ic / QPV, quad = ic - QPV * vox;
         if constexpr (REFL) {                                             // ring column cw <-> input column cw - 1, mirrored at both ends (tf.pad REFLECT); all TP depths
             const int cw = vox / TP, t = vox - cw * TP;
-            const int sw = VALID ? cw : (cw == 0 ? 1 : cw == WP - 1 ? W - 2 : cw - 1);
+            const int gcw = cw + sp * W;                                   // the ring column in the full row's numbering
+            const int sw = VALID ? cw : (gcw == 0 ? 1 : gcw == WOF + 1 ? WOF - 2 : gcw - 1);
             s_src[k] = ((sw * TP + t) * CIN + 4 * quad) * 4;
             s_dst[k] = (cw * TP + t) * 64 + quad * 8;
             s_scz[k] = 1.f;
         } else {
             const int w = vox / T, t = vox - w * T;
-            s_src[k] = (vox * CIN + 4 * quad) * 4;
-            s_dst[k] = ((w + 1) * TP + t + 1) * 64 + quad * 8;
+            const int cb = sp ? W * sp - 1 : 0;                            // first input column a half stages (its W + 1 columns are consecutive in memory)
+            s_src[k] = ((vox + cb * T) * CIN + 4 * quad) * 4;
+            s_dst[k] = ((w + ((NSPLIT == 2 && sp) ? 0 : 1)) * TP + t + 1) * 64 + quad * 8;
             s_scz[k] = (CIN == 25 && quad == 6) ? 0.f : 1.f;
         }
     }
@@ -248,12 +257,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
     // voxel pair l >> 4 of fragment lane 16 w + (l & 15): two 4-byte requests, four mixed fmas, two bias-sum additions, two 4-byte LDS stores (a wave's 64 stores of a piece
     // are 256 consecutive bytes).  Every wave then reads a k-block's two fragments with two ds_read_b128.  (Cut by every wave for itself -- the first version -- the
     // eight requests, sixteen fmas and eight additions per k-block were a third of all the instructions between the MFMAs.)
-    const long dyrow0 = (((long)n * a.H + hb) * W) * T * 32;
-    auto dy_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + dyrow0 + (long)i * NV * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
+    const long dyrow0 = (((long)n * a.H + hb) * WOF + sp * W) * T * 32;
+    auto dy_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + dyrow0 + (long)i * WOF * T * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
     const int lp = 16 * wave + li, pp = lane >> 4;                       // fragment lane (channel lp & 31, voxels 8 (lp >> 5) ..), pair of its eight voxels
     const int dvo = (8 * (lp >> 5) + 2 * pp) * 128 + (lp & 31) * 4;
     const int fbw = FB0 + lp * 16 + pp * 4, fbr = FB0 + lane * 16;
-    auto gt_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((REFL ? gate : dy) + dyrow0 + (long)i * NV * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
+    auto gt_rsrc = [&](int i) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((REFL ? gate : dy) + dyrow0 + (long)i * WOF * T * 32), 0, i < SRr ? (unsigned)NV * 128u : 0u, 0x00020000); };
     float raw[NKB][2];                                                   // requested values of the units in flight (indexed by unit: compile-time everywhere)
     float rawg[REFL ? NKB : 1][2];                                       // REFL: the layer's output at the same voxels (its ReLU mask)
     __amdgpu_buffer_rsrc_t drs = dy_rsrc(0), drsN = dy_rsrc(1), grs = gt_rsrc(0), grsN = gt_rsrc(1);
@@ -543,23 +552,26 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 static bool wg4_plan(const ConvGeom& g, const float* gate, Wg4Args& p, int& grid)
 {
     if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_t || g.Cout != 32) return false;
-    if (g.Cin == 25) {                                                   // normConv: 'same' padding with zeros, no gate
+    int nsplit = 1;
+    if (g.Cin == 25) {                                                   // normConv: 'same' padding with zeros, no gate (depth 13: column halves)
         if (g.Wo != 22 || g.Wi != 22 || g.Ho != g.Hi || g.ph != 1 || g.pw != 1) return false;
-        if (g.reflect_hw || g.pt != 1 || g.To != g.Ti || gate || (g.To != 9 && g.To != 7)) return false;
-    } else if (g.Cin == 32 && g.reflect_hw) {                            // the first reducer: tf.pad(REFLECT) in rows / columns, no depth pads, dY masked by the layer's output
+        if (g.reflect_hw || g.pt != 1 || g.To != g.Ti || gate || (g.To != 13 && g.To != 9 && g.To != 7)) return false;
+        if (g.To == 13) nsplit = 2;
+    } else if (g.Cin == 32 && g.reflect_hw) {                            // the mirrored-pad reducers: tf.pad(REFLECT) in rows / columns, no depth pads, dY masked by the layer's output (depth 13 -> 11: column halves)
         if (g.Wo != 22 || g.Wi != 22 || g.Ho != g.Hi || g.ph != 1 || g.pw != 1) return false;
-        if (g.pt != 0 || g.To != g.Ti - 2 || !gate || g.Hi < 2 || (g.To != 7 && g.To != 5 && g.To != 3)) return false;
+        if (g.pt != 0 || g.To != g.Ti - 2 || !gate || g.Hi < 2 || (g.To != 11 && g.To != 9 && g.To != 7 && g.To != 5 && g.To != 3)) return false;
+        if (g.To == 11) nsplit = 2;
     } else if (g.Cin == 32) {                                            // the reducers behind it: no pads at all, dY masked
         if (g.ph != 0 || g.pw != 0 || g.pt != 0 || g.Ho != g.Hi - 2 || g.Wo != g.Wi - 2 || g.To != g.Ti - 2 || !gate) return false;
         if (!((g.Wo == 20 && g.To == 5) || (g.Wo == 18 && g.To == 3))) return false;
     } else return false;
-    if (g.N < 1 || g.N > 256 || g.Ho < 1) return false;                  // one slab per workgroup, at most 256 of them (x6_wgrad_partial_floats)
-    int nstrips = 256 / g.N;
+    if (g.N < 1 || g.N * nsplit > 256 || g.Ho < 1) return false;         // one slab per workgroup, at most 256 of them (x6_wgrad_partial_floats)
+    int nstrips = 256 / (g.N * nsplit);
     if (nstrips > g.Ho) nstrips = g.Ho;
     const int SR = (g.Ho + nstrips - 1) / nstrips;
     nstrips = (g.Ho + SR - 1) / SR;
-    p.N = g.N; p.H = g.Ho; p.SR = SR; p.nstrips = nstrips;
-    grid = g.N * nstrips;
+    p.N = g.N; p.H = g.Ho; p.SR = SR; p.nstrips = nstrips; p.nsplit = nsplit;
+    grid = g.N * nsplit * nstrips;
     return true;
 }
 
@@ -590,15 +602,19 @@ int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const flo
     std::call_once(once, [] {
 #define WG4_BIG(W, TP, RT, C, M) note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_w4_kernel<W, TP, RT, C, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840))
         WG4_BIG(22, 11, WG4_RT, 25, 0); WG4_BIG(22, 9, WG4_RT, 25, 0); WG4_BIG(22, 9, 32, 32, 1); WG4_BIG(22, 7, 32, 32, 1); WG4_BIG(22, 5, 32, 32, 1);
-        WG4_BIG(20, 7, 32, 32, 2); WG4_BIG(18, 5, 32, 32, 2); });
+        WG4_BIG(20, 7, 32, 32, 2); WG4_BIG(18, 5, 32, 32, 2);
+        WG4_BIG(11, 15, WG4_RT, 25, 0); WG4_BIG(11, 13, 32, 32, 1); WG4_BIG(22, 11, 32, 32, 1); });
 #undef WG4_BIG
     const long nw = (long)27 * g.Cin * g.Cout;
     float* partial_b = partial + (size_t)grid * nw;
     const int Tp = g.To + 2;
-    const size_t lds_bytes = (size_t)4 * 2 * (g.Wo + 2) * Tp * 64 + 1024 + (size_t)((g.Wo * g.To + 15) / 16) * 2048;      // ring, slack, the row's dY fragments
+    const int Wk = g.Wo / p.nsplit;                                        // columns of a workgroup's rows
+    const size_t lds_bytes = (size_t)4 * 2 * (Wk + 2) * Tp * 64 + 1024 + (size_t)((Wk * g.To + 15) / 16) * 2048;      // ring, slack, the row's dY fragments
 #define WG4_LAUNCH(W, TP, RT, C, M) hipLaunchKernelGGL((conv3_wgrad_w4_kernel<W, TP, RT, C, M>), dim3(grid), dim3(256), lds_bytes, s, p, x, dy, gate, partial, partial_b, am)
-    if (g.Cin == 25) { if (g.To == 9) WG4_LAUNCH(22, 11, WG4_RT, 25, 0); else WG4_LAUNCH(22, 9, WG4_RT, 25, 0); }
+    if (g.Cin == 25) { if (g.To == 13) WG4_LAUNCH(11, 15, WG4_RT, 25, 0); else if (g.To == 9) WG4_LAUNCH(22, 11, WG4_RT, 25, 0); else WG4_LAUNCH(22, 9, WG4_RT, 25, 0); }
     else if (!g.reflect_hw) { if (g.Wo == 20) WG4_LAUNCH(20, 7, 32, 32, 2); else WG4_LAUNCH(18, 5, 32, 32, 2); }
+    else if (g.To == 11) WG4_LAUNCH(11, 13, 32, 32, 1);
+    else if (g.To == 9) WG4_LAUNCH(22, 11, 32, 32, 1);
     else if (g.To == 7) WG4_LAUNCH(22, 9, 32, 32, 1);
     else if (g.To == 5) WG4_LAUNCH(22, 7, 32, 32, 1);
     else WG4_LAUNCH(22, 5, 32, 32, 1);

@@ -116,6 +116,11 @@ CONV_CASES = [
     ("unpadded reducer 15x22x7 -> 13x20x5", 3, (15, 22, 7), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
     ("unpadded reducer 9x20x5 -> 7x18x3", 5, (9, 20, 5), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
     ("unpadded reducer 3x20x5 -> 1x18x3", 2, (3, 20, 5), 32, 32, (3, 3, 3), (0, 0, 0), 0, 1, 0, 0),
+    # depth 13 through conv3_wgrad_w4_kernel: a workgroup takes half the columns of a row (the neighbour half's edge column beside its own)
+    ("T=13 normConv, three patches + skip", 3, (22, 22, 13), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("T=13 normConv 5 rows", 2, (5, 22, 13), 25, 32, (3, 3, 3), (1, 1, 1), 0, 0, 0, 1),
+    ("mirrored-pad reducer, depth 13 -> 11, three patches", 3, (22, 22, 13), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
+    ("mirrored-pad reducer, depth 11 -> 9", 2, (22, 22, 11), 32, 32, (3, 3, 3), (1, 1, 0), 1, 1, 0, 0),
 ]
 
 
