@@ -153,13 +153,15 @@ def test_one_wave_per_simd_convolution_agrees_with_the_general_form(B, T, tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(5, 9), (2, 7), (128, 9)], ids=["b5-t9", "b2-t7", "b128-t9"])
+@pytest.mark.parametrize("B,T", [(5, 9), (2, 7), (128, 9), (3, 13)], ids=["b5-t9", "b2-t7", "b128-t9", "b3-t13"])
 def test_one_wave_per_simd_backward_filter_agrees_with_the_general_form(B, T, tmp_path):
     """The backward-filter of the residual blocks and of the reducers in round 5 (conv3_wgrad_w4_kernel: one wave per SIMD, 64-byte piece planes of the input ring, dY cut
     once per workgroup, a tile's k-blocks ONE accumulation chain per row; the reducers' layer with mirrored pads, no depth pads and dY masked by the layer's output) evaluates
     the products of the general form (conv3_wgrad_x6_kernel<25 | 32, H3>, PROBAV_GEN1=wg: two k-block parities added at the end) -- the same scaled fp16 pieces with the same
     two tensor-wide scales, another order of the fp32 additions inside a workgroup's slab.  The forward pass and every other gradient are untouched: identical predictions, the
-    flat gradient vector to 1e-5 of its max-norm.  (T = 9: reducer rows of 10 / 7 / 5 k-blocks; T = 7: 7 / 5.)"""
+    flat gradient vector to 1e-5 of its max-norm.  (T = 9: reducer rows of 10 / 7 / 4 k-blocks, the last two unpadded; T = 7: 7 / 5; T = 13: column halves for normConv and the
+    first reducer.  Since the end of round 5 the one-wave-per-SIMD kernel's second pieces are lifted by 2^11 and its cross products have their own accumulator: the same products, summed
+    more exactly.)"""
     import numpy as np
     a, b = str(tmp_path / "w4.npz"), str(tmp_path / "gen1.npz")
     _run({}, B, T, 1, a)
