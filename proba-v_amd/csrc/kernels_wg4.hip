@@ -26,6 +26,13 @@
 #include <cstdlib>
 #include <mutex>
 
+// The kernel's ten instances are one unrolled instruction stream each and 6 min 40 s of hipcc in one translation unit: kernels_wg4b.hip / kernels_wg4c.hip include THIS file with
+// WG4_PART = 1 / 2 and instantiate their share of them (WG4_PART1 / WG4_PART2 below); part 0 -- this file compiled for itself -- declares those `extern template`, instantiates the
+// residual blocks' three by use and holds the host side.  (tools/wg4*.hip include the file as probav::diag: everything in one unit.)
+#ifndef WG4_PART
+#define WG4_PART 0
+#endif
+
 namespace probav {
 #ifdef WG4_DIAG                 // tools/wg4bench.hip includes this file as probav::diag (stamped / ablated builds beside the product's copy in the library)
 namespace diag {
@@ -545,10 +552,29 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #endif
 }
 
-// ---- host side ----
 #ifndef WG4_RT
 #define WG4_RT 28                // (32: 27 tap tiles, conflict-free reads, 12.5 % more MFMAs -- measured 9 % slower)
 #endif
+// ---- the instances of the other translation units (the reducers': mirrored pads at depths 9 / 7 / 5 / 11 and 13 on column halves, the two unpadded layers) ----
+#define WG4_SIG(W, TP, RT, C, M) __global__ void conv3_wgrad_w4_kernel<W, TP, RT, C, M>(Wg4Args, const float*, const float*, const float*, float*, float*, Amax)
+#define WG4_PART1(X) X(22, 9, 32, 32, 1) X(22, 7, 32, 32, 1) X(22, 5, 32, 32, 1) X(18, 5, 32, 32, 2)
+#define WG4_PART2(X) X(22, 11, 32, 32, 1) X(11, 13, 32, 32, 1) X(20, 7, 32, 32, 2)
+#ifndef WG4_DIAG
+#define WG4_DEF(W, TP, RT, C, M) template WG4_SIG(W, TP, RT, C, M);
+#define WG4_EXT(W, TP, RT, C, M) extern template WG4_SIG(W, TP, RT, C, M);
+#if WG4_PART == 0
+WG4_PART1(WG4_EXT) WG4_PART2(WG4_EXT)
+#elif WG4_PART == 1
+WG4_PART1(WG4_DEF)
+#else
+WG4_PART2(WG4_DEF)
+#endif
+#undef WG4_DEF
+#undef WG4_EXT
+#endif
+
+#if WG4_PART == 0
+// ---- host side ----
 static bool wg4_plan(const ConvGeom& g, const float* gate, Wg4Args& p, int& grid)
 {
     if (g.kh != 3 || g.kw != 3 || g.kt != 3 || g.reflect_t || g.Cout != 32) return false;
@@ -623,6 +649,8 @@ int wg4_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const flo
     if (rc) return rc;
     return mfma_wgrad_reduce(partial, partial_b, dw, db, nw, g.Cout, grid, s);
 }
+
+#endif  // WG4_PART == 0
 
 #ifdef WG4_DIAG
 }  // namespace diag
