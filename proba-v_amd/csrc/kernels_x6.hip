@@ -1421,8 +1421,15 @@ int x6_conv_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
 {
     if (!x6_wgrad_supported(g)) { set_error("x6_conv_wgrad: unsupported geometry", hipSuccess); return PROBAV_EINVAL; }
     if (arith == 2 && (!am.x || !am.w)) { set_error("x6_conv_wgrad: H3 arithmetic needs the per-sample amax slots of x (am.x) and dY (am.w)", hipSuccess); return PROBAV_EINVAL; }
-    // round 5: the residual blocks' layer as one-wave-per-SIMD kernel (kernels_wg4.hip); this kernel is the general form (any extent, pads, reflect, gate, 32 channels)
-    if (arith == 2 && wg4_enabled() && wg4_wgrad_supported(g, gate)) return wg4_conv_wgrad(g, x, dy, gate, dw, db, partial, am, s);
+    // round 5: the residual blocks' and the reducers' layers as one-wave-per-SIMD kernel (kernels_wg4.hip); this kernel is the general form (any extent, pads, reflect, gate, 32 channels).
+    // H3 on the general form would be H3 with PLAIN second pieces: one scale per operand tensor and a channel 2^-24 below its mates resolved to 7e-5 (the lifted pieces of
+    // conv3_wgrad_w4_kernel need a second accumulator set, and this kernel's 112 accumulator registers live in a budget of 128).  A layer without an instance of that kernel
+    // (depth 19, other extents, more than 256 samples) therefore runs the x6 arithmetic here -- bf16 pieces carry fp32's exponent, no operand is scaled, every slice is resolved;
+    // the H3 instance stays reachable for A/B runs (PROBAV_GEN1 = wg | 1: every layer on this kernel, H3 as in rounds 2 - 4).
+    if (arith == 2 && wg4_enabled()) {
+        if (wg4_wgrad_supported(g, gate)) return wg4_conv_wgrad(g, x, dy, gate, dw, db, partial, am, s);
+        arith = 1;
+    }
     if (arith == 2 && x6_wgrad_split(g, 2) == 0) arith = 1;                  // (the H3 form also needs room for the dY image; the scale-free form serves the rest)
     WgArgs a;
     a.nsplit = x6_wgrad_split(g, arith); a.Wt = (g.Wo + a.nsplit - 1) / a.nsplit;

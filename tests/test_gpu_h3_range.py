@@ -10,10 +10,11 @@ channel -- against ITS OWN maximum, holding impl 4 to the bound the native fp32-
   * filter columns with log-uniform gains over 2^-30 .. 1;
   * channel gains on the CONTRACTED index (input channels): the small channels' contributions are small in every output, so the
     per-slice error stays at fp32 level although those inputs are represented coarsely;
-  * the one documented limit: in the backward-FILTER products the contraction runs over voxels, the slices are (cin, cout) pairs,
-    and the operands are scaled per tensor -- a channel 2^-30 below its tensor mates gets a coarse gradient slice (graceful: the
-    error stays below 2^-38 of the product of the tensor maxima, test_wgrad_limit_of_the_general_form_is_graceful; the
-    one-wave-per-SIMD kernel of the shipped network resolves every slice: test_wgrad_resolves_every_channel_slice).
+  * the backward-FILTER products contract over the voxels of all samples: the slices are (cin, cout) pairs and the operands take one
+    scale per tensor.  Rounds 2 - 4 documented a limit here (a channel 2^-24 below its tensor mates got a coarse gradient slice);
+    since the end of round 5 the second pieces are stored lifted by 2^11 (conv3_wgrad_w4_kernel) and every slice is held to the bar
+    (test_wgrad_resolves_every_channel_slice, test_reducer_wgrad_resolves_every_channel_slice); a layer that kernel has no instance
+    for runs the unscaled x6 arithmetic (test_wgrad_without_an_instance_of_the_lifted_kernel_is_not_scaled).
 
 The forward result of a sample does not depend on its batch mates, bit for bit (the reference's model(x) has no cross-sample
 term, models/modelsTF.py:15-43): test_forward_is_bitwise_independent_of_the_batch."""
@@ -256,27 +257,22 @@ def test_reducer_wgrad_resolves_every_channel_slice(dev, layer):
         assert e < BAR, (layer, impl, e)
 
 
-def test_wgrad_limit_of_the_general_form_is_graceful(dev):
-    """What is left of the documented limit: the GENERAL backward-filter kernel (conv3_wgrad_x6_kernel<H3>: depth 19, extents conv3_wgrad_w4_kernel has no instance
-    for -- here rows of 14 columns) keeps plain second pieces -- its register budget has no room for the second accumulator.  An input channel far below its tensor mates loses relative accuracy in ITS
-    gradient slices gradually: channels down to 2^-10 of the tensor maximum keep fp32-level slices, the smallest here (2^-24) still has 1e-2; the whole-tensor metric does
-    not see any of it, and the x6 family (impl 3, no scaling) resolves every slice."""
-    rng = np.random.default_rng(7)
-    N, hwt, Cin, Cout = 2, (22, 14, 9), 25, 32
-    x = rng.normal(size=(N,) + hwt + (Cin,)).astype(np.float32)
-    dy = rng.normal(size=(N,) + hwt + (Cout,)).astype(np.float32)
-    gains = _gains(rng, Cin, -24)
-    x *= gains
-    g = _geom(N, 22, 14, 9, Cin, 22, 14, 9, Cout, (3, 3, 3), (1, 1, 1))
+@pytest.mark.parametrize("hwt", [(22, 14, 9), (22, 22, 19), (9, 30, 5)], ids=["22x14x9", "22x22x19", "9x30x5"])
+def test_wgrad_without_an_instance_of_the_lifted_kernel_is_not_scaled(dev, hwt):
+    """A layer conv3_wgrad_w4_kernel has no instance for (depth 19, rows that are not 22 columns) runs the general backward-filter kernel with the x6 arithmetic also in the
+    default family: H3 there would be H3 with plain second pieces and one scale per tensor -- a channel 2^-24 below its mates resolved to 7e-5 (rounds 2 - 4: the documented limit;
+    profiles/r05_wgrad_lift_ab.txt) -- while bf16 pieces carry fp32's exponent and need no scale.  Channel gains on both operands, every (cin, cout) slice held to BAR."""
+    rng = np.random.default_rng(zlib.crc32(repr(hwt).encode()))
+    N, Cin, Cout = 2, 25, 32
+    x = (rng.normal(size=(N,) + hwt + (Cin,)) * _gains(rng, Cin, -24)).astype(np.float32)
+    dy = (rng.normal(size=(N,) + hwt + (Cout,)) * _gains(rng, Cout, -24)).astype(np.float32)
+    g = _geom(N, hwt[0], hwt[1], hwt[2], Cin, hwt[0], hwt[1], hwt[2], Cout, (3, 3, 3), (1, 1, 1))
+    if _L().lib().probav_conv3d_wgrad_scratch_bytes(ctypes.byref(g), 4) == 0:
+        pytest.skip("geometry not covered by the MFMA backward-filter kernels (the engine falls back to the VALU kernel)")
     ref = _oracle_wgrad(x, dy, 1)
-    got4, got3 = _wgrad(dev, 4, g, x, dy), _wgrad(dev, 3, g, x, dy)
-    assert np.abs(got4 - ref).max() < 2e-6 * np.abs(ref).max()                      # the whole-tensor metric does not see it at all
-    per3 = np.abs(got3 - ref).max(axis=(0, 1, 2, 4)) / np.abs(ref).max(axis=(0, 1, 2, 4))          # slice = input channel
-    per4 = np.abs(got4 - ref).max(axis=(0, 1, 2, 4)) / np.abs(ref).max(axis=(0, 1, 2, 4))
-    for c in np.argsort(gains):
-        print("input channel gain 2^%6.2f: slice error x6 %.2e  H3 (general form) %.2e" % (np.log2(gains[c]), per3[c], per4[c]))
-    assert per3.max() < 1e-5
-    assert per4[gains >= 2.0 ** -10].max() < 1e-5 and per4.max() < 1e-2
+    e = _slice_err(_wgrad(dev, 4, g, x, dy), ref, (0, 1, 2))
+    print("impl 4 wgrad on %s (no instance of the lifted kernel): worst (cin, cout) slice error %.3g" % (hwt, e))
+    assert e < BAR, (hwt, e)
 
 
 def _model(dev, params, T=9):
