@@ -67,3 +67,14 @@ def test_initial_state_is_the_reference_first_call_state():
         assert float(b.abs().max()) == 0.0
         fan = (v.numel() // (v.shape[-1] * v.shape[-2])) * (v.shape[-1] + v.shape[-2])
         assert float(v.abs().max()) <= (6.0 / fan) ** 0.5 + 1e-7
+
+
+def test_build_knows_the_units_that_include_other_units():
+    """kernels_wg4b.hip / kernels_wg4c.hip are the backward-filter kernel's other instances: they include kernels_wg4.hip (three translation units for the build time's sake),
+    so build() must rebuild them when THAT file changes and compile them with its flags."""
+    import __graft_entry__ as ge
+    for name in ("kernels_wg4b.hip", "kernels_wg4c.hip"):
+        deps = ge._included_units(os.path.join(ge.CSRC, name))
+        assert [os.path.basename(d) for d in deps] == ["kernels_wg4.hip"], (name, deps)
+        assert ge.UNIT_FLAGS[name] == ge.UNIT_FLAGS["kernels_wg4.hip"]
+    assert ge._included_units(os.path.join(ge.CSRC, "kernels_wg4.hip")) == []
