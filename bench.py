@@ -50,7 +50,7 @@ DTYPES = {3: "f32 (products as 6 bf16-piece MFMA products, f32 accumulate)", 4: 
 
 
 def hbm_profile_path():
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             return p
@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short T=13 training and full-frame inference legs")
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not start the child process that samples board power and sclk (always give this under rocprofv3)")
+    ap.add_argument("--no-trainer-loop", action="store_true", help="skip the ModelTrainer.fitTrainData leg of other_configs")
+    ap.add_argument("--trainer-steps", type=int, default=240, help="steps of the ModelTrainer.fitTrainData leg (>= 200 for a stable median)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--side-stream-mode", type=int, default=-1, choices=(-1, 0, 1, 2),
                     help="probav_engine_side_stream: 2 = slab sums, residual path AND the backward-filter kernels on the engine's low-priority "
@@ -155,6 +158,89 @@ def percentiles(ms):
     q = lambda f: s[min(len(s) - 1, max(0, int(round(f * (len(s) - 1)))))]
     return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(s[0], 4), "max": round(s[-1], 4), "n": len(s),
             "argmax": max(range(len(ms)), key=lambda i: ms[i])}       # which step of the timed region was the slowest (0 = the first)
+
+
+# -----------------------------------------------------------------------------------------------------------------------------
+# Board power and shader clock beside the timed region.  A CHILD process that never touches the GPU (no torch, no HIP) reads the
+# amdgpu hwmon files (power1_input in microwatts, freq1_input = sclk in Hz) every ~10 ms and prints "time power sclk" lines; the bench keeps the
+# samples that fall inside the timed region's wall-clock window.  Not started under rocprofv3 (--no-power, and skipped by itself when a profiler's
+# library is preloaded): the profiler's tool library would initialise in the child as well.
+_SAMPLER_SRC = r"""
+import glob, sys, time
+paths = sys.argv[1:]
+def rd(p):
+    try:
+        with open(p) as fh:
+            return fh.read().strip()
+    except OSError:
+        return "nan"
+while True:
+    t = time.time()
+    sys.stdout.write(" ".join([repr(t)] + [rd(p + "/power1_input") + " " + rd(p + "/freq1_input") for p in paths]) + "\n")
+    sys.stdout.flush()
+    time.sleep(0.008)
+"""
+
+
+class PowerSampler:
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.proc, self.paths, self.pci = None, [], pci_bus_id
+        if pci_bus_id:
+            self.paths = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % pci_bus_id))
+        if not self.paths:                      # the device's PCI address is unknown: every board's sensors, the one whose power moves with the run is ours
+            self.paths = sorted(p for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(p + "/power1_input"))
+            self.pci = None
+        self.paths = self.paths[:16]
+
+    def start(self):
+        if not self.paths or any(k in os.environ.get("LD_PRELOAD", "") for k in ("rocprof", "roctracer")) or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+            return False
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_SRC] + self.paths, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                         env={k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",)}, text=True)
+        except OSError:
+            self.proc = None
+        return self.proc is not None
+
+    def stop(self, windows):
+        """windows: {name: (t0, t1)} in time.time() -> {name: {board_power_W, sclk_GHz, ...}} of the samples inside each window."""
+        if self.proc is None:
+            return None
+        self.proc.terminate()
+        try:
+            text, _ = self.proc.communicate(timeout=5)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+            text, _ = self.proc.communicate()
+        rows = []
+        for line in text.splitlines():
+            f = line.split()
+            if len(f) == 1 + 2 * len(self.paths):
+                try:
+                    rows.append([float(v) for v in f])
+                except ValueError:
+                    pass
+        if not rows:
+            return None
+        col = 0
+        if len(self.paths) > 1:                 # the board whose power rose the most above its first samples
+            base = rows[:5]
+            rise = [max(r[1 + 2 * c] for r in rows) - sum(r[1 + 2 * c] for r in base) / len(base) for c in range(len(self.paths))]
+            col = max(range(len(self.paths)), key=lambda c: rise[c] if rise[c] == rise[c] else -1)
+        out = {"sensor": self.paths[col], "pci_bus_id": self.pci, "sample_period_ms": round((rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1) * 1e3, 2),
+               "note": "amdgpu hwmon power1_input (socket power) and freq1_input (sclk) read by a child process that never touches the GPU; mean / "
+                       "min / max of the samples inside each wall-clock window"}
+        for name, (t0, t1) in windows.items():
+            sel = [r for r in rows if t0 <= r[0] <= t1 and r[1 + 2 * col] == r[1 + 2 * col]]
+            if not sel:
+                out[name] = None
+                continue
+            pw = [r[1 + 2 * col] * 1e-6 for r in sel]
+            ck = [r[2 + 2 * col] * 1e-9 for r in sel if r[2 + 2 * col] == r[2 + 2 * col]]
+            out[name] = {"samples": len(sel), "board_power_W": {"mean": round(sum(pw) / len(pw), 1), "min": round(min(pw), 1), "max": round(max(pw), 1)},
+                         "sclk_GHz": {"mean": round(sum(ck) / len(ck), 3), "min": round(min(ck), 3), "max": round(max(ck), 3)} if ck else None}
+        return out
 
 
 def dry_run(args, world, rank):
@@ -298,6 +384,16 @@ def run_rank(args):
     side_probe = None
     if args.side_stream_mode >= 0:
         _lib.check(L.probav_engine_side_stream(h, args.side_stream_mode), "probav_engine_side_stream")
+    sampler, windows = None, {}
+    if rank == 0 and not args.no_power:
+        props = torch.cuda.get_device_properties(dev)
+        try:
+            pci = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        except AttributeError:
+            pci = None
+        sampler = PowerSampler(pci)
+        if not sampler.start():
+            sampler = None
     for _ in range(args.warmup):
         step()
     sync()
@@ -317,7 +413,9 @@ def run_rank(args):
         return {c: {"ms": ms[i], "macs": macs[i], "launches": int(cnt[i])} for i, c in enumerate(CLASSES)}
 
     # THE timed region: exactly K steps, nothing else on the stream but the K + 1 step-boundary events.
+    w0 = time.time()
     dt, step_ms, loss = timed(step, args.steps)
+    windows["headline_timed_region"] = (w0, time.time())
     digest = None
     if args.digest:
         import hashlib
@@ -396,6 +494,7 @@ def run_rank(args):
         sink = torch.empty(256 * 256, device=dev)
         iters, launches = 2000, 8
         shapes = {}
+        w0 = time.time()
         for shape, name in ((0, "32x32x16"), (1, "16x16x32")):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             _lib.check(L.probav_mfma_probe_shape(_lib.ptr(seed), _lib.ptr(sink), iters, 4, shape, _lib.current_stream()), "probav_mfma_probe_shape")
@@ -405,6 +504,7 @@ def run_rank(args):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
             shapes[name] = {"tflops": round(launches * 256 * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 3)}
+        windows["sustained_mfma_probe"] = (w0, time.time())
         mfma_probe = {"tflops": shapes["32x32x16"]["tflops"], "ms": shapes["32x32x16"]["ms"], "by_shape": shapes,
                       "note": "dependent fp16 MFMA chains, one wave per SIMD on every CU, random operands: the fp16 matrix rate this device "
                               "sustains (data sheet: 2 500 dense) with v_mfma_f32_32x32x16_f16 (the shape the H3 kernels issue, three per fp32 "
@@ -417,10 +517,19 @@ def run_rank(args):
         for _ in range(2):
             step()
         k2 = max(3, args.steps // 10)
+        w0 = time.time()
         t2, _, _ = timed(step, k2)
+        windows["fp32_mfma_leg"] = (w0, time.time())
         fp32_leg = {"value": round(world * B * k2 / t2, 2), "unit": "patches/s", "ms_per_step": round(t2 / k2 * 1e3, 4), "steps": k2,
                     "note": "same step on the native fp32-MFMA kernels (--impl 2), for reference"}
         model.set_impl(args.impl)
+    power = None
+    if sampler is not None:
+        if args.steps * (dt / max(1, args.steps)) < 0.5:        # a short headline region holds few 10-ms samples: a second, untimed stretch of the same steps for the sensors
+            w0 = time.time()
+            timed(step, max(args.steps, int(0.8 / (dt / args.steps))))
+            windows["same_steps_untimed_0.8s"] = (w0, time.time())
+        power = sampler.stop(windows)
 
     other = None
     if world == 1 and T == 9 and not args.no_other_configs:
@@ -466,12 +575,76 @@ def run_rank(args):
         assert img.shape == (32, 384, 384)
         other["config4_inference"] = {"workload": "32 image sets x 9 frames of 128x128 resident in HBM -> unfold to 2048 patches of [22,22,9,1] -> forward -> "
                                                   "clip[0,2^16] + round-half-even -> stitch to 32 x [384,384] (test.py path)", **inf}
+        if not args.no_trainer_loop:
+            # The reference's own entry point (train.py -> ModelTrainer.fitTrainData, models/trainClass.py:61-122): host arrays -> shuffle / repeat / batch -> pinned
+            # prefetch -> trainStep (forward, shift-L1, backward, Nadam fused with the next step's weight norm, cPSNR, running means, the per-step log line) on
+            # synthetic host data; beside it the bare full step (the same device work launched by this file's loop, data resident).  VERDICT r5 #6.
+            import logging
+            import tempfile
+            from probav_amd.trainClass import ModelTrainer
+            model._ws.clear()
+            mt, dtr_ = make(9)
+            mt.set_side_stream_mode(args.side_stream_mode)
+            opt_t = make_optimizer("nadam", mt, 5e-4)
+            s_full = stepper(mt, dtr_, opt_t)
+            for _ in range(3):
+                s_full(True)
+            kf = 40
+            tf_, msf, _ = timed(s_full, kf, True)
+            full_med = percentiles(msf)["median"]
+            nsamp = 4 * B
+            xh, hh, mh = synth.synth_batch(nsamp, seed=99)
+            lvl = logging.root.manager.disable
+            logging.disable(logging.CRITICAL)
+            try:
+                with tempfile.TemporaryDirectory() as d:
+                    tr = ModelTrainer(model=mt, loss=losses.shiftCompensatedL1Loss, metric=losses.shiftCompensatedcPSNR, optimizer=opt_t, ckptDir=d, logDir=d,
+                                      evalStep=10 ** 9)
+                    tr.tune_side_stream = False                       # (the mode is the headline run's; the trainer's own probe would spend 36 of these steps on it)
+                    val = (xh[:B], hh[:B], mh[:B])
+                    tr.fitTrainData(xh[:2 * B], (hh[:2 * B], mh[:2 * B]), B, 4, val)      # warm-up: 8 steps
+                    evs_t, inner = [], tr.trainStep
+
+                    def stamped(*a):
+                        e = torch.cuda.Event(enable_timing=True)
+                        e.record()
+                        evs_t.append(e)
+                        return inner(*a)
+                    tr.trainStep = stamped
+                    want = max(8, args.trainer_steps)
+                    epochs_t = (want * B + nsamp - 1) // nsamp
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    s0 = tr.step
+                    tr.fitTrainData(xh, (hh, mh), B, epochs_t, val)
+                    torch.cuda.synchronize()
+                    wall = time.perf_counter() - t0
+                    kt = tr.step - s0
+            finally:
+                logging.disable(lvl)
+            ms_t = [evs_t[i].elapsed_time(evs_t[i + 1]) for i in range(len(evs_t) - 1)]
+            st_t = percentiles(ms_t)
+            other["trainer_loop"] = {"steps": kt, "ms_per_step_median": st_t["median"], "ms_per_step_wall_mean": round(wall / kt * 1e3, 4), "step_ms": st_t,
+                                     "patches_per_s_at_median_step": round(B / (st_t["median"] * 1e-3), 1),
+                                     "bare_full_step_ms_median": full_med, "bare_full_step_steps": kf,
+                                     "trainer_over_bare_full_step": round(st_t["median"] / full_med, 4),
+                                     "workload": "ModelTrainer.fitTrainData on %d synthetic host patches (numpy), batch %d: shuffle/repeat/batch + pinned prefetch + "
+                                                 "trainStep (fwd + shift-L1 + bwd + fused Nadam/weight-norm + cPSNR + running means + log line); step_ms = HIP events "
+                                                 "at the head of every trainStep; bare_full_step = the same device work from bench.py's loop on resident data" % (nsamp, B)}
+            mt._ws.clear()
+            del mt, dtr_, s_full, opt_t
 
     if rank == 0:
         value = world * B * args.steps / dt
         out = {
             "metric": "LR-patches/sec fwd+bwd (WDSR-B r12 t%d, 16x16, bs%d)" % (T, B),
-            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "patches/s", "n_gpus": world,
+            # (early in the line so that a truncated tail still shows them: the same step on the native fp32-MFMA kernels, and the headline at the MEDIAN timed step --
+            #  the first step behind the synchronize that opens the timed region refills the launch pipeline and is ~1.2 ms longer than the others, so the mean of a
+            #  20-step region sits ~1 % under the steady state)
+            "fp32_mfma_path_value": fp32_leg["value"] if fp32_leg is not None else None,
+            "value_at_median_step": round(world * B / (percentiles(step_ms)["median"] * 1e-3), 2),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPES.get(args.impl, "f32"), "data": "synthetic",
             "step_ms": dict(percentiles(step_ms), note="rank 0, HIP events on the launch stream at every step boundary of the timed steps"),
@@ -519,6 +692,8 @@ def run_rank(args):
             out["sustained_mfma"] = mfma_probe
             # the pool's boxes differ by several percent in what their matrix pipe sustains: the headline per sustained TFLOP/s compares builds across boxes
             out["normalised_value"] = {"value": round(value / world / mfma_probe["tflops"], 4), "unit": "patches/s per sustained fp16-MFMA TFLOP/s (32x32x16), per GPU"}
+        if power is not None:
+            out["power"] = power
         if fp32_leg is not None:
             out["fp32_mfma_path"] = fp32_leg
             # the pool's boxes fall into two classes under fp16-MFMA load (~8 % apart on the H3 kernels, < 1 % apart on the fp32-MFMA path):

@@ -183,7 +183,16 @@ int probav_conv3d_wgrad(const int32_t geom[17], const float* x, const float* dy,
 int probav_pw_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* dec,
                       int64_t nvox, int64_t vox_per_sample, int D, int impl, void* stream);
 /* its reverse pass: d_dec [nvox,D], d_skip [nvox,32] (gradient arriving over the residual connection)
- * -> dx = d_skip + dL/dx [nvox,32], dw1 [32,256], db1 [256], dw2 [256,D], db2 [D]                              */
+ * -> dx = d_skip + dL/dx [nvox,32], dw1 [32,256], db1 [256], dw2 [256,D], db2 [D]
+ * ACCURACY OF THE FILTER GRADIENTS, impl 4 (declared bound; tests/test_gpu_h3_range.py::test_pointwise_filter_gradients_slice_by_slice
+ * asserts it).  dx, db1, db2 and every slice of dw1 / dw2 whose channel is within 2^-18 of its sample's largest value are at fp32 level
+ * (<= 5e-6 of the slice's own maximum, the bar impl 2 and 3 meet on every slice).  dw1 (a ROW = one input channel of x) and dw2 (a
+ * COLUMN = one channel of d_dec) contract over the voxels, but the kernel cuts x and d_dec into their two fp16 pieces ONCE per tile
+ * with the per-SAMPLE power-of-two scale that the products contracting over those channels need; a channel that sits 2^-k below its
+ * sample's maximum keeps both pieces normal only down to k = 18, and loses one bit of its second piece per binade below: the row /
+ * column of such a channel is resolved to <= 1e-4 of its own maximum at k = 24 (measured 4.8e-5 / 9.0e-5) -- still far inside
+ * north_star's 1e-3, and invisible in a whole-tensor norm.  The cure of the 3x3x3 backward-filter kernel (second pieces lifted by 2^11,
+ * the cross products in an accumulator set of their own) needs 256 more accumulator registers than a wave has.  impl 2 / 3: no such floor. */
 size_t probav_pw_backward_scratch_bytes(int D);
 int probav_pw_backward(const float* x, const float* d_dec, const float* d_skip, const float* w1, const float* b1,
                        const float* w2, float* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch,

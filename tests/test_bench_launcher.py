@@ -40,3 +40,30 @@ def test_bench_parent_does_not_import_torch():
     e.pop("RANK", None); e.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=e, cwd=ROOT)
     assert p.returncode == 0 and p.stdout.strip() == "False", p.stdout + p.stderr
+
+
+def test_power_sampler_reads_hwmon_files_from_a_child_process(tmp_path):
+    """bench.py's board-power / shader-clock sampler: a child process that reads amdgpu's hwmon files, windows cut by wall clock.
+    Here on two fake sensors: the one whose power moves is taken for the device, its samples inside the window are averaged."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    paths = []
+    for k, (uw, hz) in enumerate(((255000000, 95000000), (250000000, 500000000))):
+        d = tmp_path / ("hwmon%d" % k)
+        d.mkdir()
+        (d / "power1_input").write_text("%d\n" % uw)
+        (d / "freq1_input").write_text("%d\n" % hz)
+        paths.append(str(d))
+    s = bench.PowerSampler(None)
+    s.paths, s.pci = paths, None
+    assert s.start()
+    time.sleep(0.15)
+    t0 = time.time()
+    (tmp_path / "hwmon1" / "power1_input").write_text("1000000000\n")            # the load arrives on the second board: 1 kW at 1.6 GHz
+    (tmp_path / "hwmon1" / "freq1_input").write_text("1600000000\n")
+    time.sleep(0.25)
+    t1 = time.time()
+    out = s.stop({"run": (t0 + 0.05, t1), "nothing": (t1 + 10, t1 + 11)})
+    assert out["sensor"] == paths[1] and out["nothing"] is None
+    assert out["run"]["samples"] >= 5 and out["run"]["board_power_W"]["mean"] == 1000.0 and out["run"]["sclk_GHz"]["max"] == 1.6

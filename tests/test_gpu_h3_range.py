@@ -138,8 +138,10 @@ def test_fused_pointwise_slices_under_dynamic_range(dev, scenario, impl):
         x[0, 100] *= np.float32(2.0 ** 20); ddec[1, 7] *= np.float32(2.0 ** 20)
     if scenario == "w2_column_gains":
         w2 *= _gains(rng, D)
+    gx = np.ones(32, np.float32)
     if scenario == "input_channel_gains":
-        x *= _gains(rng, 32, -24)
+        gx = _gains(rng, 32, -24)
+        x *= gx
     X, W1, W2 = x.reshape(nvox, 32).astype(np.float64), w1.astype(np.float64), w2.astype(np.float64)
     Hpre = X @ W1 + b1
     Hh = np.maximum(Hpre, 0)
@@ -157,11 +159,93 @@ def test_fused_pointwise_slices_under_dynamic_range(dev, scenario, impl):
     L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
                                        L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, vps, D, impl, L.current_stream()))
     e_dx = _slice_err(dx.cpu().numpy().reshape(ns, vps, 32), rdx, (1,))
-    # the weight gradients sum over the samples: whole-tensor metric (a dead sample contributes nothing, by construction)
-    e_dw1 = np.abs(dw1.cpu().double().numpy() - X.T @ dH).max() / np.abs(X.T @ dH).max()
-    e_dw2 = np.abs(dw2.cpu().double().numpy() - Hh.T @ ddec.reshape(nvox, D)).max() / np.abs(Hh.T @ ddec.reshape(nvox, D)).max()
-    print("impl %d pointwise / %s: forward slice %.3g, dX slice %.3g, dW1 %.3g, dW2 %.3g" % (impl, scenario, e_fwd, e_dx, e_dw1, e_dw2))
+    # the weight gradients sum over the samples (a dead sample contributes nothing, by construction); slices: a ROW of dW1 (one input channel) and a COLUMN of dW2 (one
+    # output channel), each against its own maximum (a whole-tensor norm hid the quiet channels' rows).  A gate the oracle itself calls undecidable in fp32
+    # may go either way: its voxel's term is the only slack (see test_pointwise_filter_gradients_slice_by_slice)
+    r1, r2 = X.T @ dH, Hh.T @ ddec.reshape(nvox, D)
+    amb = np.abs(Hpre) < 4e-6 * (np.abs(X) @ np.abs(W1) + np.abs(b1))
+    slack1 = np.abs(X).T @ (np.abs(ddec.reshape(nvox, D).astype(np.float64) @ W2.T) * amb)
+    e1 = np.maximum(np.abs(dw1.cpu().double().numpy() - r1) - slack1, 0).max(axis=1) / np.maximum(np.abs(r1).max(axis=1), 1e-300)
+    e2 = np.abs(dw2.cpu().double().numpy() - r2).max(axis=0) / np.maximum(np.abs(r2).max(axis=0), 1e-300)
+    loud = gx >= 2.0 ** -18                                          # input channels whose two fp16 pieces are both normal at the sample's scale
+    e_dw1, e_dw2 = float(e1[loud].max()), float(e2.max())
+    e_dw1_quiet = float(e1[~loud].max()) if (~loud).any() else 0.0
+    print("impl %d pointwise / %s: forward slice %.3g, dX slice %.3g, dW1 rows %.3g (rows of channels below 2^-18: %.3g), dW2 columns %.3g"
+          % (impl, scenario, e_fwd, e_dx, e_dw1, e_dw1_quiet, e_dw2))
     assert e_fwd < 5e-6 and e_dx < 5e-6 and e_dw1 < 5e-6 and e_dw2 < 5e-6, (scenario, impl, e_fwd, e_dx, e_dw1, e_dw2)
+    # the declared floor of the fused kernel's dW1 / dW2 (include/probav_hip.h, probav_pw_backward): impl 4 only; the other families hold every row to the bar
+    assert e_dw1_quiet < (PW_DW_BAR_H3_FLOOR if impl == 4 else 5e-6), (scenario, impl, e_dw1_quiet)
+
+
+# ---- the fused pointwise backward's FILTER gradients, slice by slice ----
+# dW1[cin, hidden] = sum_voxels x[v, cin] dH'[v, hidden] and dW2[hidden, out] = sum_voxels H'[v, hidden] d_dec[v, out] contract over the voxels: the input channel of
+# x and the output channel of d_dec are FREE indices there, but the kernel cuts x / d_dec ONCE per tile with the per-SAMPLE scale that products (a) / (b) -- which contract
+# over those very channels -- need, and it has no register for a second accumulator set (conv3_wgrad_w4_kernel's cure: lifted second pieces).  So a channel that sits
+# 2^-k below its sample's maximum keeps both fp16 pieces normal only down to k = 18 .. 19; below that the second piece loses one bit per binade.  The bound is DECLARED
+# (include/probav_hip.h, probav_pw_backward) and asserted here per slice instead of hiding behind a whole-tensor norm:
+PW_DW_BAR_FP32 = 5e-6        # every slice whose channel gain is >= 2^-18: the bar test_fused_pointwise_slices_under_dynamic_range holds all three families to (impl 2 meets it on EVERY slice)
+PW_DW_BAR_H3_FLOOR = 1e-4    # impl 4, slices whose channel gain is below 2^-18 (down to 2^-24): the declared fp16 floor
+
+
+def _pw_backward(dev, impl, x, w1, b1, w2, ddec, vps):
+    L = _L()
+    nvox, D = x.shape[0], w2.shape[1]
+    xd, w1d, b1d, w2d, ddd = (_t(a, dev) for a in (x, w1, b1, w2, ddec))
+    dsd = torch.zeros((nvox, 32), device=dev)
+    nbytes = L.lib().probav_pw_backward_scratch_bytes(D)
+    scratch = torch.empty(nbytes // 4 + 1, device=dev)
+    dx, dw1, db1 = torch.full((nvox, 32), float("nan"), device=dev), torch.full((32, 256), float("nan"), device=dev), torch.full((256,), float("nan"), device=dev)
+    dw2, db2 = torch.full((256, D), float("nan"), device=dev), torch.full((D,), float("nan"), device=dev)
+    L.check(L.lib().probav_pw_backward(L.ptr(xd), L.ptr(ddd), L.ptr(dsd), L.ptr(w1d), L.ptr(b1d), L.ptr(w2d), L.ptr(dx), L.ptr(dw1),
+                                       L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(scratch), nbytes, nvox, vps, D, impl, L.current_stream()))
+    return [t.cpu().double().numpy() for t in (dx, dw1, db1, dw2, db2)]
+
+
+@pytest.mark.parametrize("which", ["x", "d_dec", "both"])
+def test_pointwise_filter_gradients_slice_by_slice(dev, which):
+    """Channel gains of 2^-24 .. 1 on the block's input channels (rows of dW1) and on d_dec's channels (columns of dW2); every row / column judged against ITS OWN
+    maximum, against the fp64 oracle.  A ReLU gate is a step: a hidden value within rounding of zero may be gated either way by an fp32 device, and one such voxel is
+    1 / sqrt(17 424) of a random-walk sum -- the oracle's tolerance for an element therefore carries the terms of the voxels whose pre-activation the oracle itself calls
+    undecidable in fp32 (|pre| below 4e-6 of sum |x||w1| + |b1|), and nothing else."""
+    D, vps, ns = 25, 22 * 22 * 9, 4
+    nvox = vps * ns
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(nvox, 32)).astype(np.float32)
+    w1 = (rng.normal(size=(32, 256)) / np.sqrt(32)).astype(np.float32)
+    b1 = rng.normal(scale=0.3, size=256).astype(np.float32)
+    w2 = (rng.normal(size=(256, D)) / 16).astype(np.float32)
+    ddec = rng.normal(size=(nvox, D)).astype(np.float32)
+    gx, gd = _gains(rng, 32, -24), _gains(rng, D, -24)
+    if which in ("x", "both"):
+        x *= gx
+    else:
+        gx = np.ones(32, np.float32)
+    if which in ("d_dec", "both"):
+        ddec *= gd
+    else:
+        gd = np.ones(D, np.float32)
+    X, W1, W2, DD = x.astype(np.float64), w1.astype(np.float64), w2.astype(np.float64), ddec.astype(np.float64)
+    pre = X @ W1 + b1
+    Hh = np.maximum(pre, 0)
+    draw = DD @ W2.T                                               # dH before the gate
+    dH = draw * (pre > 0)
+    r1, r2 = X.T @ dH, Hh.T @ DD
+    amb = np.abs(pre) < 4e-6 * (np.abs(X) @ np.abs(W1) + np.abs(b1))      # gates fp32 cannot be asked to decide
+    slack1 = np.abs(X).T @ (np.abs(draw) * amb)                  # what those voxels may move in dW1 [cin, hidden]
+    print("pointwise backward, gains on %s: %d of %d gates undecidable in fp32" % (which, int(amb.sum()), amb.size))
+    for impl in (4, 2):
+        _, dw1, _, dw2, _ = _pw_backward(dev, impl, x, w1, b1, w2, ddec, vps)
+        m1, m2 = np.abs(r1).max(axis=1), np.abs(r2).max(axis=0)   # a row of dW1 (one input channel), a column of dW2 (one output channel)
+        e1 = (np.maximum(np.abs(dw1 - r1) - slack1, 0)).max(axis=1) / m1
+        e2 = np.abs(dw2 - r2).max(axis=0) / m2
+        hi1, hi2 = gx >= 2.0 ** -18, gd >= 2.0 ** -18
+        def worst(e, sel):
+            return float(e[sel].max()) if sel.any() else 0.0
+        print("impl %d  dW1 rows: gain >= 2^-18 worst %.2e, below worst %.2e | dW2 columns: gain >= 2^-18 worst %.2e, below worst %.2e"
+              % (impl, worst(e1, hi1), worst(e1, ~hi1), worst(e2, hi2), worst(e2, ~hi2)))
+        assert worst(e1, hi1) < PW_DW_BAR_FP32 and worst(e2, hi2) < PW_DW_BAR_FP32, (which, impl, e1, e2)
+        bar_lo = PW_DW_BAR_H3_FLOOR if impl == 4 else PW_DW_BAR_FP32
+        assert worst(e1, ~hi1) < bar_lo and worst(e2, ~hi2) < bar_lo, (which, impl, e1, e2)
 
 
 def _wgrad(dev, impl, g, x, dy, gate=None):
