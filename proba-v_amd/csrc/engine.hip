@@ -170,6 +170,11 @@ static void reducer_extents(const probav_engine* e, std::vector<int>& hh, std::v
 }
 
 // slab floats of the backward-filter launch conv_wgrad() makes for geometry g under the engine's kernel family (the same decisions)
+// the low-frequency residual path runs as one launch each way (kernels_direct.hip: resid_path_*) in every family but 0, which stays on the generic direct kernels
+static bool resid_path_fused(const probav_engine* e)
+{
+    return e->impl >= 1 && resid_path_supported(e->Hin, e->cfg.in_channels, e->cfg.scale * e->cfg.scale);
+}
 static size_t wgrad_need(const probav_engine* e, const ConvGeom& g)
 {
     const bool exotic = g.reflect_t || g.ph > 1 || g.pw > 1 || g.pt > 1 || (g.kh != 3 && g.kh != 1);
@@ -251,6 +256,7 @@ static Plan make_plan(const probav_engine* e, int B, int training)
             std::vector<size_t> need;
             const int nred = (int)e->iRed.size();
             need.push_back(wgrad_need(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0)));           // residConv3, 2, 1
+            if (resid_path_fused(e)) need.back() = std::max(need.back(), resid_path_slab_floats(B, c.in_channels));        // (the fused reverse pass: one slab per patch, in the first region)
             need.push_back(wgrad_need(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0)));
             need.push_back(wgrad_need(e, make_geom(B, Hin, 1, c.in_channels, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1)));
             need.push_back(wgrad_need(e, make_geom(B, p.redH[nred - 1], p.redT[nred - 1], F, P, 1, s2, 3, 3, 3, 0, 0, 0, 0)));   // upscaleConv1
@@ -702,9 +708,14 @@ static int forward_impl(probav_engine* e, const float* params, const float* x, f
     SideGuard side_guard((side_stream_disabled() || e->side_mode == 0) ? nullptr : engine_side(e), s);
     {
         hipStream_t rs = reduce_fork(s);
+        if (resid_path_fused(e)) {                         // the three layers as one launch (kernels_direct.hip); family 0 keeps the generic direct kernels
+            CK(resid_path_forward(B, Hin, c.in_channels, W + p.mn, weff(e->iResid1), bias(e->iResid1), weff(e->iResid2), bias(e->iResid2), weff(e->iResid3), bias(e->iResid3),
+                                  W + p.r1, W + p.r2, W + p.r3, rs));
+        } else {
         CK(conv_fwd(e, make_geom(B, Hin, 1, c.in_channels, Hin - 2, 1, s2, 3, 3, 1, 0, 0, 0, 1), W + p.mn, nullptr, weff(e->iResid1), frag(e->iResid1), bias(e->iResid1), nullptr, W + p.r1, Amax(), rs));
         CK(conv_fwd(e, make_geom(B, Hin - 2, 1, s2, Hin - 4, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r1, nullptr, weff(e->iResid2), frag(e->iResid2), bias(e->iResid2), nullptr, W + p.r2, Amax(), rs));
         CK(conv_fwd(e, make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0), W + p.r2, nullptr, weff(e->iResid3), frag(e->iResid3), bias(e->iResid3), nullptr, W + p.r3, Amax(), rs));
+        }
     }
     CK(conv_fwd(e, make_geom(B, Hin, T, c.in_channels, Hin, T, F, 3, 3, 3, 1, 1, 0, 1), W + p.xn, nullptr, weff(e->iMain), frag(e->iMain), bias(e->iMain), nullptr, W + p.act[0], amx(nullptr, e->iMain, A.act(0)), s));
     for (int i = 0; i < R; ++i) {
@@ -817,6 +828,11 @@ static int backward_impl(probav_engine* e, const float* params, const float* dy,
         float *dtail = S + p.dtail, *dr2 = S + p.dr2, *dr1 = S + p.dr1;
         float *dw3 = dweff(e->iResid3), *db3 = dbias(e->iResid3), *dw2 = dweff(e->iResid2), *db2 = dbias(e->iResid2), *dw1 = dweff(e->iResid1), *db1 = dbias(e->iResid1);
         const int inch = c.in_channels;
+        const float *w2r = Wweff + e->layers[e->iResid2].wn.w_off, *w3r = Wweff + e->layers[e->iResid3].wn.w_off;
+        if (resid_path_fused(e))
+            CK(reduce_later(s, [=](hipStream_t rs) -> int {    // one launch + one slab sum (rp0 holds the patches' slabs: make_plan sized it)
+                return resid_path_backward(B, Hin, inch, mn, r1, r2, dtail, w2r, w3r, dw1, db1, dw2, db2, dw3, db3, rp0, rs); }));
+        else
         CK(reduce_later(s, [=](hipStream_t rs) -> int {
             const ConvGeom g3 = make_geom(B, Hin - 4, 1, s2, P, 1, s2, 3, 3, 1, 0, 0, 0, 0);
             CK(conv_wgrad(e, g3, r2, dtail, nullptr, dw3, db3, rp0, Amax(), rs));

@@ -664,4 +664,176 @@ int conv3d_direct_wgrad(const ConvGeom& g, const float* x, const float* dy, cons
     return sum_partials(partial, dw, nw, partial_b, db, cout, chunks, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The low-frequency residual path (models/modelsTF.py:45-53: residConv1 3x3 valid Cx -> 9 + ReLU, residConv2 and residConv3 3x3 valid 9 -> 9 on the
+// temporal-mean image) as ONE launch each way.  0.46 MMAC per patch forward: as three launches of the generic direct kernel it was 21 + 35 + 40 us on the side
+// stream, and its reverse pass three backward-filter launches, two backward-data launches and three slab sums (31 + 55 + 22 + 67 + 55 us of kernels that run
+// beside the first residual blocks' reverse pass and stretch it: VERDICT r5 #4).  One workgroup per patch, the whole chain in LDS:
+//   forward   mean image -> r1 -> r2 -> r3; a thread owns an output voxel and its nine channels (the filter values are wave-uniform: scalar loads);
+//   backward  d r3 -> d r2 -> d r1 (full correlations with the same filters, d r1 gated by r1 > 0), then the three backward-filters and bias sums of the patch:
+//             one output (tap, cin, cout) per thread, ONE slab per patch [dw3 | db3 | dw2 | db2 | dw1 | db1], summed over the patches by slab_sum_later (fp64, fixed order).
+// ---------------------------------------------------------------------------------------------------
+constexpr int RP_C = 9;                    // scale^2: the reference graph only closes for scale = 3 (probav_engine_create)
+static size_t rp_fwd_lds(int Hin, int Cx) { return ((size_t)Hin * Hin * Cx + (size_t)(Hin - 2) * (Hin - 2) * RP_C + (size_t)(Hin - 4) * (Hin - 4) * RP_C) * sizeof(float); }
+static size_t rp_bwd_lds(int Hin, int Cx)
+{
+    const size_t H1 = Hin - 2, H2 = Hin - 4, H3 = Hin - 6;
+    return ((size_t)Hin * Hin * Cx + 2 * H1 * H1 * RP_C + 2 * H2 * H2 * RP_C + H3 * H3 * RP_C + 2 * 9 * RP_C * RP_C) * sizeof(float);
+}
+static long rp_slab_floats(int Cx) { return 2L * (9 * RP_C * RP_C + RP_C) + 9L * Cx * RP_C + RP_C; }
+bool resid_path_supported(int Hin, int Cx, int C)
+{
+    return C == RP_C && Hin >= 7 && Cx >= 1 && Cx <= 4 && rp_bwd_lds(Hin, Cx) <= 150 * 1024;
+}
+size_t resid_path_slab_floats(int N, int Cx) { return (size_t)N * (size_t)rp_slab_floats(Cx); }
+
+template <bool RELU, bool KEEP>
+__device__ __forceinline__ void rp_conv(const float* src, int Hi, int Cin, const float* __restrict__ w, const float* __restrict__ bias,
+                                        float* keep, float* __restrict__ out, int tid, int nthr)
+{
+    const int Ho = Hi - 2;
+    for (int v = tid; v < Ho * Ho; v += nthr) {
+        const int h = v / Ho, x = v - h * Ho;
+        float acc[RP_C];
+#pragma unroll
+        for (int j = 0; j < RP_C; ++j) acc[j] = bias[j];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const float* xp = src + ((h + a) * Hi + (x + b)) * Cin;
+                const float* wp = w + (a * 3 + b) * Cin * RP_C;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float xv = xp[ci];
+#pragma unroll
+                    for (int j = 0; j < RP_C; ++j) acc[j] = fmaf(xv, wp[ci * RP_C + j], acc[j]);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < RP_C; ++j) {
+            const float o = RELU ? fmaxf(acc[j], 0.f) : acc[j];
+            if (KEEP) keep[v * RP_C + j] = o;
+            out[v * RP_C + j] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void resid_path_fwd_kernel(int Hin, int Cx, const float* __restrict__ mn,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             const float* __restrict__ w3, const float* __restrict__ b3,
+                                                             float* __restrict__ r1, float* __restrict__ r2, float* __restrict__ r3)
+{
+    extern __shared__ float rp_lds[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int H1 = Hin - 2, H2 = Hin - 4, H3 = Hin - 6;
+    float* in0 = rp_lds;
+    float* a1 = in0 + Hin * Hin * Cx;
+    float* a2 = a1 + H1 * H1 * RP_C;
+    for (int i = tid; i < Hin * Hin * Cx; i += 512) in0[i] = mn[(long)n * Hin * Hin * Cx + i];
+    __syncthreads();
+    rp_conv<true, true>(in0, Hin, Cx, w1, b1, a1, r1 + (long)n * H1 * H1 * RP_C, tid, 512);
+    __syncthreads();
+    rp_conv<false, true>(a1, H1, RP_C, w2, b2, a2, r2 + (long)n * H2 * H2 * RP_C, tid, 512);
+    __syncthreads();
+    rp_conv<false, false>(a2, H2, RP_C, w3, b3, nullptr, r3 + (long)n * H3 * H3 * RP_C, tid, 512);
+}
+
+// d src[y][x][ci] = sum over taps (a, b) and co of d dst[y - a][x - b][co] w[a][b][ci][co]   (dst = the 'valid' convolution's output, Ho = Hi - 2)
+template <bool GATED>
+__device__ __forceinline__ void rp_bwd_data(const float* dd, int Ho, const float* wl, const float* act, float* ds, int tid, int nthr)
+{
+    const int Hi = Ho + 2;
+    for (int o = tid; o < Hi * Hi * RP_C; o += nthr) {
+        const int ci = o % RP_C, v = o / RP_C, y = v / Hi, x = v - y * Hi;
+        float acc = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            const int yy = y - a;
+            if (yy < 0 || yy >= Ho) continue;
+            for (int b = 0; b < 3; ++b) {
+                const int xx = x - b;
+                if (xx < 0 || xx >= Ho) continue;
+                const float* dp = dd + (yy * Ho + xx) * RP_C;
+                const float* wp = wl + ((a * 3 + b) * RP_C + ci) * RP_C;
+#pragma unroll
+                for (int co = 0; co < RP_C; ++co) acc = fmaf(dp[co], wp[co], acc);
+            }
+        }
+        ds[o] = (!GATED || act[o] > 0.f) ? acc : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(1024) void resid_path_bwd_kernel(int Hin, int Cx, const float* __restrict__ mn, const float* __restrict__ r1, const float* __restrict__ r2,
+                                                              const float* __restrict__ dtail, const float* __restrict__ w2, const float* __restrict__ w3,
+                                                              float* __restrict__ slabs)
+{
+    extern __shared__ float rp_lds[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int H1 = Hin - 2, H2 = Hin - 4, H3 = Hin - 6;
+    float* in0 = rp_lds;                       // [Hin][Hin][Cx]   the temporal-mean image
+    float* a1 = in0 + Hin * Hin * Cx;          // [H1][H1][9]      r1 (behind its ReLU)
+    float* a2 = a1 + H1 * H1 * RP_C;           // [H2][H2][9]      r2
+    float* d3 = a2 + H2 * H2 * RP_C;           // [H3][H3][9]      d loss / d r3
+    float* d2 = d3 + H3 * H3 * RP_C;           // [H2][H2][9]      d loss / d r2
+    float* d1 = d2 + H2 * H2 * RP_C;           // [H1][H1][9]      d loss / d (residConv1's pre-activation)
+    float* W2 = d1 + H1 * H1 * RP_C;           // [3][3][9][9]
+    float* W3 = W2 + 9 * RP_C * RP_C;
+    for (int i = tid; i < Hin * Hin * Cx; i += 1024) in0[i] = mn[(long)n * Hin * Hin * Cx + i];
+    for (int i = tid; i < H1 * H1 * RP_C; i += 1024) a1[i] = r1[(long)n * H1 * H1 * RP_C + i];
+    for (int i = tid; i < H2 * H2 * RP_C; i += 1024) a2[i] = r2[(long)n * H2 * H2 * RP_C + i];
+    for (int i = tid; i < H3 * H3 * RP_C; i += 1024) d3[i] = dtail[(long)n * H3 * H3 * RP_C + i];
+    for (int i = tid; i < 9 * RP_C * RP_C; i += 1024) { W2[i] = w2[i]; W3[i] = w3[i]; }
+    __syncthreads();
+    rp_bwd_data<false>(d3, H3, W3, nullptr, d2, tid, 1024);
+    __syncthreads();
+    rp_bwd_data<true>(d2, H2, W2, a1, d1, tid, 1024);
+    __syncthreads();
+    // the patch's slab: [dw3 9*9*9 | db3 9 | dw2 9*9*9 | db2 9 | dw1 9*Cx*9 | db1 9]
+    const int nw = 9 * RP_C * RP_C, nw1 = 9 * Cx * RP_C, total = 2 * (nw + RP_C) + nw1 + RP_C;
+    float* sl = slabs + (long)n * total;
+    for (int o = tid; o < total; o += 1024) {
+        int k = o;
+        const float *A, *D; int Wi, Cin;
+        if (k < nw + RP_C) { A = a2; D = d3; Wi = H2; Cin = RP_C; }
+        else if (k < 2 * (nw + RP_C)) { k -= nw + RP_C; A = a1; D = d2; Wi = H1; Cin = RP_C; }
+        else { k -= 2 * (nw + RP_C); A = in0; D = d1; Wi = Hin; Cin = Cx; }
+        const int Wo = Wi - 2, nf = 9 * Cin * RP_C;
+        float acc = 0.f;
+        if (k < nf) {
+            const int co = k % RP_C, rest = k / RP_C, ci = rest % Cin, tap = rest / Cin, a = tap / 3, b = tap - 3 * a;
+            const float* xp = A + (a * Wi + b) * Cin + ci;
+            const float* dp = D + co;
+            for (int h = 0; h < Wo; ++h)
+                for (int x = 0; x < Wo; ++x) acc = fmaf(xp[(h * Wi + x) * Cin], dp[(h * Wo + x) * RP_C], acc);
+        } else {
+            const float* dp = D + (k - nf);
+            for (int i = 0; i < Wo * Wo; ++i) acc += dp[i * RP_C];
+        }
+        sl[o] = acc;
+    }
+}
+
+int resid_path_forward(int N, int Hin, int Cx, const float* mn, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                       float* r1, float* r2, float* r3, hipStream_t s)
+{
+    if (!resid_path_supported(Hin, Cx, RP_C) || N < 1) { set_error("resid_path_forward: unsupported shape", hipSuccess); return PROBAV_EINVAL; }
+    static std::once_flag once;
+    std::call_once(once, [] { note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(resid_path_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); });
+    hipLaunchKernelGGL(resid_path_fwd_kernel, dim3((unsigned)N), dim3(512), rp_fwd_lds(Hin, Cx), s, Hin, Cx, mn, w1, b1, w2, b2, w3, b3, r1, r2, r3);
+    return check_launch("resid_path_fwd");
+}
+
+int resid_path_backward(int N, int Hin, int Cx, const float* mn, const float* r1, const float* r2, const float* dtail, const float* w2, const float* w3,
+                        float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* slabs, hipStream_t s)
+{
+    if (!resid_path_supported(Hin, Cx, RP_C) || N < 1) { set_error("resid_path_backward: unsupported shape", hipSuccess); return PROBAV_EINVAL; }
+    static std::once_flag once;
+    std::call_once(once, [] { note_attr_error(hipFuncSetAttribute(reinterpret_cast<const void*>(resid_path_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); });
+    hipLaunchKernelGGL(resid_path_bwd_kernel, dim3((unsigned)N), dim3(1024), rp_bwd_lds(Hin, Cx), s, Hin, Cx, mn, r1, r2, dtail, w2, w3, slabs);
+    const int rc = check_launch("resid_path_bwd");
+    if (rc) return rc;
+    const long nw = 9L * RP_C * RP_C, nw1 = 9L * Cx * RP_C, total = rp_slab_floats(Cx);
+    const SlabSumJob jobs[6] = {{slabs, dw3, total, (int)nw, N}, {slabs + nw, db3, total, RP_C, N},
+                                {slabs + nw + RP_C, dw2, total, (int)nw, N}, {slabs + 2 * nw + RP_C, db2, total, RP_C, N},
+                                {slabs + 2 * (nw + RP_C), dw1, total, (int)nw1, N}, {slabs + 2 * (nw + RP_C) + nw1, db1, total, RP_C, N}};
+    return slab_sum_later(s, jobs, 6);
+}
+
 }  // namespace probav

@@ -84,6 +84,14 @@ int reduce_join(hipStream_t s);
 // mainConv1 forward (one input channel -> 32, 3x3x3, zero pads of 1): dedicated store-bound kernel; amax = per-sample slots of y or null
 bool conv3d_cin1_forward_supported(const ConvGeom& g);
 int conv3d_cin1_forward(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, unsigned* amax, hipStream_t s);
+// the low-frequency residual path (models/modelsTF.py:45-53) as ONE launch each way (kernels_direct.hip): mn [N][Hin][Hin][Cx] -> r1 [N][Hin-2]^2[9] (ReLU) -> r2 -> r3;
+// weights [3][3][1][Cin][9] (the effective, weight-normalised filters).  Backward: d r3 = dtail -> the six gradients; slabs: resid_path_slab_floats(N, Cx) floats.
+bool resid_path_supported(int Hin, int Cx, int C);
+size_t resid_path_slab_floats(int N, int Cx);
+int resid_path_forward(int N, int Hin, int Cx, const float* mn, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                       float* r1, float* r2, float* r3, hipStream_t s);
+int resid_path_backward(int N, int Hin, int Cx, const float* mn, const float* r1, const float* r2, const float* dtail, const float* w2, const float* w3,
+                        float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* slabs, hipStream_t s);
 // geometries for which conv3d_direct_wgrad runs a dedicated kernel that beats the matrix kernels (one input channel: mainConv1)
 // upscaleConv1 (32 -> 9, valid, depth 3 -> 1) and its backward-data (9 -> 32, full, depth 1 -> 3; w = the flipped, channel-swapped filter): small VALU kernels
 bool conv3d_up_forward_supported(const ConvGeom& g);
