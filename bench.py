@@ -42,7 +42,7 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 SPLIT_PRODUCTS = {3: 6, 4: 3}      # 16-bit MFMA products issued per fp32 product: x6 kernels (bf16 pieces) / H3 kernels (scaled fp16 pieces)
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak
 ALGO_MB_PER_PATCH = 402.414        # layer-boundary byte model, fwd + bwd (un-fused)
-PLAN_MB_PER_PATCH = 81.0           # DESIGN.md §3/§5: bytes the fused plan moves (256-channel tensor never reaches HBM)
+PLAN_MB_PER_PATCH = 81.0           # DESIGN.md §3: bytes the fused plan moves (256-channel tensor never reaches HBM)
 ALGO_GFLOP_PER_PATCH = 12.436      # SURVEY.md §8d / BASELINE.md §2: fwd + bwd, p16t9c85r12
 PW_BWD_ALGO_MAC, PW_BWD_ISSUED_MAC = 29184, 37376     # per voxel: §8d (bwd of expConv + decConv) / incl. the recompute of the hidden tile
 IMPL_NAMES = {0: "direct", 1: "mfma-rowtile", 2: "mfma-strip", 3: "x6-split-bf16", 4: "h3-split-fp16"}
@@ -700,7 +700,7 @@ def run_rank(args):
             # the ratio of the two step times tells a reader which class produced this line
             ratio = (dt / args.steps * 1e3) / fp32_leg["ms_per_step"]
             out["box_class"] = {"h3_step_over_fp32_step": round(ratio, 4), "class": "faster" if ratio < 0.405 else "slower",
-                                "note": "same build on both classes; DESIGN.md section 5 lists the per-class numbers"}
+                                "note": "same build on both classes; docs/notebook_r1-r5.md section 5 lists the per-class numbers"}
         if full is not None:
             out["full_step"] = {"ms_per_step": round(full, 4), "patches_per_s": round(world * B / full * 1e3, 2),
                                 "includes": "fwd + L1 loss + bwd + Nadam update + cPSNR metric"}

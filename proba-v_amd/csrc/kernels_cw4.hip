@@ -3,7 +3,7 @@
 // Reference semantics: models/modelsTF.py:179-186 (ResConv3D: normConv_i = weight-normalised Conv3D, 'same' padding, + the block's skip) and
 // tape.gradient through it (backward-data = the same convolution with the flipped, transposed filter: engine.hip packs it that way).
 //
-// What rounds 3 / 4 measured on conv3_pp_kernel: 88 100 cycles of matrix work per SIMD, 183 000-187 000 cycles per wave.  The tap loop
+// What rounds 3 / 4 measured on conv3_pp_kernel (docs/notebook_r1-r5.md appendix A.4): 88 100 cycles of matrix work per SIMD, 183 000-187 000 cycles per wave.  The tap loop
 // streams 90-108 KB of filter fragments per 32-voxel tile from the vector L1 / L2 (they do not fit the LDS beside the ring) -- 64 B/clk/CU is what a tap costs,
 // not its MFMAs -- and the finishing half of the workgroup (epilogue, staging) adds another 30 000 cycles beside it.
 // This kernel removes the stream instead of tuning it:

@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(StripArgs a, const flo
 #endif
     // K32: the two waves of a PAIR (tsel >> 1) share a 64-voxel tile and split its TAPS -- member 0 taps 0..13, member 1 taps 14..26 -- so that a tap's
     // 4 KB of filter fragments feed 24 MFMAs instead of 12: four waves x 4 KB per 12-MFMA tap are exactly the 64 B/clk of the vector L1 and made that tap
-    // 256 cycles long instead of 192 (tools/mfma_feed.hip).  Each member ends with partial sums of all 64 voxels, keeps the 32 it finishes
+    // 256 cycles long instead of 192 (tools/mfma_feed.hip, docs/notebook_r1-r5.md 4.1f).  Each member ends with partial sums of all 64 voxels, keeps the 32 it finishes
     // and hands the other 32 to its partner through LDS (xbuf: the 16 KB behind the ring; second barrier at the end of the segment).
     constexpr int KT0 = 14;                                                  // first tap of member 1
 #ifdef PPX_AD

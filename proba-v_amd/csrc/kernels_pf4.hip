@@ -14,7 +14,7 @@
 //   * four independent waves per workgroup, each with a contiguous run of tiles, no barrier in the loop;
 //   * one hand-pipelined instruction stream per wave: iteration (tile, chunk c) issues the second product of chunk c - 1 and the first product of chunk c + 1 -- twelve MFMAs --
 //     and in their gaps the vector work of chunk c (bias / ReLU, the cut: 56 instructions), plus its share of the tile's other work (the epilogue of the previous tile, the
-//     cut of the next tile's X, requests).  The stream is bound by the vector instructions it issues (~6 per MFMA, v_cvt_pk / v_fma_mix at 8-9 cycles: DESIGN.md 4.0).
+//     cut of the next tile's X, requests).  The stream is bound by the vector instructions it issues (~6 per MFMA, v_cvt_pk / v_fma_mix at 8-9 cycles: docs/notebook_r1-r5.md 4.0).
 #include "kernels_x6.h"
 #include "x6_device.h"
 #include <cstdlib>

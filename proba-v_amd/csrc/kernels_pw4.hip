@@ -1,7 +1,7 @@
 // Fused backward of expConv + ReLU + decConv (1x1x1), H3 arithmetic -- ONE WAVE PER SIMD, the whole 512-register file (round 5).
 // Reference semantics: tape.gradient through models/modelsTF.py:179-183 (ResConv3D: expConv_i -> ReLU -> decConv_i).
 //
-// What round 4 measured on pw_bwd_h3t_kernel: two waves per SIMD, 228 VGPRs each, every wave one 32-channel hidden chunk of a tile
+// What round 4 measured on pw_bwd_h3t_kernel (docs/notebook_r1-r5.md 4.0): two waves per SIMD, 228 VGPRs each, every wave one 32-channel hidden chunk of a tile
 // shared by the eight waves of the workgroup; matrix pipe 41 % busy, the rest dependent chains through LDS hand-offs (both H' and dH' cross the LDS
 // for their transposes, the dX partials of the eight chunks meet there, the two halves of the workgroup alternate phases behind s_barrier).
 // This kernel removes the hand-offs instead of tuning them:
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void pw_bwd_w4_kernel(
     const bool active = n < nsamp;
     const int tps = (vps + 31) >> 5;
     // The sample's tiles over its wps waves: tps / wps each, and the remainder one apiece to the waves of EVEN workgroups first.  Workgroup b runs on XCD b % 8, the odd
-    // XCDs hold ~2.5 % less clock than the even ones in every kernel looked at ('The XCDs do not run at one speed'), and the launch ends with its
+    // XCDs hold ~2.5 % less clock than the even ones in every kernel looked at (docs/notebook_r1-r5.md 4.0, 'The XCDs do not run at one speed'), and the launch ends with its
     // slowest wave: 137 tiles over 8 waves leave one wave with 18, which the plain split tps * jw / wps puts into an odd workgroup.  (Speed only: any split is correct.)
     int tb = 0, te = 0;
     if (active) {

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 #endif
 
     // ---- the rows ----
-    // A single wave issues one instruction per ~4.9 cycles whatever its kind (MI355X_MICROARCH.md): an MFMA leaves room for about five beside itself.  Per tile
+    // A single wave issues one instruction per ~4.9 cycles whatever its kind (MI355X_MICROARCH.md; docs/notebook_r1-r5.md section 4.00): an MFMA leaves room for about five beside itself.  Per tile
     // the gap behind the first MFMA takes the two address sums and two transposed reads of the tile PD ahead (piece 0), the second gap the other two reads; a k-block's
     // fillers -- the units it cuts (COPS each) and requests (LOPS each), the staging micro-operations (k-blocks MB .. NKB - 2) -- are dealt evenly over its second and third gaps.
     // Two barriers per row (a wave arrives with s_waitcnt lgkmcnt(n), n = the LDS operations it has issued behind its last LDS store -- wg4_lds_behind_last_store):
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wgrad_w4_kernel(Wg4Args a, const
 }
 
 #ifndef WG4_RT
-#define WG4_RT 28                // (32: 27 tap tiles, conflict-free reads, 12.5 % more MFMAs -- measured 9 % slower)
+#define WG4_RT 28                // (32: 27 tap tiles, conflict-free reads, 12.5 % more MFMAs -- measured 9 % slower, docs/notebook_r1-r5.md section 4.00)
 #endif
 // ---- the instances of the other translation units (the reducers': mirrored pads at depths 9 / 7 / 5 / 11 and 13 on column halves, the two unpadded layers) ----
 #define WG4_SIG(W, TP, RT, C, M) __global__ void conv3_wgrad_w4_kernel<W, TP, RT, C, M>(Wg4Args, const float*, const float*, const float*, float*, float*, Amax)

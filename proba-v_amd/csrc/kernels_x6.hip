@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * PwfShape<AR>::WAVES, PwfShape<AR>::WGS) void p
 //                   which in the W2 image (k-slot kp = rowmap(8 kb + j', half)) is fragment kb = j >> 2, lane (16 o + m) + 32 (kq & 1), bytes 8 (kq >> 1) .. + 7
 //                   (two ds_read_b64 per fragment)
 //   second product  T^T[out 16 o + 4 kq + i][voxel 16 u + n]: a lane holds four consecutive output channels of one voxel -> 16-byte stores
-// Why: cycles per FLOP are the same, but the chip holds a higher clock on this shape, and this kernel ran at the lowest clock of the set.
+// Why: cycles per FLOP are the same, but the chip holds a higher clock on this shape (docs/notebook_r1-r5.md 4.1f), and this kernel ran at the lowest clock of the set.
 // The hidden tile's sums are NOT bit-identical to the 32x32x16 kernel's (32 against 16 products per instruction); the backward pass recomputes the tile
 // with the 32x32x16 arrangement, and so does probav_debug_hidden: gates of pre-activations that sit at zero to the last bit can differ between the passes.
 // ---------------------------------------------------------------------------------------------------
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void pw_fwd_h3k_kernel(const float* __restr
     // Bias + ReLU as ONE instruction: v_fma_f32 ... clamp computes min(max(H c + b, 0), 1), so the accumulator is brought to 2^-16 of the hidden tile's
     // scale (where the tile's bound is < 1/2: the upper clamp never acts), and an exact multiplication by 2^16 follows.  The bits are those of
     // max(fma(H, c1, b), 0) * 2^eh (powers of two commute with the fma's one rounding); what is gone is the v_max_f32 per element -- this kernel is bound by
-    // its vector instructions at their real prices (a hidden element costs fma 5.7 + max 5.6 + scale 6.2 + cvt 2.9 + mix 9.6 cycles of its SIMD).
+    // its vector instructions at their real prices (docs/notebook_r1-r5.md 4.0: a hidden element costs fma 5.7 + max 5.6 + scale 6.2 + cvt 2.9 + mix 9.6 cycles of its SIMD).
     float sx = 1.f, c1c = 1.f, sb2 = 1.f; int eh = 0;
     const unsigned aw1 = *am.w1, ab1 = *am.b1;
     const int ew1 = h3_exp_w(aw1);

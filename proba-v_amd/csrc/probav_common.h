@@ -75,7 +75,7 @@ int reduce_flush(hipStream_t s);                            // one fork for ever
 // One slab sum: dst[i] = the fixed-order fp64 sum over c < slabs of src[c * stride + i], i < count (bitwise reproducible; any alignment).  slab_sum_later launches the
 // jobs as ONE kernel on reduce_fork(s) -- or, while launches are being deferred, adds them to the batch that the next reduce_flush launches as one kernel ON THE LAUNCH
 // STREAM (the backward pass's 27 slab sums of 15-22 MB each were 27 launches at 1.5 TB/s on the side stream; a flush's worth of them in one launch streams at 3.7 TB/s,
-// and on the launch stream it costs no event and nothing is left for the join to wait for: DESIGN.md section 4.00, the slab sums)
+// and on the launch stream it costs no event and nothing is left for the join to wait for: docs/notebook_r1-r5.md section 4.00, the slab sums)
 struct SlabSumJob { const float* src; float* dst; long stride; int count; int slabs; };
 int slab_sum_later(hipStream_t s, const SlabSumJob* jobs, int njobs);
 void reduce_free_pending(ReduceSide* ctx);                // the engine is going away: release the queue object

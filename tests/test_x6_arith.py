@@ -1,6 +1,6 @@
 """The arithmetic of the x6 kernels, restated in numpy (no GPU): an fp32 value is cut into three bf16 pieces by truncation
 (proba-v_amd/csrc/x6_device.h::pieces) and a product is the sum of the six largest piece products (mac6).  These tests pin
-the two claims DESIGN.md §4.1 rests on: the cut is exact, and the six-product sum is as accurate as an fp32 product."""
+the two claims DESIGN.md §4.1 (docs/notebook_r1-r5.md §4.1) rests on: the cut is exact, and the six-product sum is as accurate as an fp32 product."""
 import numpy as np
 
 HI = np.uint32(0xFFFF0000)

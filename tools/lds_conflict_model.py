@@ -6,7 +6,7 @@ A wave64 ds_read_b128 is served in four groups of sixteen lanes -- {0-3, 12-15, 
 (bank = (address / 4) mod 64), one more for every further distinct address on a busy quad.  The model walks every tile and tap of the
 benchmark geometry (22 x 22 x 9 voxels per sample, strips of 11 rows, records of 128 bytes, row pitch Tp = 11) for both lane maps
 (32x32x16: lane = voxel, half-wave = chunk; 16x16x32: lane = (voxel & 15, chunk)) and both swizzle keys (of the record index: rounds
-2-3a; of the unpadded voxel run: DESIGN.md section 4.1f) and prints cycles per read and the conflict share
+2-3a; of the unpadded voxel run: docs/notebook_r1-r5.md section 4.1f) and prints cycles per read and the conflict share
 (conflict cycles / active cycles = rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: measured 0.62 before, 0.11-0.13 after)."""
 import collections
 

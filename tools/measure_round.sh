@@ -30,6 +30,7 @@ python3 tools/pmc_summary.py "$O/pmc_b" > "$O/pmc_b.txt"
 python3 tools/hbm_summary.py "$O/hbm_f" "$O/hbm_w" 4 > "$O/hbm_traffic.json"
 # keep what is archived small: the kernel-stats csv and the summaries (the raw counter csvs stay on the box)
 find "$O/stats" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \;
+python3 tools/step_timeline.py "$O/stats" > "$O/step_timeline.txt" || true
 test -s "$O/kernel_stats.csv" && test -s "$O/bench_line.json" && test -s "$O/hbm_traffic.json"
 rm -rf "$O/stats" "$O/pmc_a" "$O/pmc_b" "$O/hbm_f" "$O/hbm_w"
 ls -la "$O"
