@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short T=13 training and full-frame inference legs")
     ap.add_argument("--full-step", action="store_true", help="also time loss+metric+Nadam (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spin-up", type=int, default=2, help="untimed steps between the interpreter's collector run and the synchronize that opens every timed region")
     ap.add_argument("--no-power", action="store_true", help="do not start the child process that samples board power and sclk (always give this under rocprofv3)")
     ap.add_argument("--no-trainer-loop", action="store_true", help="skip the ModelTrainer.fitTrainData leg of other_configs")
     ap.add_argument("--trainer-steps", type=int, default=240, help="steps of the ModelTrainer.fitTrainData leg (>= 200 for a stable median)")
@@ -360,6 +361,11 @@ def run_rank(args):
         gc_was = gc.isenabled()
         gc.disable()
         try:
+            # the collector run above leaves the device idle for tens of milliseconds and its shader clock gated (sclk 95 MHz in amdgpu's deep-sleep state); a region that
+            # opens on a gated device pays the ramp in its first step (+1.2 ms at batch 128).  --spin-up untimed steps stand between the collector and the opening synchronize
+            # (untimed warm-up like the W before them; the timed region stays exactly k steps between two synchronizes)
+            for _ in range(args.spin_up):
+                step(*a)
             sync()
             t0 = time.perf_counter()
             evs[0].record()

@@ -10,7 +10,7 @@ rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # per-kernel passes (durations, counters, bytes) with the backward-filter kernels on the launch stream: on the side stream (the default,
 # mode 2) they run beside the other kernels and every per-kernel figure would be a figure of two kernels
-B="--no-cpu-baseline --no-fp32-mfma-leg --no-other-configs --no-kernel-events --no-power --side-stream-mode 1"
+B="--no-cpu-baseline --no-fp32-mfma-leg --no-other-configs --no-kernel-events --no-power --spin-up 0 --side-stream-mode 1"      # (--spin-up 0: the summaries divide by the steps the command line names)
 prof() {            # prof <out dir> <log> <rocprofv3 args...> -- the profiled program goes DIRECTLY after `--` (no env / bash hop)
     local d="$1" log="$2"; shift 2
     if ! rocprofv3 "$@" --kernel-trace --output-format csv -d "$d" -o p -- python3 "$R/bench.py" $B --steps "${STEPS:-3}" --warmup "${WARM:-1}" > "$log" 2>&1; then
