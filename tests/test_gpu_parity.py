@@ -989,3 +989,31 @@ def test_config4_full_size_inference_is_deterministic_and_micro_batch_independen
         want = np.round(np.clip(po, 0, 2 ** 16))[..., 0].reshape(8, 8, 48, 48).transpose(0, 2, 1, 3).reshape(384, 384)       # np.round: half to even, like tf.round
         d = np.abs(full[s].cpu().numpy().astype(np.float64) - want)
         assert d.max() <= 1.0 and (d > 0).mean() < 2e-3, (s, d.max(), (d > 0).mean())
+
+
+@pytest.mark.parametrize("C", [1, 3], ids=["gray", "three-channel"])
+@pytest.mark.parametrize("impl", [4, 0], ids=["one-launch", "generic"])
+def test_residual_path_first_layer_and_output_match_the_oracle(dev, impl, C):
+    """The low-frequency residual path (models/modelsTF.py:45-53) runs as ONE launch each way in every kernel family but 0 (kernels_direct.hip: resid_path_fwd_kernel /
+    resid_path_bwd_kernel; round 6), family 0 keeps the generic direct kernels.  Forward, layer by layer as far as the boundary shows it: residConv1's output r1 (the saved
+    activation behind its ReLU: probav_workspace_view RESID1) against the fp64 numpy oracle, and the network's output -- main path + depth_to_space(r3) -- against
+    the oracle's.  (The reverse pass of the three layers is held element-wise by the gate-masked gradient tests above, for one and for three input channels.)"""
+    B, T = 3, 9
+    x, _, _ = synth.synth_batch(B, seed=77 + C, numImgLR=T, inChannels=C)
+    params = synth.synth_params(seed=78, perturb=True, inChannels=C)
+    m = _model(dev, T, params, gray=(C == 1))
+    m.set_impl(impl)
+    pred = m(torch.as_tensor(x).to(dev), training=True)
+    torch.cuda.synchronize()
+    L = _lib()
+    off, cnt = ctypes.c_int64(), ctypes.c_int64()
+    L.check(L.lib().probav_workspace_view(m._handle(), B, 1, 3, 0, ctypes.byref(off), ctypes.byref(cnt)), "probav_workspace_view")
+    r1 = m._workspace(B, True)[off.value: off.value + cnt.value].cpu().double().numpy().reshape(B, 20, 20, 9)
+    xm = np.asarray(x, np.float64)
+    mn = (xm.mean(axis=3) - synth.NIR_MEAN) / synth.NIR_STD                       # [B, 22, 22, C]: :23, :27
+    ref1 = on.wn_conv(mn, params["residConv1"], "valid", True)                     # a 2-D layer: [B, 20, 20, 9]
+    e1 = np.abs(r1 - ref1).max() / np.abs(ref1).max()
+    ref = on.wdsr_forward(x, params, synth.NIR_MEAN, synth.NIR_STD)
+    e = np.abs(pred.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max()
+    print("impl %d, %d input channel(s): residConv1 output rel err %.3g, network output rel err %.3g" % (impl, C, e1, e))
+    assert e1 < 2e-6 and e < 2e-5, (impl, C, e1, e)
